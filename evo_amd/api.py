@@ -1,0 +1,368 @@
+"""ctypes binding of include/evofst.h (evo_amd/libevofst.so).
+
+This is plumbing: every statistic is computed by the HIP kernels behind the C ABI.  There is no
+CPU fallback -- loading fails loudly when the shared library is missing and `EvoFst()` raises
+when no GPU is available.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevofst.so")
+
+EVOFST_OK = 0
+ERR_ARG, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+REF, ALT, MISSING = 0, 1, 2
+SITE_SKIP = 1
+MODE_FST, MODE_GLOBAL = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+
+
+class Geometry(C.Structure):
+    _fields_ = [("n_samples", C.c_int32), ("n_pops", C.c_int32), ("n_haplotypes", C.c_int32),
+                ("words_per_site", C.c_int32), ("tile_sites", C.c_int32), ("count_bytes", C.c_int32),
+                ("tile_bytes", C.c_int64)]
+
+
+# every symbol include/evofst.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "evofst_create": (_vp, [C.c_int]),
+    "evofst_destroy": (None, [_vp]),
+    "evofst_last_error": (C.c_char_p, [_vp]),
+    "evofst_version": (C.c_char_p, []),
+    "evofst_set_stream": (C.c_int, [_vp, _vp]),
+    "evofst_set_layout": (C.c_int, [_vp, C.c_int, C.c_int, _i32p]),
+    "evofst_get_geometry": (C.c_int, [_vp, C.POINTER(Geometry)]),
+    "evofst_get_pop_chroms": (C.c_int, [_vp, _i32p]),
+    "evofst_tiles_bytes": (C.c_size_t, [_vp, C.c_int64]),
+    "evofst_pack_codes": (C.c_int, [_vp, C.c_int64, C.c_int64, _u8p, _vp]),
+    "evofst_unpack_codes": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _u8p]),
+    "evofst_codes_from_vcf_line": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _u8p, C.POINTER(C.c_uint32),
+                                             C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
+    "evofst_reserve": (C.c_int, [_vp, C.c_int64]),
+    "evofst_alloc_pinned": (_vp, [_vp, C.c_size_t]),
+    "evofst_free_pinned": (None, [_vp, _vp]),
+    "evofst_upload": (C.c_int, [_vp, C.c_int64, _vp, _u8p, _i32p]),
+    "evofst_attach_device": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    "evofst_synth": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_uint64, C.c_double]),
+    "evofst_download_tiles": (C.c_int, [_vp, _vp]),
+    "evofst_set_pairs": (C.c_int, [_vp, _i32p, _i32p, C.c_int]),
+    "evofst_set_against_all": (C.c_int, [_vp, _i32p, C.c_int, _i64p]),
+    "evofst_set_windows": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "evofst_set_base_offsets": (C.c_int, [_vp, _i64p]),
+    "evofst_run_counts": (C.c_int, [_vp]),
+    "evofst_run_stats": (C.c_int, [_vp]),
+    "evofst_run": (C.c_int, [_vp]),
+    "evofst_sync": (C.c_int, [_vp]),
+    "evofst_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "evofst_get_kernel_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
+    "evofst_get_counts": (C.c_int, [_vp, C.c_int64, C.c_int64, _i32p, _i32p]),
+    "evofst_get_included_totals": (C.c_int, [_vp, _i64p]),
+    "evofst_get_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp, _u8p]),
+    "evofst_get_pop_site_div": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp]),
+    "evofst_max_segments": (C.c_int64, [_vp]),
+    "evofst_get_segments": (C.c_int, [_vp, _i64p, _i64p, _dp, _dp, _dp, _i32p]),
+    "evofst_get_boundary": (C.c_int, [_vp, _dp]),
+    "evofst_get_totals": (C.c_int, [_vp, _dp]),
+    "evofst_get_global_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _u8p]),
+    "evofst_max_global_rows": (C.c_int64, [_vp]),
+    "evofst_get_global_windows": (C.c_int, [_vp, _i64p, _i32p, _i32p, _dp, _dp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Loads libevofst.so (built by __graft_entry__.build() / evo_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("evo_amd: %s is missing -- build it with `make -C evo_amd/csrc` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the library does not export the symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class EvoFstError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("evofst error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def codes_from_vcf_line(line, mode, n_samples):
+    """One VCF data line -> (codes[2N], site_flags, chrom, pos) with the rules of `mode`."""
+    L = load_library()
+    buf = C.create_string_buffer(line.encode() if isinstance(line, str) else line)
+    codes = np.empty(2 * n_samples, np.uint8)
+    fl = C.c_uint32(0)
+    chrom = C.c_char_p(); pos = C.c_char_p()
+    rc = L.evofst_codes_from_vcf_line(buf, mode, n_samples, _ptr(codes, _u8p), C.byref(fl), C.byref(chrom),
+                                      C.byref(pos))
+    if rc != 0:
+        raise EvoFstError(rc, "malformed VCF line")
+    return codes, fl.value, chrom.value.decode(), pos.value.decode()
+
+
+class EvoFst:
+    """One context = one GPU.  Mirrors the C ABI one to one; results come back as numpy arrays."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = self.L.evofst_create(device)
+        if not self.h:
+            raise EvoFstError(ERR_HIP, self.L.evofst_last_error(None).decode())
+        self.n_pairs = 0
+        self.n_use = 0
+        self.n_pops = 0
+        self.n_samples = 0
+        self.n_sites = 0
+
+    def close(self):
+        if self.h:
+            self.L.evofst_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EvoFstError(rc, self.L.evofst_last_error(self.h).decode())
+
+    # ---- layout / packing
+    def set_layout(self, sample_pop, n_pops):
+        sp = np.ascontiguousarray(sample_pop, np.int32)
+        self._chk(self.L.evofst_set_layout(self.h, len(sp), n_pops, _ptr(sp, _i32p)))
+        self.n_samples, self.n_pops = len(sp), n_pops
+        self.n_pairs = self.n_use = 0
+
+    def geometry(self):
+        g = Geometry()
+        self._chk(self.L.evofst_get_geometry(self.h, C.byref(g)))
+        return g
+
+    def pop_chroms(self):
+        out = np.empty(self.n_pops, np.int32)
+        self._chk(self.L.evofst_get_pop_chroms(self.h, _ptr(out, _i32p)))
+        return out
+
+    def tiles_bytes(self, n_sites):
+        return self.L.evofst_tiles_bytes(self.h, n_sites)
+
+    def pack_codes(self, codes):
+        codes = np.ascontiguousarray(codes, np.uint8)
+        S = codes.shape[0]
+        assert codes.shape[1] == 2 * self.n_samples
+        tiles = np.zeros(self.tiles_bytes(S) // 8, np.uint64)
+        self._chk(self.L.evofst_pack_codes(self.h, 0, S, _ptr(codes, _u8p), tiles.ctypes.data_as(_vp)))
+        return tiles
+
+    def unpack_codes(self, tiles, n_sites):
+        codes = np.empty((n_sites, 2 * self.n_samples), np.uint8)
+        self._chk(self.L.evofst_unpack_codes(self.h, 0, n_sites, tiles.ctypes.data_as(_vp), _ptr(codes, _u8p)))
+        return codes
+
+    # ---- data
+    def reserve(self, max_sites):
+        self._chk(self.L.evofst_reserve(self.h, max_sites))
+
+    def upload(self, tiles, n_sites, site_flags=None, pos=None):
+        self._tiles_keep = np.ascontiguousarray(tiles)
+        self._fl_keep = np.ascontiguousarray(site_flags, np.uint8) if site_flags is not None else None
+        self._pos_keep = np.ascontiguousarray(pos, np.int32) if pos is not None else None
+        self._chk(self.L.evofst_upload(self.h, n_sites, self._tiles_keep.ctypes.data_as(_vp),
+                                       _ptr(self._fl_keep, _u8p), _ptr(self._pos_keep, _i32p)))
+        self.sync()
+        self.n_sites = n_sites
+
+    def attach_device(self, n_sites, d_tiles, d_flags=None, d_pos=None):
+        self._chk(self.L.evofst_attach_device(self.h, n_sites, d_tiles, d_flags, d_pos))
+        self.n_sites = n_sites
+
+    def synth(self, n_sites, seed=20261110, missing_rate=0.0, first_site_global=0):
+        self._chk(self.L.evofst_synth(self.h, n_sites, first_site_global, seed, missing_rate))
+        self.n_sites = n_sites
+
+    def download_tiles(self):
+        tiles = np.empty(self.tiles_bytes(self.n_sites) // 8, np.uint64)
+        self._chk(self.L.evofst_download_tiles(self.h, tiles.ctypes.data_as(_vp)))
+        return tiles
+
+    # ---- modes
+    def set_pairs(self, pair_i=None, pair_j=None):
+        if pair_i is None:
+            self._chk(self.L.evofst_set_pairs(self.h, None, None, 0))
+            self.n_pairs = self.n_pops * (self.n_pops - 1) // 2
+        else:
+            pi = np.ascontiguousarray(pair_i, np.int32); pj = np.ascontiguousarray(pair_j, np.int32)
+            self._chk(self.L.evofst_set_pairs(self.h, _ptr(pi, _i32p), _ptr(pj, _i32p), len(pi)))
+            self.n_pairs = len(pi)
+        self.n_use = 0
+
+    def all_pairs(self):
+        P = self.n_pops
+        i, j = np.triu_indices(P, 1)
+        return i.astype(np.int32), j.astype(np.int32)
+
+    def set_against_all(self, use_pops, set_sizes):
+        up = np.ascontiguousarray(use_pops, np.int32); ss = np.ascontiguousarray(set_sizes, np.int64)
+        self._chk(self.L.evofst_set_against_all(self.h, _ptr(up, _i32p), len(up), _ptr(ss, _i64p)))
+        self.n_use = len(up)
+        self.n_pairs = 0
+
+    def set_windows(self, size, step):
+        self._chk(self.L.evofst_set_windows(self.h, size, step))
+        self.size, self.step = size, step
+
+    def set_base_offsets(self, offsets):
+        o = np.ascontiguousarray(offsets, np.int64)
+        self._chk(self.L.evofst_set_base_offsets(self.h, _ptr(o, _i64p)))
+
+    # ---- compute
+    def run_counts(self):
+        self._chk(self.L.evofst_run_counts(self.h))
+
+    def run_stats(self):
+        self._chk(self.L.evofst_run_stats(self.h))
+
+    def run(self):
+        self._chk(self.L.evofst_run(self.h))
+
+    def sync(self):
+        self._chk(self.L.evofst_sync(self.h))
+
+    def set_profiling(self, on=True):
+        self._chk(self.L.evofst_set_profiling(self.h, 1 if on else 0))
+
+    def kernel_ms(self, which):
+        ms = C.c_float(0)
+        self._chk(self.L.evofst_get_kernel_ms(self.h, which, C.byref(ms)))
+        return ms.value
+
+    # ---- results
+    def counts(self, first=0, n=None):
+        n = self.n_sites - first if n is None else n
+        alt = np.empty((n, self.n_pops), np.int32); nm = np.empty((n, self.n_pops), np.int32)
+        self._chk(self.L.evofst_get_counts(self.h, first, n, _ptr(alt, _i32p), _ptr(nm, _i32p)))
+        return alt, nm
+
+    def included_totals(self):
+        out = np.empty(self.n_pairs if self.n_pairs else 2, np.int64)
+        self._chk(self.L.evofst_get_included_totals(self.h, _ptr(out, _i64p)))
+        return out
+
+    def site_stats(self, first=0, n=None):
+        """-> num, den, dxy [n_pairs, n], include [n_pairs, n]"""
+        n = self.n_sites - first if n is None else n
+        Q = self.n_pairs
+        num = np.empty((Q, n)); den = np.empty((Q, n)); dxy = np.empty((Q, n)); inc = np.empty((Q, n), np.uint8)
+        self._chk(self.L.evofst_get_site_stats(self.h, first, n, _ptr(num, _dp), _ptr(den, _dp), _ptr(dxy, _dp),
+                                               _ptr(inc, _u8p)))
+        return num, den, dxy, inc
+
+    def pop_site_div(self, first=0, n=None):
+        n = self.n_sites - first if n is None else n
+        P = self.n_pops
+        het = np.empty((P, n)); hn = np.empty((P, n)); pi = np.empty((P, n))
+        self._chk(self.L.evofst_get_pop_site_div(self.h, first, n, _ptr(het, _dp), _ptr(hn, _dp), _ptr(pi, _dp)))
+        return het, hn, pi
+
+    def segments(self):
+        cap = self.L.evofst_max_segments(self.h)
+        Q = self.n_pairs
+        first = np.empty(Q, np.int64); rows = np.empty(Q, np.int64)
+        sn = np.empty((cap, Q)); sd = np.empty((cap, Q)); sk = np.empty((cap, Q)); es = np.empty((cap, Q), np.int32)
+        self._chk(self.L.evofst_get_segments(self.h, _ptr(first, _i64p), _ptr(rows, _i64p), _ptr(sn, _dp),
+                                             _ptr(sd, _dp), _ptr(sk, _dp), _ptr(es, _i32p)))
+        return dict(first_segment=first, n_segments=rows, sum_num=sn, sum_den=sd, sum_dxy_k=sk, end_site=es)
+
+    def boundary(self):
+        out = np.empty((self.n_pairs, 4))
+        self._chk(self.L.evofst_get_boundary(self.h, _ptr(out, _dp)))
+        return out
+
+    def totals(self):
+        out = np.empty((self.n_pairs, 4))
+        self._chk(self.L.evofst_get_totals(self.h, _ptr(out, _dp)))
+        return out
+
+    def global_site_stats(self, first=0, n=None):
+        n = self.n_sites - first if n is None else n
+        U = self.n_use
+        num = np.empty((U, n)); den = np.empty((U, n)); kept = np.empty(n, np.uint8)
+        self._chk(self.L.evofst_get_global_site_stats(self.h, first, n, _ptr(num, _dp), _ptr(den, _dp),
+                                                      _ptr(kept, _u8p)))
+        return num, den, kept
+
+    def global_windows(self):
+        cap = self.L.evofst_max_global_rows(self.h)
+        U = self.n_use
+        n = C.c_int64(0)
+        ss = np.empty(cap, np.int32); es = np.empty(cap, np.int32)
+        mn = np.empty((cap, U)); md = np.empty((cap, U))
+        self._chk(self.L.evofst_get_global_windows(self.h, C.byref(n), _ptr(ss, _i32p), _ptr(es, _i32p),
+                                                   _ptr(mn, _dp), _ptr(md, _dp)))
+        r = n.value
+        return dict(start_site=ss[:r], end_site=es[:r], mean_num=mn[:r], mean_den=md[:r])
+
+
+# ---------------------------------------------------------------------------
+# host-side composition of windows from device segment sums
+# ---------------------------------------------------------------------------
+
+def compose_snp_windows(seg, pair, size, step, n_full_i, n_full_j, carry_in=None):
+    """Windows of process_vcf_fst.cpp:638-650 for one pair from the device's segment sums.
+
+    A window ends at included-site rank e (a multiple of `step`, e >= size) and is the sum of the
+    size/g segments that precede it.  Returns first_var, end_site, sum_num, sum_den, sum_dxy, fst,
+    mean_dxy like the oracle's snp_windows().  carry_in = (num, den, k) to add to the first
+    segment of a shard (multi-GPU).
+    """
+    g = math.gcd(size, step)
+    first = int(seg["first_segment"][pair]); rows = int(seg["n_segments"][pair])
+    sn = seg["sum_num"][:rows, pair].copy(); sd = seg["sum_den"][:rows, pair].copy()
+    sk = seg["sum_dxy_k"][:rows, pair].copy(); es = seg["end_site"][:rows, pair]
+    if carry_in is not None and rows > 0:
+        sn[0] = carry_in[0] + sn[0]; sd[0] = carry_in[1] + sd[0]; sk[0] = carry_in[2] + sk[0]
+    per = size // g
+    out = dict(first_var=[], end_site=[], sum_num=[], sum_den=[], sum_dxy=[], fst=[], mean_dxy=[])
+    denom = float(n_full_i) * float(n_full_j)
+    for r in range(rows):
+        m = first + r                 # global segment index; segment ends at rank (m+1)*g
+        e = (m + 1) * g
+        if e % step != 0 or e < size:
+            continue
+        lo = r - per + 1
+        if lo < 0:
+            continue                  # window starts in a previous shard
+        wn = 0.0; wd = 0.0; wk = 0.0
+        for t in range(lo, r + 1):
+            wn += sn[t]; wd += sd[t]; wk += sk[t]
+        with np.errstate(all="ignore"):
+            f = float(np.float64(wn / size) / np.float64(wd / size))   # calculateFst, fst.cpp:354-360
+        if f < 0:
+            f = 0.0
+        out["first_var"].append(e - size + 1); out["end_site"].append(int(es[r]))
+        out["sum_num"].append(wn); out["sum_den"].append(wd); out["sum_dxy"].append(wk / denom)
+        out["fst"].append(f); out["mean_dxy"].append(wk / denom / size)
+    return {k: np.asarray(v) for k, v in out.items()}

@@ -1,0 +1,1060 @@
+// evofst_api.cpp -- the C ABI declared in include/evofst.h (host side, HIP runtime calls only).
+//
+// There is no CPU fallback: every compute entry point launches the kernels of
+// evofst_kernels.hip and fails with EVOFST_ERR_HIP when no GPU is available.
+#include "../../include/evofst.h"
+#include "evofst_internal.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace evofst;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+constexpr int kNumKernels = 4;
+
+}  // namespace
+
+struct evofst_ctx {
+    int device = 0;
+    bool host_only = false;  // evofst_create(-1): packer-only context, no GPU is touched
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+
+    // layout
+    int n_samples = 0, n_pops = 0, H = 0, W = 0, count_bytes = 2;
+    std::vector<int32_t> sample_pop, n_full, pop_off;
+    std::vector<int32_t> src_hap;  // packed haplotype -> input haplotype (2*sample + allele)
+    std::vector<SegDesc> segs;
+    std::vector<int32_t> word_seg_start;
+    DevBuf d_segs, d_wss, d_nfull;
+
+    // mode
+    int mode = MODE_COUNTS;
+    std::vector<uint32_t> pairs;
+    std::vector<int32_t> use_idx;
+    std::vector<double> thresholds;
+    DevBuf d_pairs, d_use, d_thr;
+    int snp_size = 0, snp_step = 0, g = INT_MAX;
+    std::vector<int64_t> base;  // n_pairs (pairs mode) or 2 (against-all)
+    DevBuf d_base, d_first_seg;
+    bool offsets_dirty = true;
+
+    // data
+    int64_t cap_sites = 0, n_sites = 0;
+    int n_tiles = 0, chunk_tiles = 0, n_chunks = 0;
+    DevBuf d_tiles, d_flags, d_pos, d_counts;
+    const void *tiles = nullptr;  // d_tiles.p or an attached pointer
+    const uint8_t *flags = nullptr;
+    const int32_t *pos = nullptr;
+    bool have_flags = false, have_pos = false;
+
+    // pairs-mode work buffers
+    DevBuf d_census, d_offsets, d_incl_totals, d_seg_num, d_seg_den, d_seg_k, d_seg_end, d_head, d_head_site, d_tail,
+        d_nrows, d_totals;
+    int64_t seg_cap = 0;
+    // against-all work buffers
+    DevBuf d_gtotals, d_kept, d_skip, d_used_kept, d_uk_off, d_uk_tot, d_chunk_rows, d_row_off, d_row_tot, d_row_start,
+        d_row_end, d_row_num, d_row_den;
+    int64_t row_cap = 0;
+
+    bool counts_done = false, stats_done = false;
+    bool profiling = false;
+    hipEvent_t ev[kNumKernels][2] = {};
+    bool ev_valid[kNumKernels] = {};
+};
+
+namespace {
+
+int fail(evofst_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int hip_fail(evofst_ctx *c, hipError_t e, const char *what) {
+    return fail(c, EVOFST_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define NEED_GPU(c)                                                                                   \
+    do {                                                                                              \
+        if ((c)->host_only) return fail(c, EVOFST_ERR_STATE, "host-only context (evofst_create(-1)): no GPU work possible"); \
+    } while (0)
+#define HIPCHK(c, call)                                        \
+    do {                                                       \
+        hipError_t e__ = (call);                               \
+        if (e__ != hipSuccess) return hip_fail(c, e__, #call); \
+    } while (0)
+
+int ensure(evofst_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return EVOFST_OK;
+    if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { b.p = nullptr; return fail(c, EVOFST_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    b.bytes = bytes;
+    return EVOFST_OK;
+}
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+}
+template <typename T>
+int upload_vec(evofst_ctx *c, DevBuf &b, const std::vector<T> &v) {
+    int rc = ensure(c, b, v.size() * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) {
+        HIPCHK(c, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // v may be a temporary
+    }
+    return EVOFST_OK;
+}
+
+int n_tiles_of(int64_t n_sites) { return (int)((n_sites + kTileSites - 1) / kTileSites); }
+
+int upload_layout(evofst_ctx *c) {
+    // flags of the segment table depend on the against-all selection
+    std::vector<uint8_t> use(c->n_pops, 0);
+    int first_use = -1;
+    if (c->mode == MODE_GLOBAL) {
+        for (size_t u = 0; u < c->use_idx.size(); ++u) use[c->use_idx[u]] = 1;
+        if (!c->use_idx.empty()) first_use = c->use_idx[0];
+    }
+    for (auto &d : c->segs) {
+        d.flags &= kSegLast;
+        if (use[d.pop]) d.flags |= kSegUse;
+        if ((int)d.pop == first_use) d.flags |= kSegFirstUse;
+    }
+    int rc;
+    if ((rc = upload_vec(c, c->d_segs, c->segs))) return rc;
+    if ((rc = upload_vec(c, c->d_wss, c->word_seg_start))) return rc;
+    if ((rc = upload_vec(c, c->d_nfull, c->n_full))) return rc;
+    return EVOFST_OK;
+}
+
+void record(evofst_ctx *c, int which, int end) {
+    if (!c->profiling) return;
+    if (!c->ev[which][end]) (void)hipEventCreate(&c->ev[which][end]);
+    (void)hipEventRecord(c->ev[which][end], c->stream);
+    if (end) c->ev_valid[which] = true;
+}
+
+int plan_chunks(evofst_ctx *c) {
+    c->n_tiles = n_tiles_of(c->n_sites);
+    int ct = 0;
+    if (const char *e = getenv("EVOFST_CHUNK_TILES")) ct = atoi(e);
+    if (ct <= 0) ct = std::max(4, (c->n_tiles + 2047) / 2048);
+    c->chunk_tiles = ct;
+    c->n_chunks = (c->n_tiles + ct - 1) / ct;
+    return EVOFST_OK;
+}
+
+int run_scan(evofst_ctx *c) {
+    if (c->mode == MODE_PAIRS) {
+        const int np = (int)c->pairs.size();
+        int rc;
+        if ((rc = ensure(c, c->d_offsets, (size_t)c->n_chunks * np * 8))) return rc;
+        if ((rc = ensure(c, c->d_incl_totals, (size_t)np * 8))) return rc;
+        record(c, 1, 0);
+        HIPCHK(c, launch_scan((const uint32_t *)c->d_census.p, (const int64_t *)c->d_base.p, (int64_t *)c->d_offsets.p,
+                              (int64_t *)c->d_incl_totals.p, c->n_chunks, np, c->stream));
+        record(c, 1, 1);
+    } else if (c->mode == MODE_GLOBAL) {
+        int rc;
+        if ((rc = ensure(c, c->d_uk_off, (size_t)c->n_chunks * 2 * 8))) return rc;
+        if ((rc = ensure(c, c->d_uk_tot, 2 * 8))) return rc;
+        record(c, 1, 0);
+        HIPCHK(c, launch_scan((const uint32_t *)c->d_used_kept.p, (const int64_t *)c->d_base.p, (int64_t *)c->d_uk_off.p,
+                              (int64_t *)c->d_uk_tot.p, c->n_chunks, 2, c->stream));
+        record(c, 1, 1);
+    }
+    c->offsets_dirty = false;
+    return EVOFST_OK;
+}
+
+int set_base_internal(evofst_ctx *c, const int64_t *offsets) {
+    size_t n = c->mode == MODE_PAIRS ? c->pairs.size() : 2;
+    c->base.assign(n, 0);
+    if (offsets) std::copy(offsets, offsets + n, c->base.begin());
+    int rc = upload_vec(c, c->d_base, c->base);
+    if (rc) return rc;
+    c->offsets_dirty = true;
+    c->stats_done = false;
+    return EVOFST_OK;
+}
+
+K2Params make_k2(evofst_ctx *c) {
+    K2Params p{};
+    p.counts = c->d_counts.p;
+    p.site_flags = c->have_flags ? c->flags : nullptr;
+    p.n_sites = c->n_sites;
+    p.n_tiles = c->n_tiles; p.P = c->n_pops;
+    p.n_full = (const int32_t *)c->d_nfull.p;
+    p.pairs = (const uint32_t *)c->d_pairs.p;
+    p.n_pairs = (int)c->pairs.size();
+    p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
+    p.chunk_offsets = (const int64_t *)c->d_offsets.p;
+    p.first_segment = (const int64_t *)c->d_first_seg.p;
+    p.g = c->g; p.seg_cap = c->seg_cap;
+    p.seg_num = (double *)c->d_seg_num.p; p.seg_den = (double *)c->d_seg_den.p; p.seg_k = (double *)c->d_seg_k.p;
+    p.seg_end = (int32_t *)c->d_seg_end.p;
+    p.head = (double *)c->d_head.p; p.head_site = (int32_t *)c->d_head_site.p; p.tail = (double *)c->d_tail.p;
+    return p;
+}
+
+GlobalParams make_global(evofst_ctx *c) {
+    GlobalParams p{};
+    p.counts = c->d_counts.p;
+    p.totals = (const uint2 *)c->d_gtotals.p;
+    p.kept_mask = (const uint64_t *)c->d_kept.p; p.skip_mask = (const uint64_t *)c->d_skip.p;
+    p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.P = c->n_pops;
+    p.use_idx = (const int32_t *)c->d_use.p; p.thresholds = (const double *)c->d_thr.p;
+    p.n_use = (int)c->use_idx.size();
+    p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
+    p.chunk_used_kept_off = (const int64_t *)c->d_uk_off.p;
+    p.size = c->snp_size; p.step = c->snp_step;
+    p.row_cap = c->row_cap;
+    p.row_start = (int32_t *)c->d_row_start.p; p.row_end = (int32_t *)c->d_row_end.p;
+    p.row_num = (double *)c->d_row_num.p; p.row_den = (double *)c->d_row_den.p;
+    p.chunk_row_off = (const int64_t *)c->d_row_off.p;
+    return p;
+}
+
+template <typename T>
+int d2h(evofst_ctx *c, T *dst, const void *src, size_t n) {
+    if (!dst || n == 0) return EVOFST_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    return EVOFST_OK;
+}
+
+}  // namespace
+
+// ================================================================== lifecycle
+
+extern "C" evofst_ctx *evofst_create(int device_id) {
+    if (device_id == -1) {
+        evofst_ctx *h = new (std::nothrow) evofst_ctx();
+        if (!h) { g_create_error = "out of host memory"; return nullptr; }
+        h->host_only = true; h->device = -1; h->own_stream = false;
+        return h;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= n) { g_create_error = "device_id out of range"; return nullptr; }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    evofst_ctx *c = new (std::nothrow) evofst_ctx();
+    if (!c) { g_create_error = "out of host memory"; return nullptr; }
+    c->device = device_id;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void evofst_destroy(evofst_ctx *c) {
+    if (!c) return;
+    if (c->host_only) { delete c; return; }
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->d_segs, &c->d_wss, &c->d_nfull, &c->d_pairs, &c->d_use, &c->d_thr, &c->d_base, &c->d_first_seg,
+                      &c->d_tiles, &c->d_flags, &c->d_pos, &c->d_counts, &c->d_census, &c->d_offsets, &c->d_incl_totals,
+                      &c->d_seg_num, &c->d_seg_den, &c->d_seg_k, &c->d_seg_end, &c->d_head, &c->d_head_site, &c->d_tail,
+                      &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
+                      &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
+                      &c->d_row_num, &c->d_row_den};
+    for (DevBuf *b : bufs) release(*b);
+    for (auto &pair : c->ev)
+        for (auto &e : pair)
+            if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *evofst_last_error(const evofst_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+extern "C" const char *evofst_version(void) { return "evofst 0.1 (gfx950)"; }
+
+extern "C" int evofst_set_stream(evofst_ctx *c, void *hip_stream) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return EVOFST_OK;
+}
+
+// ================================================================== layout
+
+extern "C" int evofst_set_layout(evofst_ctx *c, int n_samples, int n_pops, const int32_t *sample_pop) {
+    if (!c) return EVOFST_ERR_ARG;
+    if (n_samples <= 0 || n_pops <= 0 || !sample_pop) return fail(c, EVOFST_ERR_ARG, "set_layout: bad arguments");
+    if (n_pops > EVOFST_MAX_POPS) return fail(c, EVOFST_ERR_UNSUPPORTED, "set_layout: too many populations");
+    std::vector<int32_t> size(n_pops, 0);
+    for (int i = 0; i < n_samples; ++i) {
+        if (sample_pop[i] >= n_pops) return fail(c, EVOFST_ERR_ARG, "set_layout: population index out of range");
+        if (sample_pop[i] >= 0) size[sample_pop[i]]++;
+    }
+    for (int k = 0; k < n_pops; ++k) {
+        if (size[k] == 0) return fail(c, EVOFST_ERR_ARG, "set_layout: population without samples");
+        if (2 * size[k] > EVOFST_MAX_POP_CHROMS) return fail(c, EVOFST_ERR_UNSUPPORTED, "set_layout: population too large");
+    }
+    if (!c->host_only) HIPCHK(c, hipSetDevice(c->device));
+    c->n_samples = n_samples; c->n_pops = n_pops;
+    c->sample_pop.assign(sample_pop, sample_pop + n_samples);
+    c->n_full.resize(n_pops); c->pop_off.resize(n_pops + 1);
+    c->pop_off[0] = 0;
+    int max_n = 0;
+    for (int k = 0; k < n_pops; ++k) {
+        c->n_full[k] = 2 * size[k];
+        c->pop_off[k + 1] = c->pop_off[k] + c->n_full[k];
+        max_n = std::max(max_n, c->n_full[k]);
+    }
+    c->H = c->pop_off[n_pops];
+    c->W = (c->H + 63) / 64;
+    c->count_bytes = max_n <= 255 ? 2 : 4;
+    // stable permutation: samples ordered by population, input order inside a population
+    c->src_hap.assign(c->H, 0);
+    std::vector<int32_t> fill(c->pop_off.begin(), c->pop_off.end() - 1);
+    for (int i = 0; i < n_samples; ++i) {
+        int k = sample_pop[i];
+        if (k < 0) continue;
+        c->src_hap[fill[k]] = 2 * i; c->src_hap[fill[k] + 1] = 2 * i + 1;
+        fill[k] += 2;
+    }
+    // (word, pop) overlap table
+    c->segs.clear(); c->word_seg_start.assign(c->W + 1, 0);
+    for (int w = 0; w < c->W; ++w) {
+        c->word_seg_start[w] = (int)c->segs.size();
+        const int b0 = w * 64, b1 = b0 + 64;
+        for (int k = 0; k < n_pops; ++k) {
+            const int lo = std::max(b0, c->pop_off[k]), hi = std::min(b1, c->pop_off[k + 1]);
+            if (lo >= hi) continue;
+            SegDesc d{};
+            const int len = hi - lo;
+            d.mask = (len == 64 ? ~0ull : ((1ull << len) - 1ull)) << (lo - b0);
+            d.pop = (uint32_t)k;
+            d.flags = (hi == c->pop_off[k + 1]) ? kSegLast : 0u;
+            c->segs.push_back(d);
+        }
+    }
+    c->word_seg_start[c->W] = (int)c->segs.size();
+    c->mode = MODE_COUNTS;
+    c->pairs.clear(); c->use_idx.clear(); c->thresholds.clear();
+    c->counts_done = c->stats_done = false;
+    c->cap_sites = 0; c->n_sites = 0;
+    if (c->host_only) return EVOFST_OK;
+    return upload_layout(c);
+}
+
+extern "C" int evofst_get_geometry(const evofst_ctx *c, evofst_geometry *out) {
+    if (!c || !out) return EVOFST_ERR_ARG;
+    if (c->n_pops == 0) return EVOFST_ERR_STATE;
+    out->n_samples = c->n_samples; out->n_pops = c->n_pops; out->n_haplotypes = c->H;
+    out->words_per_site = c->W; out->tile_sites = kTileSites; out->count_bytes = c->count_bytes;
+    out->tile_bytes = (int64_t)c->W * kTileSites * 16;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_pop_chroms(const evofst_ctx *c, int32_t *n_full) {
+    if (!c || !n_full) return EVOFST_ERR_ARG;
+    std::copy(c->n_full.begin(), c->n_full.end(), n_full);
+    return EVOFST_OK;
+}
+
+// ================================================================== host packer (K0)
+
+extern "C" size_t evofst_tiles_bytes(const evofst_ctx *c, int64_t n_sites) {
+    if (!c || c->n_pops == 0 || n_sites < 0) return 0;
+    return (size_t)n_tiles_of(n_sites) * c->W * kTileSites * 16;
+}
+
+extern "C" int evofst_pack_codes(const evofst_ctx *c, int64_t first_site, int64_t n_sites, const uint8_t *codes,
+                                 void *tiles) {
+    if (!c || !codes || !tiles || first_site < 0 || n_sites < 0) return EVOFST_ERR_ARG;
+    if (c->n_pops == 0) return EVOFST_ERR_STATE;
+    uint64_t *out = (uint64_t *)tiles;
+    const size_t row = (size_t)2 * c->n_samples;
+    const int W = c->W, H = c->H;
+    for (int64_t s = 0; s < n_sites; ++s) {
+        const uint8_t *r = codes + (size_t)s * row;
+        const int64_t site = first_site + s;
+        uint64_t *tp = out + ((size_t)(site >> 6) * W * kTileSites + (size_t)(site & 63)) * 2;
+        for (int w = 0; w < W; ++w) {
+            uint64_t alt = 0, miss = 0;
+            const int b1 = std::min(64, H - w * 64);
+            const int32_t *src = c->src_hap.data() + (size_t)w * 64;
+            for (int b = 0; b < b1; ++b) {
+                const uint8_t code = r[src[b]];
+                alt |= (uint64_t)(code == EVOFST_ALT) << b;
+                miss |= (uint64_t)(code == EVOFST_MISSING) << b;
+            }
+            tp[(size_t)w * kTileSites * 2] = alt;
+            tp[(size_t)w * kTileSites * 2 + 1] = miss;
+        }
+    }
+    // zero the padding sites of the last tile
+    const int64_t end = first_site + n_sites;
+    for (int64_t site = end; (site & 63) != 0; ++site) {
+        uint64_t *tp = out + ((size_t)(site >> 6) * W * kTileSites + (size_t)(site & 63)) * 2;
+        for (int w = 0; w < W; ++w) { tp[(size_t)w * kTileSites * 2] = 0; tp[(size_t)w * kTileSites * 2 + 1] = 0; }
+    }
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_unpack_codes(const evofst_ctx *c, int64_t first_site, int64_t n_sites, const void *tiles,
+                                   uint8_t *codes) {
+    if (!c || !codes || !tiles || first_site < 0 || n_sites < 0) return EVOFST_ERR_ARG;
+    if (c->n_pops == 0) return EVOFST_ERR_STATE;
+    const uint64_t *in = (const uint64_t *)tiles;
+    const size_t row = (size_t)2 * c->n_samples;
+    for (int64_t s = 0; s < n_sites; ++s) {
+        uint8_t *r = codes + (size_t)s * row;
+        std::memset(r, EVOFST_REF, row);
+        const int64_t site = first_site + s;
+        const uint64_t *tp = in + ((size_t)(site >> 6) * c->W * kTileSites + (size_t)(site & 63)) * 2;
+        for (int h = 0; h < c->H; ++h) {
+            const int w = h >> 6, b = h & 63;
+            const uint64_t alt = tp[(size_t)w * kTileSites * 2], miss = tp[(size_t)w * kTileSites * 2 + 1];
+            uint8_t code = EVOFST_REF;
+            if ((miss >> b) & 1ull) code = EVOFST_MISSING;
+            else if ((alt >> b) & 1ull) code = EVOFST_ALT;
+            r[c->src_hap[h]] = code;
+        }
+    }
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, uint8_t *codes, uint32_t *site_flags,
+                                          const char **chrom, const char **pos) {
+    if (!line || !codes || !site_flags || n_samples <= 0) return EVOFST_ERR_ARG;
+    // columns: CHROM POS ID REF ALT QUAL FILTER INFO FORMAT samples...
+    char *col[9];
+    char *p = line;
+    for (int i = 0; i < 9; ++i) {
+        col[i] = p;
+        char *t = std::strchr(p, '\t');
+        if (!t) return EVOFST_ERR_ARG;
+        *t = '\0';
+        p = t + 1;
+    }
+    if (chrom) *chrom = col[0];
+    if (pos) *pos = col[1];
+    const char *ref = col[3];
+    char *alt = col[4];
+    uint32_t fl = 0;
+    int alt_code = 1, allele_as_missing = -1;
+    if (mode == EVOFST_MODE_FST) {
+        // ALT parse of getVariantCountsForFst (process_vcf_fst.cpp:222-238); split() drops a trailing
+        // empty field and yields no field for an empty string (process_vcf_utils.cpp:104-110)
+        int n_alt = 0, idx = 0;
+        bool indel = false;
+        const char *a = alt;
+        if (*a != '\0') {
+            for (;;) {
+                const char *e = std::strchr(a, ',');
+                const size_t len = e ? (size_t)(e - a) : std::strlen(a);
+                ++idx; ++n_alt;
+                if (len == 1 && a[0] == '*') { --n_alt; allele_as_missing = idx; }
+                if (len > 1) indel = true;
+                if (!e) break;
+                a = e + 1;
+                if (*a == '\0') break;
+            }
+        }
+        if (n_alt == 1 && allele_as_missing == 1) alt_code = 2;
+        if (std::strlen(ref) > 1 || n_alt != 1 || indel) fl |= EVOFST_SITE_SKIP;  // :529-532, :543
+    } else {
+        if (std::strlen(ref) > 1 || std::strlen(alt) > 1 || std::strcmp(alt, "*") == 0)
+            fl |= EVOFST_SITE_SKIP;                                               // FstAgainstAll.cpp:185
+    }
+    *site_flags = fl;
+    for (int i = 0; i < n_samples; ++i) {
+        // genotype column i: chars [0] and [2] (process_vcf_fst.cpp:244, process_vcf_utils.cpp:67,75)
+        if (p[0] == '\0' || p[0] == '\t' || p[1] == '\0' || p[1] == '\t' || p[2] == '\0' || p[2] == '\t')
+            return EVOFST_ERR_ARG;
+        for (int h = 0; h < 2; ++h) {
+            const char ch = p[2 * h];
+            uint8_t code;
+            if (mode == EVOFST_MODE_FST) {
+                const int v = ch - '0';
+                if (v == alt_code) code = EVOFST_ALT;
+                else if (ch == '.' || v == allele_as_missing) code = EVOFST_MISSING;
+                else code = EVOFST_REF;
+            } else {
+                code = ch == '1' ? EVOFST_ALT : (ch == '0' ? EVOFST_REF : EVOFST_MISSING);
+            }
+            codes[2 * i + h] = code;
+        }
+        char *t = std::strchr(p, '\t');
+        if (!t) {
+            if (i != n_samples - 1) return EVOFST_ERR_ARG;
+            break;
+        }
+        p = t + 1;
+    }
+    return EVOFST_OK;
+}
+
+// ================================================================== device data
+
+extern "C" int evofst_reserve(evofst_ctx *c, int64_t max_sites) {
+    if (!c || max_sites <= 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_pops == 0) return fail(c, EVOFST_ERR_STATE, "reserve: set_layout first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nt = (size_t)n_tiles_of(max_sites);
+    int rc;
+    if ((rc = ensure(c, c->d_tiles, nt * c->W * kTileSites * 16))) return rc;
+    if ((rc = ensure(c, c->d_flags, nt * kTileSites))) return rc;
+    if ((rc = ensure(c, c->d_pos, nt * kTileSites * 4))) return rc;
+    if ((rc = ensure(c, c->d_counts, nt * c->n_pops * kTileSites * c->count_bytes))) return rc;
+    c->cap_sites = (int64_t)nt * kTileSites;
+    return EVOFST_OK;
+}
+
+extern "C" void *evofst_alloc_pinned(evofst_ctx *c, size_t bytes) {
+    void *p = nullptr;
+    if (!c || c->host_only) return nullptr;
+    (void)hipSetDevice(c->device);
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { c->err = std::string("hipHostMalloc: ") + hipGetErrorString(e); return nullptr; }
+    return p;
+}
+extern "C" void evofst_free_pinned(evofst_ctx *c, void *p) {
+    if (c && p) (void)hipHostFree(p);
+}
+
+static int begin_data(evofst_ctx *c, int64_t n_sites) {
+    if (n_sites <= 0) return fail(c, EVOFST_ERR_ARG, "n_sites must be positive");
+    if (c->n_pops == 0) return fail(c, EVOFST_ERR_STATE, "set_layout first");
+    if ((int64_t)n_tiles_of(n_sites) * kTileSites > (int64_t)INT_MAX) return fail(c, EVOFST_ERR_UNSUPPORTED, "too many sites for one shard");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->counts_done = c->stats_done = false;
+    c->offsets_dirty = true;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_upload(evofst_ctx *c, int64_t n_sites, const void *tiles, const uint8_t *site_flags,
+                             const int32_t *pos) {
+    if (!c || !tiles) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    int rc = begin_data(c, n_sites);
+    if (rc) return rc;
+    if (n_sites > c->cap_sites && (rc = evofst_reserve(c, n_sites))) return rc;
+    c->n_sites = n_sites;
+    HIPCHK(c, hipMemcpyAsync(c->d_tiles.p, tiles, evofst_tiles_bytes(c, n_sites), hipMemcpyHostToDevice, c->stream));
+    c->tiles = c->d_tiles.p;
+    c->have_flags = site_flags != nullptr;
+    if (site_flags) HIPCHK(c, hipMemcpyAsync(c->d_flags.p, site_flags, (size_t)n_sites, hipMemcpyHostToDevice, c->stream));
+    c->flags = (const uint8_t *)c->d_flags.p;
+    c->have_pos = pos != nullptr;
+    if (pos) HIPCHK(c, hipMemcpyAsync(c->d_pos.p, pos, (size_t)n_sites * 4, hipMemcpyHostToDevice, c->stream));
+    c->pos = (const int32_t *)c->d_pos.p;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_attach_device(evofst_ctx *c, int64_t n_sites, const void *d_tiles, const uint8_t *d_site_flags,
+                                    const int32_t *d_pos) {
+    if (!c || !d_tiles) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    int rc = begin_data(c, n_sites);
+    if (rc) return rc;
+    const size_t nt = (size_t)n_tiles_of(n_sites);
+    if ((rc = ensure(c, c->d_counts, nt * c->n_pops * kTileSites * c->count_bytes))) return rc;
+    c->n_sites = n_sites;
+    c->tiles = d_tiles;
+    c->flags = d_site_flags; c->have_flags = d_site_flags != nullptr;
+    c->pos = d_pos; c->have_pos = d_pos != nullptr;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_synth(evofst_ctx *c, int64_t n_sites, int64_t first_site_global, uint64_t seed,
+                            double missing_rate) {
+    if (!c || missing_rate < 0.0 || missing_rate >= 1.0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    int rc = begin_data(c, n_sites);
+    if (rc) return rc;
+    if (n_sites > c->cap_sites && (rc = evofst_reserve(c, n_sites))) return rc;
+    c->n_sites = n_sites;
+    SynthParams p{};
+    p.tiles = (ulonglong2 *)c->d_tiles.p; p.pos = (int32_t *)c->d_pos.p;
+    p.n_sites = n_sites; p.first_site_global = first_site_global;
+    p.n_tiles = n_tiles_of(n_sites); p.W = c->W; p.P = c->n_pops;
+    p.segs = (const SegDesc *)c->d_segs.p; p.word_seg_start = (const int32_t *)c->d_wss.p;
+    p.seed = seed;
+    p.miss_thr = (uint32_t)std::min(4294967295.0, missing_rate * 4294967296.0);
+    HIPCHK(c, launch_synth(p, c->stream));
+    c->tiles = c->d_tiles.p;
+    c->flags = nullptr; c->have_flags = false;
+    c->pos = (const int32_t *)c->d_pos.p; c->have_pos = true;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_download_tiles(evofst_ctx *c, void *tiles) {
+    if (!c || !tiles) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_sites == 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "no data on the device");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(tiles, c->tiles, evofst_tiles_bytes(c, c->n_sites), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EVOFST_OK;
+}
+
+// ================================================================== modes
+
+extern "C" int evofst_set_pairs(evofst_ctx *c, const int32_t *pair_i, const int32_t *pair_j, int n_pairs) {
+    if (!c || n_pairs < 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_pops == 0) return fail(c, EVOFST_ERR_STATE, "set_pairs: set_layout first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint32_t> pr;
+    if (n_pairs == 0) {
+        for (int i = 0; i < c->n_pops; ++i)
+            for (int j = i + 1; j < c->n_pops; ++j) pr.push_back((uint32_t)i | ((uint32_t)j << 16));
+    } else {
+        if (!pair_i || !pair_j) return fail(c, EVOFST_ERR_ARG, "set_pairs: null pair arrays");
+        for (int q = 0; q < n_pairs; ++q) {
+            if (pair_i[q] < 0 || pair_i[q] >= c->n_pops || pair_j[q] < 0 || pair_j[q] >= c->n_pops)
+                return fail(c, EVOFST_ERR_ARG, "set_pairs: population index out of range");
+            pr.push_back((uint32_t)pair_i[q] | ((uint32_t)pair_j[q] << 16));
+        }
+    }
+    if (pr.empty()) return fail(c, EVOFST_ERR_ARG, "set_pairs: no pairs");
+    c->pairs.swap(pr);
+    c->mode = MODE_PAIRS;
+    int rc;
+    if ((rc = upload_layout(c))) return rc;
+    if ((rc = upload_vec(c, c->d_pairs, c->pairs))) return rc;
+    c->counts_done = c->stats_done = false;
+    return set_base_internal(c, nullptr);
+}
+
+extern "C" int evofst_set_against_all(evofst_ctx *c, const int32_t *use_pops, int n_use, const int64_t *set_sizes) {
+    if (!c || !use_pops || !set_sizes || n_use <= 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_pops == 0) return fail(c, EVOFST_ERR_STATE, "set_against_all: set_layout first");
+    if (n_use > 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "set_against_all: more than 1024 populations");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int32_t> ui(use_pops, use_pops + n_use);
+    for (int u = 0; u < n_use; ++u)
+        if (ui[u] < 0 || ui[u] >= c->n_pops) return fail(c, EVOFST_ERR_ARG, "set_against_all: population index out of range");
+    c->use_idx.swap(ui);
+    c->thresholds.resize(n_use);
+    for (int u = 0; u < n_use; ++u) c->thresholds[u] = (double)(uint64_t)set_sizes[u] * 0.8;  // FstAgainstAll.cpp:253
+    c->mode = MODE_GLOBAL;
+    int rc;
+    if ((rc = upload_layout(c))) return rc;
+    if ((rc = upload_vec(c, c->d_use, c->use_idx))) return rc;
+    if ((rc = upload_vec(c, c->d_thr, c->thresholds))) return rc;
+    c->counts_done = c->stats_done = false;
+    return set_base_internal(c, nullptr);
+}
+
+extern "C" int evofst_set_windows(evofst_ctx *c, int snp_size, int snp_step) {
+    if (!c) return EVOFST_ERR_ARG;
+    if (snp_size < 0 || (snp_size > 0 && snp_step <= 0)) return fail(c, EVOFST_ERR_ARG, "set_windows: bad size/step");
+    c->snp_size = snp_size; c->snp_step = snp_size > 0 ? snp_step : 0;
+    c->g = snp_size > 0 ? std::gcd(snp_size, snp_step) : INT_MAX;
+    c->stats_done = false;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_set_base_offsets(evofst_ctx *c, const int64_t *offsets) {
+    if (!c || !offsets) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->mode == MODE_COUNTS) return fail(c, EVOFST_ERR_STATE, "set_base_offsets: choose a mode first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return set_base_internal(c, offsets);
+}
+
+// ================================================================== compute
+
+extern "C" int evofst_run_counts(evofst_ctx *c) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_sites == 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "run_counts: no data");
+    HIPCHK(c, hipSetDevice(c->device));
+    plan_chunks(c);
+    K1Params p{};
+    p.tiles = (const ulonglong2 *)c->tiles;
+    p.site_flags = c->have_flags ? c->flags : nullptr;
+    p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.W = c->W; p.P = c->n_pops;
+    p.segs = (const SegDesc *)c->d_segs.p; p.word_seg_start = (const int32_t *)c->d_wss.p;
+    p.n_full = (const int32_t *)c->d_nfull.p;
+    p.counts = c->d_counts.p;
+    p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
+    int rc;
+    if (c->mode == MODE_PAIRS) {
+        p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)c->pairs.size();
+        if ((rc = ensure(c, c->d_census, (size_t)c->n_chunks * p.n_pairs * 4))) return rc;
+        p.chunk_census = (uint32_t *)c->d_census.p;
+    } else if (c->mode == MODE_GLOBAL) {
+        if ((rc = ensure(c, c->d_gtotals, (size_t)c->n_tiles * kTileSites * 8))) return rc;
+        if ((rc = ensure(c, c->d_kept, (size_t)c->n_tiles * 8))) return rc;
+        if ((rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8))) return rc;
+        if ((rc = ensure(c, c->d_used_kept, (size_t)c->n_chunks * 2 * 4))) return rc;
+        p.totals = (uint2 *)c->d_gtotals.p; p.kept_mask = (uint64_t *)c->d_kept.p; p.skip_mask = (uint64_t *)c->d_skip.p;
+        p.chunk_used_kept = (uint32_t *)c->d_used_kept.p;
+    }
+    record(c, 0, 0);
+    HIPCHK(c, launch_k1(p, c->count_bytes, c->mode, c->stream));
+    record(c, 0, 1);
+    c->counts_done = true; c->stats_done = false;
+    if (c->mode != MODE_COUNTS && (rc = run_scan(c))) return rc;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_run_stats(evofst_ctx *c) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "run_stats: run_counts first");
+    if (c->mode == MODE_COUNTS) return fail(c, EVOFST_ERR_STATE, "run_stats: choose a mode (set_pairs / set_against_all)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if (c->offsets_dirty && (rc = run_scan(c))) return rc;
+    if (c->mode == MODE_PAIRS) {
+        const size_t np = c->pairs.size();
+        const int64_t g = c->g;
+        c->seg_cap = c->n_sites / g + 2;
+        std::vector<int64_t> fs(np);
+        for (size_t q = 0; q < np; ++q) fs[q] = c->base[q] / g;
+        if ((rc = upload_vec(c, c->d_first_seg, fs))) return rc;
+        const size_t seg_elems = (size_t)c->seg_cap * np;
+        if ((rc = ensure(c, c->d_seg_num, seg_elems * 8))) return rc;
+        if ((rc = ensure(c, c->d_seg_den, seg_elems * 8))) return rc;
+        if ((rc = ensure(c, c->d_seg_k, seg_elems * 8))) return rc;
+        if ((rc = ensure(c, c->d_seg_end, seg_elems * 4))) return rc;
+        const size_t cq = (size_t)c->n_chunks * np;
+        if ((rc = ensure(c, c->d_head, cq * 3 * 8))) return rc;
+        if ((rc = ensure(c, c->d_head_site, cq * 4))) return rc;
+        if ((rc = ensure(c, c->d_tail, cq * 5 * 8))) return rc;
+        if (k2_lds_bytes(c->n_pops) > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: too many populations for the LDS table");
+        K2Params p = make_k2(c);
+        record(c, 2, 0);
+        HIPCHK(c, launch_k2(p, c->count_bytes, c->stream));
+        record(c, 2, 1);
+        record(c, 3, 0);
+        HIPCHK(c, launch_stitch(p, c->stream));
+        record(c, 3, 1);
+    } else {
+        if (c->snp_size <= 0) return fail(c, EVOFST_ERR_ARG, "run_stats: against-all mode needs set_windows(size, step)");
+        const int nu = (int)c->use_idx.size();
+        const size_t lds = global_lds_bytes(c->n_pops, nu, c->snp_size);
+        if (lds > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: SIZE * populations too large for the LDS deque");
+        if ((rc = ensure(c, c->d_chunk_rows, (size_t)c->n_chunks * 4))) return rc;
+        if ((rc = ensure(c, c->d_row_off, (size_t)c->n_chunks * 8))) return rc;
+        if ((rc = ensure(c, c->d_row_tot, 8))) return rc;
+        c->row_cap = c->n_sites / c->snp_step + 2;
+        if ((rc = ensure(c, c->d_row_start, (size_t)c->row_cap * 4))) return rc;
+        if ((rc = ensure(c, c->d_row_end, (size_t)c->row_cap * 4))) return rc;
+        if ((rc = ensure(c, c->d_row_num, (size_t)c->row_cap * nu * 8))) return rc;
+        if ((rc = ensure(c, c->d_row_den, (size_t)c->row_cap * nu * 8))) return rc;
+        record(c, 3, 0);
+        HIPCHK(c, launch_global_rows((const uint64_t *)c->d_kept.p, (const uint64_t *)c->d_skip.p,
+                                     (const int64_t *)c->d_uk_off.p, c->n_chunks, c->chunk_tiles, c->n_tiles, c->snp_size,
+                                     c->snp_step, (uint32_t *)c->d_chunk_rows.p, c->stream));
+        HIPCHK(c, launch_scan((const uint32_t *)c->d_chunk_rows.p, nullptr, (int64_t *)c->d_row_off.p,
+                              (int64_t *)c->d_row_tot.p, c->n_chunks, 1, c->stream));
+        record(c, 3, 1);
+        GlobalParams p = make_global(c);
+        record(c, 2, 0);
+        HIPCHK(c, launch_global(p, c->count_bytes, lds, c->stream));
+        record(c, 2, 1);
+    }
+    c->stats_done = true;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_run(evofst_ctx *c) {
+    int rc = evofst_run_counts(c);
+    if (rc) return rc;
+    return evofst_run_stats(c);
+}
+
+extern "C" int evofst_sync(evofst_ctx *c) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_set_profiling(evofst_ctx *c, int enabled) {
+    if (!c) return EVOFST_ERR_ARG;
+    c->profiling = enabled != 0;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_kernel_ms(evofst_ctx *c, int which, float *ms) {
+    if (!c || !ms || which < 0 || which >= kNumKernels) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->ev_valid[which]) return fail(c, EVOFST_ERR_STATE, "get_kernel_ms: kernel was not profiled");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev[which][1]));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev[which][0], c->ev[which][1]));
+    return EVOFST_OK;
+}
+
+// ================================================================== results
+
+static int check_range(evofst_ctx *c, int64_t first, int64_t n) {
+    if (first < 0 || n <= 0 || first + n > c->n_sites) return fail(c, EVOFST_ERR_ARG, "site range out of bounds");
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_counts(evofst_ctx *c, int64_t first_site, int64_t n_sites, int32_t *alt, int32_t *nm) {
+    if (!c || !alt || !nm) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "get_counts: run_counts first");
+    int rc = check_range(c, first_site, n_sites);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_sites * c->n_pops;
+    DevBuf da, dn;
+    if ((rc = ensure(c, da, n * 4)) || (rc = ensure(c, dn, n * 4))) { release(da); release(dn); return rc; }
+    hipError_t e = launch_unpack_counts(c->d_counts.p, c->count_bytes, c->n_pops, first_site, n_sites, (int32_t *)da.p,
+                                        (int32_t *)dn.p, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(alt, da.p, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(nm, dn.p, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    release(da); release(dn);
+    if (e != hipSuccess) return hip_fail(c, e, "get_counts");
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_included_totals(evofst_ctx *c, int64_t *totals) {
+    if (!c || !totals) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->counts_done || c->mode == MODE_COUNTS) return fail(c, EVOFST_ERR_STATE, "get_included_totals: run_counts in a mode first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if (c->offsets_dirty && (rc = run_scan(c))) return rc;
+    if (c->mode == MODE_PAIRS) { if ((rc = d2h(c, totals, c->d_incl_totals.p, c->pairs.size()))) return rc; }
+    else { if ((rc = d2h(c, totals, c->d_uk_tot.p, 2))) return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_site_stats(evofst_ctx *c, int64_t first_site, int64_t n_sites, double *num, double *den,
+                                     double *dxy, uint8_t *include) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->counts_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_site_stats: pairs mode + run_counts first");
+    int rc = check_range(c, first_site, n_sites);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_sites * c->pairs.size();
+    DevBuf b[4];
+    SiteStatParams p{};
+    p.counts = c->d_counts.p; p.site_flags = c->have_flags ? c->flags : nullptr;
+    p.n_sites_total = c->n_sites; p.first_site = first_site; p.n_sites = n_sites;
+    p.P = c->n_pops; p.n_full = (const int32_t *)c->d_nfull.p;
+    p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)c->pairs.size();
+    rc = EVOFST_OK;
+    if (num && !rc) { rc = ensure(c, b[0], n * 8); p.num = (double *)b[0].p; }
+    if (den && !rc) { rc = ensure(c, b[1], n * 8); p.den = (double *)b[1].p; }
+    if (dxy && !rc) { rc = ensure(c, b[2], n * 8); p.dxy = (double *)b[2].p; }
+    if (include && !rc) { rc = ensure(c, b[3], n); p.include = (uint8_t *)b[3].p; }
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = launch_site_stats(p, c->count_bytes, c->stream);
+        if (e == hipSuccess && num) e = hipMemcpyAsync(num, b[0].p, n * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && den) e = hipMemcpyAsync(den, b[1].p, n * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && dxy) e = hipMemcpyAsync(dxy, b[2].p, n * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && include) e = hipMemcpyAsync(include, b[3].p, n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    for (auto &x : b) release(x);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(c, e, "get_site_stats");
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_pop_site_div(evofst_ctx *c, int64_t first_site, int64_t n_sites, double *het, double *het_nei,
+                                       double *pi) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "get_pop_site_div: run_counts first");
+    int rc = check_range(c, first_site, n_sites);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_sites * c->n_pops;
+    DevBuf b[3];
+    PopDivParams p{};
+    p.counts = c->d_counts.p; p.first_site = first_site; p.n_sites = n_sites; p.P = c->n_pops;
+    p.n_full = (const int32_t *)c->d_nfull.p;
+    rc = EVOFST_OK;
+    if (het && !rc) { rc = ensure(c, b[0], n * 8); p.het = (double *)b[0].p; }
+    if (het_nei && !rc) { rc = ensure(c, b[1], n * 8); p.het_nei = (double *)b[1].p; }
+    if (pi && !rc) { rc = ensure(c, b[2], n * 8); p.pi = (double *)b[2].p; }
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = launch_pop_div(p, c->count_bytes, c->stream);
+        if (e == hipSuccess && het) e = hipMemcpyAsync(het, b[0].p, n * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && het_nei) e = hipMemcpyAsync(het_nei, b[1].p, n * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && pi) e = hipMemcpyAsync(pi, b[2].p, n * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    for (auto &x : b) release(x);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(c, e, "get_pop_site_div");
+    return EVOFST_OK;
+}
+
+extern "C" int64_t evofst_max_segments(evofst_ctx *c) {
+    if (!c || !c->stats_done || c->mode != MODE_PAIRS) return 0;
+    return c->seg_cap;
+}
+
+static int segment_rows(evofst_ctx *c, std::vector<int64_t> &first, std::vector<int64_t> &rows) {
+    const size_t np = c->pairs.size();
+    std::vector<int64_t> tot(np);
+    int rc = d2h(c, tot.data(), c->d_incl_totals.p, np);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    first.resize(np); rows.resize(np);
+    for (size_t q = 0; q < np; ++q) {
+        first[q] = c->base[q] / c->g;
+        rows[q] = (c->base[q] + tot[q]) / c->g - first[q];
+    }
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_segments(evofst_ctx *c, int64_t *first_segment, int64_t *n_segments, double *sum_num,
+                                   double *sum_den, double *sum_dxy_k, int32_t *end_site) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->stats_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_segments: pairs mode + run_stats first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int64_t> first, rows;
+    int rc = segment_rows(c, first, rows);
+    if (rc) return rc;
+    const size_t np = c->pairs.size();
+    if (first_segment) std::copy(first.begin(), first.end(), first_segment);
+    if (n_segments) std::copy(rows.begin(), rows.end(), n_segments);
+    const size_t n = (size_t)c->seg_cap * np;
+    if ((rc = d2h(c, sum_num, c->d_seg_num.p, n))) return rc;
+    if ((rc = d2h(c, sum_den, c->d_seg_den.p, n))) return rc;
+    if ((rc = d2h(c, sum_dxy_k, c->d_seg_k.p, n))) return rc;
+    if ((rc = d2h(c, end_site, c->d_seg_end.p, n))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_boundary(evofst_ctx *c, double *carry_out) {
+    if (!c || !carry_out) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->stats_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_boundary: pairs mode + run_stats first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t np = c->pairs.size();
+    std::vector<double> tail((size_t)c->n_chunks * np * 5);
+    int rc = d2h(c, tail.data(), c->d_tail.p, tail.size());
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t q = 0; q < np; ++q) {
+        int cl = c->n_chunks - 1;
+        while (cl >= 0 && tail[((size_t)cl * np + q) * 5 + 4] == 0.0) --cl;
+        double a[4] = {0, 0, 0, 0};
+        for (int cc = cl < 0 ? 0 : cl; cc < c->n_chunks; ++cc) {
+            const double *t = &tail[((size_t)cc * np + q) * 5];
+            a[0] += t[0]; a[1] += t[1]; a[2] += t[2]; a[3] += t[3];
+        }
+        std::copy(a, a + 4, carry_out + q * 4);
+    }
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_totals(evofst_ctx *c, double *totals) {
+    if (!c || !totals) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->stats_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_totals: pairs mode + run_stats first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int64_t> first, rows;
+    int rc = segment_rows(c, first, rows);
+    if (rc) return rc;
+    const size_t np = c->pairs.size();
+    if ((rc = upload_vec(c, c->d_nrows, rows))) return rc;
+    if ((rc = ensure(c, c->d_totals, np * 4 * 8))) return rc;
+    K2Params p = make_k2(c);
+    HIPCHK(c, launch_totals(p, (const int64_t *)c->d_nrows.p, (double *)c->d_totals.p, c->stream));
+    if ((rc = d2h(c, totals, c->d_totals.p, np * 4))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_global_site_stats(evofst_ctx *c, int64_t first_site, int64_t n_sites, double *num, double *den,
+                                            uint8_t *kept) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->counts_done || c->mode != MODE_GLOBAL) return fail(c, EVOFST_ERR_STATE, "get_global_site_stats: against-all mode + run_counts first");
+    int rc = check_range(c, first_site, n_sites);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nu = c->use_idx.size();
+    const size_t n = (size_t)n_sites * nu;
+    DevBuf b[3];
+    GlobalParams p = make_global(c);
+    p.first_site = first_site; p.n_out_sites = n_sites;
+    rc = EVOFST_OK;
+    if (num && !rc) { rc = ensure(c, b[0], n * 8); p.site_num = (double *)b[0].p; }
+    if (den && !rc) { rc = ensure(c, b[1], n * 8); p.site_den = (double *)b[1].p; }
+    if (kept && !rc) { rc = ensure(c, b[2], (size_t)n_sites); p.site_kept = (uint8_t *)b[2].p; }
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = launch_global_sites(p, c->count_bytes, c->stream);
+        if (e == hipSuccess && num) e = hipMemcpyAsync(num, b[0].p, n * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && den) e = hipMemcpyAsync(den, b[1].p, n * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && kept) e = hipMemcpyAsync(kept, b[2].p, (size_t)n_sites, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    for (auto &x : b) release(x);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(c, e, "get_global_site_stats");
+    return EVOFST_OK;
+}
+
+extern "C" int64_t evofst_max_global_rows(evofst_ctx *c) {
+    if (!c || !c->stats_done || c->mode != MODE_GLOBAL) return 0;
+    return c->row_cap;
+}
+
+extern "C" int evofst_get_global_windows(evofst_ctx *c, int64_t *n_rows, int32_t *start_site, int32_t *end_site,
+                                         double *mean_num, double *mean_den) {
+    if (!c || !n_rows) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->stats_done || c->mode != MODE_GLOBAL) return fail(c, EVOFST_ERR_STATE, "get_global_windows: against-all mode + run_stats first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t rows = 0;
+    int rc = d2h(c, &rows, c->d_row_tot.p, 1);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_rows = rows;
+    const size_t nu = c->use_idx.size();
+    if ((rc = d2h(c, start_site, c->d_row_start.p, (size_t)rows))) return rc;
+    if ((rc = d2h(c, end_site, c->d_row_end.p, (size_t)rows))) return rc;
+    if ((rc = d2h(c, mean_num, c->d_row_num.p, (size_t)rows * nu))) return rc;
+    if ((rc = d2h(c, mean_den, c->d_row_den.p, (size_t)rows * nu))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EVOFST_OK;
+}

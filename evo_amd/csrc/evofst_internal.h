@@ -1,0 +1,145 @@
+// evofst_internal.h -- shared between the C-ABI host code and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace evofst {
+
+constexpr int kTileSites = 64;
+constexpr int kK1Threads = 256;    // 4 waves: wave w of a block walks tiles w, w+4, ... of its chunk
+constexpr int kK2Threads = 256;    // pairs per K2 block
+constexpr int kPadSites = 65;      // LDS row stride (sites + 1) -> conflict-free pop-indexed reads
+constexpr int kScanParts = 16;
+
+// One (word, population) overlap of the packed haplotype layout; sorted by bit position.
+struct SegDesc {
+    uint64_t mask;   // bits of `word` that belong to `pop`
+    uint32_t pop;
+    uint32_t flags;  // bit0: last segment of the population, bit1: pop is in populationsToUse,
+                     // bit2: pop is populationsToUse[0]
+};
+constexpr uint32_t kSegLast = 1u, kSegUse = 2u, kSegFirstUse = 4u;
+
+// packed per-(site,pop) table word of K2: a = c (alt count), b = n_full - c
+constexpr uint32_t kXBits = 14;
+constexpr uint32_t kXMask = (1u << kXBits) - 1u;
+constexpr uint32_t kXZero = 1u << 28;   // c == 0        (or site skipped)
+constexpr uint32_t kXFixed = 1u << 29;  // c == nm       (or site skipped)
+
+enum { MODE_COUNTS = 0, MODE_PAIRS = 1, MODE_GLOBAL = 2 };
+
+struct K1Params {
+    const ulonglong2 *tiles;
+    const uint8_t *site_flags;  // may be null
+    int64_t n_sites;
+    int32_t n_tiles, W, P;
+    const SegDesc *segs;
+    const int32_t *word_seg_start;  // [W+1]
+    const int32_t *n_full;          // [P]
+    void *counts;                   // CT [n_tiles][P][64], c | nm << (4*sizeof(CT))
+    int32_t chunk_tiles, n_chunks;
+    // pairs mode
+    const uint32_t *pairs;  // i | j << 16
+    int32_t n_pairs;
+    uint32_t *chunk_census;  // [n_chunks][n_pairs]
+    // against-all mode
+    uint2 *totals;            // [n_tiles*64] {sum alt, sum non-missing} over populationsToUse
+    uint64_t *kept_mask;      // [n_tiles]
+    uint64_t *skip_mask;      // [n_tiles]
+    uint32_t *chunk_used_kept;  // [n_chunks][2]
+};
+
+struct K2Params {
+    const void *counts;
+    const uint8_t *site_flags;
+    int64_t n_sites;
+    int32_t n_tiles, P;
+    const int32_t *n_full;
+    const uint32_t *pairs;
+    int32_t n_pairs;
+    int32_t chunk_tiles, n_chunks;
+    const int64_t *chunk_offsets;  // [n_chunks][n_pairs] included sites of the pair before the chunk
+    const int64_t *first_segment;  // [n_pairs]
+    int32_t g;
+    int64_t seg_cap;
+    double *seg_num, *seg_den, *seg_k;  // [seg_cap][n_pairs]
+    int32_t *seg_end;
+    double *head;        // [n_chunks][n_pairs][3]
+    int32_t *head_site;  // [n_chunks][n_pairs]
+    double *tail;        // [n_chunks][n_pairs][5] {num, den, k, n_sites, flushed}
+};
+
+struct SiteStatParams {
+    const void *counts;
+    const uint8_t *site_flags;
+    int64_t n_sites_total, first_site, n_sites;
+    int32_t P;
+    const int32_t *n_full;
+    const uint32_t *pairs;
+    int32_t n_pairs;
+    double *num, *den, *dxy;  // [n_pairs][n_sites] (device), may be null
+    uint8_t *include;
+};
+
+struct PopDivParams {
+    const void *counts;
+    int64_t first_site, n_sites;
+    int32_t P;
+    const int32_t *n_full;
+    double *het, *het_nei, *pi;  // [P][n_sites]
+};
+
+struct GlobalParams {
+    const void *counts;
+    const uint2 *totals;
+    const uint64_t *kept_mask, *skip_mask;
+    int64_t n_sites;
+    int32_t n_tiles, P;
+    const int32_t *use_idx;   // [n_use]
+    const double *thresholds; // [n_use] set_sizes[u] * 0.8
+    int32_t n_use;
+    int32_t chunk_tiles, n_chunks;
+    const int64_t *chunk_used_kept_off;  // [n_chunks][2] used / kept sites before the chunk
+    int32_t size, step;
+    int64_t row_cap;
+    int32_t *row_start, *row_end;  // [row_cap]
+    double *row_num, *row_den;     // [row_cap][n_use]
+    const int64_t *chunk_row_off;  // [n_chunks+1] first output row of the chunk
+    // per-site output (on demand)
+    double *site_num, *site_den;   // [n_use][n_sites] or null
+    uint8_t *site_kept;
+    int64_t first_site, n_out_sites;
+};
+
+struct SynthParams {
+    ulonglong2 *tiles;
+    int32_t *pos;
+    int64_t n_sites, first_site_global;
+    int32_t n_tiles, W, P;
+    const SegDesc *segs;
+    const int32_t *word_seg_start;
+    uint64_t seed;
+    uint32_t miss_thr;  // missing_rate * 2^32
+};
+
+// launchers (evofst_kernels.hip)
+hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t st);
+hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *offsets, int64_t *totals,
+                       int n_chunks, int n_cols, hipStream_t st);
+hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st);
+hipError_t launch_stitch(const K2Params &p, hipStream_t st);
+hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *totals, hipStream_t st);
+hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st);
+hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
+hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,
+                                int32_t *alt, int32_t *nm, hipStream_t st);
+hipError_t launch_global_rows(const uint64_t *kept_mask, const uint64_t *skip_mask, const int64_t *chunk_off,
+                              int n_chunks, int chunk_tiles, int n_tiles, int size, int step,
+                              uint32_t *chunk_rows, hipStream_t st);
+hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st);
+hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream_t st);
+hipError_t launch_synth(const SynthParams &p, hipStream_t st);
+size_t k2_lds_bytes(int P);
+size_t global_lds_bytes(int P, int n_use, int size);
+
+}  // namespace evofst

@@ -1,0 +1,709 @@
+// evofst_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for evo's Fst / dxy hot path.
+//
+// Built with -ffp-contract=off: every per-site double is evaluated in the reference's operation
+// order (process_vcf_fst.h:19-45, process_vcf_fst.cpp:321,346-347) with IEEE division, so per-site
+// values are bit-identical to the CPU; only window sums may differ in summation order.
+//
+//   K1  k1_count_kernel     tiles -> per-(site,pop) {alt, non-missing} counts (+ census of included
+//                           sites per chunk and pair, or kept/used masks in against-all mode).
+//                           HBM-bound: lane = site, 16-byte coalesced loads, wave-uniform masks.
+//   scan_kernel             exclusive prefix of the census over chunks.
+//   K2  k2_window_kernel    counts -> per-pop table in LDS -> lane = population pair walks the sites
+//                           of its chunk in order, accumulating segment sums (K3 fused).
+//   stitch_kernel           completes the segment that straddles a chunk boundary.
+//   site_stats / pop_div    per-site outputs on demand (parity hooks and the CLI front-end).
+//   global_*                Fst-against-all evaluation and deque windows.
+#include "evofst_internal.h"
+
+namespace evofst {
+
+template <typename CT> struct CountTraits;
+template <> struct CountTraits<uint16_t> { static constexpr int shift = 8; static constexpr uint32_t mask = 0xffu; };
+template <> struct CountTraits<uint32_t> { static constexpr int shift = 16; static constexpr uint32_t mask = 0xffffu; };
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// =====================================================================================
+// K1: allele counting.  Replaces the per-sample loops of getVariantCountsForFst
+// (process_vcf_fst.cpp:243-280) and getBasicCounts (process_vcf_utils.cpp:62-83).
+// =====================================================================================
+template <typename CT, int MODE>
+__global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    constexpr int NW = kK1Threads / 64;
+    // LDS: per wave [P] zero-masks + [P] fixed-masks, then per wave [n_pairs] census counters
+    uint64_t *zm = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * p.P;
+    uint64_t *fm = zm + p.P;
+    uint32_t *cen_all = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem) + (size_t)NW * 2 * p.P);
+    uint32_t *cen = cen_all + (size_t)wave * p.n_pairs;
+    if (MODE == MODE_PAIRS)
+        for (int q = lane; q < p.n_pairs; q += 64) cen[q] = 0;
+    uint32_t used_cnt = 0, kept_cnt = 0;
+
+    const int chunk = blockIdx.x;
+    const int t0 = chunk * p.chunk_tiles;
+    const int t1 = min(t0 + p.chunk_tiles, p.n_tiles);
+    for (int t = t0 + wave; t < t1; t += NW) {
+        const int64_t site = (int64_t)t * kTileSites + lane;
+        bool skip = site >= p.n_sites;
+        if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
+        const uint64_t skipmask = __ballot(skip);
+        const ulonglong2 *tp = p.tiles + (size_t)t * p.W * kTileSites + lane;
+        CT *cp = reinterpret_cast<CT *>(p.counts) + (size_t)t * p.P * kTileSites + lane;
+        uint32_t c = 0, mc = 0;
+        uint32_t Tc = 0, Tn = 0, c0 = 0, nm0 = 0;
+        for (int wb = 0; wb < p.W; wb += 8) {
+            ulonglong2 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (wb + u < p.W) r[u] = tp[(size_t)(wb + u) * kTileSites];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (wb + u < p.W) {
+                    const int s0 = p.word_seg_start[wb + u], s1 = p.word_seg_start[wb + u + 1];
+                    for (int s = s0; s < s1; ++s) {
+                        const SegDesc d = p.segs[s];
+                        c += __popcll(r[u].x & d.mask);
+                        mc += __popcll(r[u].y & d.mask);
+                        if (d.flags & kSegLast) {
+                            const uint32_t nm = (uint32_t)p.n_full[d.pop] - mc;
+                            cp[(size_t)d.pop * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
+                            if (MODE == MODE_PAIRS) {
+                                const uint64_t z = __ballot(c == 0) | skipmask;
+                                const uint64_t f = __ballot(c == nm) | skipmask;
+                                if (lane == 0) { zm[d.pop] = z; fm[d.pop] = f; }
+                            }
+                            if (MODE == MODE_GLOBAL) {
+                                if (d.flags & kSegUse) { Tc += c; Tn += nm; }
+                                if (d.flags & kSegFirstUse) { c0 = c; nm0 = nm; }
+                            }
+                            c = 0; mc = 0;
+                        }
+                    }
+                }
+            }
+        }
+        if (MODE == MODE_PAIRS) {
+            // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
+            // (i,j) iff both counts are 0 or both pops are fixed for ALT (or the site is skipped).
+            __builtin_amdgcn_wave_barrier();
+            for (int q = lane; q < p.n_pairs; q += 64) {
+                const uint32_t ij = p.pairs[q];
+                const uint32_t i = ij & 0xffffu, j = ij >> 16;
+                const uint64_t ex = (zm[i] & zm[j]) | (fm[i] & fm[j]);
+                cen[q] += 64u - (uint32_t)__popcll(ex);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (MODE == MODE_GLOBAL) {
+            // evo_FstAgainstAll.cpp:198-203 on populationsToUse[0], in exact integer form:
+            // AAF == 0 <=> nm > 0 && c == 0 ; AAF == 1 <=> nm > 0 && c == nm (0/0 is NaN, -1 if own nm == 0)
+            const uint32_t cc = Tc - c0, cn = Tn - nm0;
+            const bool both0 = (nm0 > 0 && c0 == 0) && (cn > 0 && cc == 0);
+            const bool both1 = (nm0 > 0 && c0 == nm0) && (cn > 0 && cc == cn);
+            const bool kept = !skip && !both0 && !both1;
+            const uint64_t km = __ballot(kept);
+            p.totals[site] = make_uint2(Tc, Tn);
+            if (lane == 0) { p.kept_mask[t] = km; p.skip_mask[t] = skipmask; }
+            used_cnt += 64u - (uint32_t)__popcll(skipmask);
+            kept_cnt += (uint32_t)__popcll(km);
+        }
+    }
+    if (MODE == MODE_PAIRS) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < p.n_pairs; q += kK1Threads) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += cen_all[(size_t)w * p.n_pairs + q];
+            p.chunk_census[(size_t)chunk * p.n_pairs + q] = s;
+        }
+    }
+    if (MODE == MODE_GLOBAL) {
+        uint32_t *red = reinterpret_cast<uint32_t *>(smem);
+        if (lane == 0) { red[wave * 2] = used_cnt; red[wave * 2 + 1] = kept_cnt; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            uint32_t s = 0;
+            for (int w = 0; w < NW; ++w) s += red[w * 2 + threadIdx.x];
+            p.chunk_used_kept[(size_t)chunk * 2 + threadIdx.x] = s;
+        }
+    }
+}
+
+hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t st) {
+    if (p.n_chunks <= 0) return hipSuccess;
+    constexpr int NW = kK1Threads / 64;
+    size_t lds = (size_t)NW * 2 * p.P * 8 + (size_t)NW * (mode == MODE_PAIRS ? p.n_pairs : 0) * 4 + 64;
+    dim3 grid(p.n_chunks), block(kK1Threads);
+#define EVOFST_K1(CT, M) hipLaunchKernelGGL((k1_count_kernel<CT, M>), grid, block, lds, st, p)
+    if (count_bytes == 2) {
+        if (mode == MODE_COUNTS) EVOFST_K1(uint16_t, MODE_COUNTS);
+        else if (mode == MODE_PAIRS) EVOFST_K1(uint16_t, MODE_PAIRS);
+        else EVOFST_K1(uint16_t, MODE_GLOBAL);
+    } else {
+        if (mode == MODE_COUNTS) EVOFST_K1(uint32_t, MODE_COUNTS);
+        else if (mode == MODE_PAIRS) EVOFST_K1(uint32_t, MODE_PAIRS);
+        else EVOFST_K1(uint32_t, MODE_GLOBAL);
+    }
+#undef EVOFST_K1
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Exclusive scan of per-chunk census columns: offsets[c][q] = base[q] + sum_{c'<c} census[c'][q]
+// =====================================================================================
+__global__ __launch_bounds__(64 * kScanParts) void scan_kernel(const uint32_t *__restrict__ census,
+                                                               const int64_t *__restrict__ base,
+                                                               int64_t *__restrict__ offsets,
+                                                               int64_t *__restrict__ totals, int n_chunks,
+                                                               int n_cols) {
+    __shared__ int64_t psum[kScanParts][64];
+    const int ql = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + ql;
+    const int per = (n_chunks + kScanParts - 1) / kScanParts;
+    const int c0 = part * per, c1 = min(c0 + per, n_chunks);
+    int64_t s = 0;
+    if (q < n_cols)
+        for (int c = c0; c < c1; ++c) s += census[(size_t)c * n_cols + q];
+    psum[part][ql] = s;
+    __syncthreads();
+    if (q >= n_cols) return;
+    int64_t run = base ? base[q] : 0;
+    for (int pp = 0; pp < part; ++pp) run += psum[pp][ql];
+    for (int c = c0; c < c1; ++c) {
+        offsets[(size_t)c * n_cols + q] = run;
+        run += census[(size_t)c * n_cols + q];
+    }
+    if (part == kScanParts - 1 && totals) {
+        // `run` of the last part is the grand total (parts past the end contribute nothing)
+        totals[q] = run - (base ? base[q] : 0);
+    }
+}
+
+hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *offsets, int64_t *totals,
+                       int n_chunks, int n_cols, hipStream_t st) {
+    if (n_cols <= 0) return hipSuccess;
+    dim3 grid((n_cols + 63) / 64), block(64 * kScanParts);
+    hipLaunchKernelGGL(scan_kernel, grid, block, 0, st, census, base, offsets, totals, n_chunks, n_cols);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// K2 (+K3): per-pair Hudson numerator / denominator / dxy numerator and segment sums.
+// Replaces process_vcf_fst.cpp:543-553 + 638-650 for every population pair at once.
+// =====================================================================================
+size_t k2_lds_bytes(int P) { return (size_t)P * kPadSites * (8 + 8 + 4) + 16; }
+
+template <typename CT>
+__global__ __launch_bounds__(kK2Threads) void k2_window_kernel(K2Params p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *pt = reinterpret_cast<double *>(smem);           // [P][65] allele frequency c/nm
+    double *ht = pt + (size_t)p.P * kPadSites;               // [P][65] p(1-p)/(nm-1)
+    uint32_t *xt = reinterpret_cast<uint32_t *>(ht + (size_t)p.P * kPadSites);  // [P][65] packed ints
+
+    const int chunk = blockIdx.x;
+    const int q = blockIdx.y * kK2Threads + threadIdx.x;
+    const bool active = q < p.n_pairs;
+    uint32_t pi = 0, pj = 0;
+    int64_t m = 0;
+    int32_t left = p.g;
+    if (active) {
+        const uint32_t ij = p.pairs[q];
+        pi = ij & 0xffffu; pj = ij >> 16;
+        const int64_t g0 = p.chunk_offsets[(size_t)chunk * p.n_pairs + q];
+        m = g0 / p.g;
+        left = p.g - (int32_t)(g0 - m * p.g);
+    }
+    const int64_t first_seg = active ? p.first_segment[q] : 0;
+    double sn = 0.0, sd = 0.0;
+    uint64_t sk = 0;
+    bool flushed = false;
+    const size_t cq = (size_t)chunk * p.n_pairs + q;
+
+    const int t0 = chunk * p.chunk_tiles;
+    const int t1 = min(t0 + p.chunk_tiles, p.n_tiles);
+    const uint32_t io = pi * kPadSites, jo = pj * kPadSites;
+    for (int t = t0; t < t1; ++t) {
+        // ---- derive: one (pop, site) entry per thread-iteration, coalesced over sites
+        const CT *cp = reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites;
+        for (int e = threadIdx.x; e < p.P * kTileSites; e += kK2Threads) {
+            const int k = e >> 6, s = e & 63;
+            const int64_t site = (int64_t)t * kTileSites + s;
+            const uint32_t v = cp[e];
+            const uint32_t c = v & CountTraits<CT>::mask, nm = v >> CountTraits<CT>::shift;
+            bool skip = site >= p.n_sites;
+            if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
+            const double pp = (double)c / (double)nm;                        // utils.h:272-275
+            const double hh = (pp * (1.0 - pp)) / (double)((int)nm - 1);     // fst.h:21-22
+            uint32_t x = c | (((uint32_t)p.n_full[k] - c) << kXBits);
+            if (skip || c == 0) x |= kXZero;
+            if (skip || c == nm) x |= kXFixed;
+            const int o = k * kPadSites + s;
+            pt[o] = pp; ht[o] = hh; xt[o] = x;
+        }
+        __syncthreads();
+        // ---- pairs: lane = pair, sites in order (the reference's push_back order)
+        if (active) {
+            const int site0 = t * kTileSites;
+#pragma unroll 4
+            for (int s = 0; s < kTileSites; ++s) {
+                const uint32_t xi = xt[io + s], xj = xt[jo + s];
+                if (((xi & xj) >> 28) == 0u) {                               // fst.cpp:543-544
+                    const double p1 = pt[io + s], p2 = pt[jo + s];
+                    const double h1 = ht[io + s], h2 = ht[jo + s];
+                    const double d = p1 - p2;
+                    const double num = d * d - h1 - h2;                      // fst.h:20-23
+                    const double den = (p1 * (1.0 - p2)) + (p2 * (1.0 - p1));  // fst.h:28
+                    const uint32_t ai = xi & kXMask, bi = (xi >> kXBits) & kXMask;
+                    const uint32_t aj = xj & kXMask, bj = (xj >> kXBits) & kXMask;
+                    sn += num; sd += den;
+                    sk += (uint64_t)(ai * bj + aj * bi);                     // sumKij, fst.cpp:299-321
+                    if (--left == 0) {
+                        if (!flushed) {
+                            p.head[cq * 3 + 0] = sn; p.head[cq * 3 + 1] = sd; p.head[cq * 3 + 2] = (double)sk;
+                            p.head_site[cq] = site0 + s;
+                            flushed = true;
+                        } else {
+                            const size_t o = (size_t)(m - first_seg) * p.n_pairs + q;
+                            p.seg_num[o] = sn; p.seg_den[o] = sd; p.seg_k[o] = (double)sk;
+                            p.seg_end[o] = site0 + s;
+                        }
+                        ++m; left = p.g; sn = 0.0; sd = 0.0; sk = 0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        p.tail[cq * 5 + 0] = sn; p.tail[cq * 5 + 1] = sd; p.tail[cq * 5 + 2] = (double)sk;
+        p.tail[cq * 5 + 3] = (double)(p.g - left);
+        p.tail[cq * 5 + 4] = flushed ? 1.0 : 0.0;
+    }
+}
+
+hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st) {
+    if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
+    dim3 grid(p.n_chunks, (p.n_pairs + kK2Threads - 1) / kK2Threads), block(kK2Threads);
+    size_t lds = k2_lds_bytes(p.P);
+    if (lds > 48 * 1024) {
+        hipError_t e = count_bytes == 2
+            ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_window_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_window_kernel<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (count_bytes == 2) hipLaunchKernelGGL((k2_window_kernel<uint16_t>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((k2_window_kernel<uint32_t>), grid, block, lds, st, p);
+    return hipGetLastError();
+}
+
+// The first segment a chunk completes started in an earlier chunk: add, in site order, the tail of
+// the last chunk that completed a segment and the whole-chunk sums of the chunks in between.
+__global__ void stitch_kernel(K2Params p) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (q >= p.n_pairs) return;
+    const size_t cq = (size_t)c * p.n_pairs + q;
+    if (p.tail[cq * 5 + 4] == 0.0) return;
+    int cp = c - 1;
+    while (cp >= 0 && p.tail[((size_t)cp * p.n_pairs + q) * 5 + 4] == 0.0) --cp;
+    double an = 0.0, ad = 0.0, ak = 0.0;
+    for (int cc = (cp < 0 ? 0 : cp); cc < c; ++cc) {
+        const size_t o = ((size_t)cc * p.n_pairs + q) * 5;
+        an += p.tail[o]; ad += p.tail[o + 1]; ak += p.tail[o + 2];
+    }
+    an += p.head[cq * 3]; ad += p.head[cq * 3 + 1]; ak += p.head[cq * 3 + 2];
+    const int64_t m0 = p.chunk_offsets[cq] / p.g;
+    const size_t o = (size_t)(m0 - p.first_segment[q]) * p.n_pairs + q;
+    p.seg_num[o] = an; p.seg_den[o] = ad; p.seg_k[o] = ak;
+    p.seg_end[o] = p.head_site[cq];
+}
+
+hipError_t launch_stitch(const K2Params &p, hipStream_t st) {
+    if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
+    dim3 block(64), grid((p.n_pairs + 63) / 64, p.n_chunks);
+    hipLaunchKernelGGL(stitch_kernel, grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
+// Whole-shard sums per pair: complete segments in order, then the carry after the last one.
+__global__ void totals_kernel(K2Params p, const int64_t *__restrict__ n_rows, double *__restrict__ totals) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.n_pairs) return;
+    double an = 0.0, ad = 0.0, ak = 0.0, cnt = 0.0;
+    const int64_t rows = n_rows[q];
+    for (int64_t r = 0; r < rows; ++r) {
+        const size_t o = (size_t)r * p.n_pairs + q;
+        an += p.seg_num[o]; ad += p.seg_den[o]; ak += p.seg_k[o];
+    }
+    cnt = (double)rows * (double)p.g;
+    int cl = p.n_chunks - 1;
+    while (cl >= 0 && p.tail[((size_t)cl * p.n_pairs + q) * 5 + 4] == 0.0) --cl;
+    for (int cc = (cl < 0 ? 0 : cl); cc < p.n_chunks; ++cc) {
+        const size_t o = ((size_t)cc * p.n_pairs + q) * 5;
+        an += p.tail[o]; ad += p.tail[o + 1]; ak += p.tail[o + 2]; cnt += p.tail[o + 3];
+    }
+    totals[(size_t)q * 4 + 0] = an; totals[(size_t)q * 4 + 1] = ad;
+    totals[(size_t)q * 4 + 2] = ak; totals[(size_t)q * 4 + 3] = cnt;
+}
+
+hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *totals, hipStream_t st) {
+    if (p.n_pairs <= 0) return hipSuccess;
+    dim3 block(64), grid((p.n_pairs + 63) / 64);
+    hipLaunchKernelGGL(totals_kernel, grid, block, 0, st, p, n_rows, totals);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Per-site outputs on demand (lane = site).  These are the parity hooks and what the CLI front-end
+// feeds to its replay of the reference's window state machines.
+// =====================================================================================
+template <typename CT>
+__global__ __launch_bounds__(256) void site_stats_kernel(SiteStatParams p) {
+    const int64_t ls = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index in the request
+    if (ls >= p.n_sites) return;
+    const int64_t site = p.first_site + ls;
+    const int64_t t = site >> 6;
+    const int s = (int)(site & 63);
+    const CT *cp = reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites + s;
+    bool skip = p.site_flags ? ((p.site_flags[site] & 1u) != 0) : false;
+    for (int q = blockIdx.y; q < p.n_pairs; q += gridDim.y) {
+        const uint32_t ij = p.pairs[q];
+        const uint32_t i = ij & 0xffffu, j = ij >> 16;
+        const uint32_t vi = cp[(size_t)i * kTileSites], vj = cp[(size_t)j * kTileSites];
+        const int c1 = (int)(vi & CountTraits<CT>::mask), nm1 = (int)(vi >> CountTraits<CT>::shift);
+        const int c2 = (int)(vj & CountTraits<CT>::mask), nm2 = (int)(vj >> CountTraits<CT>::shift);
+        const int n1 = p.n_full[i], n2 = p.n_full[j];
+        const double p1 = (double)c1 / (double)nm1, p2 = (double)c2 / (double)nm2;
+        const double power = (p1 - p2) * (p1 - p2);
+        const double f1 = (p1 * (1.0 - p1)) / (double)(nm1 - 1);
+        const double f2 = (p2 * (1.0 - p2)) / (double)(nm2 - 1);
+        const double num = power - f1 - f2;
+        const double den = (p1 * (1.0 - p2)) + (p2 * (1.0 - p1));
+        const int sumKij = c1 * (n2 - c2) + c2 * (n1 - c1);
+        const double dxy = (double)sumKij / (double)(n1 * n2);
+        const bool inc = !skip && (c1 > 0 || c2 > 0) && (c1 < nm1 || c2 < nm2);
+        const size_t o = (size_t)q * p.n_sites + ls;
+        if (p.num) p.num[o] = num;
+        if (p.den) p.den[o] = den;
+        if (p.dxy) p.dxy[o] = dxy;
+        if (p.include) p.include[o] = inc ? 1 : 0;
+    }
+}
+
+hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st) {
+    if (p.n_sites <= 0 || p.n_pairs <= 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((p.n_sites + 255) / 256), (unsigned)min(p.n_pairs, 1024));
+    if (count_bytes == 2) hipLaunchKernelGGL((site_stats_kernel<uint16_t>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((site_stats_kernel<uint32_t>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void pop_div_kernel(PopDivParams p) {
+    const int64_t ls = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ls >= p.n_sites) return;
+    const int64_t site = p.first_site + ls;
+    const CT *cp = reinterpret_cast<const CT *>(p.counts) + (size_t)(site >> 6) * p.P * kTileSites + (site & 63);
+    for (int k = blockIdx.y; k < p.P; k += gridDim.y) {
+        const uint32_t v = cp[(size_t)k * kTileSites];
+        const int c = (int)(v & CountTraits<CT>::mask), nm = (int)(v >> CountTraits<CT>::shift);
+        const int n = p.n_full[k];
+        const double pp = (double)c / (double)n;                  // fst.cpp:364-365 (full n)
+        const double qq = 1.0 - pp;
+        const double het = 1.0 - (pp * pp + qq * qq);             // fst.h:33-37
+        const double nei = ((double)n * het) / (double)(n - 1);   // fst.h:40-45
+        const double kk = (double)(c * (n - c));
+        const double pi = (2.0 / (double)(nm * (nm - 1))) * kk;   // fst.cpp:346
+        const size_t o = (size_t)k * p.n_sites + ls;
+        if (p.het) p.het[o] = het;
+        if (p.het_nei) p.het_nei[o] = nei;
+        if (p.pi) p.pi[o] = pi;
+    }
+}
+
+hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st) {
+    if (p.n_sites <= 0 || p.P <= 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((p.n_sites + 255) / 256), (unsigned)min(p.P, 1024));
+    if (count_bytes == 2) hipLaunchKernelGGL((pop_div_kernel<uint16_t>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((pop_div_kernel<uint32_t>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void unpack_counts_kernel(const void *counts, int P, int64_t first_site,
+                                                            int64_t n_sites, int32_t *alt, int32_t *nm) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_sites * P) return;
+    const int64_t ls = e / P;
+    const int k = (int)(e - ls * P);
+    const int64_t site = first_site + ls;
+    const uint32_t v = reinterpret_cast<const CT *>(counts)[((size_t)(site >> 6) * P + k) * kTileSites + (site & 63)];
+    alt[e] = (int32_t)(v & CountTraits<CT>::mask);
+    nm[e] = (int32_t)(v >> CountTraits<CT>::shift);
+}
+
+hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,
+                                int32_t *alt, int32_t *nm, hipStream_t st) {
+    const int64_t n = n_sites * P;
+    if (n <= 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    if (count_bytes == 2)
+        hipLaunchKernelGGL((unpack_counts_kernel<uint16_t>), grid, block, 0, st, counts, P, first_site, n_sites, alt, nm);
+    else
+        hipLaunchKernelGGL((unpack_counts_kernel<uint32_t>), grid, block, 0, st, counts, P, first_site, n_sites, alt, nm);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Fst-against-all (evo FstGlobal).
+// =====================================================================================
+
+// Number of window rows each chunk emits (evo_FstAgainstAll.cpp:238): a kept site emits when
+// (used > SIZE || SIZE == STEP) && used % STEP == 0.  One thread per chunk walks its masks.
+__global__ void global_rows_kernel(const uint64_t *__restrict__ kept_mask, const uint64_t *__restrict__ skip_mask,
+                                   const int64_t *__restrict__ chunk_off, int n_chunks, int chunk_tiles,
+                                   int n_tiles, int size, int step, uint32_t *__restrict__ chunk_rows) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    int64_t used = chunk_off[(size_t)c * 2];
+    uint32_t rows = 0;
+    const int t0 = c * chunk_tiles, t1 = min(t0 + chunk_tiles, n_tiles);
+    for (int t = t0; t < t1; ++t) {
+        const uint64_t km = kept_mask[t], sm = skip_mask[t];
+        for (int s = 0; s < 64; ++s) {
+            if ((sm >> s) & 1ull) continue;
+            ++used;
+            if (((km >> s) & 1ull) && (used > size || size == step) && (used % step == 0)) ++rows;
+        }
+    }
+    chunk_rows[c] = rows;
+}
+
+hipError_t launch_global_rows(const uint64_t *kept_mask, const uint64_t *skip_mask, const int64_t *chunk_off,
+                              int n_chunks, int chunk_tiles, int n_tiles, int size, int step,
+                              uint32_t *chunk_rows, hipStream_t st) {
+    if (n_chunks <= 0) return hipSuccess;
+    dim3 block(64), grid((n_chunks + 63) / 64);
+    hipLaunchKernelGGL(global_rows_kernel, grid, block, 0, st, kept_mask, skip_mask, chunk_off, n_chunks,
+                       chunk_tiles, n_tiles, size, step, chunk_rows);
+    return hipGetLastError();
+}
+
+size_t global_lds_bytes(int P, int n_use, int size) {
+    // counts tile transposed [64][P] u32 + ring [size][n_use] x {num, den} + ring of site ids
+    return (size_t)kTileSites * P * 4 + (size_t)size * n_use * 16 + (size_t)size * 4 + 64;
+}
+
+__device__ __forceinline__ void global_eval(uint32_t c, uint32_t nm, uint32_t Tc, uint32_t Tn, double thr,
+                                            double &num, double &den) {
+    // evo_FstAgainstAll.cpp:245-261 with p1 = setAAFs (-1.0 when the pop has no alleles,
+    // utils.h:75 + utils.cpp:56-58), p2 = complement AAF (utils.cpp:95)
+    const int n1 = (int)nm, n2 = (int)(Tn - nm);
+    if ((double)n1 >= thr) {
+        const double p1 = nm > 0 ? (double)c / (double)nm : -1.0;
+        const double p2 = (double)(int)(Tc - c) / (double)n2;
+        const double power = (p1 - p2) * (p1 - p2);
+        const double f1 = (p1 * (1.0 - p1)) / (double)(n1 - 1);
+        const double f2 = (p2 * (1.0 - p2)) / (double)(n2 - 1);
+        num = power - f1 - f2;
+        den = (p1 * (1.0 - p2)) + (p2 * (1.0 - p1));
+    } else {
+        num = 0.0; den = 0.0;
+    }
+}
+
+// lane = population of populationsToUse; one block per chunk.  Each lane owns one column of the two
+// deques (a ring in LDS), so the site loop needs no barrier; the chunk first replays the last
+// SIZE kept sites before it (the deque contents at its first site).
+template <typename CT>
+__global__ void global_window_kernel(GlobalParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *ct = reinterpret_cast<uint32_t *>(smem);                       // [64][P]
+    double *ring = reinterpret_cast<double *>(smem + (((size_t)kTileSites * p.P * 4 + 15) & ~(size_t)15));
+    double *ring_n = ring;                                                   // [size][n_use]
+    double *ring_d = ring + (size_t)p.size * p.n_use;
+    int32_t *ring_s = reinterpret_cast<int32_t *>(ring_d + (size_t)p.size * p.n_use);  // [size]
+
+    const int c = blockIdx.x;
+    const int u = threadIdx.x;
+    const bool active = u < p.n_use;
+    const int k = active ? p.use_idx[u] : 0;
+    const double thr = active ? p.thresholds[u] : 0.0;
+    for (int i = threadIdx.x; i < p.size * p.n_use; i += blockDim.x) { ring_n[i] = 0.0; ring_d[i] = 0.0; }
+    for (int i = threadIdx.x; i < p.size; i += blockDim.x) ring_s[i] = -1;
+
+    const int t0 = c * p.chunk_tiles, t1 = min(t0 + p.chunk_tiles, p.n_tiles);
+    // ---- find where the replay starts: walk back until SIZE kept sites are found
+    int th = t0;          // first tile to process
+    int need = p.size;
+    int64_t kept_before = p.chunk_used_kept_off[(size_t)c * 2 + 1];
+    if (kept_before < need) need = (int)kept_before;   // the rest is the zero-initialised deque
+    int drop = 0;         // kept sites of tile th to ignore (older than the window)
+    while (need > 0 && th > 0) {
+        --th;
+        const int n = __popcll(p.kept_mask[th]);
+        if (n >= need) { drop = n - need; need = 0; }
+        else need -= n;
+    }
+    int64_t used = p.chunk_used_kept_off[(size_t)c * 2];
+    int64_t row = p.chunk_row_off[c];
+    int head = 0;  // ring slot of the oldest element
+    __syncthreads();
+    for (int t = th; t < t1; ++t) {
+        const uint64_t km = p.kept_mask[t], sm = p.skip_mask[t];
+        if (km == 0 && t < t0) continue;
+        // stage the tile's counts transposed: ct[s][k]
+        const CT *cp = reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites;
+        __syncthreads();
+        for (int e = threadIdx.x; e < p.P * kTileSites; e += blockDim.x) {
+            const int kk = e >> 6, s = e & 63;
+            ct[s * p.P + kk] = cp[e];
+        }
+        __syncthreads();
+        const bool replay = t < t0;
+        for (int s = 0; s < kTileSites; ++s) {
+            if ((sm >> s) & 1ull) continue;
+            if (!replay) ++used;
+            if (!((km >> s) & 1ull)) continue;
+            if (replay && drop > 0) { --drop; continue; }
+            const int site = t * kTileSites + s;
+            const uint2 T = p.totals[site];
+            if (active) {
+                const uint32_t v = ct[s * p.P + k];
+                double num, den;
+                global_eval(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, T.x, T.y, thr, num, den);
+                ring_n[(size_t)head * p.n_use + u] = num;
+                ring_d[(size_t)head * p.n_use + u] = den;
+            }
+            if (threadIdx.x == 0) ring_s[head] = site;
+            head = head + 1 == p.size ? 0 : head + 1;
+            if (!replay && (used > p.size || p.size == p.step) && (used % p.step == 0)) {
+                if (active) {
+                    double an = 0.0, ad = 0.0;
+                    int idx = head;
+                    for (int i = 0; i < p.size; ++i) {      // oldest -> newest, as vector_average on the deque
+                        an += ring_n[(size_t)idx * p.n_use + u];
+                        ad += ring_d[(size_t)idx * p.n_use + u];
+                        idx = idx + 1 == p.size ? 0 : idx + 1;
+                    }
+                    p.row_num[(size_t)row * p.n_use + u] = an / (double)p.size;
+                    p.row_den[(size_t)row * p.n_use + u] = ad / (double)p.size;
+                }
+                if (threadIdx.x == 0) {
+                    p.row_start[row] = ring_s[head];
+                    p.row_end[row] = site;
+                }
+                ++row;
+            }
+        }
+    }
+}
+
+hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st) {
+    if (p.n_chunks <= 0 || p.n_use <= 0) return hipSuccess;
+    int threads = ((p.n_use + 63) / 64) * 64;
+    dim3 grid(p.n_chunks), block(threads);
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = count_bytes == 2
+            ? hipFuncSetAttribute(reinterpret_cast<const void *>(&global_window_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+            : hipFuncSetAttribute(reinterpret_cast<const void *>(&global_window_kernel<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    if (count_bytes == 2) hipLaunchKernelGGL((global_window_kernel<uint16_t>), grid, block, lds_bytes, st, p);
+    else hipLaunchKernelGGL((global_window_kernel<uint32_t>), grid, block, lds_bytes, st, p);
+    return hipGetLastError();
+}
+
+// per-site against-all values on demand: lane = site
+template <typename CT>
+__global__ __launch_bounds__(256) void global_site_kernel(GlobalParams p) {
+    const int64_t ls = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ls >= p.n_out_sites) return;
+    const int64_t site = p.first_site + ls;
+    const int64_t t = site >> 6;
+    const int s = (int)(site & 63);
+    const CT *cp = reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites + s;
+    const uint2 T = p.totals[site];
+    if (blockIdx.y == 0 && p.site_kept) p.site_kept[ls] = (uint8_t)((p.kept_mask[t] >> s) & 1ull);
+    for (int u = blockIdx.y; u < p.n_use; u += gridDim.y) {
+        const uint32_t v = cp[(size_t)p.use_idx[u] * kTileSites];
+        double num, den;
+        global_eval(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, T.x, T.y, p.thresholds[u], num, den);
+        if (p.site_num) p.site_num[(size_t)u * p.n_out_sites + ls] = num;
+        if (p.site_den) p.site_den[(size_t)u * p.n_out_sites + ls] = den;
+    }
+}
+
+hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream_t st) {
+    if (p.n_out_sites <= 0 || p.n_use <= 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((p.n_out_sites + 255) / 256), (unsigned)min(p.n_use, 1024));
+    if (count_bytes == 2) hipLaunchKernelGGL((global_site_kernel<uint16_t>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((global_site_kernel<uint32_t>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Synthetic workload generator, device side so that full-size inputs never cross
+// PCIe.  Counter-based: every bit is a hash of (seed, global site, haplotype).
+// =====================================================================================
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t h) { return (float)((h >> 40) + 1) * (1.0f / 16777217.0f); }
+
+__global__ __launch_bounds__(256) void synth_kernel(SynthParams p) {
+    const int64_t site = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = site >> 6;
+    if (t >= p.n_tiles) return;
+    const int s = (int)(site & 63);
+    const bool valid = site < p.n_sites;
+    const uint64_t gs = (uint64_t)(p.first_site_global + site);
+    const uint64_t key = mix64(p.seed ^ (gs * 0xD1B54A32D192ED03ull));
+    // base frequency f ~ Beta(0.5, 0.5) = sin^2(pi*u/2)
+    const float sb = __sinf(1.57079632679f * u01(mix64(key ^ 0x1111ull)));
+    const float f = sb * sb;
+    ulonglong2 *tp = p.tiles + (size_t)t * p.W * kTileSites + s;
+    uint32_t thr = 0;
+    for (int w = 0; w < p.W; ++w) {
+        uint64_t alt = 0, miss = 0;
+        for (int sg = p.word_seg_start[w]; sg < p.word_seg_start[w + 1]; ++sg) {
+            const SegDesc d = p.segs[sg];
+            // per-pop frequency p_k = clip(f + N(0, 0.15))
+            const uint64_t hk = mix64(key ^ (0x2222ull + (uint64_t)d.pop * 0x9E3779B1ull));
+            const float g = sqrtf(-2.0f * __logf(u01(hk))) * __cosf(6.28318530718f * u01(mix64(hk)));
+            float pk = f + 0.15f * g;
+            pk = fminf(fmaxf(pk, 0.0f), 1.0f);
+            thr = (uint32_t)fminf(pk * 4294967296.0f, 4294967295.0f);
+            uint64_t mm = d.mask;
+            while (mm) {
+                const int b = __ffsll((unsigned long long)mm) - 1;
+                mm &= mm - 1;
+                const uint64_t hap = (uint64_t)w * 64 + b;
+                const uint64_t hh = mix64(key ^ (0x3333ull + hap * 0xC2B2AE3D27D4EB4Full));
+                if ((uint32_t)hh < thr && pk > 0.0f) alt |= 1ull << b;
+                const uint64_t hm = mix64(key ^ (0x4444ull + (hap >> 1) * 0x165667B19E3779F9ull));
+                if ((uint32_t)hm < p.miss_thr) miss |= 1ull << b;
+            }
+        }
+        alt &= ~miss;
+        if (!valid) { alt = 0; miss = 0; }
+        tp[(size_t)w * kTileSites] = make_ulonglong2(alt, miss);
+    }
+    if (valid && p.pos) p.pos[site] = (int32_t)(((uint64_t)(p.first_site_global + site)) * 100ull + (mix64(key ^ 0x5555ull) % 100ull) + 1ull);
+}
+
+hipError_t launch_synth(const SynthParams &p, hipStream_t st) {
+    if (p.n_tiles <= 0) return hipSuccess;
+    const int64_t n = (int64_t)p.n_tiles * kTileSites;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(synth_kernel, grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace evofst

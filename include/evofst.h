@@ -1,0 +1,223 @@
+/*
+ * evofst.h -- C ABI of the MI355X-native engine for evo's pairwise Fst / dxy hot path.
+ *
+ * The reference (millanek/evo) has no plugin / FFI seam: its only entry points for this path
+ * are `int fstMain(int, char**)` (process_vcf_fst.h:16, dispatched at process_vcf.cpp:171-172)
+ * and `int FstGlobalMain(int, char**)` (evo_FstAgainstAll.h:16, process_vcf.cpp:217-218).
+ * Each function below names the part of those two programs it replaces (file:line relative to
+ * the reference tree).  A maintainer's binding is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every call returns EVOFST_OK (0) or a negative
+ * error code and never exits or throws; evofst_last_error() gives the message.  The caller
+ * owns all host buffers; the library owns device memory.  One context = one GPU = one HIP
+ * stream; calls on one context must come from one thread at a time.  Compute calls are
+ * asynchronous on the context's stream; evofst_sync() and every evofst_get_* call wait.
+ *
+ * Packed genotype format ("tiles"): haplotypes are permuted so that each population is a
+ * contiguous bit range (population k = bits [off_k, off_k + 2*size_k)); a site is W =
+ * ceil(H/64) pairs of 64-bit words {ALT bits, MISSING bits}; sites are grouped in tiles of 64
+ * and a tile is stored word-major: tiles[t][w][s] = {alt, missing} (16 bytes) for site 64*t+s.
+ * Two bits per haplotype => N/2 bytes per site (+ padding of H to 64 and of S to 64).
+ */
+#ifndef EVOFST_H
+#define EVOFST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVOFST_OK 0
+#define EVOFST_ERR_ARG (-1)         /* bad argument */
+#define EVOFST_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define EVOFST_ERR_STATE (-3)       /* call made in the wrong order */
+#define EVOFST_ERR_NOMEM (-4)       /* host or device allocation failed */
+#define EVOFST_ERR_UNSUPPORTED (-5) /* outside the limits of this build */
+
+#define EVOFST_TILE_SITES 64
+#define EVOFST_MAX_POP_CHROMS 16383 /* 2 * samples of one population */
+#define EVOFST_MAX_POPS 4096
+
+/* allele codes accepted by the packer: one per haplotype */
+#define EVOFST_REF 0
+#define EVOFST_ALT 1
+#define EVOFST_MISSING 2
+
+/* site flags */
+#define EVOFST_SITE_SKIP 1u /* site fails the REF/ALT filters of the mode in use */
+
+/* genotype-text interpretation, evofst_codes_from_vcf_line() */
+#define EVOFST_MODE_FST 0    /* `evo fst` rules   (process_vcf_fst.cpp:222-280, 529-532) */
+#define EVOFST_MODE_GLOBAL 1 /* `evo FstGlobal`   (process_vcf_utils.cpp:62-83, evo_FstAgainstAll.cpp:184-188) */
+
+typedef struct evofst_ctx evofst_ctx;
+
+typedef struct {
+    int32_t n_samples;      /* samples in the input order */
+    int32_t n_pops;
+    int32_t n_haplotypes;   /* H: 2 * samples that belong to a population */
+    int32_t words_per_site; /* W */
+    int32_t tile_sites;     /* 64 */
+    int32_t count_bytes;    /* 2 or 4: bytes of one packed (alt, non-missing) count */
+    int64_t tile_bytes;     /* W * 64 * 16 */
+} evofst_geometry;
+
+/* ------------------------------------------------------------------ lifecycle */
+
+/* Creates a context on HIP device `device_id` (its own stream).  NULL on failure;
+ * evofst_last_error(NULL) then tells why.  device_id == -1 creates a HOST-ONLY context for the
+ * packer functions (set_layout / pack / unpack / geometry); every device call on it fails with
+ * EVOFST_ERR_STATE -- there is no CPU compute path. */
+evofst_ctx *evofst_create(int device_id);
+void evofst_destroy(evofst_ctx *ctx);
+const char *evofst_last_error(const evofst_ctx *ctx);
+const char *evofst_version(void);
+/* Use an existing HIP stream (hipStream_t passed as void*) instead of the context's own. */
+int evofst_set_stream(evofst_ctx *ctx, void *hip_stream);
+
+/* ------------------------------------------------------------------ layout
+ * Replaces locateSet + the per-line set loops (process_vcf_utils.cpp:923-936,
+ * process_vcf_fst.cpp:489-491, evo_FstAgainstAll.cpp:153-168): sample_pop[i] is the population
+ * of sample column i, or -1 when the sample is in no population. */
+int evofst_set_layout(evofst_ctx *ctx, int n_samples, int n_pops, const int32_t *sample_pop);
+int evofst_get_geometry(const evofst_ctx *ctx, evofst_geometry *out);
+/* n_full[k] = 2 * size of population k (the `n1`,`n2` of process_vcf_fst.cpp:491) */
+int evofst_get_pop_chroms(const evofst_ctx *ctx, int32_t *n_full);
+
+/* ------------------------------------------------------------------ host packer (stage K0)
+ * Replaces split() + the genotype char tests (process_vcf_utils.cpp:104-130,
+ * process_vcf_fst.cpp:243-280, process_vcf_utils.cpp:62-83). */
+
+/* Bytes of the tile buffer that holds n_sites sites. */
+size_t evofst_tiles_bytes(const evofst_ctx *ctx, int64_t n_sites);
+/* codes: [n_sites][2*n_samples] allele codes in the INPUT sample order -> tiles.
+ * first_site lets a caller fill one tile buffer in several calls (must be a multiple of 64
+ * except for the last call). */
+int evofst_pack_codes(const evofst_ctx *ctx, int64_t first_site, int64_t n_sites,
+                      const uint8_t *codes, void *tiles);
+/* Inverse of evofst_pack_codes (used by tests and by callers that want to audit a buffer). */
+int evofst_unpack_codes(const evofst_ctx *ctx, int64_t first_site, int64_t n_sites,
+                        const void *tiles, uint8_t *codes);
+/* One VCF data line -> allele codes [2*n_samples] + site flags, with the rules of `mode`.
+ * `line` is modified in place (tabs become NULs).  chrom/pos point into `line`.
+ * Returns EVOFST_ERR_ARG for lines with fewer than 9+n_samples columns or genotype fields
+ * shorter than 3 characters (the reference reads chars [0] and [2] unchecked). */
+int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, uint8_t *codes,
+                               uint32_t *site_flags, const char **chrom, const char **pos);
+
+/* ------------------------------------------------------------------ device data */
+
+/* (Re)allocates device buffers for up to max_sites sites in the current layout/mode. */
+int evofst_reserve(evofst_ctx *ctx, int64_t max_sites);
+/* Pinned host staging memory for evofst_upload (hipHostMalloc / hipHostFree). */
+void *evofst_alloc_pinned(evofst_ctx *ctx, size_t bytes);
+void evofst_free_pinned(evofst_ctx *ctx, void *p);
+/* Asynchronous H2D of n_sites packed sites.  site_flags may be NULL (no site skipped);
+ * pos may be NULL.  Buffers must stay valid until evofst_sync(). */
+int evofst_upload(evofst_ctx *ctx, int64_t n_sites, const void *tiles,
+                  const uint8_t *site_flags, const int32_t *pos);
+/* Use tiles that already live in HBM (device pointers; not copied, caller keeps them alive). */
+int evofst_attach_device(evofst_ctx *ctx, int64_t n_sites, const void *d_tiles,
+                         const uint8_t *d_site_flags, const int32_t *d_pos);
+/* Fills the device tile buffer with the synthetic workload of SURVEY.md 8(d) (benchmarks and
+ * full-size property tests; no reference counterpart).  first_site_global keys the generator so
+ * that a shard regenerates exactly its slice.  Also fills pos (cumulative steps of 1..199). */
+int evofst_synth(evofst_ctx *ctx, int64_t n_sites, int64_t first_site_global, uint64_t seed,
+                 double missing_rate);
+/* D2H copy of the tile buffer (tests). */
+int evofst_download_tiles(evofst_ctx *ctx, void *tiles);
+
+/* ------------------------------------------------------------------ modes */
+
+/* Two-set statistics for population pairs: the path of getFstFromVCF
+ * (process_vcf_fst.cpp:535-557) applied to (pair_i[q], pair_j[q]).  n_pairs == 0 selects all
+ * P*(P-1)/2 pairs i<j in lexicographic order. */
+int evofst_set_pairs(evofst_ctx *ctx, const int32_t *pair_i, const int32_t *pair_j, int n_pairs);
+/* Fst-against-all (evo_FstAgainstAll.cpp:191-203, 244-261): use_pops = populationsToUse as
+ * population indices, set_sizes[u] = the value the reference reads as c->setSizes[u]. */
+int evofst_set_against_all(evofst_ctx *ctx, const int32_t *use_pops, int n_use,
+                           const int64_t *set_sizes);
+/* SNP-count windows: -w SIZE,STEP of both programs (process_vcf_fst.cpp:638-650,
+ * evo_FstAgainstAll.cpp:238, 276-280).  size == 0 disables windows (totals only). */
+int evofst_set_windows(evofst_ctx *ctx, int snp_size, int snp_step);
+/* Multi-GPU: number of included sites per pair (pairs mode) that precede this shard
+ * (n_pairs values), or {used, kept} sites preceding it (against-all mode, 2 values). */
+int evofst_set_base_offsets(evofst_ctx *ctx, const int64_t *offsets);
+
+/* ------------------------------------------------------------------ compute */
+
+/* Stage K1: per-population allele counts (getVariantCountsForFst counting loops,
+ * process_vcf_fst.cpp:243-280 / getBasicCounts, process_vcf_utils.cpp:62-83) + the per-chunk
+ * census of included sites (filter process_vcf_fst.cpp:543-544 / evo_FstAgainstAll.cpp:198-203). */
+int evofst_run_counts(evofst_ctx *ctx);
+/* Stages K2+K3: per-pair numerator / denominator / dxy and segmented window sums
+ * (process_vcf_fst.h:19-30, process_vcf_fst.cpp:297-323, 354-360, 638-650), or the
+ * against-all evaluation and deque windows (evo_FstAgainstAll.cpp:244-280). */
+int evofst_run_stats(evofst_ctx *ctx);
+/* evofst_run_counts + evofst_run_stats. */
+int evofst_run(evofst_ctx *ctx);
+int evofst_sync(evofst_ctx *ctx);
+
+/* When enabled, evofst_run_* bracket every kernel with HIP events on the context's stream. */
+int evofst_set_profiling(evofst_ctx *ctx, int enabled);
+/* Milliseconds of the last run of kernel `which` (0 = counts, 1 = offsets scan, 2 = pair/global
+ * stats, 3 = stitch).  Waits for the stream. */
+int evofst_get_kernel_ms(evofst_ctx *ctx, int which, float *ms);
+
+/* ------------------------------------------------------------------ results */
+
+/* Bit-exact parity hook: alt[s*n_pops+k] = alt-allele count, nm[...] = non-missing alleles
+ * (set{1,2}Count / set{1,2}_n_withoutMissing, process_vcf_utils.h:262-265). */
+int evofst_get_counts(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, int32_t *alt,
+                      int32_t *nm);
+/* Included sites of this shard per pair (n_pairs values), available after evofst_run_counts.
+ * Against-all mode: 2 values {used, kept}. */
+int evofst_get_included_totals(evofst_ctx *ctx, int64_t *totals);
+/* Per-site statistics for pairs mode, computed on demand for sites [first_site, +n_sites):
+ * arrays are [n_pairs][n_sites]; any pointer may be NULL.  num / den / dxy are the values of
+ * calculateFstNumerator / calculateFstDenominator / calculateDxy; include is the site filter. */
+int evofst_get_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *num,
+                          double *den, double *dxy, uint8_t *include);
+/* Per-site per-population diversity (getSetHeterozygozities + calculatePiTwoSets,
+ * process_vcf_fst.cpp:325-371): arrays [n_pops][n_sites]; any pointer may be NULL. */
+int evofst_get_pop_site_div(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *het,
+                            double *het_nei, double *pi);
+/* Segment sums.  A segment is g = gcd(SIZE, STEP) consecutive included sites of a pair (in
+ * against-all mode: see evofst_get_global_windows instead).  Segment m of pair q covers the
+ * pair's included sites with 1-based global rank (m*g, (m+1)*g]; window "ending at rank e" is
+ * the sum of segments [(e-SIZE)/g, e/g).  n_segments[q] = complete segments of pair q that END
+ * in this shard; first_segment[q] = index of the first of them.  Arrays are
+ * [max_segments][n_pairs] (row = local segment index m - first_segment[q]):
+ *   sum_num, sum_den : sums of the Fst numerators / denominators,
+ *   sum_dxy_k        : sum of the integer dxy numerators (sumKij, process_vcf_fst.cpp:299-321);
+ *                      dxy sum = sum_dxy_k / (n_full[i]*n_full[j]),
+ *   end_site         : shard-local site index of the last site of the segment.
+ * The first segment of a shard with a non-zero base offset lacks the previous shard's carry:
+ * add carry_in (see evofst_get_boundary). */
+int64_t evofst_max_segments(evofst_ctx *ctx);
+int evofst_get_segments(evofst_ctx *ctx, int64_t *first_segment, int64_t *n_segments,
+                        double *sum_num, double *sum_den, double *sum_dxy_k, int32_t *end_site);
+/* Boundary partials of this shard, 4 doubles per pair: {sum_num, sum_den, sum_dxy_k, n_sites}
+ * of the included sites after the last complete segment (the carry handed to the next shard). */
+int evofst_get_boundary(evofst_ctx *ctx, double *carry_out);
+/* Whole-shard sums per pair: {sum_num, sum_den, sum_dxy_k, n_included} (genome-wide Fst of
+ * process_vcf_fst.cpp:701 = sum_num / sum_den). */
+int evofst_get_totals(evofst_ctx *ctx, double *totals);
+
+/* Against-all mode: per-site values [n_use][n_sites] and the kept flag [n_sites]. */
+int evofst_get_global_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sites,
+                                 double *num, double *den, uint8_t *kept);
+/* Against-all deque windows (evo_FstAgainstAll.cpp:237-240, 276-280): row r has
+ * start_site/end_site (shard-local site indices; start -1 = the initial "0" coordinate) and
+ * mean_num / mean_den [max_rows][n_use] (= vector_average of the two deques, left to right).
+ * Returns the number of rows through *n_rows. */
+int64_t evofst_max_global_rows(evofst_ctx *ctx);
+int evofst_get_global_windows(evofst_ctx *ctx, int64_t *n_rows, int32_t *start_site,
+                              int32_t *end_site, double *mean_num, double *mean_den);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVOFST_H */

@@ -1,0 +1,974 @@
+/*
+ * evo_oracle.c -- CPU restatement of millanek/evo's pairwise Fst / dxy hot path.
+ * TEST INFRASTRUCTURE ONLY (see evo_oracle.h for the pinning status).
+ * Plain C99, single thread, no FMA contraction (build with -ffp-contract=off).
+ * File:line citations are relative to /root/reference/.
+ */
+#define _GNU_SOURCE
+#include "evo_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+/* ===================================================================== */
+/* small helpers                                                          */
+/* ===================================================================== */
+
+/* split() of process_vcf_utils.cpp:104-130: std::getline on a stringstream, so a
+ * trailing delimiter does not create a trailing empty field and "" has no fields.
+ * Splits in place; returns the number of fields. */
+static int split_inplace(char *s, char delim, char ***out, int *cap) {
+    int n = 0;
+    if (*s == '\0') return 0;
+    char *p = s;
+    for (;;) {
+        if (n == *cap) {
+            *cap = *cap ? *cap * 2 : 64;
+            *out = (char **)realloc(*out, sizeof(char *) * (size_t)*cap);
+        }
+        (*out)[n++] = p;
+        char *q = strchr(p, delim);
+        if (!q) break;
+        *q = '\0';
+        p = q + 1;
+        if (*p == '\0') break; /* trailing delimiter: getline yields no further item */
+    }
+    return n;
+}
+
+typedef struct { double *v; size_t n, cap; } dvec;
+static void dv_push(dvec *d, double x) {
+    if (d->n == d->cap) {
+        d->cap = d->cap ? d->cap * 2 : 1024;
+        d->v = (double *)realloc(d->v, d->cap * sizeof(double));
+    }
+    d->v[d->n++] = x;
+}
+static void dv_clear(dvec *d) { d->n = 0; }
+static void dv_free(dvec *d) { free(d->v); d->v = NULL; d->n = d->cap = 0; }
+
+/* line reader over zlib (plain files pass through gzread transparently), mirroring
+ * createReader (process_vcf_utils.cpp:872-886) + std::getline */
+typedef struct { gzFile f; char *buf; size_t cap; } lreader;
+static int lr_open(lreader *r, const char *path) {
+    r->f = gzopen(path, "rb");
+    r->buf = NULL; r->cap = 0;
+    if (!r->f) return -1;
+    gzbuffer(r->f, 1 << 20);
+    return 0;
+}
+static char *lr_getline(lreader *r) {
+    size_t len = 0;
+    if (!r->buf) { r->cap = 1 << 16; r->buf = (char *)malloc(r->cap); }
+    for (;;) {
+        if (!gzgets(r->f, r->buf + len, (int)(r->cap - len))) {
+            if (len == 0) return NULL;
+            break;
+        }
+        len += strlen(r->buf + len);
+        if (len && r->buf[len - 1] == '\n') { r->buf[--len] = '\0'; return r->buf; }
+        if (len + 1 >= r->cap) { r->cap *= 2; r->buf = (char *)realloc(r->buf, r->cap); }
+        else if (gzeof(r->f)) break;
+    }
+    r->buf[len] = '\0';
+    return r->buf;
+}
+static void lr_close(lreader *r) { if (r->f) gzclose(r->f); free(r->buf); }
+
+/* ===================================================================== */
+/* per-site math                                                          */
+/* ===================================================================== */
+
+/* process_vcf_fst.h:19-25.  pow(x,2) is x*x at -O2 (and agrees with libm to the bit
+ * for every case tests/test_oracle_vs_ref.py tries). */
+double orc_fst_numerator(double p1, double p2, int n1, int n2) {
+    double power = (p1 - p2) * (p1 - p2);
+    double fraction1 = (p1 * (1 - p1)) / (n1 - 1);
+    double fraction2 = (p2 * (1 - p2)) / (n2 - 1);
+    double numerator = power - fraction1 - fraction2;
+    return numerator;
+}
+
+/* process_vcf_fst.h:27-30 */
+double orc_fst_denominator(double p1, double p2) {
+    return (p1 * (1 - p2)) + (p2 * (1 - p1));
+}
+
+/* process_vcf_fst.h:33-37 */
+double orc_het_simple(double p) {
+    double q = 1 - p;
+    return 1 - (p * p + q * q);
+}
+
+/* process_vcf_fst.h:40-45 */
+double orc_het_nei78(double p, int n) {
+    double q = 1 - p;
+    double simple = 1 - (p * p + q * q);
+    return (n * simple) / (n - 1);
+}
+
+/* process_vcf_utils.h:350-356 */
+double orc_vector_sum(const double *v, size_t n) {
+    double sum = 0;
+    for (size_t i = 0; i < n; i++) sum += v[i];
+    return sum;
+}
+/* process_vcf_utils.h:369-376 */
+double orc_vector_average(const double *v, size_t n) {
+    double sum = 0;
+    for (size_t i = 0; i < n; i++) sum += v[i];
+    return (double)sum / (double)n;
+}
+/* process_vcf_utils.h:378-385 */
+double orc_vector_average_with_region(const double *v, size_t n, int region) {
+    double sum = 0;
+    for (size_t i = 0; i < n; i++) sum += v[i];
+    return (double)sum / (double)region;
+}
+/* process_vcf_fst.cpp:354-360 */
+double orc_calculate_fst(const double *num, const double *den, size_t n) {
+    double na = orc_vector_average(num, n);
+    double da = orc_vector_average(den, n);
+    double fst = na / da;
+    if (fst < 0) fst = 0;
+    return fst;
+}
+
+/* process_vcf_fst.cpp:297-323, the nine-way if-chain kept literally */
+double orc_dxy_literal(const int *a, const int *b, int n1, int n2) {
+    int sumKij = 0;
+    for (int i = 0; i != n1 / 2; i++) {
+        for (int j = 0; j != n2 / 2; j++) {
+            if (a[i] == 0 && b[j] == 0) {
+            } else if (a[i] == 1 && b[j] == 0) { sumKij += 2;
+            } else if (a[i] == 0 && b[j] == 1) { sumKij += 2;
+            } else if (a[i] == 1 && b[j] == 1) { sumKij += 2;
+            } else if (a[i] == 2 && b[j] == 1) { sumKij += 2;
+            } else if (a[i] == 1 && b[j] == 2) { sumKij += 2;
+            } else if (a[i] == 2 && b[j] == 2) {
+            } else if (a[i] == 2 && b[j] == 0) { sumKij += 4;
+            } else if (a[i] == 0 && b[j] == 2) { sumKij += 4;
+            }
+        }
+    }
+    return (double)sumKij / (n1 * n2);
+}
+
+/* process_vcf_fst.cpp:325-351 for one set */
+double orc_pi_literal(const int *hap, int n, int nm) {
+    double pi = 0;
+    for (int i = 0; i < n - 1; i++)
+        for (int j = i + 1; j < n; j++) {
+            if (hap[i] == 1 && hap[j] == 0) pi++;
+            else if (hap[i] == 0 && hap[j] == 1) pi++;
+        }
+    pi = (2.0 / (nm * (nm - 1))) * pi;
+    return pi;
+}
+
+/* sumKij = c1*(n2-c2) + c2*(n1-c1) with the FULL chromosome counts */
+double orc_dxy_closed(int c1, int c2, int n1, int n2) {
+    int sumKij = c1 * (n2 - c2) + c2 * (n1 - c1);
+    return (double)sumKij / (n1 * n2);
+}
+/* k = c*(n-c); (2.0/(nm*(nm-1))) * k with an int product */
+double orc_pi_closed(int c, int n, int nm) {
+    double k = (double)(c * (n - c));
+    return (2.0 / (nm * (nm - 1))) * k;
+}
+
+/* ===================================================================== */
+/* genotype counting, string level                                        */
+/* ===================================================================== */
+
+static void parse_alt_fst(const char *alt_field, int *n_alt, int *allele_as_missing, int *indel) {
+    /* process_vcf_fst.cpp:222-233 */
+    char *tmp = strdup(alt_field);
+    char **f = NULL; int cap = 0;
+    int nf = split_inplace(tmp, ',', &f, &cap);
+    *n_alt = nf; *allele_as_missing = -1; *indel = 0;
+    for (int i = 0; i < nf; i++) {
+        if (strcmp(f[i], "*") == 0) { *n_alt = *n_alt - 1; *allele_as_missing = i + 1; }
+        if (strlen(f[i]) > 1) *indel = 1;
+    }
+    free(f); free(tmp);
+}
+
+void orc_fst_variant_counts(const char *alt_field, const char *const *genotypes,
+                            const size_t *set1_loci, int len1,
+                            const size_t *set2_loci, int len2,
+                            orc_setcounts *out,
+                            int *set1_indiv, int *set2_indiv, int *set1_hap, int *set2_hap) {
+    memset(out, 0, sizeof(*out));
+    int n1 = len1 * 2, n2 = len2 * 2;
+    if (set1_indiv) memset(set1_indiv, 0, sizeof(int) * (size_t)len1);
+    if (set2_indiv) memset(set2_indiv, 0, sizeof(int) * (size_t)len2);
+    if (set1_hap) memset(set1_hap, 0, sizeof(int) * (size_t)n1);
+    if (set2_hap) memset(set2_hap, 0, sizeof(int) * (size_t)n2);
+    out->set1_n_withoutMissing = n1;   /* :219-220 */
+    out->set2_n_withoutMissing = n2;
+    int alleleAsMissing;
+    parse_alt_fst(alt_field, &out->n_alt_alleles, &alleleAsMissing, &out->bIndel);
+    out->allele_as_missing = alleleAsMissing;
+    out->alt_code = 1;
+    if (out->n_alt_alleles == 1) {      /* :235 */
+        int alt = 1;
+        if (alleleAsMissing == 1) alt = 2;   /* :238 */
+        out->alt_code = alt;
+        for (int s = 0; s < len1; s++) {     /* :243-262 */
+            const char *g = genotypes[set1_loci[s]];
+            int v1 = g[0] - '0', v2 = g[2] - '0';
+            if (v1 == alt) {
+                out->set1Count++;
+                if (set1_indiv) set1_indiv[s]++;
+                if (set1_hap) set1_hap[2 * s]++;
+            } else if (g[0] == '.' || v1 == alleleAsMissing) {
+                out->set1_n_withoutMissing--;
+            }
+            if (v2 == alt) {
+                out->set1Count++;
+                if (set1_indiv) set1_indiv[s]++;
+                if (set1_hap) set1_hap[2 * s + 1]++;
+            } else if (g[2] == '.' || v2 == alleleAsMissing) {
+                out->set1_n_withoutMissing--;
+            }
+        }
+        for (int s = 0; s < len2; s++) {     /* :263-280 */
+            const char *g = genotypes[set2_loci[s]];
+            int v1 = g[0] - '0', v2 = g[2] - '0';
+            if (v1 == alt) {
+                out->set2Count++;
+                if (set2_indiv) set2_indiv[s]++;
+                if (set2_hap) set2_hap[2 * s]++;
+            } else if (g[0] == '.' || v1 == alleleAsMissing) {
+                out->set2_n_withoutMissing--;
+            }
+            if (v2 == alt) {
+                out->set2Count++;
+                if (set2_indiv) set2_indiv[s]++;
+                if (set2_hap) set2_hap[2 * s + 1]++;
+            } else if (g[2] == '.' || v2 == alleleAsMissing) {
+                out->set2_n_withoutMissing--;
+            }
+        }
+    }
+}
+
+int orc_fst_site_included(const orc_setcounts *c) {
+    /* process_vcf_fst.cpp:543-544 */
+    return c->n_alt_alleles == 1 && c->bIndel == 0 && (c->set1Count > 0 || c->set2Count > 0) &&
+           (c->set1Count < c->set1_n_withoutMissing || c->set2Count < c->set2_n_withoutMissing);
+}
+
+void orc_general_counts(const char *const *genotypes, int n_samples,
+                        const int32_t *sample_pop, int n_pops, const uint8_t *use_pop,
+                        int *alt, int *alleles, double *aaf,
+                        int *alleles_compl, double *aaf_compl) {
+    for (int k = 0; k < n_pops; k++) { alt[k] = 0; alleles[k] = 0; aaf[k] = -1.0; }
+    /* getBasicCounts, process_vcf_utils.cpp:62-83 */
+    for (int i = 0; i < n_samples; i++) {
+        int k = sample_pop[i];
+        const char *g = genotypes[i];
+        if (g[0] == '1') { if (k >= 0) { alt[k]++; alleles[k]++; } }
+        else if (g[0] == '0') { if (k >= 0) alleles[k]++; }
+        if (g[2] == '1') { if (k >= 0) { alt[k]++; alleles[k]++; } }
+        else if (g[2] == '0') { if (k >= 0) alleles[k]++; }
+    }
+    /* getSetVariantCountsSimple, :55-59 */
+    for (int k = 0; k < n_pops; k++)
+        if (alleles[k] > 0) aaf[k] = (double)alt[k] / alleles[k];
+    /* getComplementCounts, :85-98 */
+    for (int k = 0; k < n_pops; k++) {
+        int ca = 0, ct = 0;
+        for (int u = 0; u < n_pops; u++) {
+            if (!use_pop[u]) continue;
+            if (u != k) { ca += alt[u]; ct += alleles[u]; }
+        }
+        aaf_compl[k] = (double)ca / ct;
+        alleles_compl[k] = ct;
+    }
+}
+
+/* ===================================================================== */
+/* text -> codes                                                          */
+/* ===================================================================== */
+
+uint32_t orc_fst_site_flags(const char *ref_field, const char *alt_field,
+                            int *alt_code, int *allele_as_missing) {
+    int n_alt, aam, indel;
+    parse_alt_fst(alt_field, &n_alt, &aam, &indel);
+    *allele_as_missing = aam;
+    *alt_code = (n_alt == 1 && aam == 1) ? 2 : 1;
+    uint32_t fl = 0;
+    if (strlen(ref_field) > 1) fl |= ORC_SITE_SKIP;      /* fst.cpp:529-532 */
+    if (n_alt != 1 || indel) fl |= ORC_SITE_SKIP;        /* fst.cpp:543 */
+    return fl;
+}
+
+uint8_t orc_fst_allele_code(char ch, int alt_code, int allele_as_missing) {
+    int v = ch - '0';
+    if (v == alt_code) return ORC_ALT;
+    if (ch == '.' || v == allele_as_missing) return ORC_MISSING;
+    return ORC_REF;
+}
+
+uint32_t orc_general_site_flags(const char *ref_field, const char *alt_field) {
+    /* evo_FstAgainstAll.cpp:184-188 */
+    if (strlen(ref_field) > 1 || strlen(alt_field) > 1 || strcmp(alt_field, "*") == 0)
+        return ORC_SITE_SKIP;
+    return 0;
+}
+
+uint8_t orc_general_allele_code(char ch) {
+    if (ch == '1') return ORC_ALT;
+    if (ch == '0') return ORC_REF;
+    return ORC_MISSING;
+}
+
+/* ===================================================================== */
+/* code-level restatements                                                */
+/* ===================================================================== */
+
+void orc_counts_from_codes(const uint8_t *codes, int64_t n_sites, int n_samples,
+                           const int32_t *sample_pop, int n_pops,
+                           int32_t *alt, int32_t *nm) {
+    int32_t *n_full = (int32_t *)calloc((size_t)n_pops, sizeof(int32_t));
+    for (int i = 0; i < n_samples; i++)
+        if (sample_pop[i] >= 0) n_full[sample_pop[i]] += 2;
+    for (int64_t s = 0; s < n_sites; s++) {
+        const uint8_t *row = codes + (size_t)s * 2 * (size_t)n_samples;
+        int32_t *a = alt + (size_t)s * (size_t)n_pops;
+        int32_t *m = nm + (size_t)s * (size_t)n_pops;
+        for (int k = 0; k < n_pops; k++) { a[k] = 0; m[k] = n_full[k]; }
+        for (int i = 0; i < n_samples; i++) {
+            int k = sample_pop[i];
+            if (k < 0) continue;
+            for (int h = 0; h < 2; h++) {
+                uint8_t c = row[2 * i + h];
+                if (c == ORC_ALT) a[k]++;
+                else if (c == ORC_MISSING) m[k]--;
+            }
+        }
+    }
+    free(n_full);
+}
+
+void orc_pair_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, int n_pops,
+                         const int32_t *n_full, const int32_t *pair_i, const int32_t *pair_j,
+                         int n_pairs, const uint8_t *site_flags,
+                         double *num, double *den, double *dxy, uint8_t *include) {
+    for (int64_t s = 0; s < n_sites; s++) {
+        const int32_t *a = alt + (size_t)s * (size_t)n_pops;
+        const int32_t *m = nm + (size_t)s * (size_t)n_pops;
+        int skip = site_flags ? (site_flags[s] & ORC_SITE_SKIP) : 0;
+        for (int q = 0; q < n_pairs; q++) {
+            int i = pair_i[q], j = pair_j[q];
+            int c1 = a[i], c2 = a[j], nm1 = m[i], nm2 = m[j];
+            size_t o = (size_t)s * (size_t)n_pairs + (size_t)q;
+            int inc = !skip && (c1 > 0 || c2 > 0) && (c1 < nm1 || c2 < nm2);
+            if (include) include[o] = (uint8_t)inc;
+            /* values are defined for every non-skipped site; callers mask with include */
+            double p1 = (double)c1 / nm1;           /* utils.h:272-275 */
+            double p2 = (double)c2 / nm2;
+            if (num) num[o] = orc_fst_numerator(p1, p2, nm1, nm2);
+            if (den) den[o] = orc_fst_denominator(p1, p2);
+            if (dxy) dxy[o] = orc_dxy_closed(c1, c2, n_full[i], n_full[j]);
+        }
+    }
+}
+
+void orc_pop_site_div(const int32_t *alt, const int32_t *nm, int64_t n_sites, int n_pops,
+                      const int32_t *n_full, double *het, double *het_nei, double *pi) {
+    for (int64_t s = 0; s < n_sites; s++)
+        for (int k = 0; k < n_pops; k++) {
+            size_t o = (size_t)s * (size_t)n_pops + (size_t)k;
+            double p = (double)alt[o] / n_full[k];            /* fst.cpp:364-365: FULL n */
+            if (het) het[o] = orc_het_simple(p);
+            if (het_nei) het_nei[o] = orc_het_nei78(p, n_full[k]);
+            if (pi) pi[o] = orc_pi_closed(alt[o], n_full[k], nm[o]);
+        }
+}
+
+int64_t orc_snp_windows(const double *num, const double *den, const double *dxy,
+                        const uint8_t *include, int64_t n_sites, int n_pairs, int pair,
+                        int size, int step, int64_t max_windows,
+                        int64_t *first_var, int64_t *end_site,
+                        double *sum_num, double *sum_den, double *sum_dxy,
+                        double *fst, double *mean_dxy) {
+    dvec vn = {0}, vd = {0}, vx = {0};
+    int64_t counted = 0, nw = 0;
+    for (int64_t s = 0; s < n_sites; s++) {
+        size_t o = (size_t)s * (size_t)n_pairs + (size_t)pair;
+        if (!include[o]) continue;
+        counted++;
+        dv_push(&vn, num[o]); dv_push(&vd, den[o]); dv_push(&vx, dxy[o]);
+        if (counted % step == 0 && counted >= size) {      /* fst.cpp:638 */
+            const double *wn = vn.v + vn.n - size, *wd = vd.v + vd.n - size, *wx = vx.v + vx.n - size;
+            if (nw < max_windows) {
+                if (first_var) first_var[nw] = counted - size + 1;
+                if (end_site) end_site[nw] = s;
+                if (sum_num) sum_num[nw] = orc_vector_sum(wn, (size_t)size);
+                if (sum_den) sum_den[nw] = orc_vector_sum(wd, (size_t)size);
+                if (sum_dxy) sum_dxy[nw] = orc_vector_sum(wx, (size_t)size);
+                if (fst) fst[nw] = orc_calculate_fst(wn, wd, (size_t)size);
+                if (mean_dxy) mean_dxy[nw] = orc_vector_average(wx, (size_t)size);
+            }
+            nw++;
+        }
+    }
+    dv_free(&vn); dv_free(&vd); dv_free(&vx);
+    return nw;
+}
+
+void orc_global_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, int n_pops,
+                           const int32_t *use_idx, int n_use, const int64_t *set_sizes,
+                           const uint8_t *site_flags,
+                           uint8_t *kept, double *num, double *den) {
+    for (int64_t s = 0; s < n_sites; s++) {
+        const int32_t *a = alt + (size_t)s * (size_t)n_pops;
+        const int32_t *m = nm + (size_t)s * (size_t)n_pops;
+        kept[s] = 0;
+        if (site_flags && (site_flags[s] & ORC_SITE_SKIP)) continue;
+        int ta = 0, tn = 0;
+        for (int u = 0; u < n_use; u++) { ta += a[use_idx[u]]; tn += m[use_idx[u]]; }
+        /* evo_FstAgainstAll.cpp:198-203 on populationsToUse[0] */
+        {
+            int k0 = use_idx[0];
+            double aaf0 = m[k0] > 0 ? (double)a[k0] / m[k0] : -1.0;   /* utils.cpp:56-58 */
+            double aafc0 = (double)(ta - a[k0]) / (tn - m[k0]);       /* utils.cpp:95 */
+            if (aaf0 == 0 && aafc0 == 0) continue;
+            if (aaf0 == 1 && aafc0 == 1) continue;
+        }
+        kept[s] = 1;
+        for (int u = 0; u < n_use; u++) {
+            int k = use_idx[u];
+            double p1 = m[k] > 0 ? (double)a[k] / m[k] : -1.0;
+            int n1 = m[k];
+            int n2 = tn - m[k];
+            double p2 = (double)(ta - a[k]) / n2;
+            size_t o = (size_t)s * (size_t)n_use + (size_t)u;
+            if (n1 >= set_sizes[u] * 0.8) {                            /* :253 */
+                num[o] = orc_fst_numerator(p1, p2, n1, n2);
+                den[o] = orc_fst_denominator(p1, p2);
+            } else {
+                num[o] = 0; den[o] = 0;
+            }
+        }
+    }
+}
+
+int64_t orc_global_windows(const uint8_t *kept, const uint8_t *site_flags,
+                           const double *num, const double *den,
+                           int64_t n_sites, int n_use, int size, int step, int64_t max_rows,
+                           int64_t *start_site, int64_t *end_site, double *fst) {
+    /* deques of fixed length `size`, zero filled: evo_FstAgainstAll.cpp:119-122 */
+    double *dq_n = (double *)calloc((size_t)size * (size_t)n_use, sizeof(double));
+    double *dq_d = (double *)calloc((size_t)size * (size_t)n_use, sizeof(double));
+    int64_t *dq_c = (int64_t *)malloc(sizeof(int64_t) * (size_t)size);
+    for (int i = 0; i < size; i++) dq_c[i] = -1;
+    int head = 0; /* index of the oldest element in the rings */
+    int64_t used = 0, rows = 0;
+    for (int64_t s = 0; s < n_sites; s++) {
+        if (site_flags && (site_flags[s] & ORC_SITE_SKIP)) continue;
+        used++;                                            /* :189 */
+        if (!kept[s]) continue;                            /* :198-203 */
+        /* push_back + pop_front == overwrite the oldest slot and advance head */
+        dq_c[head] = s;
+        for (int u = 0; u < n_use; u++) {
+            dq_n[(size_t)head * (size_t)n_use + (size_t)u] = num[(size_t)s * (size_t)n_use + (size_t)u];
+            dq_d[(size_t)head * (size_t)n_use + (size_t)u] = den[(size_t)s * (size_t)n_use + (size_t)u];
+        }
+        head = (head + 1) % size;
+        if ((used > size || size == step) && (used % step == 0)) {   /* :238, :276 */
+            if (rows < max_rows) {
+                if (start_site) start_site[rows] = dq_c[head];
+                if (end_site) end_site[rows] = s;
+                for (int u = 0; u < n_use; u++) {
+                    double sn = 0, sd = 0;
+                    for (int t = 0; t < size; t++) {
+                        int idx = (head + t) % size;        /* oldest -> newest */
+                        sn += dq_n[(size_t)idx * (size_t)n_use + (size_t)u];
+                        sd += dq_d[(size_t)idx * (size_t)n_use + (size_t)u];
+                    }
+                    double an = sn / (double)size, ad = sd / (double)size;
+                    double f = an / ad;
+                    if (f < 0 || ad == 0) f = 0;             /* :278 */
+                    if (fst) fst[(size_t)rows * (size_t)n_use + (size_t)u] = f;
+                }
+            }
+            rows++;
+        }
+    }
+    free(dq_n); free(dq_d); free(dq_c);
+    return rows;
+}
+
+/* ===================================================================== */
+/* text-level driver: evo fst (VCF mode)                                  */
+/* ===================================================================== */
+
+static char *path_join(const char *dir, const char *name) {
+    size_t n = strlen(dir) + strlen(name) + 2;
+    char *p = (char *)malloc(n);
+    if (dir[0]) snprintf(p, n, "%s/%s", dir, name); else snprintf(p, n, "%s", name);
+    return p;
+}
+
+static int cmp_str(const void *a, const void *b) {
+    return strcmp(*(const char *const *)a, *(const char *const *)b);
+}
+
+/* locateSet, process_vcf_utils.cpp:923-936: first match per name, missing names dropped */
+static int locate_set(char **sample_names, int n_names, char **set, int n_set, size_t *locs) {
+    int n = 0;
+    for (int i = 0; i < n_set; i++) {
+        int found = -1;
+        for (int j = 0; j < n_names; j++)
+            if (strcmp(sample_names[j], set[i]) == 0) { found = j; break; }
+        if (found < 0) fprintf(stderr, "Did not find the sample: \"%s\"\n", set[i]);
+        else locs[n++] = (size_t)found;
+    }
+    return n;
+}
+
+static char *read_line_dup(FILE *f) {
+    char *line = NULL; size_t cap = 0;
+    ssize_t n = getline(&line, &cap, f);
+    if (n < 0) { free(line); return strdup(""); }
+    if (n && line[n - 1] == '\n') line[n - 1] = '\0';
+    return line;
+}
+
+static char *str3(const char *a, const char *b, const char *c) {
+    size_t n = strlen(a) + strlen(b) + strlen(c) + 1;
+    char *p = (char *)malloc(n);
+    snprintf(p, n, "%s%s%s", a, b, c);
+    return p;
+}
+
+/* first tab-separated field of s equals scaffold?  (split(windowStartEnd,'\t')[0] == scaffold) */
+static int first_field_is(const char *s, const char *scaffold, char **second_field_dup) {
+    const char *t = strchr(s, '\t');
+    size_t l = t ? (size_t)(t - s) : strlen(s);
+    if (second_field_dup) {
+        *second_field_dup = NULL;
+        if (t) {
+            const char *u = strchr(t + 1, '\t');
+            size_t l2 = u ? (size_t)(u - t - 1) : strlen(t + 1);
+            *second_field_dup = strndup(t + 1, l2);
+        }
+    }
+    return strlen(scaffold) == l && strncmp(s, scaffold, l) == 0;
+}
+
+int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples_path,
+                int windowSize, int windowStep, int physicalWindowSize, double regAbove,
+                const char *run_name, const char *out_dir, double *summary) {
+    lreader vcf;
+    if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
+    FILE *setsFile = fopen(sets_path, "r");
+    if (!setsFile) { lr_close(&vcf); return -2; }
+    char name[512];
+    /* output files, process_vcf_fst.cpp:422-437 */
+    FILE *regionsAboveFstFile = NULL; int inRegAbove = 0;
+    if (regAbove > 0) {
+        snprintf(name, sizeof name, "%s_w_%d_fst_above%g.txt", run_name, windowSize, regAbove);
+        char *p = path_join(out_dir, name); regionsAboveFstFile = fopen(p, "w"); free(p);
+    }
+    snprintf(name, sizeof name, "%s_w_%d_fst.txt", run_name, windowSize);
+    char *p1 = path_join(out_dir, name); FILE *pFst = fopen(p1, "w"); free(p1);
+    snprintf(name, sizeof name, "%s_w_%d_fixedWindowStats.txt", run_name, physicalWindowSize);
+    char *p2 = path_join(out_dir, name); FILE *fw = fopen(p2, "w"); free(p2);
+    snprintf(name, sizeof name, "%s_w_%d_heterozygosity.txt", run_name, windowSize);
+    char *p3 = path_join(out_dir, name); FILE *pHet = fopen(p3, "w"); free(p3);
+    if (!pFst || !fw || !pHet) { lr_close(&vcf); fclose(setsFile); return -3; }
+    fprintf(fw, "scaffold\tStart\tEnd\tFst\tDxy\tSet1_pi\tSet2_pi\tAccessible_bp\tSet1_VariantDensity\tSet2_VariantDensity\n");
+
+    /* sets, :440-446 */
+    char *set1String = read_line_dup(setsFile), *set2String = read_line_dup(setsFile);
+    fclose(setsFile);
+    char **set1 = NULL, **set2 = NULL; int c1cap = 0, c2cap = 0;
+    int nset1 = split_inplace(set1String, ',', &set1, &c1cap);
+    int nset2 = split_inplace(set2String, ',', &set2, &c2cap);
+    qsort(set1, (size_t)nset1, sizeof(char *), cmp_str);
+    qsort(set2, (size_t)nset2, sizeof(char *), cmp_str);
+
+    int totalVariantNumber = 0, countedVariantNumber = 0;
+    char *windowMiddleVariant = strdup("first\tWindow");   /* :451 */
+    char *windowStartEnd = strdup("scaffold_0\t0");        /* :452 */
+    int windowStart = 0, windowEnd = 0;
+    int fixedWindowStart = 0;
+    dvec fwDxy = {0}, fwNum = {0}, fwDen = {0}, fwPi1 = {0}, fwPi2 = {0};
+    dvec fstNumerators = {0}, fstDenominators = {0}, DxyVector = {0};
+    dvec het1S = {0}, het2S = {0}, het1N = {0}, het2N = {0}, pi1V = {0}, pi2V = {0};
+    size_t *set1Loci = (size_t *)malloc(sizeof(size_t) * (size_t)(nset1 + 1));
+    size_t *set2Loci = (size_t *)malloc(sizeof(size_t) * (size_t)(nset2 + 1));
+    int len1 = 0, len2 = 0; int n1 = 0, n2 = 0;
+    int *s1indiv = NULL, *s2indiv = NULL, *s1hap = NULL, *s2hap = NULL;
+    char **fields = NULL; int fcap = 0;
+    char *line;
+    while ((line = lr_getline(&vcf)) != NULL) {
+        if (line[0] == '#' && line[1] == '#') {
+        } else if (line[0] == '#' && line[1] == 'C') {
+            char *hdr = strdup(line);
+            char **hf = NULL; int hcap = 0;
+            int nh = split_inplace(hdr, '\t', &hf, &hcap);
+            char **sampleNames = NULL; int nNames = 0; char *namesBlob = NULL;
+            if (!samples_path || !samples_path[0]) {       /* :482-485 */
+                nNames = nh - 9; if (nNames < 0) nNames = 0;
+                sampleNames = hf + 9;
+            } else {                                        /* :486-488 */
+                FILE *sf = fopen(samples_path, "r");
+                size_t cap = 0; char *l = NULL; ssize_t r; int ncap = 0;
+                while (sf && (r = getline(&l, &cap, sf)) >= 0) {
+                    if (r && l[r - 1] == '\n') l[r - 1] = '\0';
+                    if (nNames == ncap) { ncap = ncap ? ncap * 2 : 64; sampleNames = (char **)realloc(sampleNames, sizeof(char *) * (size_t)ncap); }
+                    sampleNames[nNames++] = strdup(l);
+                }
+                free(l); if (sf) fclose(sf);
+                namesBlob = (char *)1;
+            }
+            len1 = locate_set(sampleNames, nNames, set1, nset1, set1Loci);
+            len2 = locate_set(sampleNames, nNames, set2, nset2, set2Loci);
+            n1 = len1 * 2; n2 = len2 * 2;                   /* :491 */
+            s1indiv = (int *)malloc(sizeof(int) * (size_t)(len1 + 1));
+            s2indiv = (int *)malloc(sizeof(int) * (size_t)(len2 + 1));
+            s1hap = (int *)malloc(sizeof(int) * (size_t)(n1 + 2));
+            s2hap = (int *)malloc(sizeof(int) * (size_t)(n2 + 2));
+            if (namesBlob) { for (int i = 0; i < nNames; i++) free(sampleNames[i]); free(sampleNames); }
+            free(hf); free(hdr);
+            if (windowSize > 0) {                           /* :507-520 */
+                if (windowSize == windowStep) {
+                    if (windowSize == 1) {
+                        fprintf(pFst, "var_num\tscaffold\tPosition\tFst\tDxy_thisVariant\n");
+                    } else {
+                        fprintf(pHet, "scaffold\tStart\tEnd\tSet1_heterozygosity\tSet2_heterozygosity\tSet1_heterozygosity_Nei\tSet2_heterozygosity_Nei\tSet1_nucleotideDiversity_pi\tSet2_nucleotideDiversity_pi\n");
+                        fprintf(pFst, "var_num\tscaffold\tStart\tEnd\tFst\tDxy_onlyVariants\tDxy_AllSites\twindowSize\n");
+                    }
+                    if (regAbove > 0) fprintf(regionsAboveFstFile, "scaffold\tStart\tEnd\n");
+                } else {
+                    fprintf(pHet, "Middle_SNP_position\tSet1_heterozygosity\tSet2_heterozygosity\tSet1_heterozygosity_Nei\tSet2_heterozygosity_Nei\tSet1_nucleotideDiversity_pi\tSet2_nucleotideDiversity_pi\n");
+                    fprintf(pFst, "var_num\tscaffold\tStart\tEnd\tFst\tDxy_onlyVariants\tDxy_AllSites\twindowSize\n");
+                }
+            }
+        } else {
+            totalVariantNumber++;
+            int nf = split_inplace(line, '\t', &fields, &fcap);
+            if (nf < 9) continue; /* the reference would index out of range */
+            const char *scaffold = fields[0];
+            const char *loc = fields[1];
+            if (strlen(fields[3]) > 1) continue;            /* :529-532 */
+            orc_setcounts c;
+            orc_fst_variant_counts(fields[4], (const char *const *)(fields + 9), set1Loci, len1, set2Loci, len2,
+                                   &c, s1indiv, s2indiv, s1hap, s2hap);
+            if (orc_fst_site_included(&c)) {
+                countedVariantNumber++;
+                double p1 = (double)c.set1Count / c.set1_n_withoutMissing;
+                double p2 = (double)c.set2Count / c.set2_n_withoutMissing;
+                double FstNumerator = orc_fst_numerator(p1, p2, c.set1_n_withoutMissing, c.set2_n_withoutMissing);
+                dv_push(&fstNumerators, FstNumerator); dv_push(&fwNum, FstNumerator);
+                double FstDenominator = orc_fst_denominator(p1, p2);
+                dv_push(&fstDenominators, FstDenominator); dv_push(&fwDen, FstDenominator);
+                double thisSNPDxy = orc_dxy_literal(s1indiv, s2indiv, n1, n2);
+                dv_push(&DxyVector, thisSNPDxy); dv_push(&fwDxy, thisSNPDxy);
+                double pf1 = (double)c.set1Count / n1, pf2 = (double)c.set2Count / n2;   /* :364-365 */
+                double h1 = orc_het_simple(pf1), h2 = orc_het_simple(pf2);
+                double hn1 = orc_het_nei78(pf1, n1), hn2 = orc_het_nei78(pf2, n2);
+                double pi1 = orc_pi_literal(s1hap, n1, c.set1_n_withoutMissing);
+                double pi2 = orc_pi_literal(s2hap, n2, c.set2_n_withoutMissing);
+                dv_push(&fwPi1, pi1); dv_push(&fwPi2, pi2);
+                dv_push(&pi1V, pi1); dv_push(&pi2V, pi2);
+                dv_push(&het1S, h1); dv_push(&het2S, h2);
+                dv_push(&het1N, hn1); dv_push(&het2N, hn2);
+
+                /* physical windows, :589-629 */
+                if (first_field_is(windowStartEnd, scaffold, NULL)) {
+                    if (atoi(loc) > (fixedWindowStart + physicalWindowSize)) {
+                        int acc = physicalWindowSize;
+                        double fDxy = orc_vector_average_with_region(fwDxy.v, fwDxy.n, acc);
+                        double fFst = orc_calculate_fst(fwNum.v, fwDen.v, fwNum.n);
+                        double fPi1 = orc_vector_average_with_region(fwPi1.v, fwPi1.n, acc);
+                        double fPi2 = orc_vector_average_with_region(fwPi2.v, fwPi2.n, acc);
+                        int z1 = 0, z2 = 0;
+                        for (size_t i = 0; i < fwPi1.n; i++) if (fwPi1.v[i] == 0) z1++;
+                        for (size_t i = 0; i < fwPi2.n; i++) if (fwPi2.v[i] == 0) z2++;
+                        int nv1 = (int)fwPi1.n - z1, nv2 = (int)fwPi2.n - z2;
+                        fprintf(fw, "%s\t%d\t%d\t%g\t%g\t%g\t%g\t%d\t%g\t%g\n", scaffold, fixedWindowStart,
+                                fixedWindowStart + physicalWindowSize, fFst, fDxy, fPi1, fPi2, acc,
+                                (double)nv1 / acc, (double)nv2 / acc);
+                        dv_clear(&fwDxy); dv_clear(&fwNum); dv_clear(&fwDen); dv_clear(&fwPi1); dv_clear(&fwPi2);
+                        int without = 0;
+                        while (atoi(loc) > (fixedWindowStart + physicalWindowSize)) {
+                            if (without > 0) {
+                                fprintf(fw, "%s\t%d\t%d\tNA\t0\t0\t0\t%d\t0\t0\n", scaffold, fixedWindowStart,
+                                        fixedWindowStart + physicalWindowSize, physicalWindowSize);
+                            }
+                            fixedWindowStart = fixedWindowStart + physicalWindowSize;
+                            without++;
+                        }
+                    }
+                } else {
+                    fixedWindowStart = 0;
+                    dv_clear(&fwDxy); dv_clear(&fwNum); dv_clear(&fwDen); dv_clear(&fwPi1); dv_clear(&fwPi2);
+                }
+
+                if (windowSize == 1) {                      /* :633-636 */
+                    double Fst = FstNumerator / FstDenominator;
+                    if (Fst < 0) Fst = 0;
+                    fprintf(pFst, "%d\t%s\t%s\t%g\t%g\n", countedVariantNumber, scaffold, loc, Fst, thisSNPDxy);
+                } else if ((windowSize > 0) && (countedVariantNumber % windowStep == 0) && countedVariantNumber >= windowSize) {
+                    size_t W = (size_t)windowSize;
+                    const double *wn = fstNumerators.v + fstNumerators.n - W;
+                    const double *wd = fstDenominators.v + fstDenominators.n - W;
+                    double windowFst = orc_calculate_fst(wn, wd, W); if (windowFst < 0) windowFst = 0;
+                    const double *wx = DxyVector.v + DxyVector.n - W;
+                    double windowDxy = orc_vector_average(wx, W);
+                    if (windowSize == windowStep) {
+                        char *s1 = NULL;
+                        if (first_field_is(windowStartEnd, scaffold, &s1)) {
+                            char *t = str3(windowStartEnd, "\t", loc); free(windowStartEnd); windowStartEnd = t;
+                            windowEnd = atoi(loc);
+                            double dxyInc = orc_vector_average_with_region(wx, W, windowEnd - windowStart);
+                            fprintf(pFst, "%d\t%s\t%g\t%g\t%g\t%zu\n", countedVariantNumber - windowSize + 1,
+                                    windowStartEnd, windowFst, windowDxy, dxyInc, W);
+                            if (regAbove > 0) {
+                                if (windowFst >= regAbove && !inRegAbove) {
+                                    inRegAbove = 1;
+                                    fprintf(regionsAboveFstFile, "%s\t%s\t", scaffold, s1 ? s1 : "");
+                                } else if (windowFst < regAbove && inRegAbove) {
+                                    inRegAbove = 0;
+                                    fprintf(regionsAboveFstFile, "%s\n", s1 ? s1 : "");
+                                }
+                            }
+                        }
+                        free(s1);
+                    } else {
+                        fprintf(pFst, "%d\t%s\t%g\t%g\t%zu\n", countedVariantNumber - windowSize + 1,
+                                windowMiddleVariant, windowFst, windowDxy, W);
+                    }
+                    double wHetS1 = orc_vector_average(het1S.v + het1S.n - W, W);
+                    double wHetS2 = orc_vector_average(het2S.v + het2S.n - W, W);
+                    double wHetN1 = orc_vector_average(het1N.v + het1N.n - W, W);
+                    double wHetN2 = orc_vector_average(het2N.v + het2N.n - W, W);
+                    double wPi1 = orc_vector_average_with_region(pi1V.v + pi1V.n - W, W, windowEnd - windowStart);
+                    double wPi2 = orc_vector_average_with_region(pi2V.v + pi2V.n - W, W, windowEnd - windowStart);
+                    if (windowSize == windowStep) {
+                        if (first_field_is(windowStartEnd, scaffold, NULL)) {
+                            fprintf(pHet, "%s\t%g\t%g\t%g\t%g\t%g\t%g\n", windowStartEnd, wHetS1, wHetS2, wHetN1, wHetN2, wPi1, wPi2);
+                            free(windowStartEnd); windowStartEnd = str3(scaffold, "\t", loc);
+                            windowStart = atoi(loc);
+                        } else {
+                            free(windowStartEnd); windowStartEnd = str3(scaffold, "\t", "0");
+                            windowStart = 0;
+                        }
+                    } else {
+                        fprintf(pHet, "%s\t%g\t%g\t%g\t%g\n", windowMiddleVariant, wHetS1, wHetS2, wHetN1, wHetN2);
+                        free(windowMiddleVariant); windowMiddleVariant = str3(scaffold, "\t", loc);
+                    }
+                }
+            }
+        }
+    }
+    double Fst = orc_calculate_fst(fstNumerators.v, fstDenominators.v, fstNumerators.n);   /* :701 */
+    double oS1 = orc_vector_average(het1S.v, het1S.n), oS2 = orc_vector_average(het2S.v, het2S.n);
+    double oN1 = orc_vector_average(het1N.v, het1N.n), oN2 = orc_vector_average(het2N.v, het2N.n);
+    fprintf(pHet, "#Heterozygosities: \tS1:%g\tS2:%g\tNei1:%g\tNei2%g\n", oS1, oS2, oN1, oN2);   /* :709 */
+    if (summary) {
+        summary[0] = Fst; summary[1] = oS1; summary[2] = oS2; summary[3] = oN1; summary[4] = oN2;
+        summary[5] = countedVariantNumber; summary[6] = totalVariantNumber;
+    }
+    fclose(pFst); fclose(fw); fclose(pHet); if (regionsAboveFstFile) fclose(regionsAboveFstFile);
+    lr_close(&vcf);
+    dv_free(&fwDxy); dv_free(&fwNum); dv_free(&fwDen); dv_free(&fwPi1); dv_free(&fwPi2);
+    dv_free(&fstNumerators); dv_free(&fstDenominators); dv_free(&DxyVector);
+    dv_free(&het1S); dv_free(&het2S); dv_free(&het1N); dv_free(&het2N); dv_free(&pi1V); dv_free(&pi2V);
+    free(set1Loci); free(set2Loci); free(s1indiv); free(s2indiv); free(s1hap); free(s2hap);
+    free(set1); free(set2); free(set1String); free(set2String);
+    free(windowMiddleVariant); free(windowStartEnd); free(fields);
+    return 0;
+}
+
+/* ===================================================================== */
+/* text-level driver: evo FstGlobal                                       */
+/* ===================================================================== */
+
+typedef struct { char *name; char **ids; int n_ids, cap; size_t *pos; int n_pos; } pop_t;
+
+static int cmp_pop(const void *a, const void *b) {
+    return strcmp(((const pop_t *)a)->name, ((const pop_t *)b)->name);
+}
+
+int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
+                      int windowSize, int windowStep, int fixedWindowSize,
+                      const char *run_name, const char *out_dir) {
+    lreader vcf;
+    if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
+    FILE *sf = fopen(pops_path, "r");
+    if (!sf) { lr_close(&vcf); return -2; }
+    /* :83-89  popToIDsMap / IDsToPopMap (later duplicate IDs overwrite the pop of the ID) */
+    pop_t *pops = NULL; int n_pops = 0, pcap = 0;
+    char **id_names = NULL; char **id_pop = NULL; int n_ids = 0, icap = 0;
+    {
+        char *l = NULL; size_t cap = 0; ssize_t r;
+        while ((r = getline(&l, &cap, sf)) >= 0) {
+            if (r && l[r - 1] == '\n') l[r - 1] = '\0';
+            char *tab = strchr(l, '\t');
+            if (!tab) continue; /* reference would read ID_Pop[1] out of range */
+            *tab = '\0';
+            char *id = l, *pn = tab + 1;
+            char *tab2 = strchr(pn, '\t'); if (tab2) *tab2 = '\0';
+            int k = -1;
+            for (int i = 0; i < n_pops; i++) if (strcmp(pops[i].name, pn) == 0) { k = i; break; }
+            if (k < 0) {
+                if (n_pops == pcap) { pcap = pcap ? pcap * 2 : 16; pops = (pop_t *)realloc(pops, sizeof(pop_t) * (size_t)pcap); }
+                k = n_pops++;
+                memset(&pops[k], 0, sizeof(pop_t));
+                pops[k].name = strdup(pn);
+            }
+            pop_t *P = &pops[k];
+            if (P->n_ids == P->cap) { P->cap = P->cap ? P->cap * 2 : 16; P->ids = (char **)realloc(P->ids, sizeof(char *) * (size_t)P->cap); }
+            P->ids[P->n_ids++] = strdup(id);
+            int found = -1;
+            for (int i = 0; i < n_ids; i++) if (strcmp(id_names[i], id) == 0) { found = i; break; }
+            if (found < 0) {
+                if (n_ids == icap) { icap = icap ? icap * 2 : 64; id_names = (char **)realloc(id_names, sizeof(char *) * (size_t)icap); id_pop = (char **)realloc(id_pop, sizeof(char *) * (size_t)icap); }
+                id_names[n_ids] = strdup(id); id_pop[n_ids] = strdup(pn); n_ids++;
+            } else { free(id_pop[found]); id_pop[found] = strdup(pn); }
+        }
+        free(l); fclose(sf);
+    }
+    qsort(pops, (size_t)n_pops, sizeof(pop_t), cmp_pop);    /* std::map order */
+    int *use_idx = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1)); int n_use = 0;
+    uint8_t *use_pop = (uint8_t *)calloc((size_t)n_pops + 1, 1);
+    for (int k = 0; k < n_pops; k++)
+        if (strcmp(pops[k].name, "Outgroup") != 0 && strcmp(pops[k].name, "xxx") != 0) { use_idx[n_use++] = k; use_pop[k] = 1; }
+    fprintf(stderr, "There are %d populations \n", n_pops);
+
+    char name[512];
+    snprintf(name, sizeof name, "%s_FstGlobal_%d_%d.txt", run_name, windowSize, windowStep);
+    char *p1 = path_join(out_dir, name); FILE *outFile = fopen(p1, "w"); free(p1);
+    snprintf(name, sizeof name, "%s_FstGlobal_FW%d.txt", run_name, fixedWindowSize);
+    char *p2 = path_join(out_dir, name); FILE *outFW = fopen(p2, "w"); free(p2);
+    if (!outFile || !outFW) { lr_close(&vcf); return -3; }
+    fprintf(outFile, "chr\tpos1\tpos2\tFstGlobal");          /* :101-102 */
+    for (int u = 0; u < n_use; u++) fprintf(outFile, "\t%s", pops[use_idx[u]].name);
+    fprintf(outFile, "\n");
+    fprintf(outFW, "chr\tpos1\tpos2\tnSNPs");                /* :104: pop names go to outFile (sic) */
+    for (int u = 0; u < n_use; u++) fprintf(outFile, "\t%s", pops[use_idx[u]].name);
+    fprintf(outFW, "\n");
+
+    size_t nu = (size_t)n_use;
+    double *dqN = (double *)calloc((size_t)windowSize * (nu + 1), sizeof(double));
+    double *dqD = (double *)calloc((size_t)windowSize * (nu + 1), sizeof(double));
+    char **coordDeque = (char **)malloc(sizeof(char *) * (size_t)(windowSize > 0 ? windowSize : 1));
+    for (int i = 0; i < windowSize; i++) coordDeque[i] = strdup("0");
+    int head = 0;
+    int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
+    int totalVariantNumber = 0, usedVariantNumber = 0;
+    int32_t *sample_pop = NULL; int n_samples = 0;
+    char **fields = NULL; int fcap = 0;
+    int *alt = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1)), *alleles = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1));
+    int *allelesC = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1));
+    double *aaf = (double *)malloc(sizeof(double) * (size_t)(n_pops + 1)), *aafC = (double *)malloc(sizeof(double) * (size_t)(n_pops + 1));
+    char *line;
+    int rc = 0;
+    while ((line = lr_getline(&vcf)) != NULL) {
+        /* :146 strip every '\r' */
+        { char *w = line; for (char *r = line; *r; r++) if (*r != '\r') *w++ = *r; *w = '\0'; }
+        if (line[0] == '#' && line[1] == '#') continue;
+        else if (line[0] == '#' && line[1] == 'C') {
+            char *hdr = strdup(line); char **hf = NULL; int hcap = 0;
+            int nh = split_inplace(hdr, '\t', &hf, &hcap);
+            n_samples = nh - 9; if (n_samples < 0) n_samples = 0;
+            sample_pop = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_samples + 1));
+            for (int i = 0; i < n_samples; i++) {            /* :153-155 */
+                sample_pop[i] = -1;
+                for (int j = 0; j < n_ids; j++)
+                    if (strcmp(id_names[j], hf[9 + i]) == 0) {
+                        for (int k = 0; k < n_pops; k++) if (strcmp(pops[k].name, id_pop[j]) == 0) sample_pop[i] = k;
+                        break;
+                    }
+            }
+            for (int k = 0; k < n_pops; k++) {               /* :158-168 */
+                pops[k].pos = (size_t *)malloc(sizeof(size_t) * (size_t)(pops[k].n_ids + 1));
+                pops[k].n_pos = locate_set(hf + 9, n_samples, pops[k].ids, pops[k].n_ids, pops[k].pos);
+                if (pops[k].n_pos == 0) {
+                    fprintf(stderr, "Did not find any samples in the VCF for \"%s\"\n", pops[k].name);
+                    rc = -4;   /* the reference aborts on assert(!spPos.empty()) */
+                }
+            }
+            free(hf); free(hdr);
+            if (rc) break;
+        } else {
+            totalVariantNumber++;
+            int nf = split_inplace(line, '\t', &fields, &fcap);
+            if (nf < 9) continue;
+            const char *chr = fields[0]; const char *coord = fields[1];
+            double coordDouble = strtod(coord, NULL);
+            if (orc_general_site_flags(fields[3], fields[4]) & ORC_SITE_SKIP) continue;   /* :185-188 */
+            usedVariantNumber++;
+            orc_general_counts((const char *const *)(fields + 9), n_samples, sample_pop, n_pops, use_pop,
+                               alt, alleles, aaf, allelesC, aafC);
+            int k0 = use_idx[0];
+            if (aaf[k0] == 0 && aafC[k0] == 0) continue;     /* :198-203 */
+            if (aaf[k0] == 1 && aafC[k0] == 1) continue;
+
+            if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {   /* :222-235 */
+                fprintf(outFW, "%s\t%d\t%d\t%d", chr, currentWindowStart, currentWindowEnd, 0);
+                for (int u = 0; u < n_use; u++) fprintf(outFW, "\t%g", 0.0);
+                fprintf(outFW, "\n");
+                if (coordDouble > currentWindowEnd) {
+                    currentWindowStart = currentWindowStart + fixedWindowSize; currentWindowEnd = currentWindowEnd + fixedWindowSize;
+                } else if (coordDouble < currentWindowStart) {
+                    currentWindowStart = 0; currentWindowEnd = 0 + fixedWindowSize;
+                }
+            }
+            /* :237 coordDeque.push_back(coord); pop_front() */
+            free(coordDeque[head]); coordDeque[head] = strdup(coord);
+            int newest = head;
+            head = (head + 1) % windowSize;
+            int emit = (usedVariantNumber > windowSize || windowSize == windowStep) && (usedVariantNumber % windowStep == 0);
+            if (emit) fprintf(outFile, "%s\t%s\t%s\tN", chr, coordDeque[head], coord);
+            for (int u = 0; u < n_use; u++) {                /* :244-282 */
+                int k = use_idx[u];
+                double p1v = aaf[k], p2v = aafC[k]; int n1v = alleles[k], n2v = allelesC[k];
+                double FstNum, FstDenom;
+                /* c->setSizes[i]: sizes in ALL-pops order indexed by position in populationsToUse */
+                size_t setSize_i = (size_t)pops[u].n_pos;
+                if (n1v >= setSize_i * 0.8) {
+                    FstNum = orc_fst_numerator(p1v, p2v, n1v, n2v);
+                    FstDenom = orc_fst_denominator(p1v, p2v);
+                } else { FstNum = 0; FstDenom = 0; }
+                dqN[(size_t)newest * (nu + 1) + (size_t)u] = FstNum;
+                dqD[(size_t)newest * (nu + 1) + (size_t)u] = FstDenom;
+                if (emit) {
+                    double sn = 0, sd = 0;
+                    for (int t = 0; t < windowSize; t++) {
+                        int idx = (head + t) % windowSize;
+                        sn += dqN[(size_t)idx * (nu + 1) + (size_t)u];
+                        sd += dqD[(size_t)idx * (nu + 1) + (size_t)u];
+                    }
+                    double an = sn / (double)windowSize, ad = sd / (double)windowSize;
+                    double Fst = an / ad; if (Fst < 0 || ad == 0) Fst = 0;
+                    fprintf(outFile, "\t%g", Fst);
+                }
+            }
+            if (emit) fprintf(outFile, "\n");
+        }
+    }
+    fclose(outFile); fclose(outFW); lr_close(&vcf);
+    for (int i = 0; i < windowSize; i++) free(coordDeque[i]);
+    free(coordDeque); free(dqN); free(dqD); free(fields); free(sample_pop);
+    free(alt); free(alleles); free(allelesC); free(aaf); free(aafC); free(use_idx); free(use_pop);
+    for (int k = 0; k < n_pops; k++) {
+        for (int i = 0; i < pops[k].n_ids; i++) free(pops[k].ids[i]);
+        free(pops[k].ids); free(pops[k].pos); free(pops[k].name);
+    }
+    free(pops);
+    for (int i = 0; i < n_ids; i++) { free(id_names[i]); free(id_pop[i]); }
+    free(id_names); free(id_pop);
+    return rc;
+}

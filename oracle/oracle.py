@@ -1,0 +1,265 @@
+"""ctypes loader for the CPU oracle (oracle/evo_oracle.c) and the reference math shim.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (evo_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libevo_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libevo_refmath.so")
+
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+_ip = C.POINTER(C.c_int)
+
+
+def build(force=False):
+    """(Re)build the oracle library; also the reference shim when /root/reference exists."""
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
+            os.path.join(_HERE, "evo_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "libevo_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class SetCounts(C.Structure):
+    _fields_ = [("set1Count", C.c_int), ("set2Count", C.c_int),
+                ("set1_n_withoutMissing", C.c_int), ("set2_n_withoutMissing", C.c_int),
+                ("n_alt_alleles", C.c_int), ("bIndel", C.c_int),
+                ("alt_code", C.c_int), ("allele_as_missing", C.c_int)]
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orc_fst_numerator.restype = C.c_double
+        L.orc_fst_numerator.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+        L.orc_fst_denominator.restype = C.c_double
+        L.orc_fst_denominator.argtypes = [C.c_double, C.c_double]
+        L.orc_het_simple.restype = C.c_double
+        L.orc_het_simple.argtypes = [C.c_double]
+        L.orc_het_nei78.restype = C.c_double
+        L.orc_het_nei78.argtypes = [C.c_double, C.c_int]
+        for f in ("orc_vector_sum", "orc_vector_average"):
+            getattr(L, f).restype = C.c_double
+            getattr(L, f).argtypes = [_dp, C.c_size_t]
+        L.orc_vector_average_with_region.restype = C.c_double
+        L.orc_vector_average_with_region.argtypes = [_dp, C.c_size_t, C.c_int]
+        L.orc_calculate_fst.restype = C.c_double
+        L.orc_calculate_fst.argtypes = [_dp, _dp, C.c_size_t]
+        L.orc_dxy_literal.restype = C.c_double
+        L.orc_dxy_literal.argtypes = [_ip, _ip, C.c_int, C.c_int]
+        L.orc_pi_literal.restype = C.c_double
+        L.orc_pi_literal.argtypes = [_ip, C.c_int, C.c_int]
+        L.orc_dxy_closed.restype = C.c_double
+        L.orc_dxy_closed.argtypes = [C.c_int] * 4
+        L.orc_pi_closed.restype = C.c_double
+        L.orc_pi_closed.argtypes = [C.c_int] * 3
+        L.orc_fst_variant_counts.restype = None
+        L.orc_fst_variant_counts.argtypes = [C.c_char_p, C.POINTER(C.c_char_p),
+                                             C.POINTER(C.c_size_t), C.c_int,
+                                             C.POINTER(C.c_size_t), C.c_int,
+                                             C.POINTER(SetCounts), _ip, _ip, _ip, _ip]
+        L.orc_fst_site_included.restype = C.c_int
+        L.orc_fst_site_included.argtypes = [C.POINTER(SetCounts)]
+        L.orc_general_counts.restype = None
+        L.orc_general_counts.argtypes = [C.POINTER(C.c_char_p), C.c_int, _i32p, C.c_int, _u8p,
+                                         _ip, _ip, _dp, _ip, _dp]
+        L.orc_fst_site_flags.restype = C.c_uint32
+        L.orc_fst_site_flags.argtypes = [C.c_char_p, C.c_char_p, _ip, _ip]
+        L.orc_fst_allele_code.restype = C.c_uint8
+        L.orc_fst_allele_code.argtypes = [C.c_char, C.c_int, C.c_int]
+        L.orc_general_site_flags.restype = C.c_uint32
+        L.orc_general_site_flags.argtypes = [C.c_char_p, C.c_char_p]
+        L.orc_general_allele_code.restype = C.c_uint8
+        L.orc_general_allele_code.argtypes = [C.c_char]
+        L.orc_counts_from_codes.restype = None
+        L.orc_counts_from_codes.argtypes = [_u8p, C.c_int64, C.c_int, _i32p, C.c_int, _i32p, _i32p]
+        L.orc_pair_site_stats.restype = None
+        L.orc_pair_site_stats.argtypes = [_i32p, _i32p, C.c_int64, C.c_int, _i32p, _i32p, _i32p,
+                                          C.c_int, _u8p, _dp, _dp, _dp, _u8p]
+        L.orc_pop_site_div.restype = None
+        L.orc_pop_site_div.argtypes = [_i32p, _i32p, C.c_int64, C.c_int, _i32p, _dp, _dp, _dp]
+        L.orc_snp_windows.restype = C.c_int64
+        L.orc_snp_windows.argtypes = [_dp, _dp, _dp, _u8p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp, _dp]
+        L.orc_global_site_stats.restype = None
+        L.orc_global_site_stats.argtypes = [_i32p, _i32p, C.c_int64, C.c_int, _i32p, C.c_int, _i64p,
+                                            _u8p, _u8p, _dp, _dp]
+        L.orc_global_windows.restype = C.c_int64
+        L.orc_global_windows.argtypes = [_u8p, _u8p, _dp, _dp, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                         C.c_int64, _i64p, _i64p, _dp]
+        L.orc_fst_run.restype = C.c_int
+        L.orc_fst_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_double, C.c_char_p, C.c_char_p, _dp]
+        L.orc_fstglobal_run.restype = C.c_int
+        L.orc_fstglobal_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_char_p, C.c_char_p]
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The reference's own inline math, or None when oracle/_ref was never built."""
+    global _ref
+    if _ref is None:
+        build()
+        if not os.path.exists(_REF):
+            return None
+        R = C.CDLL(_REF)
+        R.ref_calculateFstNumerator.restype = C.c_double
+        R.ref_calculateFstNumerator.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+        R.ref_calculateFstDenominator.restype = C.c_double
+        R.ref_calculateFstDenominator.argtypes = [C.c_double, C.c_double]
+        R.ref_calculateExpectedHeterozygositySimple.restype = C.c_double
+        R.ref_calculateExpectedHeterozygositySimple.argtypes = [C.c_double]
+        R.ref_calculateExpectedHeterozygosityNei78.restype = C.c_double
+        R.ref_calculateExpectedHeterozygosityNei78.argtypes = [C.c_double, C.c_int]
+        for f in ("ref_vector_sum", "ref_vector_average"):
+            getattr(R, f).restype = C.c_double
+            getattr(R, f).argtypes = [_dp, C.c_size_t]
+        R.ref_vector_average_withRegion.restype = C.c_double
+        R.ref_vector_average_withRegion.argtypes = [_dp, C.c_size_t, C.c_int]
+        R.ref_calculateAlleleFrequencies.restype = None
+        R.ref_calculateAlleleFrequencies.argtypes = [C.c_int] * 4 + [_dp, _dp]
+        R.ref_general_ctor.restype = C.c_int
+        R.ref_general_ctor.argtypes = [C.POINTER(C.c_char_p), _ip, C.c_int, C.POINTER(C.c_long), _dp, _dp]
+        R.ref_build_info.restype = C.c_char_p
+        _ref = R
+    return _ref
+
+
+# ---------------------------------------------------------------------------
+# numpy-level conveniences
+# ---------------------------------------------------------------------------
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def fst_variant_counts(alt_field, genotypes, set1, set2):
+    """Literal getVariantCountsForFst on genotype strings. Returns (SetCounts, indiv1, indiv2, hap1, hap2)."""
+    L = lib()
+    g = (C.c_char_p * len(genotypes))(*[s.encode() for s in genotypes])
+    s1 = (C.c_size_t * max(1, len(set1)))(*set1)
+    s2 = (C.c_size_t * max(1, len(set2)))(*set2)
+    out = SetCounts()
+    i1 = np.zeros(max(1, len(set1)), np.intc); i2 = np.zeros(max(1, len(set2)), np.intc)
+    h1 = np.zeros(max(2, 2 * len(set1)), np.intc); h2 = np.zeros(max(2, 2 * len(set2)), np.intc)
+    L.orc_fst_variant_counts(alt_field.encode(), g, s1, len(set1), s2, len(set2), C.byref(out),
+                             _p(i1, _ip), _p(i2, _ip), _p(h1, _ip), _p(h2, _ip))
+    return out, i1[:len(set1)], i2[:len(set2)], h1[:2 * len(set1)], h2[:2 * len(set2)]
+
+
+def general_counts(genotypes, sample_pop, n_pops, use_pop):
+    L = lib()
+    g = (C.c_char_p * len(genotypes))(*[s.encode() for s in genotypes])
+    sp = np.ascontiguousarray(sample_pop, np.int32)
+    up = np.ascontiguousarray(use_pop, np.uint8)
+    alt = np.zeros(n_pops, np.intc); alleles = np.zeros(n_pops, np.intc); allc = np.zeros(n_pops, np.intc)
+    aaf = np.zeros(n_pops); aafc = np.zeros(n_pops)
+    L.orc_general_counts(g, len(genotypes), _p(sp, _i32p), n_pops, _p(up, _u8p),
+                         _p(alt, _ip), _p(alleles, _ip), _p(aaf, _dp), _p(allc, _ip), _p(aafc, _dp))
+    return alt, alleles, aaf, allc, aafc
+
+
+def counts_from_codes(codes, sample_pop, n_pops):
+    """codes: uint8 [S, 2N] -> (alt, nm) int32 [S, P]."""
+    L = lib()
+    codes = np.ascontiguousarray(codes, np.uint8)
+    S, H = codes.shape
+    sp = np.ascontiguousarray(sample_pop, np.int32)
+    alt = np.empty((S, n_pops), np.int32); nm = np.empty((S, n_pops), np.int32)
+    L.orc_counts_from_codes(_p(codes, _u8p), S, H // 2, _p(sp, _i32p), n_pops, _p(alt, _i32p), _p(nm, _i32p))
+    return alt, nm
+
+
+def pair_site_stats(alt, nm, n_full, pair_i, pair_j, site_flags=None):
+    L = lib()
+    alt = np.ascontiguousarray(alt, np.int32); nm = np.ascontiguousarray(nm, np.int32)
+    S, P = alt.shape
+    nf = np.ascontiguousarray(n_full, np.int32)
+    pi = np.ascontiguousarray(pair_i, np.int32); pj = np.ascontiguousarray(pair_j, np.int32)
+    Q = len(pi)
+    fl = np.ascontiguousarray(site_flags, np.uint8) if site_flags is not None else None
+    num = np.empty((S, Q)); den = np.empty((S, Q)); dxy = np.empty((S, Q)); inc = np.empty((S, Q), np.uint8)
+    L.orc_pair_site_stats(_p(alt, _i32p), _p(nm, _i32p), S, P, _p(nf, _i32p), _p(pi, _i32p), _p(pj, _i32p), Q,
+                          _p(fl, _u8p), _p(num, _dp), _p(den, _dp), _p(dxy, _dp), _p(inc, _u8p))
+    return num, den, dxy, inc
+
+
+def pop_site_div(alt, nm, n_full):
+    L = lib()
+    alt = np.ascontiguousarray(alt, np.int32); nm = np.ascontiguousarray(nm, np.int32)
+    S, P = alt.shape
+    nf = np.ascontiguousarray(n_full, np.int32)
+    het = np.empty((S, P)); hn = np.empty((S, P)); pi = np.empty((S, P))
+    L.orc_pop_site_div(_p(alt, _i32p), _p(nm, _i32p), S, P, _p(nf, _i32p), _p(het, _dp), _p(hn, _dp), _p(pi, _dp))
+    return het, hn, pi
+
+
+def snp_windows(num, den, dxy, inc, pair, size, step):
+    L = lib()
+    S, Q = num.shape
+    mw = S // max(1, step) + 1
+    fv = np.empty(mw, np.int64); es = np.empty(mw, np.int64)
+    sn = np.empty(mw); sd = np.empty(mw); sx = np.empty(mw); fst = np.empty(mw); md = np.empty(mw)
+    n = L.orc_snp_windows(_p(num, _dp), _p(den, _dp), _p(dxy, _dp), _p(inc, _u8p), S, Q, pair, size, step, mw,
+                          _p(fv, _i64p), _p(es, _i64p), _p(sn, _dp), _p(sd, _dp), _p(sx, _dp), _p(fst, _dp), _p(md, _dp))
+    return dict(first_var=fv[:n], end_site=es[:n], sum_num=sn[:n], sum_den=sd[:n], sum_dxy=sx[:n],
+                fst=fst[:n], mean_dxy=md[:n])
+
+
+def global_site_stats(alt, nm, use_idx, set_sizes, site_flags=None):
+    L = lib()
+    alt = np.ascontiguousarray(alt, np.int32); nm = np.ascontiguousarray(nm, np.int32)
+    S, P = alt.shape
+    ui = np.ascontiguousarray(use_idx, np.int32); ss = np.ascontiguousarray(set_sizes, np.int64)
+    U = len(ui)
+    fl = np.ascontiguousarray(site_flags, np.uint8) if site_flags is not None else None
+    kept = np.zeros(S, np.uint8); num = np.zeros((S, U)); den = np.zeros((S, U))
+    L.orc_global_site_stats(_p(alt, _i32p), _p(nm, _i32p), S, P, _p(ui, _i32p), U, _p(ss, _i64p),
+                            _p(fl, _u8p), _p(kept, _u8p), _p(num, _dp), _p(den, _dp))
+    return kept, num, den
+
+
+def global_windows(kept, num, den, size, step, site_flags=None):
+    L = lib()
+    S, U = num.shape
+    fl = np.ascontiguousarray(site_flags, np.uint8) if site_flags is not None else None
+    mr = S // max(1, step) + 1
+    ss = np.empty(mr, np.int64); es = np.empty(mr, np.int64); fst = np.empty((mr, U))
+    n = L.orc_global_windows(_p(kept, _u8p), _p(fl, _u8p), _p(num, _dp), _p(den, _dp), S, U, size, step, mr,
+                             _p(ss, _i64p), _p(es, _i64p), _p(fst, _dp))
+    return dict(start_site=ss[:n], end_site=es[:n], fst=fst[:n])
+
+
+def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_above=0.0, samples=None):
+    summ = np.zeros(7)
+    rc = lib().orc_fst_run(vcf.encode(), sets.encode(), (samples or "").encode(), size, step, phys,
+                           reg_above, run_name.encode(), out_dir.encode(), _p(summ, _dp))
+    if rc != 0:
+        raise RuntimeError("orc_fst_run failed: %d" % rc)
+    return summ
+
+
+def fstglobal_run(vcf, pops, out_dir, run_name="", size=20, step=10, fixed=10000):
+    if size <= 0 or step <= 0:
+        raise ValueError("FstGlobal needs positive window size and step")
+    rc = lib().orc_fstglobal_run(vcf.encode(), pops.encode(), size, step, fixed,
+                                 run_name.encode(), out_dir.encode())
+    if rc != 0:
+        raise RuntimeError("orc_fstglobal_run failed: %d" % rc)

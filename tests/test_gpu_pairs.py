@@ -1,0 +1,171 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle, pairs mode.
+
+Bars: allele counts, include flags and window membership bit-exact; per-site doubles bit-exact
+(the kernels keep the reference's operation order, -ffp-contract=off); window sums within
+1e-12 relative to the sum of |terms| (summation order differs at chunk boundaries only).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from tests.helpers import random_codes, round_robin_pops, n_full_of, assert_same_bits
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-12
+
+
+def _setup(engine, rng, S, N, P, miss, flags=False):
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=miss)
+    engine.set_layout(sp, P)
+    tiles = engine.pack_codes(codes)
+    fl = None
+    if flags:
+        fl = (rng.random(S) < 0.05).astype(np.uint8)
+    engine.upload(tiles, S, site_flags=fl)
+    return sp, codes, fl
+
+
+@pytest.mark.parametrize("S,N,P,miss", [(1000, 40, 4, 0.05), (777, 200, 10, 0.0), (2048, 64, 3, 0.3),
+                                        (130, 600, 2, 0.1), (5000, 90, 9, 0.15)])
+def test_counts_bit_exact(engine, S, N, P, miss):
+    rng = np.random.default_rng(S + N)
+    sp, codes, _ = _setup(engine, rng, S, N, P, miss)
+    engine.run_counts()
+    alt, nm = engine.counts()
+    oalt, onm = O.counts_from_codes(codes, sp, P)
+    assert np.array_equal(alt, oalt)
+    assert np.array_equal(nm, onm)
+
+
+def test_counts_with_unassigned_samples(engine):
+    rng = np.random.default_rng(5)
+    N, P, S = 50, 3, 300
+    sp = round_robin_pops(N, P)
+    sp[::7] = -1
+    codes = random_codes(rng, S, sp, P, miss=0.1, edge=False)
+    engine.set_layout(sp, P)
+    engine.upload(engine.pack_codes(codes), S)
+    engine.run_counts()
+    alt, nm = engine.counts()
+    oalt, onm = O.counts_from_codes(codes, sp, P)
+    assert np.array_equal(alt, oalt) and np.array_equal(nm, onm)
+
+
+@pytest.mark.parametrize("S,N,P,miss,flags", [(1500, 40, 4, 0.1, False), (900, 200, 10, 0.02, True),
+                                              (640, 24, 6, 0.4, True)])
+def test_site_stats_bit_exact(engine, S, N, P, miss, flags):
+    rng = np.random.default_rng(S * 3 + P)
+    sp, codes, fl = _setup(engine, rng, S, N, P, miss, flags)
+    engine.set_pairs()
+    engine.run_counts()
+    num, den, dxy, inc = engine.site_stats()
+    pi, pj = engine.all_pairs()
+    oalt, onm = O.counts_from_codes(codes, sp, P)
+    nf = n_full_of(sp, P)
+    onum, oden, odxy, oinc = O.pair_site_stats(oalt, onm, nf, pi, pj, fl)
+    assert np.array_equal(inc.T, oinc)
+    with np.errstate(all="ignore"):
+        assert_same_bits(num.T, onum, "num")
+        assert_same_bits(den.T, oden, "den")
+        assert_same_bits(dxy.T, odxy, "dxy")
+    het, hn, pis = engine.pop_site_div()
+    ohet, ohn, opi = O.pop_site_div(oalt, onm, nf)
+    assert_same_bits(het.T, ohet, "het")
+    assert_same_bits(hn.T, ohn, "hetNei")
+    assert_same_bits(pis.T, opi, "pi")
+    # census == number of included sites
+    assert np.array_equal(engine.included_totals(), oinc.sum(axis=0))
+
+
+def _check_windows(engine, sp, codes, fl, P, size, step):
+    pi, pj = engine.all_pairs()
+    nf = n_full_of(sp, P)
+    oalt, onm = O.counts_from_codes(codes, sp, P)
+    onum, oden, odxy, oinc = O.pair_site_stats(oalt, onm, nf, pi, pj, fl)
+    engine.set_windows(size, step)
+    engine.run()
+    seg = engine.segments()
+    tot = engine.totals()
+    from evo_amd import compose_snp_windows
+    for q in range(len(pi)):
+        ow = O.snp_windows(onum, oden, odxy, oinc, q, size, step)
+        gw = compose_snp_windows(seg, q, size, step, nf[pi[q]], nf[pj[q]])
+        assert np.array_equal(gw["first_var"], ow["first_var"]), q
+        assert np.array_equal(gw["end_site"], ow["end_site"]), q
+        m = oinc[:, q] == 1
+        for name, terms in (("sum_num", onum[m, q]), ("sum_den", oden[m, q]), ("sum_dxy", odxy[m, q])):
+            a, b = gw[name], ow[name]
+            ok_nan = np.isnan(a) == np.isnan(b)
+            assert ok_nan.all(), (q, name)
+            fin = ~np.isnan(b)
+            # scale: sum of |terms| of a window is bounded by size * max|term|
+            scale = size * np.nanmax(np.abs(terms)) if terms.size and np.isfinite(np.nanmax(np.abs(terms))) else 1.0
+            assert np.all(np.abs(a[fin] - b[fin]) <= REL_TOL * max(scale, 1e-300)), (q, name)
+        # Fst of a window: same clamp and NaN behaviour, 1e-12 where the denominator is not degenerate
+        fa, fb = gw["fst"], ow["fst"]
+        assert (np.isnan(fa) == np.isnan(fb)).all()
+        fin = np.isfinite(fb) & (fb > 1e-6)
+        assert np.all(np.abs(fa[fin] - fb[fin]) <= 1e-9 * np.abs(fb[fin]))
+        # whole-shard sums
+        assert tot[q, 3] == m.sum()
+        if m.any() and np.isfinite(onum[m, q]).all():
+            assert abs(tot[q, 0] - onum[m, q].sum()) <= REL_TOL * np.abs(onum[m, q]).sum() + 1e-300
+            assert abs(tot[q, 1] - oden[m, q].sum()) <= REL_TOL * np.abs(oden[m, q]).sum() + 1e-300
+
+
+@pytest.mark.parametrize("S,N,P,miss,size,step", [(6000, 40, 4, 0.05, 100, 100), (5000, 60, 5, 0.1, 20, 10),
+                                                  (3000, 30, 3, 0.0, 7, 7), (4000, 40, 4, 0.2, 30, 12),
+                                                  (700, 40, 4, 0.05, 1000, 1000)])
+def test_snp_windows(engine, S, N, P, miss, size, step):
+    rng = np.random.default_rng(S + size)
+    sp, codes, fl = _setup(engine, rng, S, N, P, miss, flags=True)
+    engine.set_pairs()
+    _check_windows(engine, sp, codes, fl, P, size, step)
+
+
+def test_snp_windows_small_chunks(engine, monkeypatch):
+    """Chunks of one tile: every window straddles chunk boundaries (stitch path)."""
+    monkeypatch.setenv("EVOFST_CHUNK_TILES", "1")
+    rng = np.random.default_rng(99)
+    sp, codes, fl = _setup(engine, rng, 3000, 40, 4, 0.3, flags=True)
+    engine.set_pairs()
+    _check_windows(engine, sp, codes, fl, 4, 150, 150)
+    _check_windows(engine, sp, codes, fl, 4, 64, 32)
+
+
+def test_base_offsets_shift_windows(engine):
+    """A shard that starts after `base` included sites emits the windows of the global ranks."""
+    rng = np.random.default_rng(3)
+    S, N, P = 4000, 40, 4
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=0.05)
+    engine.set_layout(sp, P)
+    engine.set_pairs()
+    engine.set_windows(50, 50)
+    # whole run
+    engine.upload(engine.pack_codes(codes), S)
+    engine.run()
+    whole = engine.segments()
+    # second half only, told how many included sites precede it
+    cut = 2048
+    engine.upload(engine.pack_codes(codes[:cut]), cut)
+    engine.run()
+    first_tot = engine.included_totals().copy()
+    carry = engine.boundary()
+    engine.upload(engine.pack_codes(codes[cut:]), S - cut)
+    engine.run_counts()
+    engine.set_base_offsets(first_tot)
+    engine.run_stats()
+    part = engine.segments()
+    for q in range(engine.n_pairs):
+        f = int(part["first_segment"][q]); n = int(part["n_segments"][q])
+        assert f == first_tot[q] // 50
+        a = part["sum_num"][:n, q].copy()
+        a[0] = carry[q, 0] + a[0]
+        b = whole["sum_num"][f:f + n, q]
+        assert np.allclose(a, b, rtol=0, atol=1e-12 * 50)
+        assert np.array_equal(part["end_site"][:n, q] + cut, whole["end_site"][f:f + n, q])
