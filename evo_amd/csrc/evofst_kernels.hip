@@ -216,6 +216,7 @@ __global__ __launch_bounds__(kK2Threads) void k2_window_kernel(K2Params p) {
         m = g0 / p.g;
         left = p.g - (int32_t)(g0 - m * p.g);
     }
+    const int32_t left0 = left;
     const int64_t first_seg = active ? p.first_segment[q] : 0;
     double sn = 0.0, sd = 0.0;
     uint64_t sk = 0;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(kK2Threads) void k2_window_kernel(K2Params p) {
     }
     if (active) {
         p.tail[cq * 5 + 0] = sn; p.tail[cq * 5 + 1] = sd; p.tail[cq * 5 + 2] = (double)sk;
-        p.tail[cq * 5 + 3] = (double)(p.g - left);
+        p.tail[cq * 5 + 3] = (double)((flushed ? p.g : left0) - left);  // sites summed in sn/sd/sk
         p.tail[cq * 5 + 4] = flushed ? 1.0 : 0.0;
     }
 }
