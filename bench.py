@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- site x pop-pair Fst+dxy evaluations per second on MI355X.
+
+A "step" is one pass of the hot path (K1 allele counts + census, offsets scan, K2 pair statistics
+with fused segment window sums, stitch) over one batch of synthetic genotypes that is already
+resident in HBM.  Workload at N=1: BASELINE.json configs[1] (1 M sites x 200 diploid samples,
+10 populations = 45 pairs, SNP windows -w 100,100).  For N>1 every rank holds its own 1 M-site
+shard of one genome (weak scaling); SNP windows couple the shards through one exchange step
+per pass: an all-gather of the per-pair included-site totals (RCCL), from which each rank derives
+the global window phase of its shard.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (sites per GPU, samples, pops, mode, size, step, missing)
+    "cfg2": dict(sites=1_000_000, samples=200, pops=10, mode="pairs", size=100, step=100, miss=0.0,
+                 label="synthetic 1M sites x 200 diploid samples, 10 pops (45 pairs), SNP windows 100,100"),
+    "cfg3s": dict(sites=2_000_000, samples=1000, pops=100, mode="global", size=20, step=10, miss=0.0,
+                  label="synthetic 2M-site shard x 1000 samples, 100 pops, Fst-against-all, windows 20,10"),
+    "cfg4s": dict(sites=6_250_000, samples=2000, pops=20, mode="pairs", size=100, step=100, miss=0.0,
+                  label="synthetic 6.25M-site shard (1/8 of 50M) x 2000 samples, 20 pops (190 pairs), windows 100,100"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(e, cfg, sample_sites):
+    """The CPU oracle (closed-form restatement, 1 thread) on the first sample_sites sites of the
+    same workload: counts from allele codes, per-site pair statistics, SNP windows."""
+    from oracle import oracle as O
+    S = sample_sites
+    tiles = e.download_tiles()
+    codes = e.unpack_codes(tiles, S)
+    sp = (np.arange(cfg["samples"]) % cfg["pops"]).astype(np.int32)
+    nf = e.pop_chroms()
+    t0 = time.perf_counter()
+    alt, nm = O.counts_from_codes(codes, sp, cfg["pops"])
+    if cfg["mode"] == "pairs":
+        pi, pj = e.all_pairs()
+        num, den, dxy, inc = O.pair_site_stats(alt, nm, nf, pi, pj)
+        for q in range(len(pi)):
+            O.snp_windows(num, den, dxy, inc, q, cfg["size"], cfg["step"])
+        evals = S * len(pi)
+    else:
+        use = np.arange(cfg["pops"], dtype=np.int32)
+        sizes = np.full(cfg["pops"], cfg["samples"] // cfg["pops"], np.int64)
+        kept, num, den = O.global_site_stats(alt, nm, use, sizes)
+        O.global_windows(kept, num, den, cfg["size"], cfg["step"])
+        evals = S * cfg["pops"]
+    dt = time.perf_counter() - t0
+    return evals / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--cpu-sites", type=int, default=-1, help="sites of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from evo_amd import EvoFst
+    e = EvoFst(local_rank)
+    S, N, P = cfg["sites"], cfg["samples"], cfg["pops"]
+    sp = (np.arange(N) % P).astype(np.int32)
+    e.set_layout(sp, P)
+    if cfg["mode"] == "pairs":
+        e.set_pairs()
+        units_per_site = e.n_pairs
+    else:
+        e.set_against_all(np.arange(P, dtype=np.int32), np.full(P, N // P, np.int64))
+        units_per_site = P
+    e.set_windows(cfg["size"], cfg["step"])
+    e.reserve(S)
+    e.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=rank * S)
+    e.sync()
+    e.set_profiling(True)
+    n_tot = e.n_pairs if cfg["mode"] == "pairs" else 2
+    gather = [torch.zeros(n_tot, dtype=torch.int64, device="cuda") for _ in range(world)] if world > 1 else None
+
+    def step():
+        if world == 1:
+            e.run()
+        else:
+            # exchange step: included-site totals of every shard -> global window phase of mine
+            e.run_counts()
+            mine = torch.from_numpy(e.included_totals()).cuda()
+            dist.all_gather(gather, mine)
+            base = torch.stack(gather[:rank]).sum(0).cpu().numpy() if rank > 0 else np.zeros(n_tot, np.int64)
+            e.set_base_offsets(base)
+            e.run_stats()
+
+    def fence():
+        e.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kms = np.zeros((args.steps, 4))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    # per-kernel durations from HIP events on the library's stream (last step; then a few more
+    # profiled steps outside the timed region to average)
+    reps = min(args.steps, 20)
+    for i in range(reps):
+        step()
+        e.sync()
+        for k in range(4):
+            try:
+                kms[i, k] = e.kernel_ms(k)
+            except Exception:
+                kms[i, k] = 0.0
+    kavg = kms[:reps].mean(axis=0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    evals = float(S) * units_per_site * world
+    value = evals / (dt / args.steps)
+
+    # roofline of the dominant kernel (algorithmic bytes)
+    cb = e.geometry().count_bytes
+    k1_bytes = S * (N / 2.0) + S * P * cb          # 2 bits per haplotype read + packed counts written
+    if cfg["mode"] == "pairs":
+        g = np.gcd(cfg["size"], cfg["step"])
+        k2_bytes = S * P * cb + (S / g) * e.n_pairs * 28.0   # counts read + segment rows written
+    else:
+        k2_bytes = S * P * cb + S * 8.0 + (S / cfg["step"]) * P * 16.0
+    names = ["k1_count_kernel", "scan_kernel", "k2_window_kernel" if cfg["mode"] == "pairs" else "global_window_kernel",
+             "stitch_kernel"]
+    dom = 0 if kavg[0] >= kavg[2] else 2
+    dom_bytes = k1_bytes if dom == 0 else k2_bytes
+    achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9 if kavg[dom] > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernels_ms": {names[k]: float(kavg[k]) for k in range(4)},
+                "k1_GBps": k1_bytes / (kavg[0] * 1e-3) / 1e9 if kavg[0] > 0 else 0.0,
+                "algorithmic_bytes": dom_bytes}
+
+    out = {
+        "metric": "site x pop-pair Fst+dxy evaluations/sec",
+        "value": value, "unit": "site*pair/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": cfg["label"], "sites_per_gpu": S, "samples": N, "pops": P,
+                   "units_per_site": units_per_site, "sharding": "contiguous site shards, one per GPU"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and args.cpu_sites != 0:
+        cs = args.cpu_sites if args.cpu_sites > 0 else min(S, max(20_000, int(6e7 / (units_per_site * 10))))
+        v, secs = cpu_baseline(e, cfg, cs)
+        out["cpu_baseline"] = {"value": v, "unit": "site*pair/s", "cores": 1, "kind": "port",
+                               "sample": "first %d sites of the same workload, oracle/evo_oracle.c closed-form "
+                                         "restatement on allele codes (counts + per-site stats + windows), %.1f s" % (cs, secs)}
+    if rank == 0:
+        print(json.dumps(out))
+    e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
