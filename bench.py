@@ -26,6 +26,8 @@ CONFIGS = {
     # name: (sites per GPU, samples, pops, mode, size, step, missing)
     "cfg2": dict(sites=1_000_000, samples=200, pops=10, mode="pairs", size=100, step=100, miss=0.0,
                  label="synthetic 1M sites x 200 diploid samples, 10 pops (45 pairs), SNP windows 100,100"),
+    "cfg2nw": dict(sites=1_000_000, samples=200, pops=10, mode="pairs", size=0, step=0, miss=0.0,
+                  label="cfg2 without windows (totals only; diagnostic)"),
     "cfg3s": dict(sites=2_000_000, samples=1000, pops=100, mode="global", size=20, step=10, miss=0.0,
                   label="synthetic 2M-site shard x 1000 samples, 100 pops, Fst-against-all, windows 20,10"),
     "cfg4s": dict(sites=6_250_000, samples=2000, pops=20, mode="pairs", size=100, step=100, miss=0.0,
@@ -154,7 +156,7 @@ def main():
     cb = e.geometry().count_bytes
     k1_bytes = S * (N / 2.0) + S * P * cb          # 2 bits per haplotype read + packed counts written
     if cfg["mode"] == "pairs":
-        g = np.gcd(cfg["size"], cfg["step"])
+        g = np.gcd(cfg["size"], cfg["step"]) if cfg["size"] else 10**9
         k2_bytes = S * P * cb + (S / g) * e.n_pairs * 28.0   # counts read + segment rows written
     else:
         k2_bytes = S * P * cb + S * 8.0 + (S / cfg["step"]) * P * 16.0

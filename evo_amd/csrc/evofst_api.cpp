@@ -155,7 +155,8 @@ int plan_chunks(evofst_ctx *c) {
     c->n_tiles = n_tiles_of(c->n_sites);
     int ct = 0;
     if (const char *e = getenv("EVOFST_CHUNK_TILES")) ct = atoi(e);
-    if (ct <= 0) ct = std::max(4, (c->n_tiles + 2047) / 2048);
+    if (ct <= 0) ct = std::max(4, (c->n_tiles + 2047) / 2048);  // <= 2048 blocks: all resident in one round
+    ct = std::min(ct, 4096);  // keeps the 32-bit per-segment count sums of K2 exact
     c->chunk_tiles = ct;
     c->n_chunks = (c->n_tiles + ct - 1) / ct;
     return EVOFST_OK;
@@ -201,6 +202,8 @@ K2Params make_k2(evofst_ctx *c) {
     p.site_flags = c->have_flags ? c->flags : nullptr;
     p.n_sites = c->n_sites;
     p.n_tiles = c->n_tiles; p.P = c->n_pops;
+    p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
+    if (const char *e = getenv("EVOFST_DEBUG_K2")) p.debug = atoi(e);
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.pairs = (const uint32_t *)c->d_pairs.p;
     p.n_pairs = (int)c->pairs.size();
@@ -749,7 +752,7 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
         if ((rc = ensure(c, c->d_head, cq * 3 * 8))) return rc;
         if ((rc = ensure(c, c->d_head_site, cq * 4))) return rc;
         if ((rc = ensure(c, c->d_tail, cq * 5 * 8))) return rc;
-        if (k2_lds_bytes(c->n_pops) > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: too many populations for the LDS table");
+        if (k2_lds_bytes(c->n_pops, *std::max_element(c->n_full.begin(), c->n_full.end())) > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: too many populations for the LDS table");
         K2Params p = make_k2(c);
         record(c, 2, 0);
         HIPCHK(c, launch_k2(p, c->count_bytes, c->stream));
@@ -974,12 +977,11 @@ extern "C" int evofst_get_boundary(evofst_ctx *c, double *carry_out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (size_t q = 0; q < np; ++q) {
         int cl = c->n_chunks - 1;
-        while (cl >= 0 && tail[((size_t)cl * np + q) * 5 + 4] == 0.0) --cl;
+        const size_t plane = np * (size_t)c->n_chunks, row = q * (size_t)c->n_chunks;
+        while (cl >= 0 && tail[4 * plane + row + cl] == 0.0) --cl;
         double a[4] = {0, 0, 0, 0};
-        for (int cc = cl < 0 ? 0 : cl; cc < c->n_chunks; ++cc) {
-            const double *t = &tail[((size_t)cc * np + q) * 5];
-            a[0] += t[0]; a[1] += t[1]; a[2] += t[2]; a[3] += t[3];
-        }
+        for (int cc = cl < 0 ? 0 : cl; cc < c->n_chunks; ++cc)
+            for (int f = 0; f < 4; ++f) a[f] += tail[f * plane + row + cc];
         std::copy(a, a + 4, carry_out + q * 4);
     }
     return EVOFST_OK;

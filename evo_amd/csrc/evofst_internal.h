@@ -41,12 +41,12 @@ struct K1Params {
     // pairs mode
     const uint32_t *pairs;  // i | j << 16
     int32_t n_pairs;
-    uint32_t *chunk_census;  // [n_chunks][n_pairs]
+    uint32_t *chunk_census;  // [n_pairs][n_chunks]
     // against-all mode
     uint2 *totals;            // [n_tiles*64] {sum alt, sum non-missing} over populationsToUse
     uint64_t *kept_mask;      // [n_tiles]
     uint64_t *skip_mask;      // [n_tiles]
-    uint32_t *chunk_used_kept;  // [n_chunks][2]
+    uint32_t *chunk_used_kept;  // [2][n_chunks]
 };
 
 struct K2Params {
@@ -54,19 +54,21 @@ struct K2Params {
     const uint8_t *site_flags;
     int64_t n_sites;
     int32_t n_tiles, P;
+    int32_t max_n;  // largest n_full
+    int32_t debug;  // EVOFST_DEBUG_K2 (profiling experiments only): 1 = skip pair phase, 2 = skip derive
     const int32_t *n_full;
     const uint32_t *pairs;
     int32_t n_pairs;
     int32_t chunk_tiles, n_chunks;
-    const int64_t *chunk_offsets;  // [n_chunks][n_pairs] included sites of the pair before the chunk
+    const int64_t *chunk_offsets;  // [n_pairs][n_chunks] included sites of the pair before the chunk
     const int64_t *first_segment;  // [n_pairs]
     int32_t g;
     int64_t seg_cap;
     double *seg_num, *seg_den, *seg_k;  // [seg_cap][n_pairs]
     int32_t *seg_end;
-    double *head;        // [n_chunks][n_pairs][3]
-    int32_t *head_site;  // [n_chunks][n_pairs]
-    double *tail;        // [n_chunks][n_pairs][5] {num, den, k, n_sites, flushed}
+    double *head;        // [3][n_pairs][n_chunks] {num, den, k} of the first segment a chunk completes
+    int32_t *head_site;  // [n_pairs][n_chunks]
+    double *tail;        // [5][n_pairs][n_chunks] {num, den, k, n_sites, flushed} after the last one
 };
 
 struct SiteStatParams {
@@ -99,7 +101,7 @@ struct GlobalParams {
     const double *thresholds; // [n_use] set_sizes[u] * 0.8
     int32_t n_use;
     int32_t chunk_tiles, n_chunks;
-    const int64_t *chunk_used_kept_off;  // [n_chunks][2] used / kept sites before the chunk
+    const int64_t *chunk_used_kept_off;  // [2][n_chunks] used / kept sites before the chunk
     int32_t size, step;
     int64_t row_cap;
     int32_t *row_start, *row_end;  // [row_cap]
@@ -139,7 +141,7 @@ hipError_t launch_global_rows(const uint64_t *kept_mask, const uint64_t *skip_ma
 hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st);
 hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
-size_t k2_lds_bytes(int P);
+size_t k2_lds_bytes(int P, int max_n);
 size_t global_lds_bytes(int P, int n_use, int size);
 
 }  // namespace evofst

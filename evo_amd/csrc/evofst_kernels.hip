@@ -15,6 +15,8 @@
 //   global_*                Fst-against-all evaluation and deque windows.
 #include "evofst_internal.h"
 
+#include <algorithm>
+
 namespace evofst {
 
 template <typename CT> struct CountTraits;
@@ -57,8 +59,8 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
         for (int wb = 0; wb < p.W; wb += 8) {
             ulonglong2 r[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (wb + u < p.W) r[u] = tp[(size_t)(wb + u) * kTileSites];
+            for (int u = 0; u < 8; ++u)   // unconditional (clamped) so that all 8 loads are in flight together
+                r[u] = tp[(size_t)min(wb + u, p.W - 1) * kTileSites];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (wb + u < p.W) {
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             uint32_t s = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += cen_all[(size_t)w * p.n_pairs + q];
-            p.chunk_census[(size_t)chunk * p.n_pairs + q] = s;
+            p.chunk_census[(size_t)q * p.n_chunks + chunk] = s;
         }
     }
     if (MODE == MODE_GLOBAL) {
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
         if (threadIdx.x < 2) {
             uint32_t s = 0;
             for (int w = 0; w < NW; ++w) s += red[w * 2 + threadIdx.x];
-            p.chunk_used_kept[(size_t)chunk * 2 + threadIdx.x] = s;
+            p.chunk_used_kept[(size_t)threadIdx.x * p.n_chunks + chunk] = s;
         }
     }
 }
@@ -152,40 +154,53 @@ hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t s
 }
 
 // =====================================================================================
-// Exclusive scan of per-chunk census columns: offsets[c][q] = base[q] + sum_{c'<c} census[c'][q]
+// Exclusive scan of the census over chunks, one wave per column (pair):
+// offsets[q][c] = base[q] + sum_{c'<c} census[q][c'].  Column-major so that a wave reads 64
+// consecutive chunks per load and scans them with lane shuffles.
 // =====================================================================================
-__global__ __launch_bounds__(64 * kScanParts) void scan_kernel(const uint32_t *__restrict__ census,
-                                                               const int64_t *__restrict__ base,
-                                                               int64_t *__restrict__ offsets,
-                                                               int64_t *__restrict__ totals, int n_chunks,
-                                                               int n_cols) {
-    __shared__ int64_t psum[kScanParts][64];
-    const int ql = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int q = blockIdx.x * 64 + ql;
-    const int per = (n_chunks + kScanParts - 1) / kScanParts;
-    const int c0 = part * per, c1 = min(c0 + per, n_chunks);
-    int64_t s = 0;
-    if (q < n_cols)
-        for (int c = c0; c < c1; ++c) s += census[(size_t)c * n_cols + q];
-    psum[part][ql] = s;
-    __syncthreads();
+__global__ __launch_bounds__(256) void scan_kernel(const uint32_t *__restrict__ census,
+                                                   const int64_t *__restrict__ base,
+                                                   int64_t *__restrict__ offsets,
+                                                   int64_t *__restrict__ totals, int n_chunks, int n_cols) {
+    const int lane = lane_id();
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= n_cols) return;
-    int64_t run = base ? base[q] : 0;
-    for (int pp = 0; pp < part; ++pp) run += psum[pp][ql];
-    for (int c = c0; c < c1; ++c) {
-        offsets[(size_t)c * n_cols + q] = run;
-        run += census[(size_t)c * n_cols + q];
+    const uint32_t *in = census + (size_t)q * n_chunks;
+    int64_t *out = offsets + (size_t)q * n_chunks;
+    const int64_t b0 = base ? base[q] : 0;
+    int64_t carry = b0;
+    constexpr int PER = 32;  // chunks per lane and pass, all loads of a pass in flight together
+    for (int c0 = 0; c0 < n_chunks; c0 += 64 * PER) {
+        const int first = c0 + lane * PER;
+        uint32_t v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) v[i] = in[min(first + i, n_chunks - 1)];   // unconditional: no branch per load
+#pragma unroll
+        for (int i = 0; i < PER; ++i) v[i] = first + i < n_chunks ? v[i] : 0u;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) mine += v[i];
+        uint32_t x = mine;  // inclusive scan of the lane totals
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        int64_t run = carry + (int64_t)(x - mine);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (first + i < n_chunks) out[first + i] = run;
+            run += v[i];
+        }
+        carry += (int64_t)__shfl(x, 63);
     }
-    if (part == kScanParts - 1 && totals) {
-        // `run` of the last part is the grand total (parts past the end contribute nothing)
-        totals[q] = run - (base ? base[q] : 0);
-    }
+    if (lane == 0 && totals) totals[q] = carry - b0;
 }
 
 hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *offsets, int64_t *totals,
                        int n_chunks, int n_cols, hipStream_t st) {
     if (n_cols <= 0) return hipSuccess;
-    dim3 grid((n_cols + 63) / 64), block(64 * kScanParts);
+    dim3 grid((n_cols + 3) / 4), block(256);
     hipLaunchKernelGGL(scan_kernel, grid, block, 0, st, census, base, offsets, totals, n_chunks, n_cols);
     return hipGetLastError();
 }
@@ -193,85 +208,163 @@ hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *off
 // =====================================================================================
 // K2 (+K3): per-pair Hudson numerator / denominator / dxy numerator and segment sums.
 // Replaces process_vcf_fst.cpp:543-553 + 638-650 for every population pair at once.
+//
+// Per tile of 64 sites the block first derives, per (population, site), p = c/nm and
+// h = p(1-p)/(nm-1) into an LDS table (the only divisions of the path: P per site instead of
+// 2 per pair), then every lane (= one population pair) walks the 64 sites in order.
+//
+// Division: when every population has <= kRcpMax chromosomes the two quotients are formed from a
+// table of correctly rounded reciprocals with one residual correction,
+//     q0 = a*r;  e = fma(-q0, b, a);  q = fma(e, r, q0)          (Markstein),
+// which is bit-identical to IEEE a/b for every (c, nm) this path can produce: checked
+// exhaustively for 0 <= c <= nm <= 16383 (tests/test_division_identity.py).  0/0 and x/0 come
+// out as NaN through r = inf exactly as in the reference.
 // =====================================================================================
-size_t k2_lds_bytes(int P) { return (size_t)P * kPadSites * (8 + 8 + 4) + 16; }
+constexpr int kRcpMax = 2047;
+size_t k2_lds_bytes(int P, int max_n) {
+    return (size_t)P * kPadSites * (8 + 8 + 4) + (max_n <= kRcpMax ? (size_t)(max_n + 1) * 8 : 0) + 32;
+}
 
 template <typename CT>
 __global__ __launch_bounds__(kK2Threads) void k2_window_kernel(K2Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     double *pt = reinterpret_cast<double *>(smem);           // [P][65] allele frequency c/nm
     double *ht = pt + (size_t)p.P * kPadSites;               // [P][65] p(1-p)/(nm-1)
-    uint32_t *xt = reinterpret_cast<uint32_t *>(ht + (size_t)p.P * kPadSites);  // [P][65] packed ints
+    double *rcp = ht + (size_t)p.P * kPadSites;              // [max_n+1] 1/x (when use_rcp)
+    const bool use_rcp = p.max_n <= kRcpMax;
+    uint32_t *xt = reinterpret_cast<uint32_t *>(rcp + (use_rcp ? p.max_n + 1 : 0));  // [P][65] c | flags
 
+    const int nthreads = blockDim.x;
     const int chunk = blockIdx.x;
-    const int q = blockIdx.y * kK2Threads + threadIdx.x;
+    const int q = blockIdx.y * nthreads + threadIdx.x;
     const bool active = q < p.n_pairs;
     uint32_t pi = 0, pj = 0;
     int64_t m = 0;
     int32_t left = p.g;
+    uint32_t ni = 0, nj = 0;
+    const size_t cq = (size_t)q * p.n_chunks + chunk;       // [pair][chunk] arrays
+    const size_t plane = (size_t)p.n_pairs * p.n_chunks;
     if (active) {
         const uint32_t ij = p.pairs[q];
         pi = ij & 0xffffu; pj = ij >> 16;
-        const int64_t g0 = p.chunk_offsets[(size_t)chunk * p.n_pairs + q];
+        ni = (uint32_t)p.n_full[pi]; nj = (uint32_t)p.n_full[pj];
+        const int64_t g0 = p.chunk_offsets[cq];
         m = g0 / p.g;
         left = p.g - (int32_t)(g0 - m * p.g);
     }
     const int32_t left0 = left;
     const int64_t first_seg = active ? p.first_segment[q] : 0;
     double sn = 0.0, sd = 0.0;
-    uint64_t sk = 0;
+    uint32_t sci = 0, scj = 0;   // sums of the two alt counts over the open segment
+    uint64_t scc = 0;            // sum of c_i * c_j
     bool flushed = false;
-    const size_t cq = (size_t)chunk * p.n_pairs + q;
+    if (use_rcp)
+        for (int i = threadIdx.x; i <= p.max_n; i += nthreads) rcp[i] = 1.0 / (double)i;
 
     const int t0 = chunk * p.chunk_tiles;
     const int t1 = min(t0 + p.chunk_tiles, p.n_tiles);
     const uint32_t io = pi * kPadSites, jo = pj * kPadSites;
-    for (int t = t0; t < t1; ++t) {
-        // ---- derive: one (pop, site) entry per thread-iteration, coalesced over sites
-        const CT *cp = reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites;
-        for (int e = threadIdx.x; e < p.P * kTileSites; e += kK2Threads) {
-            const int k = e >> 6, s = e & 63;
+    __syncthreads();
+    // The counts of a tile ([P][64] packed CT) are fetched as 16-byte vectors (EPT consecutive sites of
+    // one population); the vectors of tile t+1 are requested before the pair phase of tile t.
+    constexpr int EPT = 16 / (int)sizeof(CT);
+    constexpr int NV = 4;
+    const int nvec = p.P * kTileSites / EPT;
+    uint4 pre[NV];
+    auto fetch = [&](int t) {
+        const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int vi = threadIdx.x + j * nthreads;
+            pre[j] = vp[min(vi, nvec - 1)];   // unconditional: keeps the NV loads in flight together
+        }
+    };
+    auto derive_vec = [&](int t, int vi, const uint4 &vv) {
+        const int e0 = vi * EPT;
+        const int k = e0 >> 6, s0 = e0 & 63;
+        const uint32_t nfull = (uint32_t)p.n_full[k];
+        (void)nfull;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            uint32_t v;
+            if (sizeof(CT) == 2) v = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu; else v = w[j];
+            const int s = s0 + j;
             const int64_t site = (int64_t)t * kTileSites + s;
-            const uint32_t v = cp[e];
             const uint32_t c = v & CountTraits<CT>::mask, nm = v >> CountTraits<CT>::shift;
             bool skip = site >= p.n_sites;
             if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
-            const double pp = (double)c / (double)nm;                        // utils.h:272-275
-            const double hh = (pp * (1.0 - pp)) / (double)((int)nm - 1);     // fst.h:21-22
-            uint32_t x = c | (((uint32_t)p.n_full[k] - c) << kXBits);
+            double pp, hh;
+            const double dc = (double)c, dn = (double)nm, dn1 = (double)((int)nm - 1);
+            if (use_rcp) {
+                const double r = rcp[nm], r1 = rcp[nm > 0 ? nm - 1 : 0];
+                double q0 = dc * r;
+                pp = fma(fma(-q0, dn, dc), r, q0);                           // == c / nm
+                const double tt = pp * (1.0 - pp);
+                q0 = tt * r1;
+                hh = fma(fma(-q0, dn1, tt), r1, q0);                         // == tt / (nm - 1)
+            } else {
+                pp = dc / dn;                                                // utils.h:272-275
+                hh = (pp * (1.0 - pp)) / dn1;                                // fst.h:21-22
+            }
+            uint32_t x = c;
             if (skip || c == 0) x |= kXZero;
             if (skip || c == nm) x |= kXFixed;
             const int o = k * kPadSites + s;
             pt[o] = pp; ht[o] = hh; xt[o] = x;
         }
+    };
+    if (t0 < t1) fetch(t0);
+    for (int t = t0; t < t1; ++t) {
+        // ---- derive the per-(pop, site) table of this tile
+        if (!(p.debug & 2))
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int vi = threadIdx.x + j * nthreads;
+            if (vi < nvec) derive_vec(t, vi, pre[j]);
+        }
+        {
+            const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites);
+            for (int vi = threadIdx.x + NV * nthreads; vi < nvec; vi += nthreads) derive_vec(t, vi, vp[vi]);
+        }
+        if (t + 1 < t1) fetch(t + 1);
         __syncthreads();
         // ---- pairs: lane = pair, sites in order (the reference's push_back order)
-        if (active) {
+        if (active && !(p.debug & 1)) {
             const int site0 = t * kTileSites;
-#pragma unroll 4
-            for (int s = 0; s < kTileSites; ++s) {
-                const uint32_t xi = xt[io + s], xj = xt[jo + s];
-                if (((xi & xj) >> 28) == 0u) {                               // fst.cpp:543-544
-                    const double p1 = pt[io + s], p2 = pt[jo + s];
-                    const double h1 = ht[io + s], h2 = ht[jo + s];
-                    const double d = p1 - p2;
-                    const double num = d * d - h1 - h2;                      // fst.h:20-23
-                    const double den = (p1 * (1.0 - p2)) + (p2 * (1.0 - p1));  // fst.h:28
-                    const uint32_t ai = xi & kXMask, bi = (xi >> kXBits) & kXMask;
-                    const uint32_t aj = xj & kXMask, bj = (xj >> kXBits) & kXMask;
-                    sn += num; sd += den;
-                    sk += (uint64_t)(ai * bj + aj * bi);                     // sumKij, fst.cpp:299-321
-                    if (--left == 0) {
-                        if (!flushed) {
-                            p.head[cq * 3 + 0] = sn; p.head[cq * 3 + 1] = sd; p.head[cq * 3 + 2] = (double)sk;
-                            p.head_site[cq] = site0 + s;
-                            flushed = true;
-                        } else {
-                            const size_t o = (size_t)(m - first_seg) * p.n_pairs + q;
-                            p.seg_num[o] = sn; p.seg_den[o] = sd; p.seg_k[o] = (double)sk;
-                            p.seg_end[o] = site0 + s;
+            for (int sb = 0; sb < kTileSites; sb += 8) {
+                uint32_t xi[8], xj[8];
+                double p1[8], p2[8], h1[8], h2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    xi[u] = xt[io + sb + u]; xj[u] = xt[jo + sb + u];
+                    p1[u] = pt[io + sb + u]; p2[u] = pt[jo + sb + u];
+                    h1[u] = ht[io + sb + u]; h2[u] = ht[jo + sb + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (((xi[u] & xj[u]) >> 28) == 0u) {                     // fst.cpp:543-544
+                        const double d = p1[u] - p2[u];
+                        const double num = d * d - h1[u] - h2[u];            // fst.h:20-23
+                        const double den = (p1[u] * (1.0 - p2[u])) + (p2[u] * (1.0 - p1[u]));  // fst.h:28
+                        const uint32_t ci = xi[u] & kXMask, cj = xj[u] & kXMask;
+                        sn += num; sd += den;
+                        sci += ci; scj += cj;
+                        scc += (uint64_t)(ci * cj);
+                        if (--left == 0) {
+                            // sumKij = c1*(n2-c2) + c2*(n1-c1), fst.cpp:299-321, summed over the segment
+                            const double sk = (double)((uint64_t)nj * sci + (uint64_t)ni * scj - 2ull * scc);
+                            if (!flushed) {
+                                p.head[cq] = sn; p.head[plane + cq] = sd; p.head[2 * plane + cq] = sk;
+                                p.head_site[cq] = site0 + sb + u;
+                                flushed = true;
+                            } else {
+                                const size_t o = (size_t)(m - first_seg) * p.n_pairs + q;
+                                p.seg_num[o] = sn; p.seg_den[o] = sd; p.seg_k[o] = sk;
+                                p.seg_end[o] = site0 + sb + u;
+                            }
+                            ++m; left = p.g; sn = 0.0; sd = 0.0; sci = 0; scj = 0; scc = 0;
                         }
-                        ++m; left = p.g; sn = 0.0; sd = 0.0; sk = 0;
                     }
                 }
             }
@@ -279,16 +372,18 @@ __global__ __launch_bounds__(kK2Threads) void k2_window_kernel(K2Params p) {
         __syncthreads();
     }
     if (active) {
-        p.tail[cq * 5 + 0] = sn; p.tail[cq * 5 + 1] = sd; p.tail[cq * 5 + 2] = (double)sk;
-        p.tail[cq * 5 + 3] = (double)((flushed ? p.g : left0) - left);  // sites summed in sn/sd/sk
-        p.tail[cq * 5 + 4] = flushed ? 1.0 : 0.0;
+        p.tail[cq] = sn; p.tail[plane + cq] = sd;
+        p.tail[2 * plane + cq] = (double)((uint64_t)nj * sci + (uint64_t)ni * scj - 2ull * scc);
+        p.tail[3 * plane + cq] = (double)((flushed ? p.g : left0) - left);  // sites summed in sn/sd/sk
+        p.tail[4 * plane + cq] = flushed ? 1.0 : 0.0;
     }
 }
 
 hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
-    dim3 grid(p.n_chunks, (p.n_pairs + kK2Threads - 1) / kK2Threads), block(kK2Threads);
-    size_t lds = k2_lds_bytes(p.P);
+    const int threads = 64 * ((std::min(p.n_pairs, kK2Threads) + 63) / 64);
+    dim3 grid(p.n_chunks, (p.n_pairs + threads - 1) / threads), block(threads);
+    size_t lds = k2_lds_bytes(p.P, p.max_n);
     if (lds > 48 * 1024) {
         hipError_t e = count_bytes == 2
             ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_window_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -303,28 +398,29 @@ hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st) {
 // The first segment a chunk completes started in an earlier chunk: add, in site order, the tail of
 // the last chunk that completed a segment and the whole-chunk sums of the chunks in between.
 __global__ void stitch_kernel(K2Params p) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
-    if (q >= p.n_pairs) return;
-    const size_t cq = (size_t)c * p.n_pairs + q;
-    if (p.tail[cq * 5 + 4] == 0.0) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;
+    if (c >= p.n_chunks) return;
+    const size_t plane = (size_t)p.n_pairs * p.n_chunks;
+    const size_t row = (size_t)q * p.n_chunks;
+    const double *flag = p.tail + 4 * plane + row;
+    if (flag[c] == 0.0) return;
     int cp = c - 1;
-    while (cp >= 0 && p.tail[((size_t)cp * p.n_pairs + q) * 5 + 4] == 0.0) --cp;
+    while (cp >= 0 && flag[cp] == 0.0) --cp;
     double an = 0.0, ad = 0.0, ak = 0.0;
     for (int cc = (cp < 0 ? 0 : cp); cc < c; ++cc) {
-        const size_t o = ((size_t)cc * p.n_pairs + q) * 5;
-        an += p.tail[o]; ad += p.tail[o + 1]; ak += p.tail[o + 2];
+        an += p.tail[row + cc]; ad += p.tail[plane + row + cc]; ak += p.tail[2 * plane + row + cc];
     }
-    an += p.head[cq * 3]; ad += p.head[cq * 3 + 1]; ak += p.head[cq * 3 + 2];
-    const int64_t m0 = p.chunk_offsets[cq] / p.g;
+    an += p.head[row + c]; ad += p.head[plane + row + c]; ak += p.head[2 * plane + row + c];
+    const int64_t m0 = p.chunk_offsets[row + c] / p.g;
     const size_t o = (size_t)(m0 - p.first_segment[q]) * p.n_pairs + q;
     p.seg_num[o] = an; p.seg_den[o] = ad; p.seg_k[o] = ak;
-    p.seg_end[o] = p.head_site[cq];
+    p.seg_end[o] = p.head_site[row + c];
 }
 
 hipError_t launch_stitch(const K2Params &p, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
-    dim3 block(64), grid((p.n_pairs + 63) / 64, p.n_chunks);
+    dim3 block(256), grid((p.n_chunks + 255) / 256, p.n_pairs);
     hipLaunchKernelGGL(stitch_kernel, grid, block, 0, st, p);
     return hipGetLastError();
 }
@@ -340,11 +436,13 @@ __global__ void totals_kernel(K2Params p, const int64_t *__restrict__ n_rows, do
         an += p.seg_num[o]; ad += p.seg_den[o]; ak += p.seg_k[o];
     }
     cnt = (double)rows * (double)p.g;
+    const size_t plane = (size_t)p.n_pairs * p.n_chunks;
+    const size_t row = (size_t)q * p.n_chunks;
     int cl = p.n_chunks - 1;
-    while (cl >= 0 && p.tail[((size_t)cl * p.n_pairs + q) * 5 + 4] == 0.0) --cl;
+    while (cl >= 0 && p.tail[4 * plane + row + cl] == 0.0) --cl;
     for (int cc = (cl < 0 ? 0 : cl); cc < p.n_chunks; ++cc) {
-        const size_t o = ((size_t)cc * p.n_pairs + q) * 5;
-        an += p.tail[o]; ad += p.tail[o + 1]; ak += p.tail[o + 2]; cnt += p.tail[o + 3];
+        an += p.tail[row + cc]; ad += p.tail[plane + row + cc]; ak += p.tail[2 * plane + row + cc];
+        cnt += p.tail[3 * plane + row + cc];
     }
     totals[(size_t)q * 4 + 0] = an; totals[(size_t)q * 4 + 1] = ad;
     totals[(size_t)q * 4 + 2] = ak; totals[(size_t)q * 4 + 3] = cnt;
@@ -469,7 +567,7 @@ __global__ void global_rows_kernel(const uint64_t *__restrict__ kept_mask, const
                                    int n_tiles, int size, int step, uint32_t *__restrict__ chunk_rows) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
-    int64_t used = chunk_off[(size_t)c * 2];
+    int64_t used = chunk_off[c];
     uint32_t rows = 0;
     const int t0 = c * chunk_tiles, t1 = min(t0 + chunk_tiles, n_tiles);
     for (int t = t0; t < t1; ++t) {
@@ -540,7 +638,7 @@ __global__ void global_window_kernel(GlobalParams p) {
     // ---- find where the replay starts: walk back until SIZE kept sites are found
     int th = t0;          // first tile to process
     int need = p.size;
-    int64_t kept_before = p.chunk_used_kept_off[(size_t)c * 2 + 1];
+    int64_t kept_before = p.chunk_used_kept_off[(size_t)p.n_chunks + c];
     if (kept_before < need) need = (int)kept_before;   // the rest is the zero-initialised deque
     int drop = 0;         // kept sites of tile th to ignore (older than the window)
     while (need > 0 && th > 0) {
@@ -549,7 +647,7 @@ __global__ void global_window_kernel(GlobalParams p) {
         if (n >= need) { drop = n - need; need = 0; }
         else need -= n;
     }
-    int64_t used = p.chunk_used_kept_off[(size_t)c * 2];
+    int64_t used = p.chunk_used_kept_off[c];
     int64_t row = p.chunk_row_off[c];
     int head = 0;  // ring slot of the oldest element
     __syncthreads();

@@ -972,3 +972,29 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
     free(id_names); free(id_pop);
     return rc;
 }
+
+/* ===================================================================== */
+/* checker for the kernels' reciprocal-table division (no reference      */
+/* counterpart): counts (c, nm) pairs for which                          */
+/*   q0 = a*r; e = fma(-q0,b,a); q = fma(e,r,q0),  r = RN(1/b)           */
+/* differs from IEEE a/b, for a/b = c/nm and (p(1-p))/(nm-1).            */
+/* ===================================================================== */
+static double rcp_div(double a, double b, double r) {
+    double q0 = a * r;
+    double e = fma(-q0, b, a);
+    return fma(e, r, q0);
+}
+long orc_check_rcp_division(int max_n) {
+    long bad = 0;
+    for (int nm = 0; nm <= max_n; nm++) {
+        double r = 1.0 / (double)nm, r1 = 1.0 / (double)(nm > 0 ? nm - 1 : 0);
+        for (int c = 0; c <= nm; c++) {
+            double p = (double)c / (double)nm, p2 = rcp_div((double)c, (double)nm, r);
+            if (memcmp(&p, &p2, 8) != 0 && !(isnan(p) && isnan(p2))) bad++;
+            double t = p * (1.0 - p);
+            double h = t / (double)(nm - 1), h2 = rcp_div(t, (double)(nm - 1), r1);
+            if (memcmp(&h, &h2, 8) != 0 && !(isnan(h) && isnan(h2))) bad++;
+        }
+    }
+    return bad;
+}

@@ -177,6 +177,9 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
                       int window_size, int window_step, int fixed_window_size,
                       const char *run_name, const char *out_dir);
 
+/* checker for the kernels' reciprocal-table division; returns the number of mismatches */
+long orc_check_rcp_division(int max_n);
+
 #ifdef __cplusplus
 }
 #endif

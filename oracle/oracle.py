@@ -108,6 +108,8 @@ def lib():
         L.orc_fstglobal_run.restype = C.c_int
         L.orc_fstglobal_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                         C.c_char_p, C.c_char_p]
+        L.orc_check_rcp_division.restype = C.c_long
+        L.orc_check_rcp_division.argtypes = [C.c_int]
         _lib = L
     return _lib
 
