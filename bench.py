@@ -101,20 +101,20 @@ def main():
     e.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=rank * S)
     e.sync()
     e.set_profiling(True)
-    n_tot = e.n_pairs if cfg["mode"] == "pairs" else 2
-    gather = [torch.zeros(n_tot, dtype=torch.int64, device="cuda") for _ in range(world)] if world > 1 else None
+    from evo_amd import shard
+    ag = shard.torch_all_gather(device="cuda") if world > 1 else None
 
     def step():
         if world == 1:
             e.run()
         else:
-            # exchange step: included-site totals of every shard -> global window phase of mine
+            # two window-boundary exchanges per pass (evo_amd/shard.py): included-site totals after K1
+            # (all-gather over RCCL) -> base offsets; carries behind the last complete segment after K2.
             e.run_counts()
-            mine = torch.from_numpy(e.included_totals()).cuda()
-            dist.all_gather(gather, mine)
-            base = torch.stack(gather[:rank]).sum(0).cpu().numpy() if rank > 0 else np.zeros(n_tot, np.int64)
-            e.set_base_offsets(base)
+            e.set_base_offsets(shard.base_offsets(ag(e.included_totals()), rank))
             e.run_stats()
+            if cfg["mode"] == "pairs":
+                shard.carry_in(ag(e.boundary()), ag(e.included_totals()), rank)
 
     def fence():
         e.sync()

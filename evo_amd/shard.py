@@ -1,0 +1,168 @@
+"""Multi-GPU sharding of the hot path: contiguous site shards, one per rank.
+
+Sites are independent; only SNP windows couple neighbouring shards.  Two small exchanges per pass,
+both all-gathers of per-pair vectors (RCCL over xGMI when the tensors live on the GPU, gloo in the
+CPU tests):
+
+  1. after K1:  included-site totals of every shard  -> each rank's base offsets (global window phase),
+  2. after K2:  the carry behind the last complete segment of every shard (+ its last SIZE/g - 1
+                complete segments when windows overlap) -> each rank completes the windows that
+                straddle its left edge.
+
+All functions work on numpy arrays (what EvoFst returns) plus an `all_gather(array) -> [array per
+rank]` callable, so the same code runs under torch.distributed and in single-process tests.
+"""
+import math
+
+import numpy as np
+
+
+def torch_all_gather(group=None, device=None):
+    """all_gather callable on top of torch.distributed (nccl = RCCL on ROCm, or gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    def ag(a):
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a)
+        if device is not None:
+            t = t.to(device)
+        out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(out, t, group=group)
+        return [o.cpu().numpy() for o in out]
+    return ag
+
+
+def base_offsets(all_totals, rank):
+    """Exchange 1: included sites (per pair) that precede shard `rank`."""
+    tot = np.asarray(all_totals[0]) * 0
+    for r in range(rank):
+        tot = tot + np.asarray(all_totals[r])
+    return tot.astype(np.int64)
+
+
+def carry_in(all_carry, all_nseg, rank):
+    """Exchange 2a: what precedes shard `rank` inside its first segment, per pair: the carries of the
+    previous shards back to (and including) the last one that completed a segment.
+    all_carry[r]: [n_pairs, 4] {num, den, k, n_sites}; all_nseg[r]: [n_pairs] complete segments."""
+    n_pairs = np.asarray(all_carry[0]).shape[0]
+    out = np.zeros((n_pairs, 4))
+    for q in range(n_pairs):
+        r = rank - 1
+        chain = []
+        while r >= 0:
+            chain.append(np.asarray(all_carry[r])[q])
+            if all_nseg[r][q] > 0:
+                break
+            r -= 1
+        acc = np.zeros(4)
+        for c in reversed(chain):          # site order: oldest shard first
+            acc = acc + c
+        out[q] = acc
+    return out
+
+
+def tail_segments(seg, per):
+    """The last per-1 complete segments of a shard, per pair, newest last: [n_pairs, per-1, 3] and the
+    number that are valid.  `seg` is EvoFst.segments() with carry_in already added to row 0."""
+    Q = seg["n_segments"].shape[0]
+    k = max(per - 1, 0)
+    out = np.zeros((Q, k, 3)); cnt = np.zeros(Q, np.int64)
+    for q in range(Q):
+        n = int(seg["n_segments"][q]); m = min(n, k)
+        cnt[q] = m
+        if m:
+            out[q, k - m:, 0] = seg["sum_num"][n - m:n, q]
+            out[q, k - m:, 1] = seg["sum_den"][n - m:n, q]
+            out[q, k - m:, 2] = seg["sum_dxy_k"][n - m:n, q]
+    return out, cnt
+
+
+def halo_segments(all_tail, all_cnt, rank, per):
+    """Exchange 2b: the per-1 complete segments that precede shard `rank` globally, newest last."""
+    Q = np.asarray(all_tail[0]).shape[0]
+    k = max(per - 1, 0)
+    out = np.zeros((Q, k, 3)); cnt = np.zeros(Q, np.int64)
+    for q in range(Q):
+        rows = []
+        r = rank - 1
+        while r >= 0 and len(rows) < k:
+            m = int(all_cnt[r][q])
+            t = np.asarray(all_tail[r])[q]
+            for i in range(m):                 # newest first
+                if len(rows) < k:
+                    rows.append(t[k - 1 - i])
+            r -= 1
+        cnt[q] = len(rows)
+        for i, row in enumerate(rows):
+            out[q, k - 1 - i] = row
+    return out, cnt
+
+
+def add_carry(seg, cin):
+    """Adds carry_in to the first complete segment of each pair (in place on copies)."""
+    seg = dict(seg)
+    for name in ("sum_num", "sum_den", "sum_dxy_k"):
+        seg[name] = seg[name].copy()
+    for q in range(seg["n_segments"].shape[0]):
+        if seg["n_segments"][q] > 0:
+            seg["sum_num"][0, q] = cin[q, 0] + seg["sum_num"][0, q]
+            seg["sum_den"][0, q] = cin[q, 1] + seg["sum_den"][0, q]
+            seg["sum_dxy_k"][0, q] = cin[q, 2] + seg["sum_dxy_k"][0, q]
+    return seg
+
+
+def shard_windows(seg, pair, size, step, n_full_i, n_full_j, halo=None, halo_cnt=None, site_offset=0):
+    """Windows (process_vcf_fst.cpp:638-650) that END in this shard, from its carried segments and the
+    halo segments of the previous shards.  Same output dict as evo_amd.compose_snp_windows; end_site
+    is made global with site_offset."""
+    g = math.gcd(size, step)
+    per = size // g
+    first = int(seg["first_segment"][pair]); rows = int(seg["n_segments"][pair])
+    loc = np.stack([seg["sum_num"][:rows, pair], seg["sum_den"][:rows, pair], seg["sum_dxy_k"][:rows, pair]], axis=1)
+    nh = int(halo_cnt[pair]) if halo is not None else 0
+    pre = halo[pair][per - 1 - nh:] if nh else np.zeros((0, 3))
+    allseg = np.concatenate([pre, loc], axis=0)
+    es = seg["end_site"][:rows, pair]
+    out = dict(first_var=[], end_site=[], sum_num=[], sum_den=[], sum_dxy=[], fst=[], mean_dxy=[])
+    denom = float(n_full_i) * float(n_full_j)
+    for r in range(rows):
+        e = (first + r + 1) * g
+        if e % step != 0 or e < size:
+            continue
+        hi = nh + r
+        lo = hi - per + 1
+        if lo < 0:
+            continue
+        w = np.zeros(3)
+        for t in range(lo, hi + 1):
+            w = w + allseg[t]
+        with np.errstate(all="ignore"):
+            f = float(np.float64(w[0] / size) / np.float64(w[1] / size))
+        if f < 0:
+            f = 0.0
+        out["first_var"].append(e - size + 1); out["end_site"].append(int(es[r]) + site_offset)
+        out["sum_num"].append(w[0]); out["sum_den"].append(w[1]); out["sum_dxy"].append(w[2] / denom)
+        out["fst"].append(f); out["mean_dxy"].append(w[2] / denom / size)
+    return {k: np.asarray(v) for k, v in out.items()}
+
+
+def run_sharded_pairs(engine, all_gather, rank, size, step):
+    """One distributed pass in pairs mode on data already loaded in `engine`.
+    Returns (segments with carry, halo, halo_cnt, base) for shard_windows()."""
+    engine.set_windows(size, step)
+    engine.run_counts()
+    base = base_offsets(all_gather(engine.included_totals()), rank)          # exchange 1
+    engine.set_base_offsets(base)
+    engine.run_stats()
+    seg = engine.segments()
+    carry = engine.boundary()
+    per = size // math.gcd(size, step)
+    all_carry = all_gather(carry)                                           # exchange 2a
+    all_nseg = all_gather(seg["n_segments"].astype(np.int64))
+    seg = add_carry(seg, carry_in(all_carry, all_nseg, rank))
+    tail, cnt = tail_segments(seg, per)
+    all_tail = all_gather(tail) if per > 1 else [tail]                       # exchange 2b
+    all_cnt = all_gather(cnt) if per > 1 else [cnt]
+    halo, hcnt = halo_segments(all_tail, all_cnt, rank, per) if per > 1 else (None, None)
+    return seg, halo, hcnt, base

@@ -50,3 +50,68 @@ def assert_same_bits(a, b, what=""):
         k = np.argwhere(bad)[0]
         raise AssertionError("%s: %d of %d doubles differ, first at %s: %r vs %r" %
                              (what, int(bad.sum()), a.size, tuple(k), a[tuple(k)], b[tuple(k)]))
+
+
+def write_vcf(path, rng, n_sites, n_samples, scaffolds=("scaffold_0", "chr2"), miss=0.05, crlf=False, weird=True):
+    """Small seeded VCF with the cases the reference's parsers treat specially: half calls, '*' ALT
+    in either position, indels, multi-allelics, long REF, several scaffolds, extra FORMAT fields."""
+    names = ["S%03d" % i for i in range(n_samples)]
+    eol = "\r\n" if crlf else "\n"
+    with open(path, "w", newline="") as f:
+        f.write("##fileformat=VCFv4.2" + eol)
+        f.write("##source=evo_amd tests" + eol)
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + eol)
+        per = max(1, n_sites // len(scaffolds))
+        for si in range(n_sites):
+            scaf = scaffolds[min(si // per, len(scaffolds) - 1)]
+            pos = (si % per) * 137 + int(rng.integers(1, 120))
+            ref, alt = "A", "G"
+            kind = rng.random() if weird else 1.0
+            if kind < 0.03: alt = "G,*"
+            elif kind < 0.05: alt = "*,G"
+            elif kind < 0.07: alt = "GT"
+            elif kind < 0.09: alt = "G,T"
+            elif kind < 0.11: ref = "AT"
+            elif kind < 0.12: alt = "*"
+            f0 = rng.beta(0.5, 0.5)
+            gts = []
+            for i in range(n_samples):
+                p = min(1.0, max(0.0, f0 + 0.25 * ((i * 7919) % 5 - 2) / 2.0 * rng.random()))
+                a = ["1" if rng.random() < p else "0" for _ in range(2)]
+                if alt in ("G,*", "*,G", "G,T") and rng.random() < 0.15:
+                    a[int(rng.integers(0, 2))] = "2"
+                r = rng.random()
+                if r < miss: a = [".", "."]
+                elif r < miss * 1.3: a[int(rng.integers(0, 2))] = "."
+                sep = "|" if rng.random() < 0.3 else "/"
+                gts.append(a[0] + sep + a[1] + ":%d:%d" % (rng.integers(0, 60), rng.integers(0, 99)))
+            f.write("\t".join([scaf, str(pos), ".", ref, alt, "999", ".", "DP=10;AA=A", "GT:DP:GQ"] + gts) + eol)
+    return names
+
+
+def emulate_shard_outputs(num, den, kk, inc, base, g):
+    """What EvoFst.segments() / boundary() / included_totals() return for one shard, computed on the CPU
+    from per-site oracle values [S, Q] (CPU stand-in for the engine in the gloo tests)."""
+    S, Q = num.shape
+    cap = S // g + 2
+    seg = dict(first_segment=np.zeros(Q, np.int64), n_segments=np.zeros(Q, np.int64),
+               sum_num=np.zeros((cap, Q)), sum_den=np.zeros((cap, Q)), sum_dxy_k=np.zeros((cap, Q)),
+               end_site=np.zeros((cap, Q), np.int32))
+    carry = np.zeros((Q, 4)); totals = np.zeros(Q, np.int64)
+    for q in range(Q):
+        rank = int(base[q]); first = rank // g
+        seg["first_segment"][q] = first
+        a = np.zeros(3); cnt = 0; row = 0
+        for s in range(S):
+            if not inc[s, q]:
+                continue
+            rank += 1; cnt += 1
+            a = a + np.array([num[s, q], den[s, q], kk[s, q]])
+            if rank % g == 0:
+                seg["sum_num"][row, q], seg["sum_den"][row, q], seg["sum_dxy_k"][row, q] = a
+                seg["end_site"][row, q] = s
+                row += 1; a = np.zeros(3); cnt = 0
+        seg["n_segments"][q] = row
+        carry[q] = [a[0], a[1], a[2], cnt]
+        totals[q] = rank - int(base[q])
+    return seg, carry, totals

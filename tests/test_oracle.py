@@ -1,0 +1,179 @@
+"""CPU tests of the oracle: pinned against the reference's own inline math (oracle/_ref, built from
+/root/reference headers) and against the known answers the survey recorded from the reference."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import assert_same_bits, write_vcf
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KA = json.load(open(os.path.join(GOLD, "survey_known_answers.json")))
+
+
+def test_known_answer_direct_call():
+    d = KA["direct_call"]
+    sc, i1, i2, h1, h2 = O.fst_variant_counts(d["alt"], d["genotypes"], d["set1"], d["set2"])
+    assert (sc.set1Count, sc.set1_n_withoutMissing, sc.set2Count, sc.set2_n_withoutMissing) == \
+        (d["c1"], d["nm1"], d["c2"], d["nm2"])
+    L = O.lib()
+    p1 = sc.set1Count / sc.set1_n_withoutMissing; p2 = sc.set2Count / sc.set2_n_withoutMissing
+    assert p1 == d["p1"] and p2 == d["p2"]
+    assert L.orc_fst_numerator(p1, p2, d["nm1"], d["nm2"]) == d["num"]
+    assert L.orc_fst_denominator(p1, p2) == d["den"]
+    assert L.orc_dxy_literal(i1.ctypes.data_as(O._ip), i2.ctypes.data_as(O._ip), 8, 8) == d["dxy"]
+    assert L.orc_dxy_closed(d["c1"], d["c2"], 8, 8) == d["dxy"]
+    assert L.orc_pi_literal(h1.ctypes.data_as(O._ip), 8, d["nm1"]) == d["pi1"]
+    assert L.orc_pi_literal(h2.ctypes.data_as(O._ip), 8, d["nm2"]) == d["pi2"]
+    assert L.orc_pi_closed(d["c1"], 8, d["nm1"]) == d["pi1"] and L.orc_pi_closed(d["c2"], 8, d["nm2"]) == d["pi2"]
+    g = d["general"]
+    alt, alleles, aaf, allc, aafc = O.general_counts(d["genotypes"], [0] * 4 + [1] * 4, 2, [1, 1])
+    assert (alt[0], alleles[0], aaf[0], aafc[0], allc[0]) == (g["alt"], g["n"], g["aaf"], g["aaf_compl"], g["n_compl"])
+
+
+def test_known_answer_sc3749(tmp_path):
+    vcf = os.path.join(GOLD, "sc3749.vcf")
+    names = open(vcf).readline().rstrip("\n").split("\t")[9:]
+    sets = tmp_path / "sets.txt"
+    sets.write_text(",".join(names[:25]) + "\n" + ",".join(names[25:]) + "\n")
+    summ = O.fst_run(vcf, str(sets), str(tmp_path), run_name="t", size=1, step=1)
+    rows = (tmp_path / "t_w_1_fst.txt").read_text().splitlines()
+    assert rows[1] == KA["sc3749"]["fst_row"]
+    assert "%g" % summ[0] == KA["sc3749"]["genome_wide_fst_6sig"]
+    # -w 1,1 on a scaffold that is not scaffold_0: fixed-window file is header-only
+    assert len((tmp_path / "t_w_10000_fixedWindowStats.txt").read_text().splitlines()) == 1
+
+
+def test_literal_loops_equal_closed_forms():
+    rng = np.random.default_rng(0)
+    L = O.lib()
+    for _ in range(300):
+        m1, m2 = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        g = []
+        for i in range(m1 + m2):
+            a = rng.choice(["0", "1", "."], 2, p=[0.45, 0.4, 0.15])
+            g.append(a[0] + "/" + a[1])
+        sc, i1, i2, h1, h2 = O.fst_variant_counts("T", g, list(range(m1)), list(range(m1, m1 + m2)))
+        n1, n2 = 2 * m1, 2 * m2
+        lit = L.orc_dxy_literal(i1.ctypes.data_as(O._ip), i2.ctypes.data_as(O._ip), n1, n2)
+        assert lit == L.orc_dxy_closed(sc.set1Count, sc.set2Count, n1, n2)
+        with np.errstate(all="ignore"):
+            a = L.orc_pi_literal(h1.ctypes.data_as(O._ip), n1, sc.set1_n_withoutMissing)
+            b = L.orc_pi_closed(sc.set1Count, n1, sc.set1_n_withoutMissing)
+        assert a == b or (np.isnan(a) and np.isnan(b))
+
+
+def test_star_alt_rules():
+    g = ["0/1", "1/2", "2/2", "0/."]
+    sc, *_ = O.fst_variant_counts("G,*", g, [0, 1], [2, 3])        # allele 2 is missing
+    assert (sc.n_alt_alleles, sc.alt_code, sc.set1Count, sc.set1_n_withoutMissing,
+            sc.set2Count, sc.set2_n_withoutMissing) == (1, 1, 2, 3, 0, 1)
+    sc, *_ = O.fst_variant_counts("*,G", g, [0, 1], [2, 3])        # allele 1 missing, allele 2 is ALT
+    assert (sc.n_alt_alleles, sc.alt_code, sc.set1Count, sc.set1_n_withoutMissing,
+            sc.set2Count, sc.set2_n_withoutMissing) == (1, 2, 1, 2, 2, 3)
+    sc, *_ = O.fst_variant_counts("G,T", g, [0, 1], [2, 3])
+    assert sc.n_alt_alleles == 2 and not O.lib().orc_fst_site_included(C.byref(sc))
+    sc, *_ = O.fst_variant_counts("GT", g, [0, 1], [2, 3])
+    assert sc.bIndel == 1 and not O.lib().orc_fst_site_included(C.byref(sc))
+
+
+@pytest.mark.skipif(O.ref() is None, reason="oracle/_ref not built (no /root/reference here)")
+def test_math_bit_equal_to_reference_headers():
+    """The oracle's per-site math vs the reference's own inline functions (process_vcf_fst.h:19-45,
+    process_vcf_utils.h:272-275, 350-385) compiled from /root/reference."""
+    R, L = O.ref(), O.lib()
+    rng = np.random.default_rng(1)
+    for _ in range(20000):
+        n1, n2 = int(rng.integers(0, 60)), int(rng.integers(0, 60))
+        c1, c2 = int(rng.integers(0, n1 + 1)), int(rng.integers(0, n2 + 1))
+        p1 = C.c_double(); p2 = C.c_double()
+        with np.errstate(all="ignore"):
+            R.ref_calculateAlleleFrequencies(c1, n1, c2, n2, C.byref(p1), C.byref(p2))
+            e1 = np.float64(c1) / np.float64(n1); e2 = np.float64(c2) / np.float64(n2)
+        assert_same_bits([p1.value, p2.value], [e1, e2], "allele frequencies")
+        a = [R.ref_calculateFstNumerator(p1.value, p2.value, n1, n2), R.ref_calculateFstDenominator(p1.value, p2.value),
+             R.ref_calculateExpectedHeterozygositySimple(p1.value), R.ref_calculateExpectedHeterozygosityNei78(p1.value, n1)]
+        b = [L.orc_fst_numerator(p1.value, p2.value, n1, n2), L.orc_fst_denominator(p1.value, p2.value),
+             L.orc_het_simple(p1.value), L.orc_het_nei78(p1.value, n1)]
+        assert_same_bits(a, b, "per-site math (c=%d/%d, %d/%d)" % (c1, n1, c2, n2))
+    for n in (1, 2, 7, 100, 1000):
+        v = rng.normal(size=n)
+        vp = v.ctypes.data_as(O._dp)
+        assert R.ref_vector_average(vp, n) == L.orc_vector_average(vp, n)
+        assert R.ref_vector_sum(vp, n) == L.orc_vector_sum(vp, n)
+        assert R.ref_vector_average_withRegion(vp, n, 37) == L.orc_vector_average_with_region(vp, n, 37)
+
+
+@pytest.mark.skipif(O.ref() is None, reason="oracle/_ref not built (no /root/reference here)")
+def test_general_ctor_order_and_init():
+    """setSizes follows std::map (sorted name) order over ALL pops and AAFs start at -1.0
+    (process_vcf_utils.h:71-82, 115-119)."""
+    R = O.ref()
+    names = [b"zeta", b"Outgroup", b"alpha", b"xxx"]
+    sizes = (C.c_int * 4)(3, 5, 7, 2)
+    arr = (C.c_char_p * 4)(*names)
+    out = (C.c_long * 4)()
+    a = C.c_double(); b = C.c_double()
+    n = R.ref_general_ctor(arr, sizes, 4, out, C.byref(a), C.byref(b))
+    assert n == 4 and list(out) == [5, 7, 2, 3]          # Outgroup, alpha, xxx, zeta
+    assert a.value == -1.0 and b.value == -1.0
+
+
+def test_rcp_division_identity():
+    """The kernels' reciprocal-table quotient is bit-identical to IEEE division on the whole domain."""
+    assert O.lib().orc_check_rcp_division(2047) == 0
+
+
+def test_text_driver_documented_quirks(tmp_path):
+    rng = np.random.default_rng(7)
+    vcf = tmp_path / "a.vcf"
+    names = write_vcf(str(vcf), rng, 600, 24, scaffolds=("chrA", "chrB"), weird=True)
+    (tmp_path / "sets.txt").write_text(",".join(names[:12]) + "\n" + ",".join(names[12:]) + "\n")
+    O.fst_run(str(vcf), str(tmp_path / "sets.txt"), str(tmp_path), run_name="q", size=50, step=50)
+    rows = (tmp_path / "q_w_50_fst.txt").read_text().splitlines()
+    assert rows[0].startswith("var_num\tscaffold\tStart\tEnd")
+    # first window swallowed (start string is "scaffold_0\t0"), the next one starts at 0
+    first = rows[1].split("\t")
+    assert first[0] == "51" and first[2] == "0"
+    # FstGlobal: misplaced header on line 2, data row glued to it; FW rows all zero
+    pops = tmp_path / "pops.txt"
+    pops.write_text("".join("%s\t%s\n" % (n, ["p1", "p2", "Outgroup"][i % 3]) for i, n in enumerate(names)))
+    O.fstglobal_run(str(vcf), str(pops), str(tmp_path), run_name="g", size=20, step=10)
+    lines = (tmp_path / "g_FstGlobal_20_10.txt").read_text().splitlines()
+    assert lines[0] == "chr\tpos1\tpos2\tFstGlobal\tp1\tp2"
+    assert lines[1].startswith("\tp1\tp2chrA\t")
+    fw = (tmp_path / "g_FstGlobal_FW10000.txt").read_text().splitlines()
+    assert fw[0] == "chr\tpos1\tpos2\tnSNPs"
+    assert all(r.split("\t")[3:] == ["0", "0", "0"] for r in fw[1:]) and len(fw) > 1
+
+
+def test_text_driver_matches_code_level(tmp_path):
+    """The string-level fst driver and the code-level path agree on every counted site."""
+    from evo_amd import codes_from_vcf_line, MODE_FST
+    rng = np.random.default_rng(3)
+    vcf = tmp_path / "b.vcf"
+    n = 30
+    names = write_vcf(str(vcf), rng, 400, n, scaffolds=("scaffold_0",), weird=True)
+    (tmp_path / "sets.txt").write_text(",".join(names[:15]) + "\n" + ",".join(names[15:]) + "\n")
+    summ = O.fst_run(str(vcf), str(tmp_path / "sets.txt"), str(tmp_path), run_name="c", size=1, step=1)
+    rows = (tmp_path / "c_w_1_fst.txt").read_text().splitlines()[1:]
+    codes, flags = [], []
+    for line in open(vcf):
+        if line.startswith("#"):
+            continue
+        c, fl, chrom, pos = codes_from_vcf_line(line.rstrip("\n"), MODE_FST, n)
+        codes.append(c); flags.append(fl)
+    codes = np.array(codes); flags = np.array(flags, np.uint8)
+    sp = np.array([0] * 15 + [1] * 15, np.int32)
+    alt, nm = O.counts_from_codes(codes, sp, 2)
+    num, den, dxy, inc = O.pair_site_stats(alt, nm, [30, 30], [0], [1], flags)
+    assert inc.sum() == len(rows) == summ[5]
+    with np.errstate(all="ignore"):
+        f = num[inc[:, 0] == 1, 0] / den[inc[:, 0] == 1, 0]
+    f[f < 0] = 0
+    for r, fv, dv in zip(rows, f, dxy[inc[:, 0] == 1, 0]):
+        parts = r.split("\t")
+        assert parts[3] == "%g" % fv and parts[4] == "%g" % dv

@@ -1,0 +1,87 @@
+"""Multi-rank path on CPU: world_size-2 (and 3) gloo process groups run the two window-boundary
+exchanges of evo_amd.shard on per-shard outputs and must reproduce the single-shard window table."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from evo_amd import shard
+from oracle import oracle as O
+from tests.helpers import random_codes, round_robin_pops, n_full_of, emulate_shard_outputs
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _problem():
+    rng = np.random.default_rng(42)
+    S, N, P = 3000, 40, 4
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=0.1)
+    alt, nm = O.counts_from_codes(codes, sp, P)
+    nf = n_full_of(sp, P)
+    pi, pj = np.triu_indices(P, 1)
+    num, den, dxy, inc = O.pair_site_stats(alt, nm, nf, pi, pj)
+    kk = np.rint(dxy * (nf[pi] * nf[pj])[None, :])          # integer dxy numerators
+    return S, nf, pi, pj, num, den, dxy, kk, inc
+
+
+def _worker(rank, world, port, size, step, cuts, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, nf, pi, pj, num, den, dxy, kk, inc = _problem()
+        lo, hi = cuts[rank], cuts[rank + 1]
+        g = math.gcd(size, step); per = size // g
+        ag = shard.torch_all_gather()
+        # exchange 1
+        _, _, tot = emulate_shard_outputs(num[lo:hi], den[lo:hi], kk[lo:hi], inc[lo:hi], np.zeros(len(pi), np.int64), g)
+        base = shard.base_offsets(ag(tot), rank)
+        seg, carry, _ = emulate_shard_outputs(num[lo:hi], den[lo:hi], kk[lo:hi], inc[lo:hi], base, g)
+        # exchange 2
+        seg = shard.add_carry(seg, shard.carry_in(ag(carry), ag(seg["n_segments"]), rank))
+        tail, cnt = shard.tail_segments(seg, per)
+        halo, hcnt = shard.halo_segments(ag(tail), ag(cnt), rank, per)
+        rows = []
+        for q in range(len(pi)):
+            w = shard.shard_windows(seg, q, size, step, nf[pi[q]], nf[pj[q]], halo, hcnt, site_offset=lo)
+            rows.append((w["first_var"], w["end_site"], w["sum_num"], w["sum_den"], w["sum_dxy"]))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows)
+        if rank == 0:
+            ok = True
+            for q in range(len(pi)):
+                ow = O.snp_windows(num, den, dxy, inc, q, size, step)
+                fv = np.concatenate([gathered[r][q][0] for r in range(world)])
+                es = np.concatenate([gathered[r][q][1] for r in range(world)])
+                sn = np.concatenate([gathered[r][q][2] for r in range(world)])
+                sd = np.concatenate([gathered[r][q][3] for r in range(world)])
+                sx = np.concatenate([gathered[r][q][4] for r in range(world)])
+                ok &= np.array_equal(fv, ow["first_var"]) and np.array_equal(es, ow["end_site"])
+                ok &= bool(np.allclose(sn, ow["sum_num"], rtol=0, atol=1e-12 * size, equal_nan=True))
+                ok &= bool(np.allclose(sd, ow["sum_den"], rtol=0, atol=1e-12 * size, equal_nan=True))
+                ok &= bool(np.allclose(sx, ow["sum_dxy"], rtol=0, atol=1e-12 * size, equal_nan=True))
+            ret.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size,step,cuts", [(2, 100, 100, [0, 1500, 3000]), (2, 60, 20, [0, 1111, 3000]),
+                                                  (3, 90, 30, [0, 40, 90, 3000]), (2, 500, 500, [0, 100, 3000])])
+def test_window_exchange_matches_single_shard(world, size, step, cuts):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, size, step, cuts, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
