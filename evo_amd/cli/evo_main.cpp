@@ -1,0 +1,602 @@
+// evo_main.cpp -- CLI front-end that keeps `evo fst` and `evo FstGlobal` (options, input files,
+// output file names and formats) and runs the statistics on the GPU through include/evofst.h.
+//
+//   reference entry points replaced:  fstMain        process_vcf_fst.cpp:936   (VCF mode only)
+//                                     FstGlobalMain  evo_FstAgainstAll.cpp:62
+//
+// Division of labour: the host parses VCF text and packs genotypes (stage K0), the device computes
+// per-site counts and statistics (K1 + per-site kernels), and the host replays the reference's two
+// window state machines over those per-site values, so that the text outputs -- including the
+// reference's load-bearing quirks -- are byte-identical.  Output goes
+// through iostreams with default formatting, exactly like the reference.
+// Not carried over: --annot, --ancSets, --accessibleGenomeBED, --ms*, --eigen (host-side
+// consumers / other modes, out of scope).
+#include <getopt.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/evofst.h"
+
+using std::string;
+
+namespace {
+
+const int kChunkSites = 1 << 15;  // sites per device batch
+
+[[noreturn]] void die(const string &msg) {
+    std::cerr << "Error: " << msg << std::endl;
+    exit(EXIT_FAILURE);
+}
+void check(evofst_ctx *c, int rc, const char *what) {
+    if (rc != EVOFST_OK) die(string(what) + ": " + evofst_last_error(c));
+}
+
+// split() of the reference (process_vcf_utils.cpp:104-130): getline on a stringstream
+std::vector<string> split(const string &s, char delim) {
+    std::vector<string> elems;
+    std::stringstream ss(s);
+    string item;
+    while (std::getline(ss, item, delim)) elems.push_back(item);
+    return elems;
+}
+template <typename T> string numToString(T i) { std::stringstream out; out << i; return out.str(); }
+
+// createReader (process_vcf_utils.cpp:872-886): gz by suffix; zlib reads plain files transparently
+struct LineReader {
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    explicit LineReader(const string &path) : buf(1 << 16) {
+        f = gzopen(path.c_str(), "rb");
+        if (!f) die("could not open " + path);
+        gzbuffer(f, 1 << 20);
+    }
+    ~LineReader() { if (f) gzclose(f); }
+    bool getline(string &line) {
+        line.clear();
+        for (;;) {
+            if (!gzgets(f, buf.data(), (int)buf.size())) return !line.empty();
+            size_t n = strlen(buf.data());
+            if (n && buf[n - 1] == '\n') { line.append(buf.data(), n - 1); return true; }
+            line.append(buf.data(), n);
+            if (gzeof(f)) return true;
+        }
+    }
+};
+
+// locateSet (process_vcf_utils.cpp:923-936)
+std::vector<size_t> locateSet(const std::vector<string> &names, const std::vector<string> &set) {
+    std::vector<size_t> locs;
+    for (const string &s : set) {
+        auto it = std::find(names.begin(), names.end(), s);
+        if (it == names.end()) std::cerr << "Did not find the sample: \"" << s << "\"" << std::endl;
+        else locs.push_back((size_t)std::distance(names.begin(), it));
+    }
+    return locs;
+}
+
+double vector_average(const std::vector<double> &v) {   // process_vcf_utils.h:369-376
+    double sum = 0;
+    for (size_t i = 0; i < v.size(); i++) sum += v[i];
+    return (double)sum / (double)v.size();
+}
+double vector_average_tail(const std::vector<double> &v, size_t n) {
+    double sum = 0;
+    for (size_t i = v.size() - n; i < v.size(); i++) sum += v[i];
+    return (double)sum / (double)n;
+}
+double vector_tail_with_region(const std::vector<double> &v, size_t n, int region) {  // utils.h:378-385
+    double sum = 0;
+    for (size_t i = v.size() - n; i < v.size(); i++) sum += v[i];
+    return (double)sum / (double)region;
+}
+double calculateFst(double numAvg, double denAvg) {      // process_vcf_fst.cpp:354-360
+    double Fst = numAvg / denAvg;
+    if (Fst < 0) Fst = 0;
+    return Fst;
+}
+
+// An invalid operation (0/0, inf*0) yields the default NaN: sign bit SET on x86 (prints "-nan", what the
+// reference writes) but CLEAR on the GPU (prints "nan").  The replay below continues the reference's
+// x86 arithmetic, so device NaNs are given the x86 default's sign before they enter it.
+void x86_nan_sign(std::vector<double> &v) {
+    for (double &x : v)
+        if (x != x) x = -__builtin_fabs(x);
+}
+
+// One batch of parsed sites waiting for the device.
+struct Batch {
+    std::vector<uint8_t> codes;   // [n][2*n_virtual]
+    std::vector<uint8_t> flags;
+    std::vector<string> chrom, pos;
+    size_t n = 0;
+    void clear() { codes.clear(); flags.clear(); chrom.clear(); pos.clear(); n = 0; }
+};
+
+struct Device {
+    evofst_ctx *ctx = nullptr;
+    std::vector<uint8_t> tiles;
+    void open() {
+        ctx = evofst_create(0);
+        if (!ctx) die(string("no usable GPU: ") + evofst_last_error(nullptr));
+    }
+    void load(const Batch &b) {
+        tiles.resize(evofst_tiles_bytes(ctx, (int64_t)b.n));
+        check(ctx, evofst_pack_codes(ctx, 0, (int64_t)b.n, b.codes.data(), tiles.data()), "pack");
+        check(ctx, evofst_upload(ctx, (int64_t)b.n, tiles.data(), b.flags.data(), nullptr), "upload");
+        check(ctx, evofst_run_counts(ctx), "run_counts");
+    }
+};
+
+// ============================================================================================ fst
+
+namespace fstopt {
+string vcfFile, sampleSets, sampleNameFile, runName = "";
+int windowSize = 0, windowStep = 0, physicalWindowSize = 10000;
+double regAbove = 0;
+}
+
+const char *FST_USAGE =
+    "Usage: evo fst [OPTIONS]\n"
+    "Calculate Fst statistic from a vcf (GPU build: VCF mode only)\n"
+    "       -h, --help                              display this help and exit\n"
+    "       -n, --run-name                          run-name will be included in the output file name(s)\n"
+    "       --vcf=VCF_FILE.vcf                      (required)\n"
+    "       --sets=SAMPLE_SETS.txt                  (required) two lines, one sample set per line\n"
+    "       -s SAMPLES.txt, --samples=SAMPLES.txt   (optional) sample identifiers to be used for the VCF file\n"
+    "       -w SIZE,STEP --window=SIZE,STEP         (optional) sliding window of SIZE SNPs moving by STEP\n"
+    "       --regions-above=minFst                  (optional, requires -w)\n"
+    "       --physicalWindowSize=SIZE               (optional; default 10000bp)\n\n";
+
+enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED };
+
+void parseFstOptions(int argc, char **argv) {
+    static const struct option longopts[] = {
+        {"vcf", required_argument, NULL, OPT_VCF}, {"sets", required_argument, NULL, OPT_SETS},
+        {"window", required_argument, NULL, 'w'}, {"regions-above", required_argument, NULL, OPT_REG_ABOVE},
+        {"physicalWindowSize", required_argument, NULL, OPT_PHYS}, {"samples", required_argument, NULL, 's'},
+        {"run-name", required_argument, NULL, 'n'}, {"help", no_argument, NULL, 'h'},
+        {"ancSets", required_argument, NULL, OPT_UNSUPPORTED}, {"annot", required_argument, NULL, OPT_UNSUPPORTED},
+        {"ms", required_argument, NULL, OPT_UNSUPPORTED}, {"eigen", required_argument, NULL, OPT_UNSUPPORTED},
+        {"accessibleGenomeBED", required_argument, NULL, OPT_UNSUPPORTED}, {NULL, 0, NULL, 0}};
+    bool dieFlag = false;
+    std::vector<string> ws;
+    for (int c; (c = getopt_long(argc, argv, "hn:s:w:", longopts, NULL)) != -1;) {
+        std::istringstream arg(optarg != NULL ? optarg : "");
+        switch (c) {
+            case OPT_VCF: arg >> fstopt::vcfFile; break;
+            case OPT_SETS: arg >> fstopt::sampleSets; break;
+            case 'w':
+                ws = split(arg.str(), ',');
+                if (ws.size() < 2) die("-w needs SIZE,STEP");
+                fstopt::windowSize = atoi(ws[0].c_str()); fstopt::windowStep = atoi(ws[1].c_str());
+                break;
+            case OPT_REG_ABOVE: arg >> fstopt::regAbove; break;
+            case OPT_PHYS: arg >> fstopt::physicalWindowSize; break;
+            case 's': arg >> fstopt::sampleNameFile; break;
+            case 'n': arg >> fstopt::runName; break;
+            case OPT_UNSUPPORTED: die("this option belongs to a mode the GPU build does not carry (see evo_main.cpp header)");
+            case '?': dieFlag = true; break;
+            case 'h': std::cout << FST_USAGE; exit(EXIT_SUCCESS);
+        }
+    }
+    if (argc - optind > 0) { std::cerr << "too many arguments\n"; dieFlag = true; }
+    if (fstopt::vcfFile.empty() || fstopt::sampleSets.empty()) {
+        std::cerr << "To calculate Fst statistics from a vcf, you need to use both the --vcf and the --sets options\n";
+        dieFlag = true;
+    }
+    if (fstopt::regAbove > 0 && fstopt::windowSize == 0) {
+        std::cerr << "The window size (-w option) needs to be set for --regions-above option to work (you can set -w 1,1 for per variant Fst)\n";
+        dieFlag = true;
+    }
+    if (fstopt::windowSize > 0 && fstopt::windowStep <= 0) { std::cerr << "window STEP must be positive\n"; dieFlag = true; }
+    if (dieFlag) { std::cout << "\n" << FST_USAGE; exit(EXIT_FAILURE); }
+}
+
+int fstMain(int argc, char **argv) {
+    using namespace fstopt;
+    parseFstOptions(argc, argv);
+    std::cerr << "Calculating Fst using variants from: " << vcfFile << std::endl;
+    std::cerr << "Between the two 'populations' defined in: " << sampleSets << std::endl;
+    LineReader vcf(vcfFile);
+    std::ifstream setsFile(sampleSets.c_str());
+    if (!setsFile.is_open()) die("could not open " + sampleSets);
+
+    std::ofstream regionsAboveFstFile; bool inRegAbove = false;
+    if (regAbove > 0) regionsAboveFstFile.open((runName + "_w_" + numToString(windowSize) + "_fst_above" + numToString(regAbove) + ".txt").c_str());
+    std::ofstream pFst((runName + "_w_" + numToString(windowSize) + "_fst.txt").c_str());
+    std::ofstream fwFile((runName + "_w_" + numToString(physicalWindowSize) + "_fixedWindowStats.txt").c_str());
+    std::ofstream pHet((runName + "_w_" + numToString(windowSize) + "_heterozygosity.txt").c_str());
+    fwFile << "scaffold" << "\t" << "Start" << "\t" << "End" << "\t" << "Fst" << "\t" << "Dxy" << "\t" << "Set1_pi" << "\t" << "Set2_pi" << "\t" << "Accessible_bp" << "\t" << "Set1_VariantDensity" << "\t" << "Set2_VariantDensity" << std::endl;
+
+    string set1String, set2String;
+    getline(setsFile, set1String); getline(setsFile, set2String);
+    std::vector<string> set1 = split(set1String, ','), set2 = split(set2String, ',');
+    std::sort(set1.begin(), set1.end()); std::sort(set2.begin(), set2.end());
+
+    // reference state (process_vcf_fst.cpp:448-472)
+    int totalVariantNumber = 0, countedVariantNumber = 0;
+    string windowMiddleVariant = "first\tWindow", windowStartEnd = "scaffold_0\t0";
+    int windowStart = 0, windowEnd = 0, fixedWindowStart = 0;
+    std::vector<double> fwDxy, fwNum, fwDen, fwPi1, fwPi2;
+    std::vector<double> fstNumerators, fstDenominators, DxyVector, het1S, het2S, het1N, het2N, pi1V, pi2V;
+    std::vector<size_t> set1Loci, set2Loci;
+
+    Device dev;
+    Batch batch;
+    int nSamples = 0, nVirtual = 0;
+    std::vector<size_t> virt;          // virtual sample -> VCF column (set 1 entries, then set 2 entries)
+    std::vector<uint8_t> lineCodes;
+    std::vector<double> num, den, dxy, het, hetNei, pi;
+    std::vector<uint8_t> inc;
+    bool haveHeader = false;
+
+    auto flush = [&]() {
+        if (batch.n == 0) return;
+        const size_t n = batch.n;
+        dev.load(batch);
+        num.resize(n); den.resize(n); dxy.resize(n); inc.resize(n);
+        het.resize(2 * n); hetNei.resize(2 * n); pi.resize(2 * n);
+        check(dev.ctx, evofst_get_site_stats(dev.ctx, 0, (int64_t)n, num.data(), den.data(), dxy.data(), inc.data()), "site_stats");
+        check(dev.ctx, evofst_get_pop_site_div(dev.ctx, 0, (int64_t)n, het.data(), hetNei.data(), pi.data()), "pop_site_div");
+        x86_nan_sign(num); x86_nan_sign(den); x86_nan_sign(dxy); x86_nan_sign(het); x86_nan_sign(hetNei); x86_nan_sign(pi);
+        for (size_t s = 0; s < n; ++s) {
+            if (!inc[s]) continue;                                  // filter, fst.cpp:543-544
+            const string &scaffold = batch.chrom[s];
+            const string &loc = batch.pos[s];
+            countedVariantNumber++;
+            const double FstNumerator = num[s], FstDenominator = den[s], thisSNPDxy = dxy[s];
+            fstNumerators.push_back(FstNumerator); fwNum.push_back(FstNumerator);
+            fstDenominators.push_back(FstDenominator); fwDen.push_back(FstDenominator);
+            DxyVector.push_back(thisSNPDxy); fwDxy.push_back(thisSNPDxy);
+            fwPi1.push_back(pi[s]); fwPi2.push_back(pi[n + s]);
+            pi1V.push_back(pi[s]); pi2V.push_back(pi[n + s]);
+            het1S.push_back(het[s]); het2S.push_back(het[n + s]);
+            het1N.push_back(hetNei[s]); het2N.push_back(hetNei[n + s]);
+            // physical windows, fst.cpp:589-629
+            std::vector<string> sse = split(windowStartEnd, '\t');
+            if (sse[0] == scaffold) {
+                if (atoi(loc.c_str()) > (fixedWindowStart + physicalWindowSize)) {
+                    int acc = physicalWindowSize;
+                    double fDxy = vector_tail_with_region(fwDxy, fwDxy.size(), acc);
+                    double fFst = calculateFst(vector_average(fwNum), vector_average(fwDen));
+                    double fPi1 = vector_tail_with_region(fwPi1, fwPi1.size(), acc);
+                    double fPi2 = vector_tail_with_region(fwPi2, fwPi2.size(), acc);
+                    int z1 = (int)std::count(fwPi1.begin(), fwPi1.end(), 0), z2 = (int)std::count(fwPi2.begin(), fwPi2.end(), 0);
+                    int nv1 = (int)fwPi1.size() - z1, nv2 = (int)fwPi2.size() - z2;
+                    fwFile << scaffold << "\t" << fixedWindowStart << "\t" << fixedWindowStart + physicalWindowSize << "\t" << fFst << "\t" << fDxy << "\t" << fPi1 << "\t" << fPi2 << "\t" << acc << "\t" << (double)nv1 / acc << "\t" << (double)nv2 / acc << std::endl;
+                    fwDxy.clear(); fwNum.clear(); fwDen.clear(); fwPi1.clear(); fwPi2.clear();
+                    int without = 0;
+                    while (atoi(loc.c_str()) > (fixedWindowStart + physicalWindowSize)) {
+                        if (without > 0)
+                            fwFile << scaffold << "\t" << fixedWindowStart << "\t" << fixedWindowStart + physicalWindowSize << "\t" << "NA" << "\t" << 0 << "\t" << 0 << "\t" << 0 << "\t" << physicalWindowSize << "\t" << 0 << "\t" << 0 << std::endl;
+                        fixedWindowStart = fixedWindowStart + physicalWindowSize;
+                        without++;
+                    }
+                }
+            } else {
+                fixedWindowStart = 0;
+                fwDxy.clear(); fwNum.clear(); fwDen.clear(); fwPi1.clear(); fwPi2.clear();
+            }
+            if (windowSize == 1) {                                   // fst.cpp:633-636
+                double Fst = FstNumerator / FstDenominator;
+                if (Fst < 0) Fst = 0;
+                pFst << countedVariantNumber << "\t" << scaffold + "\t" + loc << "\t" << Fst << "\t" << thisSNPDxy << std::endl;
+            } else if ((windowSize > 0) && (countedVariantNumber % windowStep == 0) && countedVariantNumber >= windowSize) {
+                const size_t W = (size_t)windowSize;
+                double windowFst = calculateFst(vector_average_tail(fstNumerators, W), vector_average_tail(fstDenominators, W));
+                double windowDxy = vector_average_tail(DxyVector, W);
+                if (windowSize == windowStep) {
+                    std::vector<string> s = split(windowStartEnd, '\t');
+                    if (s[0] == scaffold) {
+                        windowStartEnd = windowStartEnd + "\t" + loc;
+                        windowEnd = atoi(loc.c_str());
+                        double dxyInc = vector_tail_with_region(DxyVector, W, windowEnd - windowStart);
+                        pFst << countedVariantNumber - windowSize + 1 << "\t" << windowStartEnd << "\t" << windowFst << "\t" << windowDxy << "\t" << dxyInc << "\t" << W << std::endl;
+                        if (regAbove > 0) {
+                            if (windowFst >= regAbove && !inRegAbove) { inRegAbove = true; regionsAboveFstFile << s[0] << "\t" << s[1] << "\t"; }
+                            else if (windowFst < regAbove && inRegAbove) { inRegAbove = false; regionsAboveFstFile << s[1] << std::endl; }
+                        }
+                    }
+                } else {
+                    pFst << countedVariantNumber - windowSize + 1 << "\t" << windowMiddleVariant << "\t" << windowFst << "\t" << windowDxy << "\t" << W << std::endl;
+                }
+                double wS1 = vector_average_tail(het1S, W), wS2 = vector_average_tail(het2S, W);
+                double wN1 = vector_average_tail(het1N, W), wN2 = vector_average_tail(het2N, W);
+                double wPi1 = vector_tail_with_region(pi1V, W, windowEnd - windowStart);
+                double wPi2 = vector_tail_with_region(pi2V, W, windowEnd - windowStart);
+                if (windowSize == windowStep) {
+                    std::vector<string> s = split(windowStartEnd, '\t');
+                    if (s[0] == scaffold) {
+                        pHet << windowStartEnd << "\t" << wS1 << "\t" << wS2 << "\t" << wN1 << "\t" << wN2 << "\t" << wPi1 << "\t" << wPi2 << std::endl;
+                        windowStartEnd = scaffold + "\t" + loc;
+                        windowStart = atoi(loc.c_str());
+                    } else {
+                        windowStartEnd = scaffold + "\t0";
+                        windowStart = 0;
+                    }
+                } else {
+                    pHet << windowMiddleVariant << "\t" << wS1 << "\t" << wS2 << "\t" << wN1 << "\t" << wN2 << std::endl;
+                    windowMiddleVariant = scaffold + "\t" + loc;
+                }
+            }
+        }
+        batch.clear();
+    };
+
+    string line;
+    while (vcf.getline(line)) {
+        if (line[0] == '#' && line[1] == '#') continue;
+        if (line[0] == '#' && line[1] == 'C') {
+            std::vector<string> fields = split(line, '\t');
+            std::vector<string> sampleNames;
+            nSamples = (int)fields.size() - 9;
+            if (nSamples <= 0) die("VCF header has no sample columns");
+            if (sampleNameFile.empty()) sampleNames.assign(fields.begin() + 9, fields.end());
+            else { std::ifstream sf(sampleNameFile.c_str()); string l; while (getline(sf, l)) sampleNames.push_back(l); }
+            set1Loci = locateSet(sampleNames, set1); set2Loci = locateSet(sampleNames, set2);
+            if (set1Loci.empty() || set2Loci.empty()) die("a sample set has no samples in the VCF");
+            for (size_t i : set1Loci) virt.push_back(i);
+            for (size_t i : set2Loci) virt.push_back(i);
+            for (size_t i : virt) if ((int)i >= nSamples) die("sample index beyond the VCF columns (check the -s file)");
+            nVirtual = (int)virt.size();
+            std::vector<int32_t> sp(nVirtual, 1);
+            for (size_t i = 0; i < set1Loci.size(); ++i) sp[i] = 0;
+            dev.open();
+            check(dev.ctx, evofst_set_layout(dev.ctx, nVirtual, 2, sp.data()), "set_layout");
+            int32_t pi0 = 0, pj0 = 1;
+            check(dev.ctx, evofst_set_pairs(dev.ctx, &pi0, &pj0, 1), "set_pairs");
+            check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
+            lineCodes.resize((size_t)2 * nSamples);
+            haveHeader = true;
+            if (windowSize > 0) {                                    // fst.cpp:507-520
+                if (windowSize == windowStep) {
+                    if (windowSize == 1) {
+                        pFst << "var_num" << "\t" << "scaffold" << "\t" << "Position" << "\t" << "Fst" << "\t" << "Dxy_thisVariant" << std::endl;
+                    } else {
+                        pHet << "scaffold" << "\t" << "Start" << "\t" << "End" << "\t" << "Set1_heterozygosity" << "\t" << "Set2_heterozygosity" << "\t" << "Set1_heterozygosity_Nei" << "\t" << "Set2_heterozygosity_Nei" << "\t" << "Set1_nucleotideDiversity_pi" << "\t" << "Set2_nucleotideDiversity_pi" << std::endl;
+                        pFst << "var_num" << "\t" << "scaffold" << "\t" << "Start" << "\t" << "End" << "\t" << "Fst" << "\t" << "Dxy_onlyVariants" << "\t" << "Dxy_AllSites" << "\t" << "windowSize" << std::endl;
+                    }
+                    if (regAbove > 0) regionsAboveFstFile << "scaffold" << "\t" << "Start" << "\t" << "End" << std::endl;
+                } else {
+                    pHet << "Middle_SNP_position" << "\t" << "Set1_heterozygosity" << "\t" << "Set2_heterozygosity" << "\t" << "Set1_heterozygosity_Nei" << "\t" << "Set2_heterozygosity_Nei" << "\t" << "Set1_nucleotideDiversity_pi" << "\t" << "Set2_nucleotideDiversity_pi" << std::endl;
+                    pFst << "var_num" << "\t" << "scaffold" << "\t" << "Start" << "\t" << "End" << "\t" << "Fst" << "\t" << "Dxy_onlyVariants" << "\t" << "Dxy_AllSites" << "\t" << "windowSize" << std::endl;
+                }
+            }
+            continue;
+        }
+        if (!haveHeader) die("variant line before the #CHROM header");
+        totalVariantNumber++;
+        uint32_t fl = 0;
+        const char *chrom = nullptr, *pos = nullptr;
+        std::vector<char> lb(line.begin(), line.end()); lb.push_back('\0');
+        if (evofst_codes_from_vcf_line(lb.data(), EVOFST_MODE_FST, nSamples, lineCodes.data(), &fl, &chrom, &pos) != EVOFST_OK)
+            die("malformed VCF line " + numToString(totalVariantNumber) + " (diploid GT fields with single-digit alleles are required)");
+        const size_t o = batch.codes.size();
+        batch.codes.resize(o + (size_t)2 * nVirtual);
+        for (int v = 0; v < nVirtual; ++v) {
+            batch.codes[o + 2 * v] = lineCodes[2 * virt[v]];
+            batch.codes[o + 2 * v + 1] = lineCodes[2 * virt[v] + 1];
+        }
+        batch.flags.push_back((uint8_t)fl); batch.chrom.emplace_back(chrom); batch.pos.emplace_back(pos);
+        if (++batch.n == (size_t)kChunkSites) flush();
+        if (totalVariantNumber % 100000 == 0) std::cerr << totalVariantNumber << " variants processed..." << std::endl;
+    }
+    flush();
+    double Fst = calculateFst(vector_average(fstNumerators), vector_average(fstDenominators));   // fst.cpp:701-709
+    double oS1 = vector_average(het1S), oS2 = vector_average(het2S), oN1 = vector_average(het1N), oN2 = vector_average(het2N);
+    std::cerr << "Fst: " << Fst << std::endl;
+    std::cerr << "Heterozygosities: " << "\tS1:" << oS1 << "\tS2:" << oS2 << "\tNei1:" << oN1 << "\tNei2" << oN2 << std::endl;
+    pHet << "#Heterozygosities: " << "\tS1:" << oS1 << "\tS2:" << oS2 << "\tNei1:" << oN1 << "\tNei2" << oN2 << std::endl;
+    if (dev.ctx) evofst_destroy(dev.ctx);
+    return 0;
+}
+
+// ====================================================================================== FstGlobal
+
+namespace gopt {
+string vcfFile, setsFile, runName = "";
+int fixedWindowSize = 10000, windowSize = 20, windowStep = 10;
+}
+
+const char *FSTGLOBAL_USAGE =
+    "Usage: evo FstGlobal [OPTIONS] INPUT_FILE.vcf POPULATIONS.txt\n"
+    "Calculate the Fst statistic for each population from the POPULATIONS.txt file, when compared against the rest of the dataset\n"
+    "       -h, --help                              display this help and exit\n"
+    "       -f, --fixedW sizeKb                     fixed window size (default: 10kb)\n"
+    "       -w SIZE,STEP --window=SIZE,STEP         sliding window: SIZE SNPs, moving by STEP (default: 20,10)\n"
+    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file name\n\n";
+
+void parseFstGlobalOptions(int argc, char **argv) {
+    static const struct option longopts[] = {{"fixedW", required_argument, NULL, 'f'}, {"window", required_argument, NULL, 'w'},
+                                             {"annot", required_argument, NULL, OPT_UNSUPPORTED}, {"help", no_argument, NULL, 'h'},
+                                             {"run-name", required_argument, NULL, 'n'}, {NULL, 0, NULL, 0}};
+    bool dieFlag = false;
+    std::vector<string> ws;
+    for (int c; (c = getopt_long(argc, argv, "hw:n:f:", longopts, NULL)) != -1;) {
+        std::istringstream arg(optarg != NULL ? optarg : "");
+        switch (c) {
+            case '?': dieFlag = true; break;
+            case 'f': arg >> gopt::fixedWindowSize; break;
+            case 'w':
+                ws = split(arg.str(), ',');
+                if (ws.size() < 2) die("-w needs SIZE,STEP");
+                gopt::windowSize = atoi(ws[0].c_str()); gopt::windowStep = atoi(ws[1].c_str());
+                break;
+            case 'n': arg >> gopt::runName; break;
+            case OPT_UNSUPPORTED: die("--annot is not carried by the GPU build");
+            case 'h': std::cout << FSTGLOBAL_USAGE; exit(EXIT_SUCCESS);
+        }
+    }
+    if (argc - optind < 2) { std::cerr << "missing arguments\n"; dieFlag = true; }
+    else if (argc - optind > 2) { std::cerr << "too many arguments\n"; dieFlag = true; }
+    if (gopt::windowSize <= 0 || gopt::windowStep <= 0) { std::cerr << "window SIZE and STEP must be positive\n"; dieFlag = true; }
+    if (dieFlag) { std::cout << "\n" << FSTGLOBAL_USAGE; exit(EXIT_FAILURE); }
+    gopt::vcfFile = argv[optind++]; gopt::setsFile = argv[optind++];
+}
+
+int FstGlobalMain(int argc, char **argv) {
+    using namespace gopt;
+    parseFstGlobalOptions(argc, argv);
+    LineReader vcf(vcfFile);
+    std::ifstream setsF(setsFile.c_str());
+    if (!setsF.is_open()) die("could not open " + setsFile);
+    std::map<string, std::vector<string>> popToIDsMap;
+    std::map<string, string> IDsToPopMap;
+    string line;
+    while (getline(setsF, line)) {                                   // FstAgainstAll.cpp:83-89
+        std::vector<string> ID_Pop = split(line, '\t');
+        if (ID_Pop.size() < 2) die("POPULATIONS.txt needs two tab-separated columns per line");
+        popToIDsMap[ID_Pop[1]].push_back(ID_Pop[0]);
+        IDsToPopMap[ID_Pop[0]] = ID_Pop[1];
+    }
+    std::vector<string> populations, populationsToUse;
+    std::map<string, int> popIndex;
+    for (auto &kv : popToIDsMap) {
+        popIndex[kv.first] = (int)populations.size();
+        populations.push_back(kv.first);
+        if (kv.first != "Outgroup" && kv.first != "xxx") populationsToUse.push_back(kv.first);
+    }
+    std::cerr << "There are " << populations.size() << " populations " << std::endl;
+    if (populationsToUse.empty()) die("no population to use");
+
+    std::ofstream outFile((runName + "_FstGlobal_" + numToString(windowSize) + "_" + numToString(windowStep) + ".txt").c_str());
+    outFile << "chr\tpos1\tpos2\tFstGlobal"; for (size_t i = 0; i < populationsToUse.size(); i++) outFile << "\t" << populationsToUse[i];
+    outFile << std::endl;
+    std::ofstream outFW((runName + "_FstGlobal_FW" + numToString(fixedWindowSize) + ".txt").c_str());
+    outFW << "chr\tpos1\tpos2\tnSNPs"; for (size_t i = 0; i < populationsToUse.size(); i++) outFile << "\t" << populationsToUse[i];   // sic: FstAgainstAll.cpp:104
+    outFW << std::endl;
+
+    const size_t nUse = populationsToUse.size();
+    std::deque<double> initFst(windowSize, 0.0);
+    std::vector<std::deque<double>> numDq(nUse, initFst), denDq(nUse, initFst);
+    std::deque<string> coordDeque(windowSize, "0");
+    int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
+    int totalVariantNumber = 0, usedVariantNumber = 0;
+
+    Device dev;
+    Batch batch;
+    int nSamples = 0;
+    std::vector<double> num, den;
+    std::vector<uint8_t> kept;
+    bool haveHeader = false;
+
+    auto flush = [&]() {
+        if (batch.n == 0) return;
+        const size_t n = batch.n;
+        dev.load(batch);
+        num.resize(nUse * n); den.resize(nUse * n); kept.resize(n);
+        check(dev.ctx, evofst_get_global_site_stats(dev.ctx, 0, (int64_t)n, num.data(), den.data(), kept.data()), "global_site_stats");
+        x86_nan_sign(num); x86_nan_sign(den);
+        for (size_t s = 0; s < n; ++s) {
+            if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :185-188
+            usedVariantNumber++;                                     // :189
+            if (!kept[s]) continue;                                  // :198-203
+            const string &chr = batch.chrom[s];
+            const string &coord = batch.pos[s];
+            double coordDouble; { std::stringstream ss(coord); ss >> coordDouble; }
+            if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {   // :222-235
+                outFW << chr << "\t" << currentWindowStart << "\t" << currentWindowEnd << "\t" << 0;
+                for (size_t i = 0; i != nUse; i++) { double FstFW = 0; outFW << "\t" << FstFW; }
+                outFW << std::endl;
+                if (coordDouble > currentWindowEnd) { currentWindowStart = currentWindowStart + fixedWindowSize; currentWindowEnd = currentWindowEnd + fixedWindowSize; }
+                else if (coordDouble < currentWindowStart) { currentWindowStart = 0; currentWindowEnd = 0 + fixedWindowSize; }
+            }
+            coordDeque.push_back(coord); coordDeque.pop_front();
+            const bool emit = (usedVariantNumber > windowSize || windowSize == windowStep) && (usedVariantNumber % windowStep == 0);
+            if (emit) outFile << chr << "\t" << coordDeque[0] << "\t" << coord << "\t" << "N";
+            for (size_t i = 0; i != nUse; i++) {                     // :244-282
+                numDq[i].push_back(num[i * n + s]); numDq[i].pop_front();
+                denDq[i].push_back(den[i * n + s]); denDq[i].pop_front();
+                if (emit) {
+                    double sn = 0, sd = 0;
+                    for (size_t t = 0; t < numDq[i].size(); t++) sn += numDq[i][t];
+                    for (size_t t = 0; t < denDq[i].size(); t++) sd += denDq[i][t];
+                    const double an = (double)sn / (double)numDq[i].size(), ad = (double)sd / (double)denDq[i].size();
+                    double Fst = an / ad; if (Fst < 0 || ad == 0) Fst = 0;
+                    outFile << "\t" << Fst;
+                }
+            }
+            if (emit) outFile << std::endl;
+        }
+        batch.clear();
+    };
+
+    std::vector<uint8_t> lineCodes;
+    while (vcf.getline(line)) {
+        line.erase(std::remove(line.begin(), line.end(), '\r'), line.end());   // :146
+        if (line[0] == '#' && line[1] == '#') continue;
+        if (line[0] == '#' && line[1] == 'C') {
+            std::vector<string> fields = split(line, '\t');
+            std::vector<string> sampleNames(fields.begin() + std::min<size_t>(9, fields.size()), fields.end());
+            nSamples = (int)sampleNames.size();
+            if (nSamples <= 0) die("VCF header has no sample columns");
+            std::vector<int32_t> sp(nSamples, -1);
+            for (int i = 0; i < nSamples; ++i) {                     // :153-155
+                auto it = IDsToPopMap.find(sampleNames[i]);
+                if (it != IDsToPopMap.end()) sp[i] = popIndex[it->second];
+            }
+            std::vector<size_t> allSizes;                            // setSizes, utils.h:77 (ALL pops, sorted order)
+            for (auto &kv : popToIDsMap) {
+                std::vector<size_t> spPos = locateSet(sampleNames, kv.second);
+                if (spPos.empty()) { std::cerr << "Did not find any samples in the VCF for \"" << kv.first << "\"" << std::endl; exit(EXIT_FAILURE); }
+                allSizes.push_back(spPos.size());
+            }
+            std::vector<int32_t> use; std::vector<int64_t> setSizes;
+            for (size_t u = 0; u < nUse; ++u) { use.push_back(popIndex[populationsToUse[u]]); setSizes.push_back((int64_t)allSizes[u]); }  // c->setSizes[i], :253
+            // a population whose samples were all re-assigned by a later line of the file keeps an entry
+            // in the reference's maps but never gets an allele; give it no layout slot problems:
+            for (size_t k = 0; k < populations.size(); ++k)
+                if (std::find(sp.begin(), sp.end(), (int32_t)k) == sp.end()) die("population \"" + populations[k] + "\" has no sample column of its own");
+            dev.open();
+            check(dev.ctx, evofst_set_layout(dev.ctx, nSamples, (int)populations.size(), sp.data()), "set_layout");
+            check(dev.ctx, evofst_set_against_all(dev.ctx, use.data(), (int)nUse, setSizes.data()), "set_against_all");
+            check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
+            lineCodes.resize((size_t)2 * nSamples);
+            haveHeader = true;
+            continue;
+        }
+        if (!haveHeader) die("variant line before the #CHROM header");
+        totalVariantNumber++;
+        if (totalVariantNumber % 10000 == 0) std::cerr << "Processed " << totalVariantNumber << " variants" << std::endl;
+        uint32_t fl = 0;
+        const char *chrom = nullptr, *pos = nullptr;
+        std::vector<char> lb(line.begin(), line.end()); lb.push_back('\0');
+        if (evofst_codes_from_vcf_line(lb.data(), EVOFST_MODE_GLOBAL, nSamples, lineCodes.data(), &fl, &chrom, &pos) != EVOFST_OK)
+            die("malformed VCF line " + numToString(totalVariantNumber));
+        batch.codes.insert(batch.codes.end(), lineCodes.begin(), lineCodes.end());
+        batch.flags.push_back((uint8_t)fl); batch.chrom.emplace_back(chrom); batch.pos.emplace_back(pos);
+        if (++batch.n == (size_t)kChunkSites) flush();
+    }
+    flush();
+    if (dev.ctx) evofst_destroy(dev.ctx);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc <= 1) {
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal\n";
+        return 0;
+    }
+    string command(argv[1]);
+    if (command == "fst") return fstMain(argc - 1, argv + 1);
+    if (command == "FstGlobal") return FstGlobalMain(argc - 1, argv + 1);
+    if (command == "help" || command == "--help") {
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal\n" << FST_USAGE << FSTGLOBAL_USAGE;
+        return 0;
+    }
+    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal)\n";
+    return 1;
+}

@@ -492,6 +492,11 @@ extern "C" int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, u
             fl |= EVOFST_SITE_SKIP;                                               // FstAgainstAll.cpp:185
     }
     *site_flags = fl;
+    if (fl & EVOFST_SITE_SKIP) {
+        // the reference never looks at the genotype columns of such a line
+        std::memset(codes, EVOFST_MISSING, (size_t)2 * n_samples);
+        return EVOFST_OK;
+    }
     for (int i = 0; i < n_samples; ++i) {
         // genotype column i: chars [0] and [2] (process_vcf_fst.cpp:244, process_vcf_utils.cpp:67,75)
         if (p[0] == '\0' || p[0] == '\t' || p[1] == '\0' || p[1] == '\t' || p[2] == '\0' || p[2] == '\t')

@@ -1,0 +1,143 @@
+"""GPU, end to end: the `evo` CLI front-end (evo_amd/cli/evo -> libevofst.so -> HIP kernels) writes the
+same bytes as the oracle's restatement of `evo fst` / `evo FstGlobal` on small seeded VCFs.
+
+The expected files come from the CPU oracle (oracle/evo_oracle.c text drivers); beyond the behaviours
+recorded in tests/golden/survey_known_answers.json the text level is "parity unpinned" (the reference
+binary cannot be built in this image)."""
+import filecmp
+import gzip
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import write_vcf
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EVO = os.path.join(ROOT, "evo_amd", "cli", "evo")
+
+
+def _same_files(a_dir, b_dir):
+    names = sorted(os.listdir(b_dir))
+    assert names, "oracle wrote nothing"
+    for n in names:
+        pa, pb = os.path.join(a_dir, n), os.path.join(b_dir, n)
+        assert os.path.exists(pa), "CLI did not write %s" % n
+        if not filecmp.cmp(pa, pb, shallow=False):
+            la, lb = open(pa).read().splitlines(), open(pb).read().splitlines()
+            for i, (x, y) in enumerate(zip(la, lb)):
+                assert x == y, "%s line %d:\n cli    %r\n oracle %r" % (n, i + 1, x, y)
+            assert len(la) == len(lb), "%s: %d vs %d lines" % (n, len(la), len(lb))
+
+
+def _fst_case(tmp_path, rng, args, size, step, n_sites=900, n_samples=24, scaffolds=("scaffold_0", "chrB"),
+              crlf=False, gz=False, overlap=False, samples_file=False, phys=10000, reg_above=0.0):
+    vcf = str(tmp_path / "in.vcf")
+    names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=scaffolds, crlf=crlf, miss=0.08)
+    if gz:
+        with open(vcf, "rb") as f, gzip.open(vcf + ".gz", "wb") as g:
+            shutil.copyfileobj(f, g)
+        vcf += ".gz"
+    half = n_samples // 2
+    s1, s2 = names[:half], names[half:]
+    if overlap:
+        s2 = s2 + names[:2]           # samples that sit in both sets
+        s1 = s1 + ["NOT_THERE"]       # and a name the VCF does not have
+    sets = str(tmp_path / "sets.txt")
+    open(sets, "w").write(",".join(s1) + "\n" + ",".join(s2) + "\n")
+    sf = None
+    if samples_file:
+        sf = str(tmp_path / "samples.txt")
+        open(sf, "w").write("".join(n + "\n" for n in reversed(names)))
+    cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
+    cli_dir.mkdir(); orc_dir.mkdir()
+    cmd = [EVO, "fst", "--vcf=" + vcf, "--sets=" + sets, "-n", "run"] + args
+    if sf:
+        cmd += ["-s", sf]
+    r = subprocess.run(cmd, cwd=str(cli_dir), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    O.fst_run(vcf, sets, str(orc_dir), run_name="run", size=size, step=step, phys=phys, reg_above=reg_above, samples=sf)
+    _same_files(str(cli_dir), str(orc_dir))
+    return r
+
+
+def test_cli_fst_per_site(tmp_path):
+    _fst_case(tmp_path, np.random.default_rng(1), ["-w", "1,1"], 1, 1)
+
+
+def test_cli_fst_equal_windows_multi_scaffold(tmp_path):
+    r = _fst_case(tmp_path, np.random.default_rng(2), ["-w", "50,50", "--physicalWindowSize=5000"], 50, 50, phys=5000)
+    assert "Fst:" in r.stderr
+
+
+def test_cli_fst_first_window_swallowed_on_other_scaffold(tmp_path):
+    _fst_case(tmp_path, np.random.default_rng(3), ["-w", "40,40"], 40, 40, scaffolds=("chr7", "chr8"))
+
+
+def test_cli_fst_overlapping_windows(tmp_path):
+    _fst_case(tmp_path, np.random.default_rng(4), ["--window=40,20"], 40, 20)
+
+
+def test_cli_fst_no_windows_gz_crlf(tmp_path):
+    _fst_case(tmp_path, np.random.default_rng(5), [], 0, 0, gz=True, crlf=True)
+
+
+def test_cli_fst_sets_overlap_samples_file_regions_above(tmp_path):
+    _fst_case(tmp_path, np.random.default_rng(6), ["-w", "30,30", "--regions-above=0.05"], 30, 30, overlap=True,
+              samples_file=True, reg_above=0.05, scaffolds=("scaffold_0",))
+
+
+def test_cli_fst_sc3749(tmp_path):
+    vcf = os.path.join(ROOT, "tests", "golden", "sc3749.vcf")
+    names = open(vcf).readline().rstrip("\n").split("\t")[9:]
+    sets = tmp_path / "sets.txt"
+    sets.write_text(",".join(names[:25]) + "\n" + ",".join(names[25:]) + "\n")
+    r = subprocess.run([EVO, "fst", "--vcf=" + vcf, "--sets=" + str(sets), "-w", "1,1", "-n", "t"], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rows = (tmp_path / "t_w_1_fst.txt").read_text().splitlines()
+    assert rows[1] == "1\tscaffold_3749\t904\t0.0962099\t0.224"       # the reference's own output
+    assert "Fst: 0.0962099" in r.stderr
+
+
+def _global_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=1200, n_samples=36, crlf=False, pops=None):
+    vcf = str(tmp_path / "in.vcf")
+    names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=0.1)
+    pops = pops or ["popA", "popB", "Outgroup", "popC"]
+    pf = str(tmp_path / "pops.txt")
+    with open(pf, "w") as f:
+        for i, n in enumerate(names):
+            if i % 11 == 10:
+                continue                                          # sample that is in no population
+            f.write("%s\t%s\n" % (n, pops[i % len(pops)]))
+        f.write("GHOST\t%s\n" % pops[0])                          # ID the VCF does not have
+    cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
+    cli_dir.mkdir(); orc_dir.mkdir()
+    r = subprocess.run([EVO, "FstGlobal", "-n", "g"] + args + [vcf, pf], cwd=str(cli_dir), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    O.fstglobal_run(vcf, pf, str(orc_dir), run_name="g", size=size, step=step, fixed=fixed)
+    _same_files(str(cli_dir), str(orc_dir))
+
+
+def test_cli_fstglobal_default(tmp_path):
+    _global_case(tmp_path, np.random.default_rng(7), [], 20, 10)
+
+
+def test_cli_fstglobal_equal_windows_crlf(tmp_path):
+    _global_case(tmp_path, np.random.default_rng(8), ["-w", "25,25", "-f", "3000"], 25, 25, fixed=3000, crlf=True)
+
+
+def test_cli_fstglobal_outgroup_sorts_first(tmp_path):
+    """'Outgroup' and 'xxx' sort before the used populations: the setSizes index mismatch of
+    evo_FstAgainstAll.cpp:253 becomes visible."""
+    _global_case(tmp_path, np.random.default_rng(9), ["-w", "20,10"], 20, 10, pops=["zeta", "Outgroup", "yak", "xxx", "wolf"])
+
+
+def test_cli_rejects_unknown_command():
+    r = subprocess.run([EVO, "stats"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Unrecognized command" in r.stderr
