@@ -64,11 +64,16 @@ struct K2Params {
     const int64_t *first_segment;  // [n_pairs]
     int32_t g;
     int64_t seg_cap;
-    double *seg_num, *seg_den, *seg_k;  // [seg_cap][n_pairs]
-    int32_t *seg_end;
-    double *head;        // [3][n_pairs][n_chunks] {num, den, k} of the first segment a chunk completes
-    int32_t *head_site;  // [n_pairs][n_chunks]
-    double *tail;        // [5][n_pairs][n_chunks] {num, den, k, n_sites, flushed} after the last one
+    double *seg_num, *seg_den;     // [seg_cap][n_pairs] sums of the Fst numerators / denominators
+    uint2 *seg_c;                  // [seg_cap][n_pairs] {sum c_i, sum c_j}
+    uint64_t *seg_cc;              // [seg_cap][n_pairs] sum c_i*c_j
+    int32_t *seg_end;              // [seg_cap][n_pairs] site of the last included site of the segment
+    // chunk-boundary partials, planes [chunk][pair] (a wave writes contiguous rows)
+    double *head;                  // [2][n_chunks][n_pairs] {num, den} of the first segment the chunk completes
+    uint2 *head_c; uint64_t *head_cc; int32_t *head_site;
+    double *tail;                  // [2][n_chunks][n_pairs] {num, den} after the last completed segment
+    uint2 *tail_c; uint64_t *tail_cc;
+    int2 *tail_n;                  // {sites summed in the tail, segments the chunk completed}
 };
 
 struct SiteStatParams {
@@ -130,7 +135,8 @@ hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *off
                        int n_chunks, int n_cols, hipStream_t st);
 hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st);
 hipError_t launch_stitch(const K2Params &p, hipStream_t st);
-hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *totals, hipStream_t st);
+hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *totals, double *carry, hipStream_t st);
+hipError_t launch_seg_k(const K2Params &p, const int64_t *n_rows, int64_t max_rows, double *seg_k, hipStream_t st);
 hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,

@@ -221,18 +221,27 @@ hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *off
 // out as NaN through r = inf exactly as in the reference.
 // =====================================================================================
 constexpr int kRcpMax = 2047;
+constexpr int kSub = 32;            // sites per LDS table fill (half a tile: halves LDS, doubles resident waves)
+constexpr int kSubPad = kSub + 1;
+#ifndef EVOFST_K2_GRP
+#define EVOFST_K2_GRP 4
+#endif
+#ifndef EVOFST_K2_WPS
+#define EVOFST_K2_WPS 4
+#endif
+constexpr int kGrp = EVOFST_K2_GRP;             // sites evaluated together (independent chains)
+constexpr int kK2WavesPerSimd = EVOFST_K2_WPS;  // register budget: 512 / waves per SIMD   // row stride in entries: pop-indexed reads stay conflict-free
 size_t k2_lds_bytes(int P, int max_n) {
-    return (size_t)P * kPadSites * (8 + 8 + 4) + (max_n <= kRcpMax ? (size_t)(max_n + 1) * 8 : 0) + 32;
+    return (size_t)P * kSubPad * (16 + 4) + (max_n <= kRcpMax ? (size_t)(max_n + 1) * 8 : 0) + 32;
 }
 
 template <typename CT>
-__global__ __launch_bounds__(kK2Threads) void k2_window_kernel(K2Params p) {
+__global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(K2Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double *pt = reinterpret_cast<double *>(smem);           // [P][65] allele frequency c/nm
-    double *ht = pt + (size_t)p.P * kPadSites;               // [P][65] p(1-p)/(nm-1)
-    double *rcp = ht + (size_t)p.P * kPadSites;              // [max_n+1] 1/x (when use_rcp)
+    double2 *ph = reinterpret_cast<double2 *>(smem);         // [P][33] {p = c/nm, h = p(1-p)/(nm-1)}
+    double *rcp = reinterpret_cast<double *>(ph + (size_t)p.P * kSubPad);   // [max_n+1] 1/x (when use_rcp)
     const bool use_rcp = p.max_n <= kRcpMax;
-    uint32_t *xt = reinterpret_cast<uint32_t *>(rcp + (use_rcp ? p.max_n + 1 : 0));  // [P][65] c | flags
+    uint32_t *xt = reinterpret_cast<uint32_t *>(rcp + (use_rcp ? p.max_n + 1 : 0));  // [P][33] c | flags
 
     const int nthreads = blockDim.x;
     const int chunk = blockIdx.x;
@@ -241,65 +250,71 @@ __global__ __launch_bounds__(kK2Threads) void k2_window_kernel(K2Params p) {
     uint32_t pi = 0, pj = 0;
     int64_t m = 0;
     int32_t left = p.g;
-    uint32_t ni = 0, nj = 0;
-    const size_t cq = (size_t)q * p.n_chunks + chunk;       // [pair][chunk] arrays
+    const size_t cq = (size_t)chunk * p.n_pairs + q;        // [chunk][pair] planes: a wave writes a contiguous row
     const size_t plane = (size_t)p.n_pairs * p.n_chunks;
     if (active) {
         const uint32_t ij = p.pairs[q];
         pi = ij & 0xffffu; pj = ij >> 16;
-        ni = (uint32_t)p.n_full[pi]; nj = (uint32_t)p.n_full[pj];
-        const int64_t g0 = p.chunk_offsets[cq];
+        const int64_t g0 = p.chunk_offsets[(size_t)q * p.n_chunks + chunk];
         m = g0 / p.g;
         left = p.g - (int32_t)(g0 - m * p.g);
     }
     const int32_t left0 = left;
-    const int64_t first_seg = active ? p.first_segment[q] : 0;
+    const int64_t row0 = active ? m - p.first_segment[q] : 0;   // segment-table row of the chunk's first segment
     double sn = 0.0, sd = 0.0;
     uint32_t sci = 0, scj = 0;   // sums of the two alt counts over the open segment
     uint64_t scc = 0;            // sum of c_i * c_j
-    bool flushed = false;
+    // Where the next completed segment goes: the chunk's first one into the head planes (the stitch
+    // kernel adds what earlier chunks hold of it), later ones straight into the segment table.
+    double *o_num = p.head + cq, *o_den = p.head + plane + cq;
+    uint2 *o_c = p.head_c + cq;
+    uint64_t *o_cc = p.head_cc + cq;
+    int32_t *o_site = p.head_site + cq;
+    int32_t nflush = 0;
     if (use_rcp)
         for (int i = threadIdx.x; i <= p.max_n; i += nthreads) rcp[i] = 1.0 / (double)i;
 
     const int t0 = chunk * p.chunk_tiles;
     const int t1 = min(t0 + p.chunk_tiles, p.n_tiles);
-    const uint32_t io = pi * kPadSites, jo = pj * kPadSites;
+    const uint32_t io = pi * kSubPad, jo = pj * kSubPad;
     __syncthreads();
-    // The counts of a tile ([P][64] packed CT) are fetched as 16-byte vectors (EPT consecutive sites of
-    // one population); the vectors of tile t+1 are requested before the pair phase of tile t.
+    // The counts of a tile ([P][64] packed CT) are fetched as 16-byte vectors (EPT consecutive sites of one
+    // population); the vectors of the next half tile are requested before the pair phase of this one.
     constexpr int EPT = 16 / (int)sizeof(CT);
+    constexpr int VPR = kSub / EPT;          // vectors per population row of a half tile
     constexpr int NV = 4;
-    const int nvec = p.P * kTileSites / EPT;
+    const int nvec = p.P * VPR;
     uint4 pre[NV];
-    auto fetch = [&](int t) {
-        const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites);
+    auto fetch = [&](int st) {               // st = 2*tile + half
+        const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)(st >> 1) * p.P * kTileSites);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int vi = threadIdx.x + j * nthreads;
-            pre[j] = vp[min(vi, nvec - 1)];   // unconditional: keeps the NV loads in flight together
+            const int vi = min((int)threadIdx.x + j * nthreads, nvec - 1);   // unconditional: loads stay in flight together
+            const int k = vi / VPR, r = vi - k * VPR;
+            pre[j] = vp[k * (kTileSites / EPT) + (st & 1) * VPR + r];
         }
     };
-    auto derive_vec = [&](int t, int vi, const uint4 &vv) {
-        const int e0 = vi * EPT;
-        const int k = e0 >> 6, s0 = e0 & 63;
-        const uint32_t nfull = (uint32_t)p.n_full[k];
-        (void)nfull;
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
+    auto derive_vec = [&](int st, int vi, const uint4 &vv) {
+        const int k = vi / VPR, r = vi - k * VPR;
+        const int s0 = r * EPT;              // site inside the half tile
+        const uint64_t lo = (uint64_t)vv.x | ((uint64_t)vv.y << 32), hi = (uint64_t)vv.z | ((uint64_t)vv.w << 32);
+#pragma unroll 2
         for (int j = 0; j < EPT; ++j) {
-            uint32_t v;
-            if (sizeof(CT) == 2) v = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu; else v = w[j];
+            // element j of the 16-byte vector without a register array (keeps the loop rolled and small)
+            constexpr int EB = 8 * (int)sizeof(CT), HALF = EPT / 2;
+            const uint64_t half = j < HALF ? lo : hi;
+            const uint32_t v = (uint32_t)(half >> (EB * (j & (HALF - 1)))) & (uint32_t)((1ull << EB) - 1ull);
             const int s = s0 + j;
-            const int64_t site = (int64_t)t * kTileSites + s;
+            const int64_t site = (int64_t)st * kSub + s;
             const uint32_t c = v & CountTraits<CT>::mask, nm = v >> CountTraits<CT>::shift;
             bool skip = site >= p.n_sites;
             if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
             double pp, hh;
             const double dc = (double)c, dn = (double)nm, dn1 = (double)((int)nm - 1);
             if (use_rcp) {
-                const double r = rcp[nm], r1 = rcp[nm > 0 ? nm - 1 : 0];
-                double q0 = dc * r;
-                pp = fma(fma(-q0, dn, dc), r, q0);                           // == c / nm
+                const double r0 = rcp[nm], r1 = rcp[nm > 0 ? nm - 1 : 0];
+                double q0 = dc * r0;
+                pp = fma(fma(-q0, dn, dc), r0, q0);                          // == c / nm
                 const double tt = pp * (1.0 - pp);
                 q0 = tt * r1;
                 hh = fma(fma(-q0, dn1, tt), r1, q0);                         // == tt / (nm - 1)
@@ -310,61 +325,73 @@ __global__ __launch_bounds__(kK2Threads) void k2_window_kernel(K2Params p) {
             uint32_t x = c;
             if (skip || c == 0) x |= kXZero;
             if (skip || c == nm) x |= kXFixed;
-            const int o = k * kPadSites + s;
-            pt[o] = pp; ht[o] = hh; xt[o] = x;
+            const int o = k * kSubPad + s;
+            ph[o] = make_double2(pp, hh); xt[o] = x;
         }
     };
-    if (t0 < t1) fetch(t0);
-    for (int t = t0; t < t1; ++t) {
-        // ---- derive the per-(pop, site) table of this tile
-        if (!(p.debug & 2))
+    const int st0 = 2 * t0, st1 = 2 * t1;
+    if (st0 < st1) fetch(st0);
+    for (int st = st0; st < st1; ++st) {
+        // ---- derive the per-(pop, site) table of this half tile
+        if (!(p.debug & 2)) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int vi = threadIdx.x + j * nthreads;
-            if (vi < nvec) derive_vec(t, vi, pre[j]);
+            for (int j = 0; j < NV; ++j) {
+                const int vi = threadIdx.x + j * nthreads;
+                if (vi < nvec) derive_vec(st, vi, pre[j]);
+            }
+            const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)(st >> 1) * p.P * kTileSites);
+            for (int vi = threadIdx.x + NV * nthreads; vi < nvec; vi += nthreads) {
+                const int k = vi / VPR, r = vi - k * VPR;
+                derive_vec(st, vi, vp[k * (kTileSites / EPT) + (st & 1) * VPR + r]);
+            }
         }
-        {
-            const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites);
-            for (int vi = threadIdx.x + NV * nthreads; vi < nvec; vi += nthreads) derive_vec(t, vi, vp[vi]);
-        }
-        if (t + 1 < t1) fetch(t + 1);
+        if (st + 1 < st1) fetch(st + 1);
         __syncthreads();
         // ---- pairs: lane = pair, sites in order (the reference's push_back order)
         if (active && !(p.debug & 1)) {
-            const int site0 = t * kTileSites;
-            for (int sb = 0; sb < kTileSites; sb += 8) {
-                uint32_t xi[8], xj[8];
-                double p1[8], p2[8], h1[8], h2[8];
+            const int site0 = st * kSub;
+#pragma unroll 1
+            for (int sb = 0; sb < kSub; sb += kGrp) {
+                uint32_t xi[kGrp], xj[kGrp];
+                double2 a[kGrp], b[kGrp];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < kGrp; ++u) {
                     xi[u] = xt[io + sb + u]; xj[u] = xt[jo + sb + u];
-                    p1[u] = pt[io + sb + u]; p2[u] = pt[jo + sb + u];
-                    h1[u] = ht[io + sb + u]; h2[u] = ht[jo + sb + u];
+                    a[u] = ph[io + sb + u]; b[u] = ph[jo + sb + u];
                 }
+                // pure part: the kGrp sites are independent, no branch -> the compiler interleaves the chains.
+                // Excluded sites (fst.cpp:543-544) are masked to an exact 0 contribution.
+                double numv[kGrp], denv[kGrp];
+                uint32_t civ[kGrp], cjv[kGrp];
+                int32_t incm[kGrp];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (((xi[u] & xj[u]) >> 28) == 0u) {                     // fst.cpp:543-544
-                        const double d = p1[u] - p2[u];
-                        const double num = d * d - h1[u] - h2[u];            // fst.h:20-23
-                        const double den = (p1[u] * (1.0 - p2[u])) + (p2[u] * (1.0 - p1[u]));  // fst.h:28
-                        const uint32_t ci = xi[u] & kXMask, cj = xj[u] & kXMask;
-                        sn += num; sd += den;
-                        sci += ci; scj += cj;
-                        scc += (uint64_t)(ci * cj);
-                        if (--left == 0) {
-                            // sumKij = c1*(n2-c2) + c2*(n1-c1), fst.cpp:299-321, summed over the segment
-                            const double sk = (double)((uint64_t)nj * sci + (uint64_t)ni * scj - 2ull * scc);
-                            if (!flushed) {
-                                p.head[cq] = sn; p.head[plane + cq] = sd; p.head[2 * plane + cq] = sk;
-                                p.head_site[cq] = site0 + sb + u;
-                                flushed = true;
-                            } else {
-                                const size_t o = (size_t)(m - first_seg) * p.n_pairs + q;
-                                p.seg_num[o] = sn; p.seg_den[o] = sd; p.seg_k[o] = sk;
-                                p.seg_end[o] = site0 + sb + u;
-                            }
-                            ++m; left = p.g; sn = 0.0; sd = 0.0; sci = 0; scj = 0; scc = 0;
-                        }
+                for (int u = 0; u < kGrp; ++u) {
+                    const bool inc = ((xi[u] & xj[u]) >> 28) == 0u;
+                    const double d = a[u].x - b[u].x;
+                    const double num = d * d - a[u].y - b[u].y;              // fst.h:20-23
+                    const double den = (a[u].x * (1.0 - b[u].x)) + (b[u].x * (1.0 - a[u].x));  // fst.h:28
+                    numv[u] = inc ? num : 0.0;
+                    denv[u] = inc ? den : 0.0;
+                    incm[u] = inc ? -1 : 0;
+                    const uint32_t mk = (uint32_t)incm[u] & kXMask;
+                    civ[u] = xi[u] & mk; cjv[u] = xj[u] & mk;
+                }
+                // serial part: sums in site order, one segment-boundary test per site
+#pragma unroll
+                for (int u = 0; u < kGrp; ++u) {
+                    sn += numv[u]; sd += denv[u];
+                    sci += civ[u]; scj += cjv[u];
+                    scc += (uint64_t)(civ[u] * cjv[u]);
+                    left += incm[u];
+                    if (left == 0) {
+                        // raw sums; sumKij (fst.cpp:299-321) = n2*Sc1 + n1*Sc2 - 2*Sc1c2 is formed by the reader
+                        *o_num = sn; *o_den = sd; *o_c = make_uint2(sci, scj); *o_cc = scc;
+                        *o_site = site0 + sb + u;
+                        ++nflush;
+                        const size_t o = (size_t)(row0 + nflush) * p.n_pairs + q;
+                        o_num = p.seg_num + o; o_den = p.seg_den + o; o_c = p.seg_c + o; o_cc = p.seg_cc + o;
+                        o_site = p.seg_end + o;
+                        left = p.g; sn = 0.0; sd = 0.0; sci = 0; scj = 0; scc = 0;
                     }
                 }
             }
@@ -373,9 +400,8 @@ __global__ __launch_bounds__(kK2Threads) void k2_window_kernel(K2Params p) {
     }
     if (active) {
         p.tail[cq] = sn; p.tail[plane + cq] = sd;
-        p.tail[2 * plane + cq] = (double)((uint64_t)nj * sci + (uint64_t)ni * scj - 2ull * scc);
-        p.tail[3 * plane + cq] = (double)((flushed ? p.g : left0) - left);  // sites summed in sn/sd/sk
-        p.tail[4 * plane + cq] = flushed ? 1.0 : 0.0;
+        p.tail_c[cq] = make_uint2(sci, scj); p.tail_cc[cq] = scc;
+        p.tail_n[cq] = make_int2((nflush ? p.g : left0) - left, nflush);   // {sites summed in the tail, segments completed}
     }
 }
 
@@ -398,60 +424,102 @@ hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st) {
 // The first segment a chunk completes started in an earlier chunk: add, in site order, the tail of
 // the last chunk that completed a segment and the whole-chunk sums of the chunks in between.
 __global__ void stitch_kernel(K2Params p) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = blockIdx.y;
-    if (c >= p.n_chunks) return;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;   // lanes = pairs: rows of the [chunk][pair] planes are contiguous
+    const int c = blockIdx.y;
+    if (q >= p.n_pairs) return;
     const size_t plane = (size_t)p.n_pairs * p.n_chunks;
-    const size_t row = (size_t)q * p.n_chunks;
-    const double *flag = p.tail + 4 * plane + row;
-    if (flag[c] == 0.0) return;
+    const size_t cq = (size_t)c * p.n_pairs + q;
+    if (p.tail_n[cq].y == 0) return;                        // this chunk completed no segment
     int cp = c - 1;
-    while (cp >= 0 && flag[cp] == 0.0) --cp;
-    double an = 0.0, ad = 0.0, ak = 0.0;
-    for (int cc = (cp < 0 ? 0 : cp); cc < c; ++cc) {
-        an += p.tail[row + cc]; ad += p.tail[plane + row + cc]; ak += p.tail[2 * plane + row + cc];
+    while (cp >= 0 && p.tail_n[(size_t)cp * p.n_pairs + q].y == 0) --cp;
+    double an = 0.0, ad = 0.0;
+    uint64_t ci = 0, cj = 0, cc = 0;
+    for (int cc_ = (cp < 0 ? 0 : cp); cc_ < c; ++cc_) {
+        const size_t o = (size_t)cc_ * p.n_pairs + q;
+        an += p.tail[o]; ad += p.tail[plane + o];
+        const uint2 t = p.tail_c[o];
+        ci += t.x; cj += t.y; cc += p.tail_cc[o];
     }
-    an += p.head[row + c]; ad += p.head[plane + row + c]; ak += p.head[2 * plane + row + c];
-    const int64_t m0 = p.chunk_offsets[row + c] / p.g;
+    an += p.head[cq]; ad += p.head[plane + cq];
+    const uint2 h = p.head_c[cq];
+    ci += h.x; cj += h.y; cc += p.head_cc[cq];
+    const int64_t m0 = p.chunk_offsets[(size_t)q * p.n_chunks + c] / p.g;
     const size_t o = (size_t)(m0 - p.first_segment[q]) * p.n_pairs + q;
-    p.seg_num[o] = an; p.seg_den[o] = ad; p.seg_k[o] = ak;
-    p.seg_end[o] = p.head_site[row + c];
+    p.seg_num[o] = an; p.seg_den[o] = ad;
+    // the carried counts may exceed 32 bits only if a segment spans > 2^32 / n chromosomes-sites: g is an int
+    p.seg_c[o] = make_uint2((uint32_t)ci, (uint32_t)cj); p.seg_cc[o] = cc;
+    p.seg_end[o] = p.head_site[cq];
 }
 
 hipError_t launch_stitch(const K2Params &p, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
-    dim3 block(256), grid((p.n_chunks + 255) / 256, p.n_pairs);
+    dim3 block(64), grid((p.n_pairs + 63) / 64, p.n_chunks);
     hipLaunchKernelGGL(stitch_kernel, grid, block, 0, st, p);
     return hipGetLastError();
 }
 
+// Converts the raw integer sums of every complete segment into sumKij (as a double, exact):
+// k = n_j * Sc_i + n_i * Sc_j - 2 * Sc_ic_j.  Run by the getters, not by the timed pass.
+__global__ void seg_k_kernel(K2Params p, const int64_t *__restrict__ n_rows, double *__restrict__ seg_k) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (q >= p.n_pairs || r >= n_rows[q]) return;
+    const uint32_t ij = p.pairs[q];
+    const uint64_t ni = (uint64_t)p.n_full[ij & 0xffffu], nj = (uint64_t)p.n_full[ij >> 16];
+    const size_t o = (size_t)r * p.n_pairs + q;
+    const uint2 c = p.seg_c[o];
+    seg_k[o] = (double)(nj * c.x + ni * c.y - 2ull * p.seg_cc[o]);
+}
+
+hipError_t launch_seg_k(const K2Params &p, const int64_t *n_rows, int64_t max_rows, double *seg_k, hipStream_t st) {
+    if (p.n_pairs <= 0 || max_rows <= 0) return hipSuccess;
+    dim3 block(64), grid((p.n_pairs + 63) / 64, (unsigned)max_rows);
+    hipLaunchKernelGGL(seg_k_kernel, grid, block, 0, st, p, n_rows, seg_k);
+    return hipGetLastError();
+}
+
 // Whole-shard sums per pair: complete segments in order, then the carry after the last one.
-__global__ void totals_kernel(K2Params p, const int64_t *__restrict__ n_rows, double *__restrict__ totals) {
+// totals[q] = {num, den, k, n_included}; carry[q] = {num, den, k, n_sites} behind the last complete segment.
+__global__ void totals_kernel(K2Params p, const int64_t *__restrict__ n_rows, double *__restrict__ totals,
+                              double *__restrict__ carry) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= p.n_pairs) return;
-    double an = 0.0, ad = 0.0, ak = 0.0, cnt = 0.0;
+    const uint32_t ij = p.pairs[q];
+    const uint64_t ni = (uint64_t)p.n_full[ij & 0xffffu], nj = (uint64_t)p.n_full[ij >> 16];
+    const size_t plane = (size_t)p.n_pairs * p.n_chunks;
+    double an = 0.0, ad = 0.0;
+    uint64_t ci = 0, cj = 0, cc = 0;
     const int64_t rows = n_rows[q];
     for (int64_t r = 0; r < rows; ++r) {
         const size_t o = (size_t)r * p.n_pairs + q;
-        an += p.seg_num[o]; ad += p.seg_den[o]; ak += p.seg_k[o];
+        an += p.seg_num[o]; ad += p.seg_den[o];
+        const uint2 c = p.seg_c[o];
+        ci += c.x; cj += c.y; cc += p.seg_cc[o];
     }
-    cnt = (double)rows * (double)p.g;
-    const size_t plane = (size_t)p.n_pairs * p.n_chunks;
-    const size_t row = (size_t)q * p.n_chunks;
     int cl = p.n_chunks - 1;
-    while (cl >= 0 && p.tail[4 * plane + row + cl] == 0.0) --cl;
-    for (int cc = (cl < 0 ? 0 : cl); cc < p.n_chunks; ++cc) {
-        an += p.tail[row + cc]; ad += p.tail[plane + row + cc]; ak += p.tail[2 * plane + row + cc];
-        cnt += p.tail[3 * plane + row + cc];
+    while (cl >= 0 && p.tail_n[(size_t)cl * p.n_pairs + q].y == 0) --cl;
+    double tn = 0.0, td = 0.0, cnt = 0.0;
+    uint64_t ti = 0, tj = 0, tc = 0;
+    for (int c = (cl < 0 ? 0 : cl); c < p.n_chunks; ++c) {
+        const size_t o = (size_t)c * p.n_pairs + q;
+        tn += p.tail[o]; td += p.tail[plane + o];
+        const uint2 t = p.tail_c[o];
+        ti += t.x; tj += t.y; tc += p.tail_cc[o];
+        cnt += (double)p.tail_n[o].x;
     }
-    totals[(size_t)q * 4 + 0] = an; totals[(size_t)q * 4 + 1] = ad;
-    totals[(size_t)q * 4 + 2] = ak; totals[(size_t)q * 4 + 3] = cnt;
+    const double tk = (double)(nj * ti + ni * tj - 2ull * tc);
+    if (carry) { carry[(size_t)q * 4] = tn; carry[(size_t)q * 4 + 1] = td; carry[(size_t)q * 4 + 2] = tk; carry[(size_t)q * 4 + 3] = cnt; }
+    if (totals) {
+        totals[(size_t)q * 4 + 0] = an + tn; totals[(size_t)q * 4 + 1] = ad + td;
+        totals[(size_t)q * 4 + 2] = (double)(nj * ci + ni * cj - 2ull * cc) + tk;
+        totals[(size_t)q * 4 + 3] = (double)rows * (double)p.g + cnt;
+    }
 }
 
-hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *totals, hipStream_t st) {
+hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *totals, double *carry, hipStream_t st) {
     if (p.n_pairs <= 0) return hipSuccess;
     dim3 block(64), grid((p.n_pairs + 63) / 64);
-    hipLaunchKernelGGL(totals_kernel, grid, block, 0, st, p, n_rows, totals);
+    hipLaunchKernelGGL(totals_kernel, grid, block, 0, st, p, n_rows, totals, carry);
     return hipGetLastError();
 }
 

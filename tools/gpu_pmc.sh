@@ -1,14 +1,18 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc1 -- python3 bench.py --steps 3 --warmup 1 --cpu-sites 0 > gpurun_out/pmc1.log 2>&1 || { tail -5 gpurun_out/pmc1.log; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --steps 3 --warmup 1 --cpu-sites 0 > gpurun_out/pmc2.log 2>&1 || { tail -5 gpurun_out/pmc2.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d gpurun_out/pmc3 -- python3 bench.py --steps 3 --warmup 1 --cpu-sites 0 > gpurun_out/pmc3.log 2>&1 || { tail -5 gpurun_out/pmc3.log; exit 1; }
 python3 - <<'PY'
 import csv,glob,collections
-for d in ("pmc1","pmc2"):
-    for f in glob.glob("gpurun_out/%s/**/*counter_collection.csv"%d, recursive=True):
-        acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
-        for r in csv.DictReader(open(f)):
-            k=r["Kernel_Name"][:40]; acc[k][r["Counter_Name"]]+=float(r["Counter_Value"]); 
-            if r["Counter_Name"]==list(acc[k].keys())[0]: n[k]+=1
-        for k in acc:
-            print(d,k,n[k],{c:round(v/max(n[k],1)) for c,v in acc[k].items()})
+dur=collections.defaultdict(list)
+for f in glob.glob("gpurun_out/pmc3/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[r["Kernel_Name"][:40]].append(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
+for f in glob.glob("gpurun_out/pmc3/**/*counter_collection.csv", recursive=True):
+    acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"][:40]; acc[k][r["Counter_Name"]]+=float(r["Counter_Value"])
+        if r["Counter_Name"]=="SQ_WAVES": n[k]+=1
+    for k in acc:
+        d=sum(dur[k])/max(len(dur[k]),1)
+        a={c:v/max(n[k],1) for c,v in acc[k].items()}
+        print(k, "avg_ns=%.0f"%d, "clk_GHz=%.2f"%(a.get("GRBM_GUI_ACTIVE",0)/8/max(d,1)), {c:round(v) for c,v in a.items()})
 PY
