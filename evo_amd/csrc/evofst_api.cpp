@@ -233,6 +233,9 @@ GlobalParams make_global(evofst_ctx *c) {
     p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
     p.chunk_used_kept_off = (const int64_t *)c->d_uk_off.p;
     p.size = c->snp_size; p.step = c->snp_step;
+    p.tn_max = 0;
+    for (int32_t k : c->use_idx) p.tn_max += c->n_full[k];
+    p.base_kept = c->base.size() > 1 ? c->base[1] : 0;
     p.row_cap = c->row_cap;
     p.row_start = (int32_t *)c->d_row_start.p; p.row_end = (int32_t *)c->d_row_end.p;
     p.row_num = (double *)c->d_row_num.p; p.row_den = (double *)c->d_row_den.p;
@@ -780,7 +783,9 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
     } else {
         if (c->snp_size <= 0) return fail(c, EVOFST_ERR_ARG, "run_stats: against-all mode needs set_windows(size, step)");
         const int nu = (int)c->use_idx.size();
-        const size_t lds = global_lds_bytes(c->n_pops, nu, c->snp_size);
+        int tn_max = 0;
+        for (int32_t k : c->use_idx) tn_max += c->n_full[k];
+        const size_t lds = global_lds_bytes(tn_max, nu, c->snp_size);
         if (lds > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: SIZE * populations too large for the LDS deque");
         if ((rc = ensure(c, c->d_chunk_rows, (size_t)c->n_chunks * 4))) return rc;
         if ((rc = ensure(c, c->d_row_off, (size_t)c->n_chunks * 8))) return rc;

@@ -108,6 +108,8 @@ struct GlobalParams {
     int32_t chunk_tiles, n_chunks;
     const int64_t *chunk_used_kept_off;  // [2][n_chunks] used / kept sites before the chunk
     int32_t size, step;
+    int32_t tn_max;       // total chromosomes of populationsToUse (reciprocal-table size)
+    int64_t base_kept;    // kept sites that precede this shard
     int64_t row_cap;
     int32_t *row_start, *row_end;  // [row_cap]
     double *row_num, *row_den;     // [row_cap][n_use]
@@ -148,6 +150,6 @@ hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_byte
 hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 size_t k2_lds_bytes(int P, int max_n);
-size_t global_lds_bytes(int P, int n_use, int size);
+size_t global_lds_bytes(int tn_max, int n_use, int size);
 
 }  // namespace evofst

@@ -659,22 +659,39 @@ hipError_t launch_global_rows(const uint64_t *kept_mask, const uint64_t *skip_ma
     return hipGetLastError();
 }
 
-size_t global_lds_bytes(int P, int n_use, int size) {
-    // counts tile transposed [64][P] u32 + ring [size][n_use] x {num, den} + ring of site ids
-    return (size_t)kTileSites * P * 4 + (size_t)size * n_use * 16 + (size_t)size * 4 + 64;
+constexpr int kRcpMaxGlobal = 4095;   // reciprocal table up to the total chromosome count of populationsToUse
+size_t global_lds_bytes(int tn_max, int n_use, int size) {
+    // ring [size][n_use] x {num, den} + ring of site ids + reciprocal table
+    return (size_t)size * n_use * 16 + (size_t)size * 4 + (tn_max <= kRcpMaxGlobal ? (size_t)(tn_max + 1) * 8 : 0) + 64;
 }
 
+// a / b through the reciprocal table (bit-identical to IEEE a/b on this path's domain, see K2)
+__device__ __forceinline__ double rcp_div(double a, double b, double r) {
+    const double q0 = a * r;
+    return fma(fma(-q0, b, a), r, q0);
+}
+
+template <bool RCP>
 __device__ __forceinline__ void global_eval(uint32_t c, uint32_t nm, uint32_t Tc, uint32_t Tn, double thr,
-                                            double &num, double &den) {
+                                            const double *__restrict__ rcp, double &num, double &den) {
     // evo_FstAgainstAll.cpp:245-261 with p1 = setAAFs (-1.0 when the pop has no alleles,
     // utils.h:75 + utils.cpp:56-58), p2 = complement AAF (utils.cpp:95)
     const int n1 = (int)nm, n2 = (int)(Tn - nm);
     if ((double)n1 >= thr) {
-        const double p1 = nm > 0 ? (double)c / (double)nm : -1.0;
-        const double p2 = (double)(int)(Tc - c) / (double)n2;
+        double p1, p2, f1, f2;
+        const double dc2 = (double)(int)(Tc - c), dn1 = (double)n1, dn2 = (double)n2;
+        if (RCP) {
+            p1 = nm > 0 ? rcp_div((double)c, dn1, rcp[n1]) : -1.0;
+            p2 = rcp_div(dc2, dn2, rcp[n2]);
+            f1 = rcp_div(p1 * (1.0 - p1), (double)(n1 - 1), rcp[n1 > 0 ? n1 - 1 : 0]);
+            f2 = rcp_div(p2 * (1.0 - p2), (double)(n2 - 1), rcp[n2 > 0 ? n2 - 1 : 0]);
+        } else {
+            p1 = nm > 0 ? (double)c / dn1 : -1.0;
+            p2 = dc2 / dn2;
+            f1 = (p1 * (1.0 - p1)) / (double)(n1 - 1);
+            f2 = (p2 * (1.0 - p2)) / (double)(n2 - 1);
+        }
         const double power = (p1 - p2) * (p1 - p2);
-        const double f1 = (p1 * (1.0 - p1)) / (double)(n1 - 1);
-        const double f2 = (p2 * (1.0 - p2)) / (double)(n2 - 1);
         num = power - f1 - f2;
         den = (p1 * (1.0 - p2)) + (p2 * (1.0 - p1));
     } else {
@@ -682,31 +699,33 @@ __device__ __forceinline__ void global_eval(uint32_t c, uint32_t nm, uint32_t Tc
     }
 }
 
-// lane = population of populationsToUse; one block per chunk.  Each lane owns one column of the two
-// deques (a ring in LDS), so the site loop needs no barrier; the chunk first replays the last
-// SIZE kept sites before it (the deque contents at its first site).
-template <typename CT>
-__global__ void global_window_kernel(GlobalParams p) {
+// lane = population of populationsToUse; one block per chunk.  Each lane streams the count row of its
+// own population (16-byte vectors = EPT consecutive sites, next vector prefetched) and owns one column of
+// the two deques (a ring in LDS), so the site loop has neither a barrier nor a staging pass; the chunk
+// first replays the last SIZE kept sites before it (the deque contents at its first site).
+template <typename CT, bool RCP>
+__global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *ct = reinterpret_cast<uint32_t *>(smem);                       // [64][P]
-    double *ring = reinterpret_cast<double *>(smem + (((size_t)kTileSites * p.P * 4 + 15) & ~(size_t)15));
-    double *ring_n = ring;                                                   // [size][n_use]
-    double *ring_d = ring + (size_t)p.size * p.n_use;
-    int32_t *ring_s = reinterpret_cast<int32_t *>(ring_d + (size_t)p.size * p.n_use);  // [size]
+    double *ring_n = reinterpret_cast<double *>(smem);                       // [size][n_use]
+    double *ring_d = ring_n + (size_t)p.size * p.n_use;
+    double *rcp = ring_d + (size_t)p.size * p.n_use;                         // [tn_max+1] when RCP
+    int32_t *ring_s = reinterpret_cast<int32_t *>(rcp + (RCP ? p.tn_max + 1 : 0));  // [size]
 
     const int c = blockIdx.x;
     const int u = threadIdx.x;
     const bool active = u < p.n_use;
-    const int k = active ? p.use_idx[u] : 0;
+    const int k = active ? p.use_idx[u] : p.use_idx[0];
     const double thr = active ? p.thresholds[u] : 0.0;
     for (int i = threadIdx.x; i < p.size * p.n_use; i += blockDim.x) { ring_n[i] = 0.0; ring_d[i] = 0.0; }
     for (int i = threadIdx.x; i < p.size; i += blockDim.x) ring_s[i] = -1;
+    if (RCP)
+        for (int i = threadIdx.x; i <= p.tn_max; i += blockDim.x) rcp[i] = 1.0 / (double)i;
 
     const int t0 = c * p.chunk_tiles, t1 = min(t0 + p.chunk_tiles, p.n_tiles);
-    // ---- find where the replay starts: walk back until SIZE kept sites are found
-    int th = t0;          // first tile to process
+    // ---- where the replay starts: walk back until SIZE kept sites of this shard are found
+    int th = t0;
     int need = p.size;
-    int64_t kept_before = p.chunk_used_kept_off[(size_t)p.n_chunks + c];
+    const int64_t kept_before = p.chunk_used_kept_off[(size_t)p.n_chunks + c] - p.base_kept;
     if (kept_before < need) need = (int)kept_before;   // the rest is the zero-initialised deque
     int drop = 0;         // kept sites of tile th to ignore (older than the window)
     while (need > 0 && th > 0) {
@@ -719,69 +738,94 @@ __global__ void global_window_kernel(GlobalParams p) {
     int64_t row = p.chunk_row_off[c];
     int head = 0;  // ring slot of the oldest element
     __syncthreads();
+
+    constexpr int EPT = 16 / (int)sizeof(CT);
+    constexpr int VPT = kTileSites / EPT;
+    constexpr int EB = 8 * (int)sizeof(CT);
+    const CT *cbase = reinterpret_cast<const CT *>(p.counts);
+    auto vec_at = [&](int t, int j) {
+        return *reinterpret_cast<const uint4 *>(cbase + ((size_t)t * p.P + k) * kTileSites + (size_t)j * EPT);
+    };
+    uint4 nxt = vec_at(th, 0);
     for (int t = th; t < t1; ++t) {
         const uint64_t km = p.kept_mask[t], sm = p.skip_mask[t];
-        if (km == 0 && t < t0) continue;
-        // stage the tile's counts transposed: ct[s][k]
-        const CT *cp = reinterpret_cast<const CT *>(p.counts) + (size_t)t * p.P * kTileSites;
-        __syncthreads();
-        for (int e = threadIdx.x; e < p.P * kTileSites; e += blockDim.x) {
-            const int kk = e >> 6, s = e & 63;
-            ct[s * p.P + kk] = cp[e];
-        }
-        __syncthreads();
         const bool replay = t < t0;
-        for (int s = 0; s < kTileSites; ++s) {
-            if ((sm >> s) & 1ull) continue;
-            if (!replay) ++used;
-            if (!((km >> s) & 1ull)) continue;
-            if (replay && drop > 0) { --drop; continue; }
-            const int site = t * kTileSites + s;
-            const uint2 T = p.totals[site];
-            if (active) {
-                const uint32_t v = ct[s * p.P + k];
-                double num, den;
-                global_eval(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, T.x, T.y, thr, num, den);
-                ring_n[(size_t)head * p.n_use + u] = num;
-                ring_d[(size_t)head * p.n_use + u] = den;
+#pragma unroll 1
+        for (int j = 0; j < VPT; ++j) {
+            const uint4 cur = nxt;
+            {   // prefetch the next vector of this lane's row (clamped at the end of the chunk)
+                int tn = t, jn = j + 1;
+                if (jn == VPT) { jn = 0; tn = min(t + 1, t1 - 1); }
+                nxt = vec_at(tn, jn);
             }
-            if (threadIdx.x == 0) ring_s[head] = site;
-            head = head + 1 == p.size ? 0 : head + 1;
-            if (!replay && (used > p.size || p.size == p.step) && (used % p.step == 0)) {
+            const uint32_t kb = (uint32_t)(km >> (j * EPT)) & ((1u << EPT) - 1u);
+            const uint32_t sb = (uint32_t)(sm >> (j * EPT)) & ((1u << EPT) - 1u);
+            if (kb == 0u) {                       // nothing kept among these sites: only the used counter moves
+                if (!replay) used += EPT - __popc(sb);
+                continue;
+            }
+            const uint64_t lo = (uint64_t)cur.x | ((uint64_t)cur.y << 32), hi = (uint64_t)cur.z | ((uint64_t)cur.w << 32);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                if ((sb >> e) & 1u) continue;
+                if (!replay) ++used;
+                if (!((kb >> e) & 1u)) continue;
+                if (replay && drop > 0) { --drop; continue; }
+                const int site = t * kTileSites + j * EPT + e;
+                const uint2 T = p.totals[site];
+                const uint64_t half = e < EPT / 2 ? lo : hi;
+                const uint32_t v = (uint32_t)(half >> (EB * (e & (EPT / 2 - 1)))) & (uint32_t)((1ull << EB) - 1ull);
                 if (active) {
-                    double an = 0.0, ad = 0.0;
-                    int idx = head;
-                    for (int i = 0; i < p.size; ++i) {      // oldest -> newest, as vector_average on the deque
-                        an += ring_n[(size_t)idx * p.n_use + u];
-                        ad += ring_d[(size_t)idx * p.n_use + u];
-                        idx = idx + 1 == p.size ? 0 : idx + 1;
+                    double num, den;
+                    global_eval<RCP>(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, T.x, T.y, thr, rcp, num, den);
+                    ring_n[(size_t)head * p.n_use + u] = num;
+                    ring_d[(size_t)head * p.n_use + u] = den;
+                }
+                if (threadIdx.x == 0) ring_s[head] = site;
+                head = head + 1 == p.size ? 0 : head + 1;
+                if (!replay && (used > p.size || p.size == p.step) && (used % p.step == 0)) {
+                    if (active) {
+                        double an = 0.0, ad = 0.0;
+                        int idx = head;
+                        for (int i = 0; i < p.size; ++i) {      // oldest -> newest, as vector_average on the deque
+                            an += ring_n[(size_t)idx * p.n_use + u];
+                            ad += ring_d[(size_t)idx * p.n_use + u];
+                            idx = idx + 1 == p.size ? 0 : idx + 1;
+                        }
+                        p.row_num[(size_t)row * p.n_use + u] = an / (double)p.size;
+                        p.row_den[(size_t)row * p.n_use + u] = ad / (double)p.size;
                     }
-                    p.row_num[(size_t)row * p.n_use + u] = an / (double)p.size;
-                    p.row_den[(size_t)row * p.n_use + u] = ad / (double)p.size;
+                    if (threadIdx.x == 0) {
+                        p.row_start[row] = ring_s[head];
+                        p.row_end[row] = site;
+                    }
+                    ++row;
                 }
-                if (threadIdx.x == 0) {
-                    p.row_start[row] = ring_s[head];
-                    p.row_end[row] = site;
-                }
-                ++row;
             }
         }
     }
+}
+
+template <typename CT, bool RCP>
+static hipError_t launch_global_t(const GlobalParams &p, size_t lds_bytes, dim3 grid, dim3 block, hipStream_t st) {
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&global_window_kernel<CT, RCP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((global_window_kernel<CT, RCP>), grid, block, lds_bytes, st, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_use <= 0) return hipSuccess;
     int threads = ((p.n_use + 63) / 64) * 64;
     dim3 grid(p.n_chunks), block(threads);
-    if (lds_bytes > 48 * 1024) {
-        hipError_t e = count_bytes == 2
-            ? hipFuncSetAttribute(reinterpret_cast<const void *>(&global_window_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-            : hipFuncSetAttribute(reinterpret_cast<const void *>(&global_window_kernel<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    if (count_bytes == 2) hipLaunchKernelGGL((global_window_kernel<uint16_t>), grid, block, lds_bytes, st, p);
-    else hipLaunchKernelGGL((global_window_kernel<uint32_t>), grid, block, lds_bytes, st, p);
-    return hipGetLastError();
+    const bool rcp = p.tn_max <= kRcpMaxGlobal;
+    if (count_bytes == 2) return rcp ? launch_global_t<uint16_t, true>(p, lds_bytes, grid, block, st)
+                                     : launch_global_t<uint16_t, false>(p, lds_bytes, grid, block, st);
+    return rcp ? launch_global_t<uint32_t, true>(p, lds_bytes, grid, block, st)
+               : launch_global_t<uint32_t, false>(p, lds_bytes, grid, block, st);
 }
 
 // per-site against-all values on demand: lane = site
@@ -798,7 +842,7 @@ __global__ __launch_bounds__(256) void global_site_kernel(GlobalParams p) {
     for (int u = blockIdx.y; u < p.n_use; u += gridDim.y) {
         const uint32_t v = cp[(size_t)p.use_idx[u] * kTileSites];
         double num, den;
-        global_eval(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, T.x, T.y, p.thresholds[u], num, den);
+        global_eval<false>(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, T.x, T.y, p.thresholds[u], nullptr, num, den);
         if (p.site_num) p.site_num[(size_t)u * p.n_out_sites + ls] = num;
         if (p.site_den) p.site_den[(size_t)u * p.n_out_sites + ls] = den;
     }
