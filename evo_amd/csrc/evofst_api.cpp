@@ -65,8 +65,8 @@ struct evofst_ctx {
     bool have_flags = false, have_pos = false;
 
     // pairs-mode work buffers
-    DevBuf d_census, d_offsets, d_incl_totals, d_seg_num, d_seg_den, d_seg_k, d_seg_c, d_seg_cc, d_seg_end, d_head, d_head_c,
-        d_head_cc, d_head_site, d_tail, d_tail_c, d_tail_cc, d_tail_n, d_carry,
+    DevBuf d_census, d_offsets, d_incl_totals, d_seg_num, d_seg_den, d_seg_k, d_seg_end, d_zf, d_irr,
+        d_tail, d_tail_n, d_carry,
         d_nrows, d_totals;
     int64_t seg_cap = 0;
     // against-all work buffers
@@ -157,7 +157,8 @@ int plan_chunks(evofst_ctx *c) {
     int ct = 0;
     if (const char *e = getenv("EVOFST_CHUNK_TILES")) ct = atoi(e);
     if (ct <= 0) ct = std::max(4, (c->n_tiles + 4095) / 4096);  // ~4096 chunks: 4 K2 waves per SIMD
-    ct = std::min(ct, 4096);  // keeps the 32-bit per-segment count sums of K2 exact
+    ct = std::min(ct, 256);   // K2's accumulators run from the start of a chunk: 16k sites keep their rounding
+                              // error 1e-13 of a window's terms (and the 32-bit count prefixes far from wrapping)
     c->chunk_tiles = ct;
     c->n_chunks = (c->n_tiles + ct - 1) / ct;
     return EVOFST_OK;
@@ -213,11 +214,10 @@ K2Params make_k2(evofst_ctx *c) {
     p.first_segment = (const int64_t *)c->d_first_seg.p;
     p.g = c->g; p.seg_cap = c->seg_cap;
     p.seg_num = (double *)c->d_seg_num.p; p.seg_den = (double *)c->d_seg_den.p;
-    p.seg_c = (uint2 *)c->d_seg_c.p; p.seg_cc = (uint64_t *)c->d_seg_cc.p;
+    p.seg_k = (double *)c->d_seg_k.p;
     p.seg_end = (int32_t *)c->d_seg_end.p;
-    p.head = (double *)c->d_head.p; p.head_c = (uint2 *)c->d_head_c.p; p.head_cc = (uint64_t *)c->d_head_cc.p;
-    p.head_site = (int32_t *)c->d_head_site.p;
-    p.tail = (double *)c->d_tail.p; p.tail_c = (uint2 *)c->d_tail_c.p; p.tail_cc = (uint64_t *)c->d_tail_cc.p;
+    p.zf_masks = (const uint64_t *)c->d_zf.p; p.irr_mask = (const uint64_t *)c->d_irr.p; p.skip_mask = (const uint64_t *)c->d_skip.p;
+    p.tail = (double *)c->d_tail.p;
     p.tail_n = (int2 *)c->d_tail_n.p;
     return p;
 }
@@ -290,8 +290,8 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->d_segs, &c->d_wss, &c->d_nfull, &c->d_pairs, &c->d_use, &c->d_thr, &c->d_base, &c->d_first_seg,
                       &c->d_tiles, &c->d_flags, &c->d_pos, &c->d_counts, &c->d_census, &c->d_offsets, &c->d_incl_totals,
-                      &c->d_seg_num, &c->d_seg_den, &c->d_seg_k, &c->d_seg_c, &c->d_seg_cc, &c->d_seg_end, &c->d_head, &c->d_head_c,
-                      &c->d_head_cc, &c->d_head_site, &c->d_tail, &c->d_tail_c, &c->d_tail_cc, &c->d_tail_n, &c->d_carry,
+                      &c->d_seg_num, &c->d_seg_den, &c->d_seg_k, &c->d_seg_end, &c->d_zf, &c->d_irr,
+                      &c->d_tail, &c->d_tail_n, &c->d_carry,
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den};
@@ -726,6 +726,10 @@ extern "C" int evofst_run_counts(evofst_ctx *c) {
         p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)c->pairs.size();
         if ((rc = ensure(c, c->d_census, (size_t)c->n_chunks * p.n_pairs * 4))) return rc;
         p.chunk_census = (uint32_t *)c->d_census.p;
+        if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 16))) return rc;
+        if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
+        if ((rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8))) return rc;
+        p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
     } else if (c->mode == MODE_GLOBAL) {
         if ((rc = ensure(c, c->d_gtotals, (size_t)c->n_tiles * kTileSites * 8))) return rc;
         if ((rc = ensure(c, c->d_kept, (size_t)c->n_tiles * 8))) return rc;
@@ -760,17 +764,10 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
         const size_t seg_elems = (size_t)c->seg_cap * np;
         if ((rc = ensure(c, c->d_seg_num, seg_elems * 8))) return rc;
         if ((rc = ensure(c, c->d_seg_den, seg_elems * 8))) return rc;
-        if ((rc = ensure(c, c->d_seg_c, seg_elems * 8))) return rc;
-        if ((rc = ensure(c, c->d_seg_cc, seg_elems * 8))) return rc;
+        if ((rc = ensure(c, c->d_seg_k, seg_elems * 8))) return rc;
         if ((rc = ensure(c, c->d_seg_end, seg_elems * 4))) return rc;
         const size_t cq = (size_t)c->n_chunks * np;
-        if ((rc = ensure(c, c->d_head, cq * 2 * 8))) return rc;
-        if ((rc = ensure(c, c->d_head_c, cq * 8))) return rc;
-        if ((rc = ensure(c, c->d_head_cc, cq * 8))) return rc;
-        if ((rc = ensure(c, c->d_head_site, cq * 4))) return rc;
-        if ((rc = ensure(c, c->d_tail, cq * 2 * 8))) return rc;
-        if ((rc = ensure(c, c->d_tail_c, cq * 8))) return rc;
-        if ((rc = ensure(c, c->d_tail_cc, cq * 8))) return rc;
+        if ((rc = ensure(c, c->d_tail, cq * 3 * 8))) return rc;
         if ((rc = ensure(c, c->d_tail_n, cq * 8))) return rc;
         if (k2_lds_bytes(c->n_pops, *std::max_element(c->n_full.begin(), c->n_full.end())) > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: too many populations for the LDS table");
         K2Params p = make_k2(c);
@@ -981,16 +978,7 @@ extern "C" int evofst_get_segments(evofst_ctx *c, int64_t *first_segment, int64_
     const size_t n = (size_t)c->seg_cap * np;
     if ((rc = d2h(c, sum_num, c->d_seg_num.p, n))) return rc;
     if ((rc = d2h(c, sum_den, c->d_seg_den.p, n))) return rc;
-    if (sum_dxy_k) {
-        // sumKij of every complete segment from its integer sums (exact)
-        if ((rc = upload_vec(c, c->d_nrows, rows))) return rc;
-        if ((rc = ensure(c, c->d_seg_k, n * 8))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->d_seg_k.p, 0, n * 8, c->stream));
-        K2Params p = make_k2(c);
-        const int64_t max_rows = rows.empty() ? 0 : *std::max_element(rows.begin(), rows.end());
-        HIPCHK(c, launch_seg_k(p, (const int64_t *)c->d_nrows.p, max_rows, (double *)c->d_seg_k.p, c->stream));
-        if ((rc = d2h(c, sum_dxy_k, c->d_seg_k.p, n))) return rc;
-    }
+    if ((rc = d2h(c, sum_dxy_k, c->d_seg_k.p, n))) return rc;
     if ((rc = d2h(c, end_site, c->d_seg_end.p, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return EVOFST_OK;

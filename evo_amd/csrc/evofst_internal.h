@@ -42,10 +42,12 @@ struct K1Params {
     const uint32_t *pairs;  // i | j << 16
     int32_t n_pairs;
     uint32_t *chunk_census;  // [n_pairs][n_chunks]
+    uint64_t *zf_masks;      // [n_tiles][P][2] sites with c == 0 / c == nm (skipped sites set in both)
+    uint64_t *irr_mask;      // [n_tiles] sites with nm < 2 or c == nm < n_full in some population
     // against-all mode
     uint2 *totals;            // [n_tiles*64] {sum alt, sum non-missing} over populationsToUse
     uint64_t *kept_mask;      // [n_tiles]
-    uint64_t *skip_mask;      // [n_tiles]
+    uint64_t *skip_mask;      // [n_tiles] (both modes)
     uint32_t *chunk_used_kept;  // [2][n_chunks]
 };
 
@@ -65,14 +67,11 @@ struct K2Params {
     int32_t g;
     int64_t seg_cap;
     double *seg_num, *seg_den;     // [seg_cap][n_pairs] sums of the Fst numerators / denominators
-    uint2 *seg_c;                  // [seg_cap][n_pairs] {sum c_i, sum c_j}
-    uint64_t *seg_cc;              // [seg_cap][n_pairs] sum c_i*c_j
+    double *seg_k;                 // [seg_cap][n_pairs] sum of sumKij (dxy numerators; integers, exact)
     int32_t *seg_end;              // [seg_cap][n_pairs] site of the last included site of the segment
+    const uint64_t *zf_masks, *irr_mask, *skip_mask;   // from K1
     // chunk-boundary partials, planes [chunk][pair] (a wave writes contiguous rows)
-    double *head;                  // [2][n_chunks][n_pairs] {num, den} of the first segment the chunk completes
-    uint2 *head_c; uint64_t *head_cc; int32_t *head_site;
-    double *tail;                  // [2][n_chunks][n_pairs] {num, den} after the last completed segment
-    uint2 *tail_c; uint64_t *tail_cc;
+    double *tail;                  // [3][n_chunks][n_pairs] {num, den, k} after the last completed segment
     int2 *tail_n;                  // {sites summed in the tail, segments the chunk completed}
 };
 
@@ -138,7 +137,6 @@ hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *off
 hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st);
 hipError_t launch_stitch(const K2Params &p, hipStream_t st);
 hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *totals, double *carry, hipStream_t st);
-hipError_t launch_seg_k(const K2Params &p, const int64_t *n_rows, int64_t max_rows, double *seg_k, hipStream_t st);
 hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
         CT *cp = reinterpret_cast<CT *>(p.counts) + (size_t)t * p.P * kTileSites + lane;
         uint32_t c = 0, mc = 0;
         uint32_t Tc = 0, Tn = 0, c0 = 0, nm0 = 0;
+        bool irregular = false;
         for (int wb = 0; wb < p.W; wb += 8) {
             ulonglong2 r[8];
 #pragma unroll
@@ -75,7 +76,14 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                             if (MODE == MODE_PAIRS) {
                                 const uint64_t z = __ballot(c == 0) | skipmask;
                                 const uint64_t f = __ballot(c == nm) | skipmask;
-                                if (lane == 0) { zm[d.pop] = z; fm[d.pop] = f; }
+                                if (lane == 0) {
+                                    zm[d.pop] = z; fm[d.pop] = f;
+                                    p.zf_masks[((size_t)t * p.P + d.pop) * 2] = z;
+                                    p.zf_masks[((size_t)t * p.P + d.pop) * 2 + 1] = f;
+                                }
+                                // sites K2 must take through its general loop: a NaN in the reference (nm < 2) or an
+                                // excluded site with a dxy term (fixed with missing alleles)
+                                irregular = irregular || nm < 2 || (c == nm && nm < (uint32_t)p.n_full[d.pop]);
                             }
                             if (MODE == MODE_GLOBAL) {
                                 if (d.flags & kSegUse) { Tc += c; Tn += nm; }
@@ -88,6 +96,8 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             }
         }
         if (MODE == MODE_PAIRS) {
+            const uint64_t im = __ballot(irregular && !skip);
+            if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
             // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
             // (i,j) iff both counts are 0 or both pops are fixed for ALT (or the site is skipped).
             __builtin_amdgcn_wave_barrier();
@@ -206,42 +216,82 @@ hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *off
 }
 
 // =====================================================================================
-// K2 (+K3): per-pair Hudson numerator / denominator / dxy numerator and segment sums.
+// K2 (+K3): per-pair window sums of the Hudson numerator / denominator and of the dxy numerator.
 // Replaces process_vcf_fst.cpp:543-553 + 638-650 for every population pair at once.
 //
-// Per tile of 64 sites the block first derives, per (population, site), p = c/nm and
-// h = p(1-p)/(nm-1) into an LDS table (the only divisions of the path: P per site instead of
-// 2 per pair), then every lane (= one population pair) walks the 64 sites in order.
+// Window sums only have to agree with the reference to 1e-12 (the per-site values, which are
+// bit-exact, come from site_stats_kernel), so the sums are restated so that a lane (= one pair)
+// does as little as possible per site.  With d = p_i - p_j, t = p(1-p), h = t/(nm-1):
+//     num = d^2 - h_i - h_j                      (process_vcf_fst.h:19-25)
+//     den = p_i(1-p_j) + p_j(1-p_i) = d^2 + t_i + t_j      (process_vcf_fst.h:27-30; all terms >= 0)
+//     k   = c_i(n_j-c_j) + c_j(n_i-c_i) = n_j c_i + n_i c_j - 2 c_i c_j   (process_vcf_fst.cpp:297-321)
+// A site the filter (fst.cpp:543-544) excludes for a pair has p_i = p_j in {0,1}: d, t and h are 0
+// there (t and h exactly: t = c(nm-c)/nm^2 is formed from the integer product), so nothing has to be
+// masked.  Per site a lane therefore accumulates only D = sum d^2 (one FMA) and CC = sum c_i c_j (one
+// integer MAD); sum h, sum t and sum c are per-population prefix sums from the start of the chunk,
+// kept in LDS and read only at window boundaries.  All accumulators run from the start of the chunk; a
+// segment sum is the difference of two boundary snapshots.  The boundaries of a half tile come from
+// K1's zero / fixed masks per population (include = ~((Z_i & Z_j) | (F_i & F_j))), a popcount and an
+// n-th-set-bit search, so the site loop has no boundary test: it snapshots the accumulators once per
+// group of kGrp sites, and the few sites behind the boundary are taken out again when the segment is
+// written (once per half tile and lane).
 //
-// Division: when every population has <= kRcpMax chromosomes the two quotients are formed from a
-// table of correctly rounded reciprocals with one residual correction,
-//     q0 = a*r;  e = fma(-q0, b, a);  q = fma(e, r, q0)          (Markstein),
-// which is bit-identical to IEEE a/b for every (c, nm) this path can produce: checked
-// exhaustively for 0 <= c <= nm <= 16383 (tests/test_division_identity.py).  0/0 and x/0 come
-// out as NaN through r = inf exactly as in the reference.
+// Half tiles in which some population has < 2 called alleles (the reference's 0/0 = NaN cases) or is
+// fixed with missing alleles (c == nm < n: excluded sites with a non-zero dxy term) -- K1 flags them --
+// take the general loop, which masks D and the integer sums by the site filter and counts the sites
+// whose value is NaN in the reference.
+//
+// Reciprocals come from a per-block LDS table {1/nm, 1/nm^2, 1/(nm-1), flags} (0 where undefined).
 // =====================================================================================
-constexpr int kRcpMax = 2047;
-constexpr int kSub = 32;            // sites per LDS table fill (half a tile: halves LDS, doubles resident waves)
-constexpr int kSubPad = kSub + 1;
+constexpr int kRcpMax = 1023;
+constexpr int kSub = 32;            // sites per LDS table fill (half a tile)
+constexpr int kSubPad = kSub + 1;   // row stride in entries: pop-indexed reads stay conflict-free
 #ifndef EVOFST_K2_GRP
 #define EVOFST_K2_GRP 4
 #endif
 #ifndef EVOFST_K2_WPS
-#define EVOFST_K2_WPS 4
+#define EVOFST_K2_WPS 3
 #endif
-constexpr int kGrp = EVOFST_K2_GRP;             // sites evaluated together (independent chains)
-constexpr int kK2WavesPerSimd = EVOFST_K2_WPS;  // register budget: 512 / waves per SIMD   // row stride in entries: pop-indexed reads stay conflict-free
+constexpr int kGrp = EVOFST_K2_GRP;             // sites per snapshot group
+constexpr int kK2WavesPerSimd = EVOFST_K2_WPS;  // register budget: 512 / waves per SIMD
+constexpr uint32_t kXBadNum = 1u << 30;         // nm < 2  (h undefined)
+constexpr uint32_t kXBadDen = 1u << 31;         // nm == 0 (p undefined)
+
+struct __align__(16) RcpEntry { double r0, rr0, r1; uint32_t flags, pad; };
+
 size_t k2_lds_bytes(int P, int max_n) {
-    return (size_t)P * kSubPad * (16 + 4) + (max_n <= kRcpMax ? (size_t)(max_n + 1) * 8 : 0) + 32;
+    return (size_t)P * kSubPad * (3 * 8 + 2 * 4) + (size_t)P * (2 * 8 + 4 + 8) +
+           (max_n <= kRcpMax ? (size_t)(max_n + 1) * sizeof(RcpEntry) : 0) + 64;
 }
 
-template <typename CT>
+// position of the n-th (1-based) set bit of m; needs 1 <= n <= popc(m)
+__device__ __forceinline__ int nth_set_bit(uint32_t m, int n) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        const int c = __popc(m & ((1u << w) - 1u));
+        if (n > c) { n -= c; pos += w; m >>= w; }
+    }
+    return pos;
+}
+
+template <typename CT, bool use_rcp>
 __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(K2Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double2 *ph = reinterpret_cast<double2 *>(smem);         // [P][33] {p = c/nm, h = p(1-p)/(nm-1)}
-    double *rcp = reinterpret_cast<double *>(ph + (size_t)p.P * kSubPad);   // [max_n+1] 1/x (when use_rcp)
-    const bool use_rcp = p.max_n <= kRcpMax;
-    uint32_t *xt = reinterpret_cast<uint32_t *>(rcp + (use_rcp ? p.max_n + 1 : 0));  // [P][33] c | flags
+    constexpr int EPT = 16 / (int)sizeof(CT);     // sites per 16-byte count vector
+    constexpr int VPR = kSub / EPT;               // vectors per population row of a half tile
+    constexpr int EB = 8 * (int)sizeof(CT);
+    const int P = p.P;
+    RcpEntry *rcp = reinterpret_cast<RcpEntry *>(smem);                           // [max_n+1] when use_rcp
+    double *pt = reinterpret_cast<double *>(rcp + (use_rcp ? p.max_n + 1 : 0));   // [P][33] p = c/nm
+    double *PH = pt + (size_t)P * kSubPad;                    // [P][33] sum of h from the start of the chunk
+    double *PT = PH + (size_t)P * kSubPad;                    // [P][33] sum of t
+    double *carH = PT + (size_t)P * kSubPad;                  // [P] the same sums after the last derived half tile
+    double *carT = carH + P;
+    uint32_t *xt = reinterpret_cast<uint32_t *>(carT + P);    // [P][33] c | flags
+    uint32_t *PC = xt + (size_t)P * kSubPad;                  // [P][33] sum of c
+    uint32_t *carC = PC + (size_t)P * kSubPad;                // [P]
+    uint32_t *zfm = carC + P;                                 // [P][2] zero / fixed masks of the half tile
 
     const int nthreads = blockDim.x;
     const int chunk = blockIdx.x;
@@ -250,29 +300,40 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
     uint32_t pi = 0, pj = 0;
     int64_t m = 0;
     int32_t left = p.g;
-    const size_t cq = (size_t)chunk * p.n_pairs + q;        // [chunk][pair] planes: a wave writes a contiguous row
-    const size_t plane = (size_t)p.n_pairs * p.n_chunks;
+    uint32_t ni = 0, nj = 0;
     if (active) {
         const uint32_t ij = p.pairs[q];
         pi = ij & 0xffffu; pj = ij >> 16;
+        ni = (uint32_t)p.n_full[pi]; nj = (uint32_t)p.n_full[pj];
         const int64_t g0 = p.chunk_offsets[(size_t)q * p.n_chunks + chunk];
         m = g0 / p.g;
         left = p.g - (int32_t)(g0 - m * p.g);
     }
     const int32_t left0 = left;
-    const int64_t row0 = active ? m - p.first_segment[q] : 0;   // segment-table row of the chunk's first segment
-    double sn = 0.0, sd = 0.0;
-    uint32_t sci = 0, scj = 0;   // sums of the two alt counts over the open segment
-    uint64_t scc = 0;            // sum of c_i * c_j
-    // Where the next completed segment goes: the chunk's first one into the head planes (the stitch
-    // kernel adds what earlier chunks hold of it), later ones straight into the segment table.
-    double *o_num = p.head + cq, *o_den = p.head + plane + cq;
-    uint2 *o_c = p.head_c + cq;
-    uint64_t *o_cc = p.head_cc + cq;
-    int32_t *o_site = p.head_site + cq;
+    // Segment-table element of the next segment this lane completes.  The chunk's first one is only a part
+    // (the stitch kernel adds what earlier chunks hold of it).
+    size_t orow = active ? (size_t)(m - p.first_segment[q]) * p.n_pairs + q : 0;
+    // accumulators from the start of the chunk
+    double D = 0.0;                       // sum d^2 (masked by the site filter in general half tiles)
+    uint64_t cc = 0;                      // sum c_i c_j
+    uint32_t exi = 0, exj = 0;            // sum of c_i / c_j over excluded sites (general half tiles only)
+    uint32_t bn = 0, bd = 0;              // included sites whose numerator / denominator is NaN in the reference
+    // their values at the last boundary
+    double prevN = 0.0, prevD = 0.0;
+    uint32_t prevCi = 0, prevCj = 0, prevBn = 0, prevBd = 0;
+    uint64_t prevCC = 0;
     int32_t nflush = 0;
+    for (int i = threadIdx.x; i < P; i += nthreads) { carH[i] = 0.0; carT[i] = 0.0; carC[i] = 0u; }
     if (use_rcp)
-        for (int i = threadIdx.x; i <= p.max_n; i += nthreads) rcp[i] = 1.0 / (double)i;
+        for (int i = threadIdx.x; i <= p.max_n; i += nthreads) {
+            RcpEntry e;
+            e.r0 = i ? 1.0 / (double)i : 0.0;
+            e.rr0 = e.r0 * e.r0;
+            e.r1 = i > 1 ? 1.0 / (double)(i - 1) : 0.0;
+            e.flags = (i < 2 ? kXBadNum : 0u) | (i == 0 ? kXBadDen : 0u);
+            e.pad = 0;
+            rcp[i] = e;
+        }
 
     const int t0 = chunk * p.chunk_tiles;
     const int t1 = min(t0 + p.chunk_tiles, p.n_tiles);
@@ -280,13 +341,17 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
     __syncthreads();
     // The counts of a tile ([P][64] packed CT) are fetched as 16-byte vectors (EPT consecutive sites of one
     // population); the vectors of the next half tile are requested before the pair phase of this one.
-    constexpr int EPT = 16 / (int)sizeof(CT);
-    constexpr int VPR = kSub / EPT;          // vectors per population row of a half tile
-    constexpr int NV = 4;
-    const int nvec = p.P * VPR;
+    constexpr int NV = 2;
+    const int nvec = P * VPR;
     uint4 pre[NV];
+    uint64_t pre_zf = 0, pre_skip = 0, pre_irr = 0;   // K1's masks of the tile of the prefetched half tile
     auto fetch = [&](int st) {               // st = 2*tile + half
-        const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)(st >> 1) * p.P * kTileSites);
+        if ((st & 1) == 0 || st == 2 * t0) {
+            const int tile = st >> 1;
+            pre_zf = p.zf_masks[(size_t)tile * 2 * P + min((int)threadIdx.x, 2 * P - 1)];   // (P > nthreads / 2: see below)
+            pre_skip = p.skip_mask[tile]; pre_irr = p.irr_mask[tile];
+        }
+        const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)(st >> 1) * P * kTileSites);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int vi = min((int)threadIdx.x + j * nthreads, nvec - 1);   // unconditional: loads stay in flight together
@@ -294,135 +359,260 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
             pre[j] = vp[k * (kTileSites / EPT) + (st & 1) * VPR + r];
         }
     };
-    auto derive_vec = [&](int st, int vi, const uint4 &vv) {
+    // One vector = EPT consecutive sites of population k.  skipbits: the vector's bits of the tile's skip mask.
+    auto derive_vec = [&](int vi, const uint4 &vv, uint32_t skiphalf) {
         const int k = vi / VPR, r = vi - k * VPR;
-        const int s0 = r * EPT;              // site inside the half tile
-        const uint64_t lo = (uint64_t)vv.x | ((uint64_t)vv.y << 32), hi = (uint64_t)vv.z | ((uint64_t)vv.w << 32);
-#pragma unroll 2
+        const int o = k * kSubPad + r * EPT;
+        const uint32_t skipbits = skiphalf >> (r * EPT);
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+        double tv[EPT], hv[EPT];
+        uint32_t cv[EPT];
+        double rh = 0.0, rt = 0.0;           // sums over this vector's sites
+        uint32_t rc = 0;
+#pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            // element j of the 16-byte vector without a register array (keeps the loop rolled and small)
-            constexpr int EB = 8 * (int)sizeof(CT), HALF = EPT / 2;
-            const uint64_t half = j < HALF ? lo : hi;
-            const uint32_t v = (uint32_t)(half >> (EB * (j & (HALF - 1)))) & (uint32_t)((1ull << EB) - 1ull);
-            const int s = s0 + j;
-            const int64_t site = (int64_t)st * kSub + s;
-            const uint32_t c = v & CountTraits<CT>::mask, nm = v >> CountTraits<CT>::shift;
-            bool skip = site >= p.n_sites;
-            if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
-            double pp, hh;
-            const double dc = (double)c, dn = (double)nm, dn1 = (double)((int)nm - 1);
-            if (use_rcp) {
-                const double r0 = rcp[nm], r1 = rcp[nm > 0 ? nm - 1 : 0];
-                double q0 = dc * r0;
-                pp = fma(fma(-q0, dn, dc), r0, q0);                          // == c / nm
-                const double tt = pp * (1.0 - pp);
-                q0 = tt * r1;
-                hh = fma(fma(-q0, dn1, tt), r1, q0);                         // == tt / (nm - 1)
-            } else {
-                pp = dc / dn;                                                // utils.h:272-275
-                hh = (pp * (1.0 - pp)) / dn1;                                // fst.h:21-22
-            }
+            const uint32_t v = (w[(j * EB) / 32] >> ((j * EB) % 32)) & (uint32_t)((1ull << EB) - 1ull);
+            uint32_t c = v & CountTraits<CT>::mask;
+            const uint32_t nm = v >> CountTraits<CT>::shift;
+            if (skiphalf != 0u && ((skipbits >> j) & 1u)) c = 0;    // a skipped site contributes 0 everywhere
+            const double dc = (double)c;
+            double pp, tt, hh;
             uint32_t x = c;
-            if (skip || c == 0) x |= kXZero;
-            if (skip || c == nm) x |= kXFixed;
-            const int o = k * kSubPad + s;
-            ph[o] = make_double2(pp, hh); xt[o] = x;
+            if (use_rcp) {
+                const RcpEntry e = rcp[nm];
+                pp = dc * e.r0;                                       // c / nm to 1 ulp (0 when nm == 0)
+                tt = (double)(c * (nm - c)) * e.rr0;                  // p(1-p), exactly 0 when c is 0 or nm
+                hh = tt * e.r1;                                       // t / (nm - 1)     (0 when nm < 2)
+                x |= e.flags;
+            } else {
+                const double dn = (double)nm;
+                pp = nm ? dc / dn : 0.0;                              // utils.h:272-275
+                tt = pp * (1.0 - pp);
+                hh = nm > 1 ? tt / (dn - 1.0) : 0.0;                  // fst.h:21-22
+                if (nm < 2) x |= kXBadNum;
+                if (nm == 0) x |= kXBadDen;
+            }
+            pt[o + j] = pp; xt[o + j] = x;
+            tv[j] = tt; hv[j] = hh; cv[j] = c;
+            rh += hh; rt += tt; rc += c;
+        }
+        // exclusive scan of the vector totals over the VPR lanes of the row (consecutive lanes of one wave)
+        double eh = rh, et = rt;
+        uint32_t ec = rc;
+#pragma unroll
+        for (int d = 1; d < VPR; d <<= 1) {
+            const double yh = __shfl_up(eh, d, VPR), yt = __shfl_up(et, d, VPR);
+            const uint32_t yc = __shfl_up(ec, d, VPR);
+            if (r >= d) { eh += yh; et += yt; ec += yc; }
+        }
+        const double ch = carH[k], ct = carT[k];
+        const uint32_t ccar = carC[k];
+        if (r == VPR - 1) { carH[k] = ch + eh; carT[k] = ct + et; carC[k] = ccar + ec; }
+        double ah = ch + (eh - rh), at = ct + (et - rt);       // sums before this vector
+        uint32_t ac = ccar + (ec - rc);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            ah += hv[j]; at += tv[j]; ac += cv[j];
+            PH[o + j] = ah; PT[o + j] = at; PC[o + j] = ac;
         }
     };
+    const double kNaN = __longlong_as_double(0x7ff8000000000000ll);
     const int st0 = 2 * t0, st1 = 2 * t1;
     if (st0 < st1) fetch(st0);
     for (int st = st0; st < st1; ++st) {
-        // ---- derive the per-(pop, site) table of this half tile
+        const int tile = st >> 1, sh = (st & 1) * kSub;
+        // ---- derive the per-(pop, site) tables of this half tile
+        const uint32_t skiphalf = (uint32_t)(pre_skip >> sh);
+        const bool general = (uint32_t)(pre_irr >> sh) != 0u;   // uniform
         if (!(p.debug & 2)) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int vi = threadIdx.x + j * nthreads;
-                if (vi < nvec) derive_vec(st, vi, pre[j]);
+                if (vi < nvec) derive_vec(vi, pre[j], skiphalf);
             }
-            const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)(st >> 1) * p.P * kTileSites);
+            const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)tile * P * kTileSites);
             for (int vi = threadIdx.x + NV * nthreads; vi < nvec; vi += nthreads) {
                 const int k = vi / VPR, r = vi - k * VPR;
-                derive_vec(st, vi, vp[k * (kTileSites / EPT) + (st & 1) * VPR + r]);
+                derive_vec(vi, vp[k * (kTileSites / EPT) + (st & 1) * VPR + r], skiphalf);
             }
         }
+        if ((int)threadIdx.x < 2 * P) zfm[threadIdx.x] = (uint32_t)(pre_zf >> sh);
+        for (int i = threadIdx.x + nthreads; i < 2 * P; i += nthreads)        // more than nthreads / 2 populations
+            zfm[i] = (uint32_t)(p.zf_masks[(size_t)tile * 2 * P + i] >> sh);
         if (st + 1 < st1) fetch(st + 1);
         __syncthreads();
-        // ---- pairs: lane = pair, sites in order (the reference's push_back order)
+        // ---- pairs: lane = pair
         if (active && !(p.debug & 1)) {
-            const int site0 = st * kSub;
+            const uint32_t incl = ~((zfm[2 * pi] & zfm[2 * pj]) | (zfm[2 * pi + 1] & zfm[2 * pj + 1]));   // fst.cpp:543-544
+            int b = kSub;                                  // site of this lane's next boundary in the half tile (kSub: none)
+            {
+                const int cnt = __popc(incl);
+                if (left <= cnt) b = nth_set_bit(incl, left);
+                else left -= cnt;
+            }
+            const int bgrp = b & ~(kGrp - 1);
+            double sD = D;                                 // snapshots at the end of the boundary's group
+            uint64_t scc = cc;
+            uint32_t sexi = exi, sexj = exj, sbn = bn, sbd = bd;   // (the regular loop leaves these four alone)
+            if (p.debug & 8) {
+            } else if (!general) {
 #pragma unroll 1
-            for (int sb = 0; sb < kSub; sb += kGrp) {
-                uint32_t xi[kGrp], xj[kGrp];
-                double2 a[kGrp], b[kGrp];
+                for (int sb = 0; sb < kSub; sb += kGrp) {
+                    double a[kGrp], bb[kGrp];
+                    uint32_t xi[kGrp], xj[kGrp];
 #pragma unroll
-                for (int u = 0; u < kGrp; ++u) {
-                    xi[u] = xt[io + sb + u]; xj[u] = xt[jo + sb + u];
-                    a[u] = ph[io + sb + u]; b[u] = ph[jo + sb + u];
-                }
-                // pure part: the kGrp sites are independent, no branch -> the compiler interleaves the chains.
-                // Excluded sites (fst.cpp:543-544) are masked to an exact 0 contribution.
-                double numv[kGrp], denv[kGrp];
-                uint32_t civ[kGrp], cjv[kGrp];
-                int32_t incm[kGrp];
-#pragma unroll
-                for (int u = 0; u < kGrp; ++u) {
-                    const bool inc = ((xi[u] & xj[u]) >> 28) == 0u;
-                    const double d = a[u].x - b[u].x;
-                    const double num = d * d - a[u].y - b[u].y;              // fst.h:20-23
-                    const double den = (a[u].x * (1.0 - b[u].x)) + (b[u].x * (1.0 - a[u].x));  // fst.h:28
-                    numv[u] = inc ? num : 0.0;
-                    denv[u] = inc ? den : 0.0;
-                    incm[u] = inc ? -1 : 0;
-                    const uint32_t mk = (uint32_t)incm[u] & kXMask;
-                    civ[u] = xi[u] & mk; cjv[u] = xj[u] & mk;
-                }
-                // serial part: sums in site order, one segment-boundary test per site
-#pragma unroll
-                for (int u = 0; u < kGrp; ++u) {
-                    sn += numv[u]; sd += denv[u];
-                    sci += civ[u]; scj += cjv[u];
-                    scc += (uint64_t)(civ[u] * cjv[u]);
-                    left += incm[u];
-                    if (left == 0) {
-                        // raw sums; sumKij (fst.cpp:299-321) = n2*Sc1 + n1*Sc2 - 2*Sc1c2 is formed by the reader
-                        *o_num = sn; *o_den = sd; *o_c = make_uint2(sci, scj); *o_cc = scc;
-                        *o_site = site0 + sb + u;
-                        ++nflush;
-                        const size_t o = (size_t)(row0 + nflush) * p.n_pairs + q;
-                        o_num = p.seg_num + o; o_den = p.seg_den + o; o_c = p.seg_c + o; o_cc = p.seg_cc + o;
-                        o_site = p.seg_end + o;
-                        left = p.g; sn = 0.0; sd = 0.0; sci = 0; scj = 0; scc = 0;
+                    for (int u = 0; u < kGrp; ++u) {
+                        a[u] = pt[io + sb + u]; bb[u] = pt[jo + sb + u];
+                        xi[u] = xt[io + sb + u]; xj[u] = xt[jo + sb + u];
                     }
+                    uint32_t cch = 0;                      // c_i c_j of kGrp sites (< 2^30)
+#pragma unroll
+                    for (int u = 0; u < kGrp; ++u) {
+                        const double d = a[u] - bb[u];
+                        D = fma(d, d, D);
+                        cch += __umul24(xi[u], xj[u]);     // low 24 bits: c (the flags sit above)
+                    }
+                    cc += cch;
+                    if (sb == bgrp) { sD = D; scc = cc; }
+                }
+            } else {
+#pragma unroll 1
+                for (int sb = 0; sb < kSub; sb += kGrp) {
+                    double a[kGrp], bb[kGrp];
+                    uint32_t xi[kGrp], xj[kGrp];
+#pragma unroll
+                    for (int u = 0; u < kGrp; ++u) {
+                        a[u] = pt[io + sb + u]; bb[u] = pt[jo + sb + u];
+                        xi[u] = xt[io + sb + u]; xj[u] = xt[jo + sb + u];
+                    }
+                    uint32_t cch = 0;
+#pragma unroll
+                    for (int u = 0; u < kGrp; ++u) {
+                        const bool inc = ((incl >> (sb + u)) & 1u) != 0u;
+                        const double d = inc ? a[u] - bb[u] : 0.0;
+                        D = fma(d, d, D);
+                        const uint32_t ci = xi[u] & kXMask, cj = xj[u] & kXMask;
+                        cch += inc ? ci * cj : 0u;
+                        exi += inc ? 0u : ci; exj += inc ? 0u : cj;
+                        const uint32_t bad = inc ? (xi[u] | xj[u]) >> 30 : 0u;
+                        bn += bad & 1u; bd += bad >> 1;
+                    }
+                    cc += cch;
+                    if (sb == bgrp) { sD = D; scc = cc; sexi = exi; sexj = exj; sbn = bn; sbd = bd; }
+                }
+            }
+            // ---- write the segments that end in this half tile (usually at most one per lane)
+            // emit: the accumulators right after boundary site b -> one row of the segment table, then the next boundary
+            auto emit = [&](double cD, uint64_t ccc, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd) {
+                const double H = PH[io + b] + PH[jo + b], T = PT[io + b] + PT[jo + b];
+                const uint32_t Ci = PC[io + b] - cexi, Cj = PC[jo + b] - cexj;
+                const double cumN = cD - H, cumD = cD + T;
+                // sumKij (fst.cpp:299-321) of the segment, exact: differences are taken modulo 2^32 / 2^64
+                const uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC);
+                p.seg_num[orow] = cbn != prevBn ? kNaN : cumN - prevN;
+                p.seg_den[orow] = cbd != prevBd ? kNaN : cumD - prevD;
+                p.seg_k[orow] = (double)kk;
+                p.seg_end[orow] = st * kSub + b;
+                prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevBn = cbn; prevBd = cbd;
+                ++nflush;
+                orow += p.n_pairs;
+                const uint32_t rem = b >= kSub - 1 ? 0u : incl & ~((2u << b) - 1u);
+                const int c2 = __popc(rem);
+                if (p.g <= c2) b = nth_set_bit(rem, p.g);
+                else { left = p.g - c2; b = kSub; }
+            };
+            if (b < kSub && !(p.debug & 4)) {
+                // first boundary: the group snapshot minus the (at most kGrp - 1) sites of the group behind b
+                {
+                    double cD = sD;
+                    uint64_t ccc = scc;
+                    uint32_t cexi = sexi, cexj = sexj, cbn = sbn, cbd = sbd;
+                    double pa[kGrp - 1], pb[kGrp - 1];
+                    uint32_t xa[kGrp - 1], xb[kGrp - 1];
+                    const int room = (kGrp - 1) - (b & (kGrp - 1));   // sites of the group behind b
+#pragma unroll
+                    for (int u = 1; u < kGrp; ++u) {
+                        const int s = u <= room ? b + u : b;
+                        pa[u - 1] = pt[io + s]; pb[u - 1] = pt[jo + s]; xa[u - 1] = xt[io + s]; xb[u - 1] = xt[jo + s];
+                    }
+#pragma unroll
+                    for (int u = 1; u < kGrp; ++u) {
+                        const bool there = u <= room;
+                        const bool inc = !general || ((incl >> ((b + u) & 31)) & 1u) != 0u;
+                        const double d = there && inc ? pa[u - 1] - pb[u - 1] : 0.0;
+                        cD = fma(-d, d, cD);
+                        const uint32_t ci = there ? xa[u - 1] & kXMask : 0u, cj = there ? xb[u - 1] & kXMask : 0u;
+                        ccc -= inc ? (uint64_t)(ci * cj) : 0ull;
+                        if (general) {
+                            cexi -= inc ? 0u : ci; cexj -= inc ? 0u : cj;
+                            const uint32_t bad = there && inc ? (xa[u - 1] | xb[u - 1]) >> 30 : 0u;
+                            cbn -= bad & 1u; cbd -= bad >> 1;
+                        }
+                    }
+                    emit(cD, ccc, cexi, cexj, cbn, cbd);
+                }
+                // further boundaries of the same half tile (windows shorter than it): from the end of the half tile
+                while (b < kSub) {
+                    double cD = D;
+                    uint64_t ccc = cc;
+                    uint32_t cexi = exi, cexj = exj, cbn = bn, cbd = bd;
+                    for (int s = b + 1; s < kSub; ++s) {
+                        const uint32_t xi = xt[io + s], xj = xt[jo + s];
+                        const double d = pt[io + s] - pt[jo + s];
+                        const uint32_t ci = xi & kXMask, cj = xj & kXMask;
+                        const bool inc = !general || ((incl >> s) & 1u) != 0u;
+                        if (inc) {
+                            cD = fma(-d, d, cD);
+                            ccc -= (uint64_t)(ci * cj);
+                            if (general) { const uint32_t bad = (xi | xj) >> 30; cbn -= bad & 1u; cbd -= bad >> 1; }
+                        } else {
+                            cexi -= ci; cexj -= cj;
+                        }
+                    }
+                    emit(cD, ccc, cexi, cexj, cbn, cbd);
                 }
             }
         }
         __syncthreads();
     }
     if (active) {
-        p.tail[cq] = sn; p.tail[plane + cq] = sd;
-        p.tail_c[cq] = make_uint2(sci, scj); p.tail_cc[cq] = scc;
+        // what the chunk holds behind its last boundary
+        const size_t cq = (size_t)chunk * p.n_pairs + q;        // [chunk][pair] planes: a wave writes a contiguous row
+        const size_t plane = (size_t)p.n_pairs * p.n_chunks;
+        const double H = carH[pi] + carH[pj], T = carT[pi] + carT[pj];
+        const uint32_t Ci = carC[pi] - exi, Cj = carC[pj] - exj;
+        const uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (cc - prevCC);
+        p.tail[cq] = bn != prevBn ? kNaN : (D - H) - prevN;
+        p.tail[plane + cq] = bd != prevBd ? kNaN : (D + T) - prevD;
+        p.tail[2 * plane + cq] = (double)kk;
         p.tail_n[cq] = make_int2((nflush ? p.g : left0) - left, nflush);   // {sites summed in the tail, segments completed}
     }
+}
+
+template <typename CT, bool RCP>
+static hipError_t launch_k2_t(const K2Params &p, size_t lds, dim3 grid, dim3 block, hipStream_t st) {
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_window_kernel<CT, RCP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k2_window_kernel<CT, RCP>), grid, block, lds, st, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
     const int threads = 64 * ((std::min(p.n_pairs, kK2Threads) + 63) / 64);
     dim3 grid(p.n_chunks, (p.n_pairs + threads - 1) / threads), block(threads);
-    size_t lds = k2_lds_bytes(p.P, p.max_n);
-    if (lds > 48 * 1024) {
-        hipError_t e = count_bytes == 2
-            ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_window_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-            : hipFuncSetAttribute(reinterpret_cast<const void *>(&k2_window_kernel<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    if (count_bytes == 2) hipLaunchKernelGGL((k2_window_kernel<uint16_t>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((k2_window_kernel<uint32_t>), grid, block, lds, st, p);
-    return hipGetLastError();
+    const size_t lds = k2_lds_bytes(p.P, p.max_n);
+    const bool rcp = p.max_n <= kRcpMax;
+    if (count_bytes == 2) return rcp ? launch_k2_t<uint16_t, true>(p, lds, grid, block, st) : launch_k2_t<uint16_t, false>(p, lds, grid, block, st);
+    return rcp ? launch_k2_t<uint32_t, true>(p, lds, grid, block, st) : launch_k2_t<uint32_t, false>(p, lds, grid, block, st);
 }
 
-// The first segment a chunk completes started in an earlier chunk: add, in site order, the tail of
-// the last chunk that completed a segment and the whole-chunk sums of the chunks in between.
+// The first segment a chunk completes started in an earlier chunk: K2 wrote the chunk's own part into
+// the segment's row; add, in site order, the tail of the last chunk that completed a segment and the
+// whole-chunk sums of the chunks in between.
 __global__ void stitch_kernel(K2Params p) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;   // lanes = pairs: rows of the [chunk][pair] planes are contiguous
     const int c = blockIdx.y;
@@ -432,23 +622,14 @@ __global__ void stitch_kernel(K2Params p) {
     if (p.tail_n[cq].y == 0) return;                        // this chunk completed no segment
     int cp = c - 1;
     while (cp >= 0 && p.tail_n[(size_t)cp * p.n_pairs + q].y == 0) --cp;
-    double an = 0.0, ad = 0.0;
-    uint64_t ci = 0, cj = 0, cc = 0;
+    double an = 0.0, ad = 0.0, ak = 0.0;
     for (int cc_ = (cp < 0 ? 0 : cp); cc_ < c; ++cc_) {
         const size_t o = (size_t)cc_ * p.n_pairs + q;
-        an += p.tail[o]; ad += p.tail[plane + o];
-        const uint2 t = p.tail_c[o];
-        ci += t.x; cj += t.y; cc += p.tail_cc[o];
+        an += p.tail[o]; ad += p.tail[plane + o]; ak += p.tail[2 * plane + o];
     }
-    an += p.head[cq]; ad += p.head[plane + cq];
-    const uint2 h = p.head_c[cq];
-    ci += h.x; cj += h.y; cc += p.head_cc[cq];
     const int64_t m0 = p.chunk_offsets[(size_t)q * p.n_chunks + c] / p.g;
     const size_t o = (size_t)(m0 - p.first_segment[q]) * p.n_pairs + q;
-    p.seg_num[o] = an; p.seg_den[o] = ad;
-    // the carried counts may exceed 32 bits only if a segment spans > 2^32 / n chromosomes-sites: g is an int
-    p.seg_c[o] = make_uint2((uint32_t)ci, (uint32_t)cj); p.seg_cc[o] = cc;
-    p.seg_end[o] = p.head_site[cq];
+    p.seg_num[o] = an + p.seg_num[o]; p.seg_den[o] = ad + p.seg_den[o]; p.seg_k[o] = ak + p.seg_k[o];
 }
 
 hipError_t launch_stitch(const K2Params &p, hipStream_t st) {
@@ -458,60 +639,32 @@ hipError_t launch_stitch(const K2Params &p, hipStream_t st) {
     return hipGetLastError();
 }
 
-// Converts the raw integer sums of every complete segment into sumKij (as a double, exact):
-// k = n_j * Sc_i + n_i * Sc_j - 2 * Sc_ic_j.  Run by the getters, not by the timed pass.
-__global__ void seg_k_kernel(K2Params p, const int64_t *__restrict__ n_rows, double *__restrict__ seg_k) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t r = blockIdx.y;
-    if (q >= p.n_pairs || r >= n_rows[q]) return;
-    const uint32_t ij = p.pairs[q];
-    const uint64_t ni = (uint64_t)p.n_full[ij & 0xffffu], nj = (uint64_t)p.n_full[ij >> 16];
-    const size_t o = (size_t)r * p.n_pairs + q;
-    const uint2 c = p.seg_c[o];
-    seg_k[o] = (double)(nj * c.x + ni * c.y - 2ull * p.seg_cc[o]);
-}
-
-hipError_t launch_seg_k(const K2Params &p, const int64_t *n_rows, int64_t max_rows, double *seg_k, hipStream_t st) {
-    if (p.n_pairs <= 0 || max_rows <= 0) return hipSuccess;
-    dim3 block(64), grid((p.n_pairs + 63) / 64, (unsigned)max_rows);
-    hipLaunchKernelGGL(seg_k_kernel, grid, block, 0, st, p, n_rows, seg_k);
-    return hipGetLastError();
-}
-
 // Whole-shard sums per pair: complete segments in order, then the carry after the last one.
 // totals[q] = {num, den, k, n_included}; carry[q] = {num, den, k, n_sites} behind the last complete segment.
+// (k = sumKij is a sum of integers < 2^53 held in doubles: exact in any order.)
 __global__ void totals_kernel(K2Params p, const int64_t *__restrict__ n_rows, double *__restrict__ totals,
                               double *__restrict__ carry) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= p.n_pairs) return;
-    const uint32_t ij = p.pairs[q];
-    const uint64_t ni = (uint64_t)p.n_full[ij & 0xffffu], nj = (uint64_t)p.n_full[ij >> 16];
     const size_t plane = (size_t)p.n_pairs * p.n_chunks;
-    double an = 0.0, ad = 0.0;
-    uint64_t ci = 0, cj = 0, cc = 0;
+    double an = 0.0, ad = 0.0, ak = 0.0;
     const int64_t rows = n_rows[q];
     for (int64_t r = 0; r < rows; ++r) {
         const size_t o = (size_t)r * p.n_pairs + q;
-        an += p.seg_num[o]; ad += p.seg_den[o];
-        const uint2 c = p.seg_c[o];
-        ci += c.x; cj += c.y; cc += p.seg_cc[o];
+        an += p.seg_num[o]; ad += p.seg_den[o]; ak += p.seg_k[o];
     }
     int cl = p.n_chunks - 1;
     while (cl >= 0 && p.tail_n[(size_t)cl * p.n_pairs + q].y == 0) --cl;
-    double tn = 0.0, td = 0.0, cnt = 0.0;
-    uint64_t ti = 0, tj = 0, tc = 0;
+    double tn = 0.0, td = 0.0, tk = 0.0, cnt = 0.0;
     for (int c = (cl < 0 ? 0 : cl); c < p.n_chunks; ++c) {
         const size_t o = (size_t)c * p.n_pairs + q;
-        tn += p.tail[o]; td += p.tail[plane + o];
-        const uint2 t = p.tail_c[o];
-        ti += t.x; tj += t.y; tc += p.tail_cc[o];
+        tn += p.tail[o]; td += p.tail[plane + o]; tk += p.tail[2 * plane + o];
         cnt += (double)p.tail_n[o].x;
     }
-    const double tk = (double)(nj * ti + ni * tj - 2ull * tc);
     if (carry) { carry[(size_t)q * 4] = tn; carry[(size_t)q * 4 + 1] = td; carry[(size_t)q * 4 + 2] = tk; carry[(size_t)q * 4 + 3] = cnt; }
     if (totals) {
         totals[(size_t)q * 4 + 0] = an + tn; totals[(size_t)q * 4 + 1] = ad + td;
-        totals[(size_t)q * 4 + 2] = (double)(nj * ci + ni * cj - 2ull * cc) + tk;
+        totals[(size_t)q * 4 + 2] = ak + tk;
         totals[(size_t)q * 4 + 3] = (double)rows * (double)p.g + cnt;
     }
 }
