@@ -100,9 +100,13 @@ def main():
     e.reserve(S)
     e.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=rank * S)
     e.sync()
-    e.set_profiling(True)
+    e.set_profiling(False)          # no event records inside the timed region
+    if world > 1 and cfg["mode"] != "pairs":
+        raise SystemExit("bench.py: the against-all deque hand-off between shards is not built yet; run this config with --gpus 1")
     from evo_amd import shard
     ag = shard.torch_all_gather(device="cuda") if world > 1 else None
+
+    gseg = int(np.gcd(cfg["size"], cfg["step"])) if cfg["size"] else 2**31 - 1
 
     def step():
         if world == 1:
@@ -111,10 +115,15 @@ def main():
             # two window-boundary exchanges per pass (evo_amd/shard.py): included-site totals after K1
             # (all-gather over RCCL) -> base offsets; carries behind the last complete segment after K2.
             e.run_counts()
-            e.set_base_offsets(shard.base_offsets(ag(e.included_totals()), rank))
+            all_tot = ag(e.included_totals())
+            e.set_base_offsets(shard.base_offsets(all_tot, rank))
             e.run_stats()
-            if cfg["mode"] == "pairs":
-                shard.carry_in(ag(e.boundary()), ag(e.included_totals()), rank)
+            # complete segments of every shard follow from the totals: (base + total) / g - base / g
+            base = np.zeros_like(all_tot[0]); all_nseg = []
+            for r in range(world):
+                all_nseg.append((base + all_tot[r]) // gseg - base // gseg)
+                base = base + all_tot[r]
+            shard.carry_in(ag(e.boundary()), all_nseg, rank)
 
     def fence():
         e.sync()
@@ -135,6 +144,7 @@ def main():
     # per-kernel durations from HIP events on the library's stream (last step; then a few more
     # profiled steps outside the timed region to average)
     reps = min(args.steps, 20)
+    e.set_profiling(True)
     for i in range(reps):
         step()
         e.sync()
@@ -157,7 +167,8 @@ def main():
     k1_bytes = S * (N / 2.0) + S * P * cb          # 2 bits per haplotype read + packed counts written
     if cfg["mode"] == "pairs":
         g = np.gcd(cfg["size"], cfg["step"]) if cfg["size"] else 10**9
-        k2_bytes = S * P * cb + (S / g) * e.n_pairs * 28.0   # counts read + segment rows written
+        k1_bytes += S / 64.0 * (2 * P + 2) * 8.0         # zero / fixed / irregular / skip masks written
+        k2_bytes = S * P * cb + S / 64.0 * (2 * P + 2) * 8.0 + (S / g) * e.n_pairs * 28.0   # counts + masks read, segment rows written
     else:
         k2_bytes = S * P * cb + S * 8.0 + (S / cfg["step"]) * P * 16.0
     names = ["k1_count_kernel", "scan_kernel", "k2_window_kernel" if cfg["mode"] == "pairs" else "global_window_kernel",
@@ -181,7 +192,8 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and args.cpu_sites != 0:
-        cs = args.cpu_sites if args.cpu_sites > 0 else min(S, max(20_000, int(6e7 / (units_per_site * 10))))
+        # the oracle does ~3e7 evaluations/s on one core: 6e8 evaluations are ~20 s; the whole cfg2 workload is less
+        cs = args.cpu_sites if args.cpu_sites > 0 else min(S, max(20_000, int(6e8 / units_per_site)))
         v, secs = cpu_baseline(e, cfg, cs)
         out["cpu_baseline"] = {"value": v, "unit": "site*pair/s", "cores": 1, "kind": "port",
                                "sample": "first %d sites of the same workload, oracle/evo_oracle.c closed-form "

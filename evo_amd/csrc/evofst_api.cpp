@@ -218,7 +218,7 @@ K2Params make_k2(evofst_ctx *c) {
     p.seg_end = (int32_t *)c->d_seg_end.p;
     p.zf_masks = (const uint64_t *)c->d_zf.p; p.irr_mask = (const uint64_t *)c->d_irr.p; p.skip_mask = (const uint64_t *)c->d_skip.p;
     p.tail = (double *)c->d_tail.p;
-    p.tail_n = (int2 *)c->d_tail_n.p;
+    p.tail_n = (int4 *)c->d_tail_n.p;
     return p;
 }
 
@@ -768,7 +768,7 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
         if ((rc = ensure(c, c->d_seg_end, seg_elems * 4))) return rc;
         const size_t cq = (size_t)c->n_chunks * np;
         if ((rc = ensure(c, c->d_tail, cq * 3 * 8))) return rc;
-        if ((rc = ensure(c, c->d_tail_n, cq * 8))) return rc;
+        if ((rc = ensure(c, c->d_tail_n, cq * 16))) return rc;
         if (k2_lds_bytes(c->n_pops, *std::max_element(c->n_full.begin(), c->n_full.end())) > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: too many populations for the LDS table");
         K2Params p = make_k2(c);
         record(c, 2, 0);

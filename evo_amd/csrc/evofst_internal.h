@@ -42,7 +42,7 @@ struct K1Params {
     const uint32_t *pairs;  // i | j << 16
     int32_t n_pairs;
     uint32_t *chunk_census;  // [n_pairs][n_chunks]
-    uint64_t *zf_masks;      // [n_tiles][P][2] sites with c == 0 / c == nm (skipped sites set in both)
+    uint64_t *zf_masks;      // [n_tiles][2][P] sites with c == 0 / c == nm (skipped sites set in both)
     uint64_t *irr_mask;      // [n_tiles] sites with nm < 2 or c == nm < n_full in some population
     // against-all mode
     uint2 *totals;            // [n_tiles*64] {sum alt, sum non-missing} over populationsToUse
@@ -72,7 +72,7 @@ struct K2Params {
     const uint64_t *zf_masks, *irr_mask, *skip_mask;   // from K1
     // chunk-boundary partials, planes [chunk][pair] (a wave writes contiguous rows)
     double *tail;                  // [3][n_chunks][n_pairs] {num, den, k} after the last completed segment
-    int2 *tail_n;                  // {sites summed in the tail, segments the chunk completed}
+    int4 *tail_n;                  // {sites summed in the tail, segments the chunk completed, row of its first segment, -}
 };
 
 struct SiteStatParams {

@@ -76,11 +76,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                             if (MODE == MODE_PAIRS) {
                                 const uint64_t z = __ballot(c == 0) | skipmask;
                                 const uint64_t f = __ballot(c == nm) | skipmask;
-                                if (lane == 0) {
-                                    zm[d.pop] = z; fm[d.pop] = f;
-                                    p.zf_masks[((size_t)t * p.P + d.pop) * 2] = z;
-                                    p.zf_masks[((size_t)t * p.P + d.pop) * 2 + 1] = f;
-                                }
+                                if (lane == 0) { zm[d.pop] = z; fm[d.pop] = f; }
                                 // sites K2 must take through its general loop: a NaN in the reference (nm < 2) or an
                                 // excluded site with a dxy term (fixed with missing alleles)
                                 irregular = irregular || nm < 2 || (c == nm && nm < (uint32_t)p.n_full[d.pop]);
@@ -101,6 +97,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
             // (i,j) iff both counts are 0 or both pops are fixed for ALT (or the site is skipped).
             __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < 2 * p.P; i += 64) p.zf_masks[(size_t)t * 2 * p.P + i] = zm[i];   // [tile][z|f][P]: zm, fm are adjacent
             for (int q = lane; q < p.n_pairs; q += 64) {
                 const uint32_t ij = p.pairs[q];
                 const uint32_t i = ij & 0xffffu, j = ij >> 16;
@@ -164,54 +161,57 @@ hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t s
 }
 
 // =====================================================================================
-// Exclusive scan of the census over chunks, one wave per column (pair):
-// offsets[q][c] = base[q] + sum_{c'<c} census[q][c'].  Column-major so that a wave reads 64
-// consecutive chunks per load and scans them with lane shuffles.
+// Exclusive scan of the census over chunks, one 1024-thread block per column (pair):
+// offsets[q][c] = base[q] + sum_{c'<c} census[q][c'].  A thread owns 4 consecutive chunks, so a
+// pass covers 4096 chunks with coalesced loads and stores; wave shuffles + one LDS exchange.
 // =====================================================================================
-__global__ __launch_bounds__(256) void scan_kernel(const uint32_t *__restrict__ census,
-                                                   const int64_t *__restrict__ base,
-                                                   int64_t *__restrict__ offsets,
-                                                   int64_t *__restrict__ totals, int n_chunks, int n_cols) {
-    const int lane = lane_id();
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= n_cols) return;
+constexpr int kScanThreads = 1024, kScanPer = 4;
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(const uint32_t *__restrict__ census,
+                                                            const int64_t *__restrict__ base,
+                                                            int64_t *__restrict__ offsets,
+                                                            int64_t *__restrict__ totals, int n_chunks, int n_cols) {
+    __shared__ uint32_t wsum[kScanThreads / 64];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int q = blockIdx.x;
     const uint32_t *in = census + (size_t)q * n_chunks;
     int64_t *out = offsets + (size_t)q * n_chunks;
     const int64_t b0 = base ? base[q] : 0;
     int64_t carry = b0;
-    constexpr int PER = 32;  // chunks per lane and pass, all loads of a pass in flight together
-    for (int c0 = 0; c0 < n_chunks; c0 += 64 * PER) {
-        const int first = c0 + lane * PER;
-        uint32_t v[PER];
+    for (int c0 = 0; c0 < n_chunks; c0 += kScanThreads * kScanPer) {
+        const int first = c0 + threadIdx.x * kScanPer;
+        uint32_t v[kScanPer];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) v[i] = in[min(first + i, n_chunks - 1)];   // unconditional: no branch per load
-#pragma unroll
-        for (int i = 0; i < PER; ++i) v[i] = first + i < n_chunks ? v[i] : 0u;
+        for (int i = 0; i < kScanPer; ++i) v[i] = in[min(first + i, n_chunks - 1)];   // unconditional: no branch per load
         uint32_t mine = 0;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) mine += v[i];
-        uint32_t x = mine;  // inclusive scan of the lane totals
+        for (int i = 0; i < kScanPer; ++i) { v[i] = first + i < n_chunks ? v[i] : 0u; mine += v[i]; }
+        uint32_t x = mine;  // inclusive scan of the thread totals inside the wave
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t y = __shfl_up(x, d);
             if (lane >= d) x += y;
         }
-        int64_t run = carry + (int64_t)(x - mine);
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0, all = 0;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
+        for (int w = 0; w < kScanThreads / 64; ++w) { const uint32_t t = wsum[w]; woff += w < wave ? t : 0u; all += t; }
+        int64_t run = carry + (int64_t)woff + (int64_t)(x - mine);
+#pragma unroll
+        for (int i = 0; i < kScanPer; ++i) {
             if (first + i < n_chunks) out[first + i] = run;
             run += v[i];
         }
-        carry += (int64_t)__shfl(x, 63);
+        carry += (int64_t)all;
+        __syncthreads();
     }
-    if (lane == 0 && totals) totals[q] = carry - b0;
+    if (threadIdx.x == 0 && totals) totals[q] = carry - b0;
 }
 
 hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *offsets, int64_t *totals,
                        int n_chunks, int n_cols, hipStream_t st) {
-    if (n_cols <= 0) return hipSuccess;
-    dim3 grid((n_cols + 3) / 4), block(256);
-    hipLaunchKernelGGL(scan_kernel, grid, block, 0, st, census, base, offsets, totals, n_chunks, n_cols);
+    if (n_cols <= 0 || n_chunks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scan_kernel, dim3(n_cols), dim3(kScanThreads), 0, st, census, base, offsets, totals, n_chunks, n_cols);
     return hipGetLastError();
 }
 
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
     uint32_t *xt = reinterpret_cast<uint32_t *>(carT + P);    // [P][33] c | flags
     uint32_t *PC = xt + (size_t)P * kSubPad;                  // [P][33] sum of c
     uint32_t *carC = PC + (size_t)P * kSubPad;                // [P]
-    uint32_t *zfm = carC + P;                                 // [P][2] zero / fixed masks of the half tile
+    uint32_t *zfm = carC + P;                                 // [2][P] zero / fixed masks of the half tile
 
     const int nthreads = blockDim.x;
     const int chunk = blockIdx.x;
@@ -312,7 +312,8 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
     const int32_t left0 = left;
     // Segment-table element of the next segment this lane completes.  The chunk's first one is only a part
     // (the stitch kernel adds what earlier chunks hold of it).
-    size_t orow = active ? (size_t)(m - p.first_segment[q]) * p.n_pairs + q : 0;
+    const int32_t row0 = active ? (int32_t)(m - p.first_segment[q]) : 0;
+    size_t orow = (size_t)row0 * p.n_pairs + q;
     // accumulators from the start of the chunk
     double D = 0.0;                       // sum d^2 (masked by the site filter in general half tiles)
     uint64_t cc = 0;                      // sum c_i c_j
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
         __syncthreads();
         // ---- pairs: lane = pair
         if (active && !(p.debug & 1)) {
-            const uint32_t incl = ~((zfm[2 * pi] & zfm[2 * pj]) | (zfm[2 * pi + 1] & zfm[2 * pj + 1]));   // fst.cpp:543-544
+            const uint32_t incl = ~((zfm[pi] & zfm[pj]) | (zfm[P + pi] & zfm[P + pj]));   // fst.cpp:543-544
             int b = kSub;                                  // site of this lane's next boundary in the half tile (kSub: none)
             {
                 const int cnt = __popc(incl);
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
         p.tail[cq] = bn != prevBn ? kNaN : (D - H) - prevN;
         p.tail[plane + cq] = bd != prevBd ? kNaN : (D + T) - prevD;
         p.tail[2 * plane + cq] = (double)kk;
-        p.tail_n[cq] = make_int2((nflush ? p.g : left0) - left, nflush);   // {sites summed in the tail, segments completed}
+        p.tail_n[cq] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);   // {sites summed in the tail, segments completed, row of the first}
     }
 }
 
@@ -613,13 +614,13 @@ hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st) {
 // The first segment a chunk completes started in an earlier chunk: K2 wrote the chunk's own part into
 // the segment's row; add, in site order, the tail of the last chunk that completed a segment and the
 // whole-chunk sums of the chunks in between.
-__global__ void stitch_kernel(K2Params p) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;   // lanes = pairs: rows of the [chunk][pair] planes are contiguous
-    const int c = blockIdx.y;
-    if (q >= p.n_pairs) return;
+__global__ __launch_bounds__(256) void stitch_kernel(K2Params p) {
+    const size_t cq = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // [chunk][pair], flat
     const size_t plane = (size_t)p.n_pairs * p.n_chunks;
-    const size_t cq = (size_t)c * p.n_pairs + q;
-    if (p.tail_n[cq].y == 0) return;                        // this chunk completed no segment
+    if (cq >= plane) return;
+    const int c = (int)(cq / p.n_pairs), q = (int)(cq - (size_t)c * p.n_pairs);
+    const int4 me = p.tail_n[cq];
+    if (me.y == 0) return;                                  // this chunk completed no segment
     int cp = c - 1;
     while (cp >= 0 && p.tail_n[(size_t)cp * p.n_pairs + q].y == 0) --cp;
     double an = 0.0, ad = 0.0, ak = 0.0;
@@ -627,15 +628,14 @@ __global__ void stitch_kernel(K2Params p) {
         const size_t o = (size_t)cc_ * p.n_pairs + q;
         an += p.tail[o]; ad += p.tail[plane + o]; ak += p.tail[2 * plane + o];
     }
-    const int64_t m0 = p.chunk_offsets[(size_t)q * p.n_chunks + c] / p.g;
-    const size_t o = (size_t)(m0 - p.first_segment[q]) * p.n_pairs + q;
+    const size_t o = (size_t)me.z * p.n_pairs + q;
     p.seg_num[o] = an + p.seg_num[o]; p.seg_den[o] = ad + p.seg_den[o]; p.seg_k[o] = ak + p.seg_k[o];
 }
 
 hipError_t launch_stitch(const K2Params &p, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
-    dim3 block(64), grid((p.n_pairs + 63) / 64, p.n_chunks);
-    hipLaunchKernelGGL(stitch_kernel, grid, block, 0, st, p);
+    const size_t n = (size_t)p.n_pairs * p.n_chunks;
+    hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
