@@ -137,6 +137,7 @@ int upload_layout(evofst_ctx *c) {
         d.flags &= kSegLast;
         if (use[d.pop]) d.flags |= kSegUse;
         if ((int)d.pop == first_use) d.flags |= kSegFirstUse;
+        d.flags |= (uint32_t)c->n_full[d.pop] << kSegNFullShift;
     }
     int rc;
     if ((rc = upload_vec(c, c->d_segs, c->segs))) return rc;
@@ -717,10 +718,11 @@ extern "C" int evofst_run_counts(evofst_ctx *c) {
     p.tiles = (const ulonglong2 *)c->tiles;
     p.site_flags = c->have_flags ? c->flags : nullptr;
     p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.W = c->W; p.P = c->n_pops;
-    p.segs = (const SegDesc *)c->d_segs.p; p.word_seg_start = (const int32_t *)c->d_wss.p;
+    p.segs = (const SegDesc *)c->d_segs.p; p.word_seg_start = (const int32_t *)c->d_wss.p; p.n_segs = (int)c->segs.size();
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.counts = c->d_counts.p;
     p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
+    if (const char *e = getenv("EVOFST_DEBUG_K1")) p.debug = atoi(e);
     int rc;
     if (c->mode == MODE_PAIRS) {
         p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)c->pairs.size();

@@ -19,6 +19,8 @@ struct SegDesc {
                      // bit2: pop is populationsToUse[0]
 };
 constexpr uint32_t kSegLast = 1u, kSegUse = 2u, kSegFirstUse = 4u;
+constexpr int kSegNFullShift = 8;   // flags >> 8: n_full of the population
+
 
 // packed per-(site,pop) table word of K2: a = c (alt count), b = n_full - c
 constexpr uint32_t kXBits = 14;
@@ -38,6 +40,8 @@ struct K1Params {
     const int32_t *n_full;          // [P]
     void *counts;                   // CT [n_tiles][P][64], c | nm << (4*sizeof(CT))
     int32_t chunk_tiles, n_chunks;
+    int32_t debug;   // EVOFST_DEBUG_K1 (profiling experiments only)
+    int32_t n_segs;  // entries of segs
     // pairs mode
     const uint32_t *pairs;  // i | j << 16
     int32_t n_pairs;

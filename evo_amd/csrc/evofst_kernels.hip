@@ -40,8 +40,17 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     uint64_t *fm = zm + p.P;
     uint32_t *cen_all = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem) + (size_t)NW * 2 * p.P);
     uint32_t *cen = cen_all + (size_t)wave * p.n_pairs;
+    // block-wide copies of the layout tables: the counting loop must not queue vector loads behind the tile loads
+    const int npq = MODE == MODE_PAIRS ? p.n_pairs : 0;
+    uint32_t *lpairs = cen_all + (size_t)NW * npq;                                   // [n_pairs]
+    int32_t *lwss = reinterpret_cast<int32_t *>(lpairs + npq);                        // [W+1]
+    SegDesc *lsegs = reinterpret_cast<SegDesc *>(smem + (((reinterpret_cast<unsigned char *>(lwss + p.W + 1) - smem) + 15) & ~(size_t)15));
+    for (int i = threadIdx.x; i < npq; i += kK1Threads) lpairs[i] = p.pairs[i];
+    for (int i = threadIdx.x; i <= p.W; i += kK1Threads) lwss[i] = p.word_seg_start[i];
+    for (int i = threadIdx.x; i < p.n_segs; i += kK1Threads) lsegs[i] = p.segs[i];
     if (MODE == MODE_PAIRS)
         for (int q = lane; q < p.n_pairs; q += 64) cen[q] = 0;
+    __syncthreads();
     uint32_t used_cnt = 0, kept_cnt = 0;
 
     const int chunk = blockIdx.x;
@@ -62,24 +71,30 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)   // unconditional (clamped) so that all 8 loads are in flight together
                 r[u] = tp[(size_t)min(wb + u, p.W - 1) * kTileSites];
+            if (p.debug & 1) {   // profiling experiments only: loads without the counting loop
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { c += (uint32_t)r[u].x; mc += (uint32_t)r[u].y; }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (wb + u < p.W) {
-                    const int s0 = p.word_seg_start[wb + u], s1 = p.word_seg_start[wb + u + 1];
+                    const int s0 = lwss[wb + u], s1 = lwss[wb + u + 1];
                     for (int s = s0; s < s1; ++s) {
-                        const SegDesc d = p.segs[s];
+                        const SegDesc d = lsegs[s];
                         c += __popcll(r[u].x & d.mask);
                         mc += __popcll(r[u].y & d.mask);
                         if (d.flags & kSegLast) {
-                            const uint32_t nm = (uint32_t)p.n_full[d.pop] - mc;
-                            cp[(size_t)d.pop * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
+                            const uint32_t nfull = d.flags >> kSegNFullShift;
+                            const uint32_t nm = nfull - mc;
+                            if (!(p.debug & 2)) cp[(size_t)d.pop * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
                             if (MODE == MODE_PAIRS) {
                                 const uint64_t z = __ballot(c == 0) | skipmask;
                                 const uint64_t f = __ballot(c == nm) | skipmask;
                                 if (lane == 0) { zm[d.pop] = z; fm[d.pop] = f; }
                                 // sites K2 must take through its general loop: a NaN in the reference (nm < 2) or an
                                 // excluded site with a dxy term (fixed with missing alleles)
-                                irregular = irregular || nm < 2 || (c == nm && nm < (uint32_t)p.n_full[d.pop]);
+                                irregular = irregular || nm < 2 || (c == nm && nm < nfull);
                             }
                             if (MODE == MODE_GLOBAL) {
                                 if (d.flags & kSegUse) { Tc += c; Tn += nm; }
@@ -91,7 +106,8 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                 }
             }
         }
-        if (MODE == MODE_PAIRS) {
+        if (p.debug & 1) cp[0] = (CT)(c + mc);
+        if (MODE == MODE_PAIRS && !(p.debug & 4)) {
             const uint64_t im = __ballot(irregular && !skip);
             if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
             // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             __builtin_amdgcn_wave_barrier();
             for (int i = lane; i < 2 * p.P; i += 64) p.zf_masks[(size_t)t * 2 * p.P + i] = zm[i];   // [tile][z|f][P]: zm, fm are adjacent
             for (int q = lane; q < p.n_pairs; q += 64) {
-                const uint32_t ij = p.pairs[q];
+                const uint32_t ij = lpairs[q];
                 const uint32_t i = ij & 0xffffu, j = ij >> 16;
                 const uint64_t ex = (zm[i] & zm[j]) | (fm[i] & fm[j]);
                 cen[q] += 64u - (uint32_t)__popcll(ex);
@@ -144,7 +160,9 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
 hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t st) {
     if (p.n_chunks <= 0) return hipSuccess;
     constexpr int NW = kK1Threads / 64;
-    size_t lds = (size_t)NW * 2 * p.P * 8 + (size_t)NW * (mode == MODE_PAIRS ? p.n_pairs : 0) * 4 + 64;
+    const size_t npq = mode == MODE_PAIRS ? p.n_pairs : 0;
+    size_t lds = (size_t)NW * 2 * p.P * 8 + (NW + 1) * npq * 4 + (size_t)(p.W + 1) * 4 + 16 + (size_t)p.n_segs * sizeof(SegDesc) + 64;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;   // layouts with > ~3000 words / segments: not expected (N <= 100k samples)
     dim3 grid(p.n_chunks), block(kK1Threads);
 #define EVOFST_K1(CT, M) hipLaunchKernelGGL((k1_count_kernel<CT, M>), grid, block, lds, st, p)
     if (count_bytes == 2) {
