@@ -29,61 +29,84 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // K1: allele counting.  Replaces the per-sample loops of getVariantCountsForFst
 // (process_vcf_fst.cpp:243-280) and getBasicCounts (process_vcf_utils.cpp:62-83).
 // =====================================================================================
+//
+// One wave per chunk (a block = 4 consecutive chunks sharing the layout tables in LDS), lane = site.
+// A tile is W rows of 64 x 16 bytes {ALT word, MISSING word}; the wave reads them in batches of 8 rows
+// (8 KiB per batch) and requests the next batch -- of this tile or of the chunk's next tile -- before it
+// counts the current one, so a wave always has 8-16 KiB in flight and never waits for a load it has
+// only just issued.  Counting walks the (word, population) segments of the layout with wave-uniform masks.
 template <typename CT, int MODE>
 __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     constexpr int NW = kK1Threads / 64;
+    constexpr int NB = 8;   // rows per batch
     // LDS: per wave [P] zero-masks + [P] fixed-masks, then per wave [n_pairs] census counters
     uint64_t *zm = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * p.P;
     uint64_t *fm = zm + p.P;
     uint32_t *cen_all = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem) + (size_t)NW * 2 * p.P);
-    uint32_t *cen = cen_all + (size_t)wave * p.n_pairs;
-    // block-wide copies of the layout tables: the counting loop must not queue vector loads behind the tile loads
     const int npq = MODE == MODE_PAIRS ? p.n_pairs : 0;
+    uint32_t *cen = cen_all + (size_t)wave * npq;
+    // block-wide copies of the layout tables: the counting loop must not queue vector loads behind the tile loads
     uint32_t *lpairs = cen_all + (size_t)NW * npq;                                   // [n_pairs]
     int32_t *lwss = reinterpret_cast<int32_t *>(lpairs + npq);                        // [W+1]
     SegDesc *lsegs = reinterpret_cast<SegDesc *>(smem + (((reinterpret_cast<unsigned char *>(lwss + p.W + 1) - smem) + 15) & ~(size_t)15));
+
+    const int chunk = blockIdx.x * NW + wave;
+    const bool have = chunk < p.n_chunks;
+    const int t0 = min(chunk, p.n_chunks - 1) * p.chunk_tiles;
+    const int t1 = have ? min(t0 + p.chunk_tiles, p.n_tiles) : t0;
+    const int nb = (p.W + NB - 1) / NB;                 // batches per tile
+    const int n_items = (t1 - t0) * nb;
+    ulonglong2 cur[NB], nxt[NB];
+    auto load_item = [&](ulonglong2 (&r)[NB], int item) {
+        const int t = t0 + item / nb, wb = (item - (item / nb) * nb) * NB;
+        const ulonglong2 *tp = p.tiles + (size_t)t * p.W * kTileSites + lane;
+#pragma unroll
+        for (int u = 0; u < NB; ++u)   // unconditional (clamped) so that all loads of a batch are in flight together
+            r[u] = tp[(size_t)min(wb + u, p.W - 1) * kTileSites];
+    };
+    if (n_items > 0) load_item(cur, 0);                 // first batch goes out before the tables are staged
+
     for (int i = threadIdx.x; i < npq; i += kK1Threads) lpairs[i] = p.pairs[i];
     for (int i = threadIdx.x; i <= p.W; i += kK1Threads) lwss[i] = p.word_seg_start[i];
     for (int i = threadIdx.x; i < p.n_segs; i += kK1Threads) lsegs[i] = p.segs[i];
     if (MODE == MODE_PAIRS)
         for (int q = lane; q < p.n_pairs; q += 64) cen[q] = 0;
-    __syncthreads();
     uint32_t used_cnt = 0, kept_cnt = 0;
+    __syncthreads();
 
-    const int chunk = blockIdx.x;
-    const int t0 = chunk * p.chunk_tiles;
-    const int t1 = min(t0 + p.chunk_tiles, p.n_tiles);
-    for (int t = t0 + wave; t < t1; t += NW) {
+    // per-tile state
+    uint32_t c = 0, mc = 0;
+    uint32_t Tc = 0, Tn = 0, c0 = 0, nm0 = 0;
+    bool irregular = false, skip = false;
+    uint64_t skipmask = 0;
+    for (int item = 0; item < n_items; ++item) {
+        const int ti = item / nb, bi = item - ti * nb;
+        const int t = t0 + ti, wb = bi * NB;
         const int64_t site = (int64_t)t * kTileSites + lane;
-        bool skip = site >= p.n_sites;
-        if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
-        const uint64_t skipmask = __ballot(skip);
-        const ulonglong2 *tp = p.tiles + (size_t)t * p.W * kTileSites + lane;
+        if (item + 1 < n_items) load_item(nxt, item + 1);
+        if (bi == 0) {
+            skip = site >= p.n_sites;
+            if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
+            skipmask = __ballot(skip);
+            c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false;
+        }
         CT *cp = reinterpret_cast<CT *>(p.counts) + (size_t)t * p.P * kTileSites + lane;
-        uint32_t c = 0, mc = 0;
-        uint32_t Tc = 0, Tn = 0, c0 = 0, nm0 = 0;
-        bool irregular = false;
-        for (int wb = 0; wb < p.W; wb += 8) {
-            ulonglong2 r[8];
+        if (p.debug & 1) {   // profiling experiments only: loads without the counting loop
 #pragma unroll
-            for (int u = 0; u < 8; ++u)   // unconditional (clamped) so that all 8 loads are in flight together
-                r[u] = tp[(size_t)min(wb + u, p.W - 1) * kTileSites];
-            if (p.debug & 1) {   // profiling experiments only: loads without the counting loop
+            for (int u = 0; u < NB; ++u) { c += (uint32_t)cur[u].x; mc += (uint32_t)cur[u].y; }
+            if (bi == nb - 1) cp[0] = (CT)(c + mc);
+        } else {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { c += (uint32_t)r[u].x; mc += (uint32_t)r[u].y; }
-                continue;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 if (wb + u < p.W) {
                     const int s0 = lwss[wb + u], s1 = lwss[wb + u + 1];
                     for (int s = s0; s < s1; ++s) {
                         const SegDesc d = lsegs[s];
-                        c += __popcll(r[u].x & d.mask);
-                        mc += __popcll(r[u].y & d.mask);
+                        c += __popcll(cur[u].x & d.mask);
+                        mc += __popcll(cur[u].y & d.mask);
                         if (d.flags & kSegLast) {
                             const uint32_t nfull = d.flags >> kSegNFullShift;
                             const uint32_t nm = nfull - mc;
@@ -106,53 +129,47 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                 }
             }
         }
-        if (p.debug & 1) cp[0] = (CT)(c + mc);
-        if (MODE == MODE_PAIRS && !(p.debug & 4)) {
-            const uint64_t im = __ballot(irregular && !skip);
-            if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
-            // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
-            // (i,j) iff both counts are 0 or both pops are fixed for ALT (or the site is skipped).
-            __builtin_amdgcn_wave_barrier();
-            for (int i = lane; i < 2 * p.P; i += 64) p.zf_masks[(size_t)t * 2 * p.P + i] = zm[i];   // [tile][z|f][P]: zm, fm are adjacent
-            for (int q = lane; q < p.n_pairs; q += 64) {
-                const uint32_t ij = lpairs[q];
-                const uint32_t i = ij & 0xffffu, j = ij >> 16;
-                const uint64_t ex = (zm[i] & zm[j]) | (fm[i] & fm[j]);
-                cen[q] += 64u - (uint32_t)__popcll(ex);
+        if (bi == nb - 1) {   // the tile is complete
+            if (MODE == MODE_PAIRS && !(p.debug & 4)) {
+                const uint64_t im = __ballot(irregular && !skip);
+                if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
+                // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
+                // (i,j) iff both counts are 0 or both pops are fixed for ALT (or the site is skipped).
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < 2 * p.P; i += 64) p.zf_masks[(size_t)t * 2 * p.P + i] = zm[i];   // [tile][z|f][P]: zm, fm are adjacent
+                for (int q = lane; q < p.n_pairs; q += 64) {
+                    const uint32_t ij = lpairs[q];
+                    const uint32_t i = ij & 0xffffu, j = ij >> 16;
+                    const uint64_t ex = (zm[i] & zm[j]) | (fm[i] & fm[j]);
+                    cen[q] += 64u - (uint32_t)__popcll(ex);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
+            if (MODE == MODE_GLOBAL) {
+                // evo_FstAgainstAll.cpp:198-203 on populationsToUse[0], in exact integer form:
+                // AAF == 0 <=> nm > 0 && c == 0 ; AAF == 1 <=> nm > 0 && c == nm (0/0 is NaN, -1 if own nm == 0)
+                const uint32_t cc = Tc - c0, cn = Tn - nm0;
+                const bool both0 = (nm0 > 0 && c0 == 0) && (cn > 0 && cc == 0);
+                const bool both1 = (nm0 > 0 && c0 == nm0) && (cn > 0 && cc == cn);
+                const bool kept = !skip && !both0 && !both1;
+                const uint64_t km = __ballot(kept);
+                p.totals[site] = make_uint2(Tc, Tn);
+                if (lane == 0) { p.kept_mask[t] = km; p.skip_mask[t] = skipmask; }
+                used_cnt += 64u - (uint32_t)__popcll(skipmask);
+                kept_cnt += (uint32_t)__popcll(km);
+            }
         }
-        if (MODE == MODE_GLOBAL) {
-            // evo_FstAgainstAll.cpp:198-203 on populationsToUse[0], in exact integer form:
-            // AAF == 0 <=> nm > 0 && c == 0 ; AAF == 1 <=> nm > 0 && c == nm (0/0 is NaN, -1 if own nm == 0)
-            const uint32_t cc = Tc - c0, cn = Tn - nm0;
-            const bool both0 = (nm0 > 0 && c0 == 0) && (cn > 0 && cc == 0);
-            const bool both1 = (nm0 > 0 && c0 == nm0) && (cn > 0 && cc == cn);
-            const bool kept = !skip && !both0 && !both1;
-            const uint64_t km = __ballot(kept);
-            p.totals[site] = make_uint2(Tc, Tn);
-            if (lane == 0) { p.kept_mask[t] = km; p.skip_mask[t] = skipmask; }
-            used_cnt += 64u - (uint32_t)__popcll(skipmask);
-            kept_cnt += (uint32_t)__popcll(km);
-        }
-    }
-    if (MODE == MODE_PAIRS) {
-        __syncthreads();
-        for (int q = threadIdx.x; q < p.n_pairs; q += kK1Threads) {
-            uint32_t s = 0;
+        if (item + 1 < n_items) {
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += cen_all[(size_t)w * p.n_pairs + q];
-            p.chunk_census[(size_t)q * p.n_chunks + chunk] = s;
+            for (int u = 0; u < NB; ++u) cur[u] = nxt[u];
         }
     }
-    if (MODE == MODE_GLOBAL) {
-        uint32_t *red = reinterpret_cast<uint32_t *>(smem);
-        if (lane == 0) { red[wave * 2] = used_cnt; red[wave * 2 + 1] = kept_cnt; }
-        __syncthreads();
-        if (threadIdx.x < 2) {
-            uint32_t s = 0;
-            for (int w = 0; w < NW; ++w) s += red[w * 2 + threadIdx.x];
-            p.chunk_used_kept[(size_t)threadIdx.x * p.n_chunks + chunk] = s;
+    if (have) {
+        if (MODE == MODE_PAIRS)
+            for (int q = lane; q < p.n_pairs; q += 64) p.chunk_census[(size_t)q * p.n_chunks + chunk] = cen[q];
+        if (MODE == MODE_GLOBAL && lane == 0) {
+            p.chunk_used_kept[chunk] = used_cnt;
+            p.chunk_used_kept[(size_t)p.n_chunks + chunk] = kept_cnt;
         }
     }
 }
@@ -163,7 +180,7 @@ hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t s
     const size_t npq = mode == MODE_PAIRS ? p.n_pairs : 0;
     size_t lds = (size_t)NW * 2 * p.P * 8 + (NW + 1) * npq * 4 + (size_t)(p.W + 1) * 4 + 16 + (size_t)p.n_segs * sizeof(SegDesc) + 64;
     if (lds > 64 * 1024) return hipErrorInvalidValue;   // layouts with > ~3000 words / segments: not expected (N <= 100k samples)
-    dim3 grid(p.n_chunks), block(kK1Threads);
+    dim3 grid((p.n_chunks + NW - 1) / NW), block(kK1Threads);
 #define EVOFST_K1(CT, M) hipLaunchKernelGGL((k1_count_kernel<CT, M>), grid, block, lds, st, p)
     if (count_bytes == 2) {
         if (mode == MODE_COUNTS) EVOFST_K1(uint16_t, MODE_COUNTS);
