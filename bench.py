@@ -176,8 +176,20 @@ def main():
     dom = 0 if kavg[0] >= kavg[2] else 2
     dom_bytes = k1_bytes if dom == 0 else k2_bytes
     achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9 if kavg[dom] > 0 else 0.0
+    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 +
+    # WRITE_SIZE; profiles/README.md says how they were collected) -- null for a configuration not profiled
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tr = json.load(f).get(args.config, {}).get(names[dom])
+        if tr:
+            traffic = tr["hbm_read_bytes"] + tr["hbm_write_bytes"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    pipeline_bytes = S * (N / 2.0 + 4.0)      # packed genotypes + position per site
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "pipeline_GBps": pipeline_bytes * world / (dt / args.steps) / 1e9,
                 "kernels_ms": {names[k]: float(kavg[k]) for k in range(4)},
                 "k1_GBps": k1_bytes / (kavg[0] * 1e-3) / 1e9 if kavg[0] > 0 else 0.0,
                 "algorithmic_bytes": dom_bytes}
