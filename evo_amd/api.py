@@ -56,6 +56,10 @@ SIGNATURES = {
     "evofst_download_tiles": (C.c_int, [_vp, _vp]),
     "evofst_set_pairs": (C.c_int, [_vp, _i32p, _i32p, C.c_int]),
     "evofst_set_against_all": (C.c_int, [_vp, _i32p, C.c_int, _i64p]),
+    "evofst_set_gram": (C.c_int, [_vp]),
+    "evofst_set_site_windows": (C.c_int, [_vp, _i64p, C.c_int64]),
+    "evofst_run_gram": (C.c_int, [_vp, C.c_int64, C.c_int64]),
+    "evofst_get_gram": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "evofst_set_windows": (C.c_int, [_vp, C.c_int, C.c_int]),
     "evofst_set_base_offsets": (C.c_int, [_vp, _i64p]),
     "evofst_run_counts": (C.c_int, [_vp]),
@@ -229,6 +233,32 @@ class EvoFst:
         self._chk(self.L.evofst_set_against_all(self.h, _ptr(up, _i32p), len(up), _ptr(ss, _i64p)))
         self.n_use = len(up)
         self.n_pairs = 0
+
+    def set_gram(self):
+        """All pairs i<j through the Gram path (windows = site ranges, see set_site_windows)."""
+        self._chk(self.L.evofst_set_gram(self.h))
+        P = self.geometry().n_pops
+        self.n_pairs = P * (P - 1) // 2
+        self.n_use = 0
+
+    def set_site_windows(self, win_start):
+        ws = np.ascontiguousarray(win_start, np.int64)
+        self._chk(self.L.evofst_set_site_windows(self.h, _ptr(ws, _i64p), len(ws) - 1))
+        self.n_site_windows = len(ws) - 1
+
+    def run_gram(self, first_window=0, n_windows=None):
+        if n_windows is None:
+            n_windows = self.n_site_windows - first_window
+        self._chk(self.L.evofst_run_gram(self.h, first_window, n_windows))
+        self._gram_n = n_windows
+
+    def gram(self):
+        """dict of [n_windows][n_pairs] arrays of the last run_gram: sum_num, sum_den, sum_dxy_k, n_included."""
+        shape = (self._gram_n, self.n_pairs)
+        out = {k: np.empty(shape, np.float64) for k in ("sum_num", "sum_den", "sum_dxy_k", "n_included")}
+        self._chk(self.L.evofst_get_gram(self.h, _ptr(out["sum_num"], _dp), _ptr(out["sum_den"], _dp),
+                                         _ptr(out["sum_dxy_k"], _dp), _ptr(out["n_included"], _dp)))
+        return out
 
     def set_windows(self, size, step):
         self._chk(self.L.evofst_set_windows(self.h, size, step))

@@ -66,9 +66,12 @@ struct evofst_ctx {
 
     // pairs-mode work buffers
     DevBuf d_census, d_offsets, d_incl_totals, d_seg_num, d_seg_den, d_seg_k, d_seg_end, d_zf, d_irr,
-        d_tail, d_tail_n, d_carry,
+        d_tail, d_tail_n, d_carry, d_win, d_gU, d_gC, d_gnum, d_gden, d_gk, d_gcnt,
         d_nrows, d_totals;
     int64_t seg_cap = 0;
+    std::vector<int64_t> win_start;   // Gram mode: site windows
+    int64_t gram_windows = 0;         // windows of the last run_gram
+    int gram_missing = -1;            // -1 unknown, else whether any site needs the missing-allele correction
     // against-all work buffers
     DevBuf d_gtotals, d_kept, d_skip, d_used_kept, d_uk_off, d_uk_tot, d_chunk_rows, d_row_off, d_row_tot, d_row_start,
         d_row_end, d_row_num, d_row_den;
@@ -292,7 +295,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
     DevBuf *bufs[] = {&c->d_segs, &c->d_wss, &c->d_nfull, &c->d_pairs, &c->d_use, &c->d_thr, &c->d_base, &c->d_first_seg,
                       &c->d_tiles, &c->d_flags, &c->d_pos, &c->d_counts, &c->d_census, &c->d_offsets, &c->d_incl_totals,
                       &c->d_seg_num, &c->d_seg_den, &c->d_seg_k, &c->d_seg_end, &c->d_zf, &c->d_irr,
-                      &c->d_tail, &c->d_tail_n, &c->d_carry,
+                      &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_gU, &c->d_gC, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_carry,
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den};
@@ -689,6 +692,30 @@ extern "C" int evofst_set_against_all(evofst_ctx *c, const int32_t *use_pops, in
     return set_base_internal(c, nullptr);
 }
 
+extern "C" int evofst_set_gram(evofst_ctx *c) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_pops < 2) return fail(c, EVOFST_ERR_STATE, "set_gram: set_layout with at least two populations first");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->mode = MODE_GRAM;
+    c->pairs.clear();
+    int rc;
+    if ((rc = upload_layout(c))) return rc;
+    c->counts_done = c->stats_done = false;
+    c->gram_missing = -1;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_set_site_windows(evofst_ctx *c, const int64_t *win_start, int64_t n_windows) {
+    if (!c || !win_start || n_windows <= 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (win_start[w] < 0 || win_start[w + 1] < win_start[w]) return fail(c, EVOFST_ERR_ARG, "set_site_windows: starts must be non-negative and non-decreasing");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->win_start.assign(win_start, win_start + n_windows + 1);
+    return upload_vec(c, c->d_win, c->win_start);
+}
+
 extern "C" int evofst_set_windows(evofst_ctx *c, int snp_size, int snp_step) {
     if (!c) return EVOFST_ERR_ARG;
     if (snp_size < 0 || (snp_size > 0 && snp_step <= 0)) return fail(c, EVOFST_ERR_ARG, "set_windows: bad size/step");
@@ -732,6 +759,12 @@ extern "C" int evofst_run_counts(evofst_ctx *c) {
         if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
         if ((rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8))) return rc;
         p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
+    } else if (c->mode == MODE_GRAM) {
+        if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 32))) return rc;
+        if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
+        if ((rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8))) return rc;
+        p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
+        c->gram_missing = -1;
     } else if (c->mode == MODE_GLOBAL) {
         if ((rc = ensure(c, c->d_gtotals, (size_t)c->n_tiles * kTileSites * 8))) return rc;
         if ((rc = ensure(c, c->d_kept, (size_t)c->n_tiles * 8))) return rc;
@@ -744,7 +777,7 @@ extern "C" int evofst_run_counts(evofst_ctx *c) {
     HIPCHK(c, launch_k1(p, c->count_bytes, c->mode, c->stream));
     record(c, 0, 1);
     c->counts_done = true; c->stats_done = false;
-    if (c->mode != MODE_COUNTS && (rc = run_scan(c))) return rc;
+    if (c->mode != MODE_COUNTS && c->mode != MODE_GRAM && (rc = run_scan(c))) return rc;
     return EVOFST_OK;
 }
 
@@ -753,6 +786,7 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
     NEED_GPU(c);
     if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "run_stats: run_counts first");
     if (c->mode == MODE_COUNTS) return fail(c, EVOFST_ERR_STATE, "run_stats: choose a mode (set_pairs / set_against_all)");
+    if (c->mode == MODE_GRAM) return fail(c, EVOFST_ERR_STATE, "run_stats: Gram mode computes through evofst_run_gram");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if (c->offsets_dirty && (rc = run_scan(c))) return rc;
@@ -807,6 +841,61 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
         record(c, 2, 1);
     }
     c->stats_done = true;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_windows) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->mode != MODE_GRAM || !c->counts_done) return fail(c, EVOFST_ERR_STATE, "run_gram: set_gram + run_counts first");
+    const int64_t nw_total = (int64_t)c->win_start.size() - 1;
+    if (nw_total <= 0) return fail(c, EVOFST_ERR_STATE, "run_gram: set_site_windows first");
+    if (first_window < 0 || n_windows <= 0 || first_window + n_windows > nw_total || n_windows > 0x7fffffff)
+        return fail(c, EVOFST_ERR_ARG, "run_gram: window range out of bounds");
+    if (c->win_start.back() > c->n_sites) return fail(c, EVOFST_ERR_ARG, "run_gram: windows reach beyond the loaded sites");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if (c->gram_missing < 0) {
+        // does any site need the missing-allele terms?  (K1 flagged them; one small copy per run_counts)
+        std::vector<uint64_t> irr((size_t)c->n_tiles);
+        HIPCHK(c, hipMemcpyAsync(irr.data(), c->d_irr.p, irr.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->gram_missing = 0;
+        for (uint64_t m : irr) if (m) { c->gram_missing = 1; break; }
+    }
+    const int64_t P = c->n_pops, np = P * (P - 1) / 2;
+    if ((rc = ensure(c, c->d_gU, (size_t)n_windows * P * 8))) return rc;
+    if ((rc = ensure(c, c->d_gC, (size_t)n_windows * P * 8))) return rc;
+    const size_t out_bytes = (size_t)n_windows * np * 8;
+    if ((rc = ensure(c, c->d_gnum, out_bytes)) || (rc = ensure(c, c->d_gden, out_bytes)) ||
+        (rc = ensure(c, c->d_gk, out_bytes)) || (rc = ensure(c, c->d_gcnt, out_bytes))) return rc;
+    GramParams p{};
+    p.counts = c->d_counts.p; p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.P = c->n_pops;
+    p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
+    p.n_full = (const int32_t *)c->d_nfull.p;
+    p.masks = (const uint64_t *)c->d_zf.p; p.skip_mask = (const uint64_t *)c->d_skip.p;
+    p.win_start = (const int64_t *)c->d_win.p;
+    p.first_window = first_window; p.n_windows = (int32_t)n_windows;
+    p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p;
+    p.n_pairs = np;
+    p.out_num = (double *)c->d_gnum.p; p.out_den = (double *)c->d_gden.p; p.out_k = (double *)c->d_gk.p; p.out_cnt = (double *)c->d_gcnt.p;
+    record(c, 2, 0);
+    HIPCHK(c, launch_gram(p, c->count_bytes, c->gram_missing != 0, c->stream));
+    record(c, 2, 1);
+    c->gram_windows = n_windows;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_gram(evofst_ctx *c, double *sum_num, double *sum_den, double *sum_dxy_k, double *n_included) {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->mode != MODE_GRAM || c->gram_windows <= 0) return fail(c, EVOFST_ERR_STATE, "get_gram: run_gram first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->gram_windows * ((size_t)c->n_pops * (c->n_pops - 1) / 2);
+    int rc;
+    if ((rc = d2h(c, sum_num, c->d_gnum.p, n)) || (rc = d2h(c, sum_den, c->d_gden.p, n)) ||
+        (rc = d2h(c, sum_dxy_k, c->d_gk.p, n)) || (rc = d2h(c, n_included, c->d_gcnt.p, n))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return EVOFST_OK;
 }
 

@@ -28,7 +28,7 @@ constexpr uint32_t kXMask = (1u << kXBits) - 1u;
 constexpr uint32_t kXZero = 1u << 28;   // c == 0        (or site skipped)
 constexpr uint32_t kXFixed = 1u << 29;  // c == nm       (or site skipped)
 
-enum { MODE_COUNTS = 0, MODE_PAIRS = 1, MODE_GLOBAL = 2 };
+enum { MODE_COUNTS = 0, MODE_PAIRS = 1, MODE_GLOBAL = 2, MODE_GRAM = 3 };
 
 struct K1Params {
     const ulonglong2 *tiles;
@@ -123,6 +123,23 @@ struct GlobalParams {
     int64_t first_site, n_out_sites;
 };
 
+// K4: window sums for every pair through Gram matrices (windows whose membership does not depend on the pair)
+struct GramParams {
+    const void *counts;
+    int64_t n_sites;
+    int32_t n_tiles, P;
+    int32_t max_n;
+    const int32_t *n_full;
+    const uint64_t *masks;       // [n_tiles][4][P] from K1 (Gram mode): c == 0, c == nm, nm < 2, nm == 0
+    const uint64_t *skip_mask;   // [n_tiles]
+    const int64_t *win_start;    // [n_windows_total + 1] first site of every window (device)
+    int64_t first_window;        // this launch covers windows [first_window, first_window + n_windows)
+    int32_t n_windows;
+    double *U, *C;               // [n_windows][P] per-population sums of t + h and of c over the window
+    int64_t n_pairs;             // P (P - 1) / 2, pair (i < j) at i (2P - i - 1) / 2 + j - i - 1
+    double *out_num, *out_den, *out_k, *out_cnt;   // [n_windows][n_pairs]
+};
+
 struct SynthParams {
     ulonglong2 *tiles;
     int32_t *pos;
@@ -151,6 +168,7 @@ hipError_t launch_global_rows(const uint64_t *kept_mask, const uint64_t *skip_ma
 hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st);
 hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
+hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st);
 size_t k2_lds_bytes(int P, int max_n);
 size_t global_lds_bytes(int tn_max, int n_use, int size);
 

@@ -42,10 +42,11 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     const int wave = threadIdx.x >> 6;
     constexpr int NW = kK1Threads / 64;
     constexpr int NB = 8;   // rows per batch
-    // LDS: per wave [P] zero-masks + [P] fixed-masks, then per wave [n_pairs] census counters
-    uint64_t *zm = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * p.P;
+    // LDS: per wave [P] zero-masks, [P] fixed-masks (+ [P] nm < 2, [P] nm == 0 in Gram mode), then per wave
+    // [n_pairs] census counters
+    uint64_t *zm = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 4 * p.P;
     uint64_t *fm = zm + p.P;
-    uint32_t *cen_all = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem) + (size_t)NW * 2 * p.P);
+    uint32_t *cen_all = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem) + (size_t)NW * 4 * p.P);
     const int npq = MODE == MODE_PAIRS ? p.n_pairs : 0;
     uint32_t *cen = cen_all + (size_t)wave * npq;
     // block-wide copies of the layout tables: the counting loop must not queue vector loads behind the tile loads
@@ -111,7 +112,11 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                             const uint32_t nfull = d.flags >> kSegNFullShift;
                             const uint32_t nm = nfull - mc;
                             if (!(p.debug & 2)) cp[(size_t)d.pop * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
-                            if (MODE == MODE_PAIRS) {
+                            if (MODE == MODE_GRAM) {
+                                const uint64_t b1 = __ballot(nm < 2) & ~skipmask, b0 = __ballot(nm == 0) & ~skipmask;
+                                if (lane == 0) { zm[2 * p.P + d.pop] = b1; zm[3 * p.P + d.pop] = b0; }
+                            }
+                            if (MODE == MODE_PAIRS || MODE == MODE_GRAM) {
                                 const uint64_t z = __ballot(c == 0) | skipmask;
                                 const uint64_t f = __ballot(c == nm) | skipmask;
                                 if (lane == 0) { zm[d.pop] = z; fm[d.pop] = f; }
@@ -130,6 +135,13 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             }
         }
         if (bi == nb - 1) {   // the tile is complete
+            if (MODE == MODE_GRAM) {
+                const uint64_t im = __ballot(irregular && !skip);
+                if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < 4 * p.P; i += 64) p.zf_masks[(size_t)t * 4 * p.P + i] = zm[i];   // [tile][z|f|b1|b0][P]
+                __builtin_amdgcn_wave_barrier();
+            }
             if (MODE == MODE_PAIRS && !(p.debug & 4)) {
                 const uint64_t im = __ballot(irregular && !skip);
                 if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
@@ -178,17 +190,19 @@ hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t s
     if (p.n_chunks <= 0) return hipSuccess;
     constexpr int NW = kK1Threads / 64;
     const size_t npq = mode == MODE_PAIRS ? p.n_pairs : 0;
-    size_t lds = (size_t)NW * 2 * p.P * 8 + (NW + 1) * npq * 4 + (size_t)(p.W + 1) * 4 + 16 + (size_t)p.n_segs * sizeof(SegDesc) + 64;
+    size_t lds = (size_t)NW * 4 * p.P * 8 + (NW + 1) * npq * 4 + (size_t)(p.W + 1) * 4 + 16 + (size_t)p.n_segs * sizeof(SegDesc) + 64;
     if (lds > 64 * 1024) return hipErrorInvalidValue;   // layouts with > ~3000 words / segments: not expected (N <= 100k samples)
     dim3 grid((p.n_chunks + NW - 1) / NW), block(kK1Threads);
 #define EVOFST_K1(CT, M) hipLaunchKernelGGL((k1_count_kernel<CT, M>), grid, block, lds, st, p)
     if (count_bytes == 2) {
         if (mode == MODE_COUNTS) EVOFST_K1(uint16_t, MODE_COUNTS);
         else if (mode == MODE_PAIRS) EVOFST_K1(uint16_t, MODE_PAIRS);
+        else if (mode == MODE_GRAM) EVOFST_K1(uint16_t, MODE_GRAM);
         else EVOFST_K1(uint16_t, MODE_GLOBAL);
     } else {
         if (mode == MODE_COUNTS) EVOFST_K1(uint32_t, MODE_COUNTS);
         else if (mode == MODE_PAIRS) EVOFST_K1(uint32_t, MODE_PAIRS);
+        else if (mode == MODE_GRAM) EVOFST_K1(uint32_t, MODE_GRAM);
         else EVOFST_K1(uint32_t, MODE_GLOBAL);
     }
 #undef EVOFST_K1
@@ -708,6 +722,209 @@ hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *total
     if (p.n_pairs <= 0) return hipSuccess;
     dim3 block(64), grid((p.n_pairs + 63) / 64);
     hipLaunchKernelGGL(totals_kernel, grid, block, 0, st, p, n_rows, totals, carry);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// K4: Gram path.  For windows whose membership does not depend on the pair (bp windows, fixed
+// site blocks) the window sums of every pair follow from a few P x P contractions over the
+// window's sites, done on the FP64 matrix cores (v_mfma_f64_16x16x4_f64):
+//     sum den_ij = sum_s p_i q_j + q_i p_j                 (q = 1 - p; process_vcf_fst.h:27-30, term by term)
+//     sum num_ij = sum den_ij - U_i - U_j,   U = sum_s t + h   (num = den - t_i - t_j - h_i - h_j)
+//     sum k_ij   = n_j C_i + n_i C_j - 2 sum_s c_i c_j - sum_s [F_i F_j] (nm_i m_j + m_i nm_j)
+// with C = sum_s c, m = n - nm the missing alleles and F = [c == nm].  A site the filter
+// (process_vcf_fst.cpp:543-544) excludes contributes exactly 0 to all of them: p_i = p_j in {0, 1}
+// there (populations without a called allele get p = q = 0), and the last term removes the dxy part
+// of sites where both populations are fixed but have missing alleles.  The number of included sites
+// and the windows the reference would poison with NaN (an included site with nm < 2 resp. nm == 0)
+// come from K1's bit masks.
+//
+// A block of 4 waves owns a 64 x 64 block of pairs (only blocks on or above the diagonal), a wave a
+// 32 x 32 sub-block = 2 x 2 MFMA tiles.  Lane l holds population (l & 15) of a tile and the 8 sites
+// 8 (l >> 4) .. + 7 of every 32-site step -- the MFMA's k index is only a summation index, so each lane
+// can take 8 consecutive sites = one 16-byte vector of packed counts.
+// =====================================================================================
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <typename CT>
+__global__ __launch_bounds__(256) void gram_popsums_kernel(GramParams p) {
+    const int w = blockIdx.x;
+    const int k = blockIdx.y * blockDim.x + threadIdx.x;
+    if (k >= p.P) return;
+    const int64_t a = p.win_start[p.first_window + w], b = min(p.win_start[p.first_window + w + 1], p.n_sites);
+    double U = 0.0, C = 0.0;
+    const CT *cb = reinterpret_cast<const CT *>(p.counts);
+    for (int64_t s = a; s < b; ++s) {
+        const int t = (int)(s >> 6), o = (int)(s & 63);
+        if ((p.skip_mask[t] >> o) & 1ull) continue;
+        const uint32_t v = cb[((size_t)t * p.P + k) * kTileSites + o];
+        const uint32_t c = v & CountTraits<CT>::mask, nm = v >> CountTraits<CT>::shift;
+        const double pp = nm ? (double)c / (double)nm : 0.0;
+        const double tt = pp * (1.0 - pp);                     // exactly 0 at c == 0 and c == nm
+        const double hh = nm > 1 ? tt / (double)(nm - 1) : 0.0;
+        U += tt + hh;
+        C += (double)c;
+    }
+    p.U[(size_t)w * p.P + k] = U;
+    p.C[(size_t)w * p.P + k] = C;
+}
+
+template <typename CT, bool MISS>
+__global__ __launch_bounds__(256, 1) void gram_kernel(GramParams p) {
+    __shared__ double rcp[2048];
+    constexpr int EV = 8;                               // sites per lane and step
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    // block pair (bi <= bj) from the linear index
+    const int nblk = (p.P + 63) / 64;
+    int bi = 0, rem = blockIdx.y;
+    while (rem >= nblk - bi) { rem -= nblk - bi; ++bi; }
+    const int bj = bi + rem;
+    const int r0 = bi * 64 + (wave >> 1) * 32, c0 = bj * 64 + (wave & 1) * 32;
+    const bool use_rcp = p.max_n < 2048;
+    if (use_rcp)
+        for (int i = threadIdx.x; i <= p.max_n; i += blockDim.x) rcp[i] = i ? 1.0 / (double)i : 0.0;
+    __syncthreads();
+    if (r0 > c0 + 31 || r0 >= p.P || c0 >= p.P) return;    // below the diagonal or outside: nothing to do (after the barrier)
+    const int w = blockIdx.x;
+    const int64_t a = p.win_start[p.first_window + w], b = min(p.win_start[p.first_window + w + 1], p.n_sites);
+
+    int pop[4];                                          // row tile 0, 1, column tile 0, 1
+    pop[0] = r0 + r; pop[1] = r0 + 16 + r; pop[2] = c0 + r; pop[3] = c0 + 16 + r;
+    uint32_t nfull[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) nfull[x] = pop[x] < p.P ? (uint32_t)p.n_full[pop[x]] : 0u;
+
+    double4_t acc_den[2][2], acc_cc[2][2], acc_m[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc_den[i][j] = double4_t{0, 0, 0, 0}; acc_cc[i][j] = double4_t{0, 0, 0, 0}; acc_m[i][j] = double4_t{0, 0, 0, 0}; }
+
+    const CT *cb = reinterpret_cast<const CT *>(p.counts);
+    for (int64_t base = a & ~(int64_t)7; base < b; base += 4 * EV) {
+        const int64_t sv = base + (int64_t)kq * EV;      // this lane's 8 sites (inside one tile)
+        const int t = (int)min(sv >> 6, (int64_t)p.n_tiles - 1), o = (int)(sv & 63);
+        // sites of the vector that belong to the window and are not skipped
+        uint32_t valid = 0;
+        if (sv < b && sv + EV > a) {
+            const uint32_t lo = sv < a ? (uint32_t)(a - sv) : 0u, hi = sv + EV > b ? (uint32_t)(b - sv) : (uint32_t)EV;
+            valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+            valid &= ~(uint32_t)(p.skip_mask[t] >> o);
+        }
+        uint32_t cnt[4][EV];                             // packed counts of the 4 populations
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int pk = min(pop[x], p.P - 1);
+            const CT *src = cb + ((size_t)t * p.P + pk) * kTileSites + o;
+            if (sizeof(CT) == 2) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src);
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < EV; ++e) cnt[x][e] = (wv[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            } else {
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(src), v1 = *reinterpret_cast<const uint4 *>(src + 4);
+                cnt[x][0] = v0.x; cnt[x][1] = v0.y; cnt[x][2] = v0.z; cnt[x][3] = v0.w;
+                cnt[x][4] = v1.x; cnt[x][5] = v1.y; cnt[x][6] = v1.z; cnt[x][7] = v1.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+            double P_[4], Q_[4], C_[4], FN[4], FM[4];
+            const bool ok = (valid >> e) & 1u;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                uint32_t c = cnt[x][e] & CountTraits<CT>::mask, nm = cnt[x][e] >> CountTraits<CT>::shift;
+                if (!ok || pop[x] >= p.P) { c = 0; nm = 0; }
+                const double dc = (double)c, dn = (double)nm;
+                double pp;
+                if (use_rcp) {
+                    const double rr = rcp[nm];
+                    const double q0 = dc * rr;
+                    pp = fma(fma(-q0, dn, dc), rr, q0);          // == c / nm (Markstein, exact on this domain); 0 when nm == 0
+                } else {
+                    pp = nm ? dc / dn : 0.0;
+                }
+                P_[x] = pp; Q_[x] = nm ? 1.0 - pp : 0.0; C_[x] = dc;
+                if (MISS) {
+                    const bool fixed = c == nm && nm > 0;
+                    FN[x] = fixed ? dn : 0.0;
+                    FM[x] = c == nm && ok && pop[x] < p.P ? (double)(nfull[x] - nm) : 0.0;   // nm == 0: all n alleles missing
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(P_[i], Q_[2 + j], acc_den[i][j], 0, 0, 0);
+                    acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(Q_[i], P_[2 + j], acc_den[i][j], 0, 0, 0);
+                    acc_cc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(C_[i], C_[2 + j], acc_cc[i][j], 0, 0, 0);
+                    if (MISS) {
+                        acc_m[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(FN[i], FM[2 + j], acc_m[i][j], 0, 0, 0);
+                        acc_m[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(FM[i], FN[2 + j], acc_m[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane & 15, row = (lane >> 4) + 4 v
+    const int tw0 = (int)(a >> 6), tw1 = b > a ? (int)((b - 1) >> 6) : tw0 - 1;
+    const double kNaN = __longlong_as_double(0x7ff8000000000000ll);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int pi = r0 + i * 16 + kq + 4 * v;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pj = c0 + j * 16 + r;
+                if (pi < pj && pj < p.P) {
+                    uint32_t cnt_in = 0;
+                    uint64_t pn = 0, pd = 0;
+                    for (int tw = tw0; tw <= tw1; ++tw) {
+                        const uint64_t *mk = p.masks + (size_t)tw * 4 * p.P;
+                        uint64_t wm = ~0ull;
+                        if (tw == tw0) wm &= ~0ull << (a & 63);
+                        if (tw == tw1 && (b & 63)) wm &= ~0ull >> (64 - (b & 63));
+                        const uint64_t incl = ~((mk[pi] & mk[pj]) | (mk[p.P + pi] & mk[p.P + pj])) & wm;
+                        cnt_in += (uint32_t)__popcll(incl);
+                        pn |= (mk[2 * p.P + pi] | mk[2 * p.P + pj]) & incl;
+                        pd |= (mk[3 * p.P + pi] | mk[3 * p.P + pj]) & incl;
+                    }
+                    const size_t wp = (size_t)w * p.P;
+                    const double den = acc_den[i][j][v];
+                    const double num = den - p.U[wp + pi] - p.U[wp + pj];
+                    double kk = (double)p.n_full[pj] * p.C[wp + pi] + (double)p.n_full[pi] * p.C[wp + pj] - 2.0 * acc_cc[i][j][v];
+                    if (MISS) kk -= acc_m[i][j][v];
+                    const size_t q = (size_t)pi * (2 * (size_t)p.P - pi - 1) / 2 + (size_t)(pj - pi - 1);
+                    const size_t o = (size_t)w * p.n_pairs + q;
+                    p.out_num[o] = pn ? kNaN : num;
+                    p.out_den[o] = pd ? kNaN : den;
+                    p.out_k[o] = kk;
+                    p.out_cnt[o] = (double)cnt_in;
+                }
+            }
+        }
+}
+
+hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st) {
+    if (p.n_windows <= 0 || p.P < 2) return hipSuccess;
+    {
+        dim3 grid(p.n_windows, (p.P + 255) / 256), block(256);
+        if (count_bytes == 2) hipLaunchKernelGGL((gram_popsums_kernel<uint16_t>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gram_popsums_kernel<uint32_t>), grid, block, 0, st, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const int nblk = (p.P + 63) / 64;
+    dim3 grid(p.n_windows, nblk * (nblk + 1) / 2), block(256);
+    if (count_bytes == 2) {
+        if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gram_kernel<uint16_t, false>), grid, block, 0, st, p);
+    } else {
+        if (has_missing) hipLaunchKernelGGL((gram_kernel<uint32_t, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gram_kernel<uint32_t, false>), grid, block, 0, st, p);
+    }
     return hipGetLastError();
 }
 

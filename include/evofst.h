@@ -139,6 +139,16 @@ int evofst_set_pairs(evofst_ctx *ctx, const int32_t *pair_i, const int32_t *pair
  * population indices, set_sizes[u] = the value the reference reads as c->setSizes[u]. */
 int evofst_set_against_all(evofst_ctx *ctx, const int32_t *use_pops, int n_use,
                            const int64_t *set_sizes);
+/* Gram path (all pairs i<j at once on the FP64 matrix cores) for windows whose membership does not
+ * depend on the pair: the physical windows of process_vcf_fst.cpp:589-629 (a site belongs to a bp window
+ * whatever the pair; the per-pair filter of :543-544 only zeroes its terms) and fixed site blocks.  Meant for
+ * many populations (hundreds), where a lane per pair no longer fits; results per window and pair are the same
+ * sums K2 gives per segment.  Use with evofst_set_site_windows + evofst_run_counts + evofst_run_gram. */
+int evofst_set_gram(evofst_ctx *ctx);
+/* Windows as site ranges [win_start[w], win_start[w+1]), w < n_windows: win_start has n_windows + 1
+ * non-decreasing entries in [0, n_sites].  (bp windows: the caller cuts by position, as the window loop of
+ * process_vcf_fst.cpp:589-629 does; empty windows are allowed.) */
+int evofst_set_site_windows(evofst_ctx *ctx, const int64_t *win_start, int64_t n_windows);
 /* SNP-count windows: -w SIZE,STEP of both programs (process_vcf_fst.cpp:638-650,
  * evo_FstAgainstAll.cpp:238, 276-280).  size == 0 disables windows (totals only). */
 int evofst_set_windows(evofst_ctx *ctx, int snp_size, int snp_step);
@@ -147,6 +157,15 @@ int evofst_set_windows(evofst_ctx *ctx, int snp_size, int snp_step);
 int evofst_set_base_offsets(evofst_ctx *ctx, const int64_t *offsets);
 
 /* ------------------------------------------------------------------ compute */
+
+/* Gram path: window sums of windows [first_window, first_window + n_windows) for all P (P-1) / 2 pairs
+ * (device buffers of n_windows * n_pairs * 32 bytes are kept until the next call). */
+int evofst_run_gram(evofst_ctx *ctx, int64_t first_window, int64_t n_windows);
+/* Results of the last evofst_run_gram, each [n_windows][n_pairs] (pairs i<j lexicographic): sums of the Fst
+ * numerators and denominators (process_vcf_fst.h:19-30) and of sumKij (process_vcf_fst.cpp:299-321) over the
+ * window's included sites, and the number of included sites (process_vcf_fst.cpp:543-544).  NaN where the
+ * reference's sum is NaN.  Any pointer may be NULL. */
+int evofst_get_gram(evofst_ctx *ctx, double *sum_num, double *sum_den, double *sum_dxy_k, double *n_included);
 
 /* Stage K1: per-population allele counts (getVariantCountsForFst counting loops,
  * process_vcf_fst.cpp:243-280 / getBasicCounts, process_vcf_utils.cpp:62-83) + the per-chunk

@@ -1,0 +1,88 @@
+"""GPU parity of the Gram path (FP64 MFMA, all pairs at once over pair-independent windows) against the CPU
+oracle: per window and pair, the sums over the window's included sites of the reference's per-site numerator,
+denominator and dxy numerator (process_vcf_fst.h:19-30, process_vcf_fst.cpp:299-321, filter :543-544).
+
+Bars: included-site counts and dxy sums (integers) exact; num / den within 1e-12 of the window's sum of
+|terms| (for num: of the numerator's and the denominator's terms, since num is formed as den - t - h); NaN
+exactly where the reference's sum is NaN.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import random_codes, round_robin_pops, n_full_of
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_windows(onum, oden, odxy_k, oinc, ws):
+    nw, nq = len(ws) - 1, onum.shape[1]
+    out = {k: np.zeros((nw, nq)) for k in ("num", "den", "k", "cnt", "absnum", "absden")}
+    for w in range(nw):
+        a, b = ws[w], ws[w + 1]
+        m = oinc[a:b] == 1
+        with np.errstate(all="ignore"):
+            out["num"][w] = np.where(m, onum[a:b], 0.0).sum(axis=0)
+            out["den"][w] = np.where(m, oden[a:b], 0.0).sum(axis=0)
+            out["absnum"][w] = np.where(m & np.isfinite(onum[a:b]), np.abs(onum[a:b]), 0.0).sum(axis=0)
+            out["absden"][w] = np.where(m & np.isfinite(oden[a:b]), np.abs(oden[a:b]), 0.0).sum(axis=0)
+        out["k"][w] = np.where(m, odxy_k[a:b], 0.0).sum(axis=0)
+        out["cnt"][w] = m.sum(axis=0)
+    return out
+
+
+@pytest.mark.parametrize("S,N,P,miss,flags,edge,seed", [(1500, 48, 12, 0.0, False, False, 1), (2000, 100, 20, 0.15, True, True, 2),
+                                                        (900, 150, 75, 0.1, False, True, 3), (700, 66, 33, 0.3, True, True, 4),
+                                                        (1300, 520, 130, 0.0, False, False, 5), (640, 40, 2, 0.2, False, True, 6)])
+def test_gram_windows(engine, S, N, P, miss, flags, edge, seed):
+    rng = np.random.default_rng(seed)
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=miss, edge=edge)
+    engine.set_layout(sp, P)
+    fl = (rng.random(S) < 0.05).astype(np.uint8) if flags else None
+    engine.upload(engine.pack_codes(codes), S, site_flags=fl)
+    engine.set_gram()
+    # ragged windows incl. empty ones, not aligned to anything; the last one ends at S
+    cuts = np.sort(rng.integers(0, S, size=S // 90))
+    ws = np.concatenate([[0], cuts, [cuts[-1]], [S]]).astype(np.int64)
+    engine.set_site_windows(ws)
+    engine.run_counts()
+    engine.run_gram()
+    g = engine.gram()
+
+    nf = n_full_of(sp, P)
+    pi, pj = np.triu_indices(P, 1)
+    pi = pi.astype(np.int32); pj = pj.astype(np.int32)
+    oalt, onm = O.counts_from_codes(codes, sp, P)
+    onum, oden, odxy, oinc = O.pair_site_stats(oalt, onm, nf, pi, pj, fl)
+    # the oracle returns dxy = k / (n_i n_j); k itself is an integer
+    odxy_k = np.rint(odxy * (nf[pi] * nf[pj])[None, :].astype(np.float64))
+    ow = _oracle_windows(onum, oden, odxy_k, oinc, ws)
+
+    assert np.array_equal(g["n_included"], ow["cnt"])
+    assert np.array_equal(g["sum_dxy_k"], ow["k"])
+    for name, ref, scale in (("sum_den", ow["den"], ow["absden"]), ("sum_num", ow["num"], ow["absnum"] + ow["absden"])):
+        a = g[name]
+        assert (np.isnan(a) == np.isnan(ref)).all(), name
+        fin = ~np.isnan(ref)
+        assert np.all(np.abs(a[fin] - ref[fin]) <= 1e-12 * np.maximum(scale[fin], 1e-300) + 1e-300), name
+
+
+def test_gram_window_batches(engine):
+    """run_gram over sub-ranges of the windows gives the same rows as one call."""
+    rng = np.random.default_rng(11)
+    S, N, P = 3000, 80, 16
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=0.05)
+    engine.set_layout(sp, P)
+    engine.upload(engine.pack_codes(codes), S)
+    engine.set_gram()
+    ws = np.arange(0, S + 1, 100, dtype=np.int64)
+    engine.set_site_windows(ws)
+    engine.run_counts()
+    engine.run_gram()
+    full = engine.gram()
+    engine.run_gram(7, 11)
+    part = engine.gram()
+    for k in full:
+        assert np.array_equal(full[k][7:18], part[k], equal_nan=True)
