@@ -32,8 +32,12 @@ CONFIGS = {
                   label="synthetic 2M-site shard x 1000 samples, 100 pops, Fst-against-all, windows 20,10"),
     "cfg4s": dict(sites=6_250_000, samples=2000, pops=20, mode="pairs", size=100, step=100, miss=0.0,
                   label="synthetic 6.25M-site shard (1/8 of 50M) x 2000 samples, 20 pops (190 pairs), windows 100,100"),
+    "cfg5s": dict(sites=2_500_000, samples=5000, pops=500, mode="gram", size=100, step=100, miss=0.15,
+                  label="synthetic 2.5M-site shard (1/8 of 20M) x 5000 samples, 500 pops (124,750 pairs), 15% missing, "
+                        "Gram path (FP64 MFMA) over fixed 100-site windows"),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0
+F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def cpu_baseline(e, cfg, sample_sites):
@@ -47,7 +51,15 @@ def cpu_baseline(e, cfg, sample_sites):
     nf = e.pop_chroms()
     t0 = time.perf_counter()
     alt, nm = O.counts_from_codes(codes, sp, cfg["pops"])
-    if cfg["mode"] == "pairs":
+    if cfg["mode"] == "gram":
+        pi, pj = np.triu_indices(cfg["pops"], 1)
+        num, den, dxy, inc = O.pair_site_stats(alt, nm, nf, pi.astype(np.int32), pj.astype(np.int32))
+        starts = np.arange(0, S, cfg["size"])
+        m = inc == 1
+        for a in (num, den, dxy):
+            np.add.reduceat(np.where(m, a, 0.0), starts, axis=0)
+        evals = S * len(pi)
+    elif cfg["mode"] == "pairs":
         pi, pj = e.all_pairs()
         num, den, dxy, inc = O.pair_site_stats(alt, nm, nf, pi, pj)
         for q in range(len(pi)):
@@ -93,10 +105,19 @@ def main():
     if cfg["mode"] == "pairs":
         e.set_pairs()
         units_per_site = e.n_pairs
+    elif cfg["mode"] == "gram":
+        e.set_gram()
+        units_per_site = e.n_pairs
     else:
         e.set_against_all(np.arange(P, dtype=np.int32), np.full(P, N // P, np.int64))
         units_per_site = P
-    e.set_windows(cfg["size"], cfg["step"])
+    if cfg["mode"] == "gram":
+        ws = np.arange(0, S + cfg["size"], cfg["size"], dtype=np.int64).clip(max=S)
+        e.set_site_windows(ws)
+        n_win = len(ws) - 1
+        gram_batch = max(1, min(n_win, int(2e9 // (e.n_pairs * 32))))   # <= 2 GB of results resident
+    else:
+        e.set_windows(cfg["size"], cfg["step"])
     e.reserve(S)
     e.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=rank * S)
     e.sync()
@@ -107,9 +128,19 @@ def main():
     ag = shard.torch_all_gather(device="cuda") if world > 1 else None
 
     gseg = int(np.gcd(cfg["size"], cfg["step"])) if cfg["size"] else 2**31 - 1
+    e_prof = [False]
+
+    gram_ms = []
 
     def step():
-        if world == 1:
+        if cfg["mode"] == "gram":
+            # every rank works on its own shard; windows are cut on shard boundaries, so there is no exchange
+            e.run_counts()
+            for w0 in range(0, n_win, gram_batch):
+                e.run_gram(w0, min(gram_batch, n_win - w0))
+                if e_prof[0]:
+                    e.sync(); gram_ms.append(e.kernel_ms(2))
+        elif world == 1:
             e.run()
         else:
             # two window-boundary exchanges per pass (evo_amd/shard.py): included-site totals after K1
@@ -143,8 +174,9 @@ def main():
     dt = time.perf_counter() - t0
     # per-kernel durations from HIP events on the library's stream (last step; then a few more
     # profiled steps outside the timed region to average)
-    reps = min(args.steps, 20)
+    reps = min(args.steps, 20) if cfg["mode"] != "gram" else 1
     e.set_profiling(True)
+    e_prof[0] = True
     for i in range(reps):
         step()
         e.sync()
@@ -165,14 +197,18 @@ def main():
     # roofline of the dominant kernel (algorithmic bytes)
     cb = e.geometry().count_bytes
     k1_bytes = S * (N / 2.0) + S * P * cb          # 2 bits per haplotype read + packed counts written
-    if cfg["mode"] == "pairs":
+    if cfg["mode"] == "gram":
+        k2_bytes = 0.0
+    elif cfg["mode"] == "pairs":
         g = np.gcd(cfg["size"], cfg["step"]) if cfg["size"] else 10**9
         k1_bytes += S / 64.0 * (2 * P + 2) * 8.0         # zero / fixed / irregular / skip masks written
         k2_bytes = S * P * cb + S / 64.0 * (2 * P + 2) * 8.0 + (S / g) * e.n_pairs * 28.0   # counts + masks read, segment rows written
     else:
         k2_bytes = S * P * cb + S * 8.0 + (S / cfg["step"]) * P * 16.0
-    names = ["k1_count_kernel", "scan_kernel", "k2_window_kernel" if cfg["mode"] == "pairs" else "global_window_kernel",
-             "stitch_kernel"]
+    names = ["k1_count_kernel", "scan_kernel",
+             {"pairs": "k2_window_kernel", "gram": "gram_kernel"}.get(cfg["mode"], "global_window_kernel"), "stitch_kernel"]
+    if cfg["mode"] == "gram":
+        kavg[2] = float(np.sum(gram_ms))          # popsums + gram launches of every batch of one step
     dom = 0 if kavg[0] >= kavg[2] else 2
     dom_bytes = k1_bytes if dom == 0 else k2_bytes
     achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9 if kavg[dom] > 0 else 0.0
@@ -194,6 +230,16 @@ def main():
                 "k1_GBps": k1_bytes / (kavg[0] * 1e-3) / 1e9 if kavg[0] > 0 else 0.0,
                 "algorithmic_bytes": dom_bytes}
 
+    if cfg["mode"] == "gram" and kavg[2] > 0:
+        # flops of the dominant kernel: 2 S Ppad^2 per Gram matrix over the blocks on or above the diagonal;
+        # 3 MFMA streams without missing alleles (p q^T, q p^T, c c^T), 5 with (two more for the fixed-with-missing term)
+        Pp = 64 * ((P + 63) // 64)
+        nblk = Pp // 64
+        n_mm = 5 if cfg["miss"] > 0 else 3
+        flops = 2.0 * S * (64 * 64) * (nblk * (nblk + 1) / 2) * n_mm
+        ach = flops / (kavg[2] * 1e-3) / 1e12
+        roofline.update({"bound": "mfma", "kernel": "gram_kernel", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / F64_MFMA_PEAK_TFLOPS, "algorithmic_flops": flops, "traffic": None})
     out = {
         "metric": "site x pop-pair Fst+dxy evaluations/sec",
         "value": value, "unit": "site*pair/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,7 +251,7 @@ def main():
     }
     if rank == 0 and world == 1 and args.cpu_sites != 0:
         # the oracle does ~3e7 evaluations/s on one core: 6e8 evaluations are ~20 s; the whole cfg2 workload is less
-        cs = args.cpu_sites if args.cpu_sites > 0 else min(S, max(20_000, int(6e8 / units_per_site)))
+        cs = args.cpu_sites if args.cpu_sites > 0 else min(S, max(2_000, int(6e8 / units_per_site)))
         v, secs = cpu_baseline(e, cfg, cs)
         out["cpu_baseline"] = {"value": v, "unit": "site*pair/s", "cores": 1, "kind": "port",
                                "sample": "first %d sites of the same workload, oracle/evo_oracle.c closed-form "

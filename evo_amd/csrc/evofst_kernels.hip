@@ -191,9 +191,14 @@ hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t s
     constexpr int NW = kK1Threads / 64;
     const size_t npq = mode == MODE_PAIRS ? p.n_pairs : 0;
     size_t lds = (size_t)NW * 4 * p.P * 8 + (NW + 1) * npq * 4 + (size_t)(p.W + 1) * 4 + 16 + (size_t)p.n_segs * sizeof(SegDesc) + 64;
-    if (lds > 64 * 1024) return hipErrorInvalidValue;   // layouts with > ~3000 words / segments: not expected (N <= 100k samples)
+    if (lds > 150 * 1024) return hipErrorInvalidValue;   // layouts with thousands of populations / words: not expected
     dim3 grid((p.n_chunks + NW - 1) / NW), block(kK1Threads);
-#define EVOFST_K1(CT, M) hipLaunchKernelGGL((k1_count_kernel<CT, M>), grid, block, lds, st, p)
+#define EVOFST_K1(CT, M) do { \
+        if (lds > 48 * 1024) { \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_count_kernel<CT, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e_ != hipSuccess) return e_; \
+        } \
+        hipLaunchKernelGGL((k1_count_kernel<CT, M>), grid, block, lds, st, p); } while (0)
     if (count_bytes == 2) {
         if (mode == MODE_COUNTS) EVOFST_K1(uint16_t, MODE_COUNTS);
         else if (mode == MODE_PAIRS) EVOFST_K1(uint16_t, MODE_PAIRS);
