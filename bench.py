@@ -122,8 +122,6 @@ def main():
     e.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=rank * S)
     e.sync()
     e.set_profiling(False)          # no event records inside the timed region
-    if world > 1 and cfg["mode"] != "pairs":
-        raise SystemExit("bench.py: the against-all deque hand-off between shards is not built yet; run this config with --gpus 1")
     from evo_amd import shard
     ag = shard.torch_all_gather(device="cuda") if world > 1 else None
 
@@ -142,6 +140,9 @@ def main():
                     e.sync(); gram_ms.append(e.kernel_ms(2))
         elif world == 1:
             e.run()
+        elif cfg["mode"] == "global":
+            # {used, kept} totals and the last SIZE kept sites of every shard (all-gathers over RCCL)
+            shard.compute_sharded_global(e, ag, rank, cfg["size"], cfg["step"])
         else:
             # two window-boundary exchanges per pass (evo_amd/shard.py): included-site totals after K1
             # (all-gather over RCCL) -> base offsets; carries behind the last complete segment after K2.

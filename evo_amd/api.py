@@ -56,6 +56,7 @@ SIGNATURES = {
     "evofst_download_tiles": (C.c_int, [_vp, _vp]),
     "evofst_set_pairs": (C.c_int, [_vp, _i32p, _i32p, C.c_int]),
     "evofst_set_against_all": (C.c_int, [_vp, _i32p, C.c_int, _i64p]),
+    "evofst_set_global_halo": (C.c_int, [_vp, C.c_int, _i32p, _dp, _dp]),
     "evofst_set_gram": (C.c_int, [_vp]),
     "evofst_set_site_windows": (C.c_int, [_vp, _i64p, C.c_int64]),
     "evofst_run_gram": (C.c_int, [_vp, C.c_int64, C.c_int64]),
@@ -233,6 +234,12 @@ class EvoFst:
         self._chk(self.L.evofst_set_against_all(self.h, _ptr(up, _i32p), len(up), _ptr(ss, _i64p)))
         self.n_use = len(up)
         self.n_pairs = 0
+
+    def set_global_halo(self, tag, num, den):
+        """Against-all mode, multi-GPU: the kept sites (<= SIZE, oldest first) that precede this shard."""
+        tag = np.ascontiguousarray(tag, np.int32)
+        num = np.ascontiguousarray(num, np.float64); den = np.ascontiguousarray(den, np.float64)
+        self._chk(self.L.evofst_set_global_halo(self.h, len(tag), _ptr(tag, _i32p), _ptr(num, _dp), _ptr(den, _dp)))
 
     def set_gram(self):
         """All pairs i<j through the Gram path (windows = site ranges, see set_site_windows)."""

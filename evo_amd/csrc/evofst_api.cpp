@@ -66,10 +66,11 @@ struct evofst_ctx {
 
     // pairs-mode work buffers
     DevBuf d_census, d_offsets, d_incl_totals, d_seg_num, d_seg_den, d_seg_k, d_seg_end, d_zf, d_irr,
-        d_tail, d_tail_n, d_carry, d_win, d_gU, d_gC, d_gnum, d_gden, d_gk, d_gcnt,
+        d_tail, d_tail_n, d_carry, d_win, d_halo_num, d_halo_den, d_halo_tag, d_gU, d_gC, d_gnum, d_gden, d_gk, d_gcnt,
         d_nrows, d_totals;
     int64_t seg_cap = 0;
     std::vector<int64_t> win_start;   // Gram mode: site windows
+    int halo_n = 0;                   // against-all mode: kept sites handed over by the shards before this one
     int64_t gram_windows = 0;         // windows of the last run_gram
     int gram_missing = -1;            // -1 unknown, else whether any site needs the missing-allele correction
     // against-all work buffers
@@ -240,6 +241,9 @@ GlobalParams make_global(evofst_ctx *c) {
     p.tn_max = 0;
     for (int32_t k : c->use_idx) p.tn_max += c->n_full[k];
     p.base_kept = c->base.size() > 1 ? c->base[1] : 0;
+    p.halo_n = c->halo_n;
+    p.halo_num = (const double *)c->d_halo_num.p; p.halo_den = (const double *)c->d_halo_den.p;
+    p.halo_tag = (const int32_t *)c->d_halo_tag.p;
     p.row_cap = c->row_cap;
     p.row_start = (int32_t *)c->d_row_start.p; p.row_end = (int32_t *)c->d_row_end.p;
     p.row_num = (double *)c->d_row_num.p; p.row_den = (double *)c->d_row_den.p;
@@ -295,7 +299,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
     DevBuf *bufs[] = {&c->d_segs, &c->d_wss, &c->d_nfull, &c->d_pairs, &c->d_use, &c->d_thr, &c->d_base, &c->d_first_seg,
                       &c->d_tiles, &c->d_flags, &c->d_pos, &c->d_counts, &c->d_census, &c->d_offsets, &c->d_incl_totals,
                       &c->d_seg_num, &c->d_seg_den, &c->d_seg_k, &c->d_seg_end, &c->d_zf, &c->d_irr,
-                      &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_gU, &c->d_gC, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_carry,
+                      &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_halo_num, &c->d_halo_den, &c->d_halo_tag, &c->d_gU, &c->d_gC, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_carry,
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den};
@@ -684,12 +688,30 @@ extern "C" int evofst_set_against_all(evofst_ctx *c, const int32_t *use_pops, in
     c->thresholds.resize(n_use);
     for (int u = 0; u < n_use; ++u) c->thresholds[u] = (double)(uint64_t)set_sizes[u] * 0.8;  // FstAgainstAll.cpp:253
     c->mode = MODE_GLOBAL;
+    c->halo_n = 0;
     int rc;
     if ((rc = upload_layout(c))) return rc;
     if ((rc = upload_vec(c, c->d_use, c->use_idx))) return rc;
     if ((rc = upload_vec(c, c->d_thr, c->thresholds))) return rc;
     c->counts_done = c->stats_done = false;
     return set_base_internal(c, nullptr);
+}
+
+extern "C" int evofst_set_global_halo(evofst_ctx *c, int n, const int32_t *tag, const double *num, const double *den) {
+    if (!c || n < 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->mode != MODE_GLOBAL) return fail(c, EVOFST_ERR_STATE, "set_global_halo: against-all mode first");
+    if (n > 0 && (!tag || !num || !den)) return fail(c, EVOFST_ERR_ARG, "set_global_halo: null arrays");
+    if (c->snp_size > 0 && n > c->snp_size) return fail(c, EVOFST_ERR_ARG, "set_global_halo: more than SIZE sites");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->halo_n = n;
+    c->stats_done = false;
+    if (n == 0) return EVOFST_OK;
+    const size_t nu = c->use_idx.size();
+    int rc;
+    if ((rc = upload_vec(c, c->d_halo_tag, std::vector<int32_t>(tag, tag + n)))) return rc;
+    if ((rc = upload_vec(c, c->d_halo_num, std::vector<double>(num, num + (size_t)n * nu)))) return rc;
+    return upload_vec(c, c->d_halo_den, std::vector<double>(den, den + (size_t)n * nu));
 }
 
 extern "C" int evofst_set_gram(evofst_ctx *c) {

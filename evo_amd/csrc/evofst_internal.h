@@ -113,6 +113,9 @@ struct GlobalParams {
     int32_t size, step;
     int32_t tn_max;       // total chromosomes of populationsToUse (reciprocal-table size)
     int64_t base_kept;    // kept sites that precede this shard
+    int32_t halo_n;       // the last halo_n (<= size) of them, oldest first: what the deques hold when the shard starts
+    const double *halo_num, *halo_den;   // [halo_n][n_use]
+    const int32_t *halo_tag;             // [halo_n] reported as a row's start site while the oldest entry is a halo entry
     int64_t row_cap;
     int32_t *row_start, *row_end;  // [row_cap]
     double *row_num, *row_den;     // [row_cap][n_use]

@@ -1148,6 +1148,18 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     int64_t row = p.chunk_row_off[c];
     int head = 0;  // ring slot of the oldest element
     __syncthreads();
+    {   // multi-GPU: kept sites of the shards before this one stand where this shard has fewer than SIZE before the chunk
+        const int n_loc = (int)min((int64_t)p.size, kept_before);
+        const int n_h = min(p.size - n_loc, p.halo_n);
+        for (int e = p.halo_n - n_h; e < p.halo_n; ++e) {
+            if (active) {
+                ring_n[(size_t)head * p.n_use + u] = p.halo_num[(size_t)e * p.n_use + u];
+                ring_d[(size_t)head * p.n_use + u] = p.halo_den[(size_t)e * p.n_use + u];
+            }
+            if (threadIdx.x == 0) ring_s[head] = p.halo_tag[e];
+            head = head + 1 == p.size ? 0 : head + 1;
+        }
+    }
 
     constexpr int EPT = 16 / (int)sizeof(CT);
     constexpr int VPT = kTileSites / EPT;

@@ -166,3 +166,88 @@ def run_sharded_pairs(engine, all_gather, rank, size, step):
     all_cnt = all_gather(cnt) if per > 1 else [cnt]
     halo, hcnt = halo_segments(all_tail, all_cnt, rank, per) if per > 1 else (None, None)
     return seg, halo, hcnt, base
+
+
+# ---------------------------------------------------------------------------------------------
+# Fst-against-all (evo_FstAgainstAll.cpp): the deques of the last SIZE kept sites cross shard edges
+# ---------------------------------------------------------------------------------------------
+
+def global_tail(engine, size, block=8192):
+    """The last (up to) `size` kept sites of the shard loaded in `engine` (after run_counts), oldest first:
+    (local site index [n], num [n, U], den [n, U])."""
+    hi = engine.n_sites
+    sites, nums, dens = [], [], []
+    got = 0
+    while hi > 0 and got < size:
+        lo = max(0, hi - block)
+        num, den, kept = engine.global_site_stats(lo, hi - lo)           # [U, n]
+        idx = np.nonzero(kept)[0]
+        if len(idx) > size - got:
+            idx = idx[len(idx) - (size - got):]
+        sites.insert(0, idx + lo); nums.insert(0, num[:, idx].T); dens.insert(0, den[:, idx].T)
+        got += len(idx)
+        hi = lo
+    U = engine.n_use
+    if not sites:
+        return np.zeros(0, np.int64), np.zeros((0, U)), np.zeros((0, U))
+    return np.concatenate(sites).astype(np.int64), np.concatenate(nums), np.concatenate(dens)
+
+
+def global_halo(all_tails, all_first_site, rank, size):
+    """What the deques hold when shard `rank` starts: the last `size` kept sites of the shards before it, oldest
+    first.  all_tails[r] = (sites, num, den, n) as gathered (padded to `size` rows, n valid, newest last at the
+    end of the valid part).  Returns (global site index [m], num [m, U], den [m, U])."""
+    sites, nums, dens = [], [], []
+    got = 0
+    r = rank - 1
+    while r >= 0 and got < size:
+        s, nu, de, n = all_tails[r]
+        n = int(np.asarray(n).reshape(-1)[0])
+        take = min(n, size - got)
+        if take:
+            sites.insert(0, np.asarray(s)[n - take:n] + int(all_first_site[r]))
+            nums.insert(0, np.asarray(nu)[n - take:n]); dens.insert(0, np.asarray(de)[n - take:n])
+            got += take
+        r -= 1
+    if not sites:
+        U = np.asarray(all_tails[0][1]).shape[1]
+        return np.zeros(0, np.int64), np.zeros((0, U)), np.zeros((0, U))
+    return np.concatenate(sites), np.concatenate(nums), np.concatenate(dens)
+
+
+def compute_sharded_global(engine, all_gather, rank, size, step):
+    """The device work and the two exchanges of one distributed against-all pass ({used, kept} totals; the last
+    SIZE kept sites of every shard); leaves the window rows on the device.  Returns (global sites of the halo,
+    first global site of every shard) for run_sharded_global's bookkeeping."""
+    engine.set_windows(size, step)
+    engine.run_counts()
+    tot = engine.included_totals()                                            # {used, kept}
+    all_tot = all_gather(np.asarray(tot, np.int64))
+    all_n = all_gather(np.asarray([engine.n_sites], np.int64))
+    first_site = np.concatenate([[0], np.cumsum([int(x[0]) for x in all_n])])[:-1]
+    engine.set_base_offsets(base_offsets(all_tot, rank))                      # exchange 1
+    s, nu, de = global_tail(engine, size)
+    U = engine.n_use
+    pad = lambda a, shape: np.concatenate([a, np.zeros((size - a.shape[0],) + shape, a.dtype)])
+    all_s = all_gather(pad(s, ())); all_nu = all_gather(pad(nu, (U,))); all_de = all_gather(pad(de, (U,)))
+    all_cnt = all_gather(np.asarray([len(s)], np.int64))                      # exchange 2
+    tails = [(all_s[r], all_nu[r], all_de[r], all_cnt[r]) for r in range(len(all_cnt))]
+    hs, hn, hd = global_halo(tails, first_site, rank, size)
+    engine.set_global_halo(-2 - np.arange(len(hs)), hn, hd)        # -1 stays the reference's empty deque slot
+    engine.run_stats()
+    return hs, first_site
+
+
+def run_sharded_global(engine, all_gather, rank, size, step):
+    """One distributed pass in against-all mode on the shard loaded in `engine`.  Returns the window rows that
+    END in this shard with global site indices: dict(start_site, end_site, mean_num, mean_den)."""
+    hs, first_site = compute_sharded_global(engine, all_gather, rank, size, step)
+    w = engine.global_windows()
+    start = w["start_site"].astype(np.int64)
+    out_start = start + int(first_site[rank])
+    out_start[start == -1] = -1                                   # the reference's zero-initialised deque
+    halo_rows = start < -1
+    if halo_rows.any():
+        out_start[halo_rows] = hs[(-2 - start[halo_rows]).astype(np.int64)]
+    return dict(start_site=out_start, end_site=w["end_site"].astype(np.int64) + int(first_site[rank]),
+                mean_num=w["mean_num"], mean_den=w["mean_den"])

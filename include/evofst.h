@@ -156,6 +156,13 @@ int evofst_set_windows(evofst_ctx *ctx, int snp_size, int snp_step);
  * (n_pairs values), or {used, kept} sites preceding it (against-all mode, 2 values). */
 int evofst_set_base_offsets(evofst_ctx *ctx, const int64_t *offsets);
 
+/* Multi-GPU, against-all mode: the last n (<= SIZE) kept sites that precede this shard, oldest first --
+ * what the reference's numDeque / denomDeque (evo_FstAgainstAll.cpp:119-122, 237-240) hold when the shard's
+ * first site is read: num / den [n][n_use] as evofst_get_global_site_stats returns them on the earlier shards,
+ * tag[n] = the value to report as a window's start site while its oldest entry is one of them (a code of the
+ * caller's below -1; -1 itself is the start of a window whose oldest entry is the zero-initialised deque).  n == 0 clears.  Call after evofst_set_windows, before evofst_run_stats. */
+int evofst_set_global_halo(evofst_ctx *ctx, int n, const int32_t *tag, const double *num, const double *den);
+
 /* ------------------------------------------------------------------ compute */
 
 /* Gram path: window sums of windows [first_window, first_window + n_windows) for all P (P-1) / 2 pairs

@@ -115,3 +115,63 @@ def emulate_shard_outputs(num, den, kk, inc, base, g):
         carry[q] = [a[0], a[1], a[2], cnt]
         totals[q] = rank - int(base[q])
     return seg, carry, totals
+
+
+class CpuGlobalShard:
+    """CPU stand-in for an EvoFst context in against-all mode on one shard (gloo tests): per-site values come
+    from the oracle, the deque walk is restated here (evo_FstAgainstAll.cpp:198-203, 237-240, 276-280)."""
+
+    def __init__(self, kept, num, den, flags):
+        self.kept, self.num, self.den = kept, num, den
+        self.flags = flags if flags is not None else np.zeros(len(kept), np.uint8)
+        self.n_sites, self.n_use = num.shape
+        self.base = np.zeros(2, np.int64)
+        self.halo = (np.zeros(0, np.int32), np.zeros((0, self.n_use)), np.zeros((0, self.n_use)))
+
+    def set_windows(self, size, step):
+        self.size, self.step = size, step
+
+    def run_counts(self):
+        pass
+
+    def included_totals(self):
+        return np.array([int((self.flags == 0).sum()), int(self.kept.sum())], np.int64)
+
+    def set_base_offsets(self, base):
+        self.base = np.asarray(base, np.int64)
+
+    def global_site_stats(self, first, n):
+        sl = slice(first, first + n)
+        return self.num[sl].T.copy(), self.den[sl].T.copy(), self.kept[sl].copy()
+
+    def set_global_halo(self, tag, num, den):
+        self.halo = (np.asarray(tag), np.asarray(num), np.asarray(den))
+
+    def run_stats(self):
+        size, step, U = self.size, self.step, self.n_use
+        dq = [(-1, np.zeros(U), np.zeros(U))] * size
+        tag, hn, hd = self.halo
+        for e in range(len(tag)):
+            dq = dq[1:] + [(int(tag[e]), hn[e], hd[e])]
+        used = int(self.base[0])
+        rows = dict(start_site=[], end_site=[], mean_num=[], mean_den=[])
+        for s in range(self.n_sites):
+            if self.flags[s]:
+                continue
+            used += 1
+            if not self.kept[s]:
+                continue
+            dq = dq[1:] + [(s, self.num[s], self.den[s])]
+            if (used > size or size == step) and used % step == 0:
+                an = np.zeros(U); ad = np.zeros(U)
+                for _, a, b in dq:
+                    an = an + a; ad = ad + b
+                rows["start_site"].append(dq[0][0]); rows["end_site"].append(s)
+                rows["mean_num"].append(an / size); rows["mean_den"].append(ad / size)
+        self.rows = {k: np.asarray(v) for k, v in rows.items()}
+        if not rows["end_site"]:
+            self.rows["mean_num"] = np.zeros((0, U)); self.rows["mean_den"] = np.zeros((0, U))
+            self.rows["start_site"] = np.zeros(0, np.int32); self.rows["end_site"] = np.zeros(0, np.int32)
+
+    def global_windows(self):
+        return self.rows

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from evo_amd import shard
 from oracle import oracle as O
-from tests.helpers import random_codes, round_robin_pops, n_full_of, emulate_shard_outputs
+from tests.helpers import random_codes, round_robin_pops, n_full_of, emulate_shard_outputs, CpuGlobalShard
 
 
 def _free_port():
@@ -79,6 +79,58 @@ def test_window_exchange_matches_single_shard(world, size, step, cuts):
     ret = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, size, step, cuts, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
+
+
+def _global_problem():
+    rng = np.random.default_rng(7)
+    S, N, P = 2500, 48, 6
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=0.25)
+    fl = (rng.random(S) < 0.05).astype(np.uint8)
+    alt, nm = O.counts_from_codes(codes, sp, P)
+    use = np.arange(P, dtype=np.int32)
+    sizes = np.array([(sp == k).sum() for k in range(P)], np.int64)
+    kept, num, den = O.global_site_stats(alt, nm, use, sizes, fl)
+    return kept, num, den, fl
+
+
+def _worker_global(rank, world, port, size, step, cuts, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        kept, num, den, fl = _global_problem()
+        lo, hi = cuts[rank], cuts[rank + 1]
+        eng = CpuGlobalShard(kept[lo:hi], num[lo:hi], den[lo:hi], fl[lo:hi])
+        w = shard.run_sharded_global(eng, shard.torch_all_gather(), rank, size, step)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, w)
+        if rank == 0:
+            ow = O.global_windows(kept, num, den, size, step, fl)
+            cat = lambda k: np.concatenate([g[k] for g in gathered])
+            ok = np.array_equal(cat("end_site"), ow["end_site"]) and np.array_equal(cat("start_site"), ow["start_site"])
+            with np.errstate(all="ignore"):
+                mn, md = cat("mean_num"), cat("mean_den")
+                f = mn / md
+                f[(f < 0) | (md == 0)] = 0
+            ok = ok and np.array_equal(f, ow["fst"], equal_nan=True)
+            ret.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size,step,cuts", [(2, 20, 10, [0, 1200, 2500]), (3, 50, 25, [0, 30, 1000, 2500]),
+                                                  (2, 200, 200, [0, 150, 2500])])
+def test_against_all_exchange_matches_single_shard(world, size, step, cuts):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_global, args=(r, world, port, size, step, cuts, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
