@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-sites", type=int, default=-1, help="sites of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--dist-path", action="store_true", help="rehearsal: take the multi-rank step even with one rank")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -93,9 +94,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.dist_path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from evo_amd import EvoFst
     e = EvoFst(local_rank)
@@ -123,9 +126,16 @@ def main():
     e.sync()
     e.set_profiling(False)          # no event records inside the timed region
     from evo_amd import shard
-    ag = shard.torch_all_gather(device="cuda") if world > 1 else None
+    ag = shard.torch_all_gather(device="cuda") if multi else None
+    if multi and cfg["mode"] == "pairs":
+        # the whole pass stays on one stream: kernels, device-to-device copies and the two all-gathers (RCCL)
+        stream = torch.cuda.Stream()
+        e.set_stream(stream.cuda_stream)
+        nq = e.n_pairs
+        t_tot = torch.zeros(nq, dtype=torch.int64, device="cuda"); t_all = torch.zeros(world * nq, dtype=torch.int64, device="cuda")
+        t_carry = torch.zeros(nq * 4, dtype=torch.float64, device="cuda"); t_allc = torch.zeros(world * nq * 4, dtype=torch.float64, device="cuda")
+        keep = {}
 
-    gseg = int(np.gcd(cfg["size"], cfg["step"])) if cfg["size"] else 2**31 - 1
     e_prof = [False]
 
     gram_ms = []
@@ -138,7 +148,7 @@ def main():
                 e.run_gram(w0, min(gram_batch, n_win - w0))
                 if e_prof[0]:
                     e.sync(); gram_ms.append(e.kernel_ms(2))
-        elif world == 1:
+        elif not multi:
             e.run()
         elif cfg["mode"] == "global":
             # {used, kept} totals and the last SIZE kept sites of every shard (all-gathers over RCCL)
@@ -146,21 +156,22 @@ def main():
         else:
             # two window-boundary exchanges per pass (evo_amd/shard.py): included-site totals after K1
             # (all-gather over RCCL) -> base offsets; carries behind the last complete segment after K2.
-            e.run_counts()
-            all_tot = ag(e.included_totals())
-            e.set_base_offsets(shard.base_offsets(all_tot, rank))
-            e.run_stats()
-            # complete segments of every shard follow from the totals: (base + total) / g - base / g
-            base = np.zeros_like(all_tot[0]); all_nseg = []
-            for r in range(world):
-                all_nseg.append((base + all_tot[r]) // gseg - base // gseg)
-                base = base + all_tot[r]
-            shard.carry_in(ag(e.boundary()), all_nseg, rank)
+            # Nothing in this step waits on the host; what the gathered carries are used for (completing the
+            # windows that straddle the left edge, evo_amd.shard.carry_in) is host bookkeeping after the pass.
+            with torch.cuda.stream(stream):
+                e.run_counts()
+                e.copy_included_totals(t_tot.data_ptr())
+                dist.all_gather_into_tensor(t_all, t_tot)
+                keep["base"] = t_all.view(world, nq)[:rank].sum(0) if rank > 0 else torch.zeros_like(t_tot)
+                e.set_base_offsets_device(keep["base"].data_ptr())
+                e.run_stats()
+                e.copy_boundary(t_carry.data_ptr())
+                dist.all_gather_into_tensor(t_allc, t_carry)
 
     def fence():
         e.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -187,7 +198,7 @@ def main():
             except Exception:
                 kms[i, k] = 0.0
     kavg = kms[:reps].mean(axis=0)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -259,8 +270,12 @@ def main():
                                          "restatement on allele codes (counts + per-site stats + windows), %.1f s" % (cs, secs)}
     if rank == 0:
         print(json.dumps(out))
+    if multi and cfg["mode"] == "pairs" and rank == 0:
+        # sanity of the device-side exchange: the gathered carries equal what the host getter returns
+        own = t_allc.view(world, nq, 4)[rank].cpu().numpy()
+        assert np.array_equal(own, e.boundary(), equal_nan=True), "device-side boundary copy differs from evofst_get_boundary"
     e.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -56,6 +56,9 @@ SIGNATURES = {
     "evofst_download_tiles": (C.c_int, [_vp, _vp]),
     "evofst_set_pairs": (C.c_int, [_vp, _i32p, _i32p, C.c_int]),
     "evofst_set_against_all": (C.c_int, [_vp, _i32p, C.c_int, _i64p]),
+    "evofst_set_base_offsets_device": (C.c_int, [_vp, _vp]),
+    "evofst_copy_included_totals": (C.c_int, [_vp, _vp]),
+    "evofst_copy_boundary": (C.c_int, [_vp, _vp]),
     "evofst_set_global_halo": (C.c_int, [_vp, C.c_int, _i32p, _dp, _dp]),
     "evofst_set_gram": (C.c_int, [_vp]),
     "evofst_set_site_windows": (C.c_int, [_vp, _i64p, C.c_int64]),
@@ -234,6 +237,19 @@ class EvoFst:
         self._chk(self.L.evofst_set_against_all(self.h, _ptr(up, _i32p), len(up), _ptr(ss, _i64p)))
         self.n_use = len(up)
         self.n_pairs = 0
+
+    # device-side exchange (pointers to device memory of the caller, e.g. torch tensors; asynchronous)
+    def set_stream(self, hip_stream):
+        self._chk(self.L.evofst_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def set_base_offsets_device(self, d_ptr):
+        self._chk(self.L.evofst_set_base_offsets_device(self.h, C.c_void_p(d_ptr)))
+
+    def copy_included_totals(self, d_ptr):
+        self._chk(self.L.evofst_copy_included_totals(self.h, C.c_void_p(d_ptr)))
+
+    def copy_boundary(self, d_ptr):
+        self._chk(self.L.evofst_copy_boundary(self.h, C.c_void_p(d_ptr)))
 
     def set_global_halo(self, tag, num, den):
         """Against-all mode, multi-GPU: the kept sites (<= SIZE, oldest first) that precede this shard."""

@@ -70,6 +70,7 @@ struct evofst_ctx {
         d_nrows, d_totals;
     int64_t seg_cap = 0;
     std::vector<int64_t> win_start;   // Gram mode: site windows
+    bool base_host_valid = true;      // c->base mirrors d_base (false after a device-to-device set_base_offsets)
     int halo_n = 0;                   // against-all mode: kept sites handed over by the shards before this one
     int64_t gram_windows = 0;         // windows of the last run_gram
     int gram_missing = -1;            // -1 unknown, else whether any site needs the missing-allele correction
@@ -198,6 +199,7 @@ int set_base_internal(evofst_ctx *c, const int64_t *offsets) {
     if (offsets) std::copy(offsets, offsets + n, c->base.begin());
     int rc = upload_vec(c, c->d_base, c->base);
     if (rc) return rc;
+    c->base_host_valid = true;
     c->offsets_dirty = true;
     c->stats_done = false;
     return EVOFST_OK;
@@ -240,7 +242,7 @@ GlobalParams make_global(evofst_ctx *c) {
     p.size = c->snp_size; p.step = c->snp_step;
     p.tn_max = 0;
     for (int32_t k : c->use_idx) p.tn_max += c->n_full[k];
-    p.base_kept = c->base.size() > 1 ? c->base[1] : 0;
+    p.base = (const int64_t *)c->d_base.p;
     p.halo_n = c->halo_n;
     p.halo_num = (const double *)c->d_halo_num.p; p.halo_den = (const double *)c->d_halo_den.p;
     p.halo_tag = (const int32_t *)c->d_halo_tag.p;
@@ -755,6 +757,50 @@ extern "C" int evofst_set_base_offsets(evofst_ctx *c, const int64_t *offsets) {
     return set_base_internal(c, offsets);
 }
 
+static int launch_totals_and_carry(evofst_ctx *c, bool want_totals);
+
+// Device-side forms of the multi-GPU exchange: nothing here waits for the GPU, so a pass over a shard stays one
+// stream of kernels, copies and collectives (bench.py, N > 1).
+extern "C" int evofst_set_base_offsets_device(evofst_ctx *c, const void *d_offsets) {
+    if (!c || !d_offsets) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->mode != MODE_PAIRS && c->mode != MODE_GLOBAL) return fail(c, EVOFST_ERR_STATE, "set_base_offsets_device: choose a mode first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = c->mode == MODE_PAIRS ? c->pairs.size() : 2;
+    c->base.assign(n, 0);
+    int rc = ensure(c, c->d_base, n * 8);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_base.p, d_offsets, n * 8, hipMemcpyDeviceToDevice, c->stream));
+    c->base_host_valid = false;
+    c->offsets_dirty = true;
+    c->stats_done = false;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_copy_included_totals(evofst_ctx *c, void *d_dst) {
+    if (!c || !d_dst) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->counts_done || (c->mode != MODE_PAIRS && c->mode != MODE_GLOBAL)) return fail(c, EVOFST_ERR_STATE, "copy_included_totals: run_counts in a mode first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if (c->offsets_dirty && (rc = run_scan(c))) return rc;
+    const void *src = c->mode == MODE_PAIRS ? c->d_incl_totals.p : c->d_uk_tot.p;
+    const size_t n = c->mode == MODE_PAIRS ? c->pairs.size() : 2;
+    HIPCHK(c, hipMemcpyAsync(d_dst, src, n * 8, hipMemcpyDeviceToDevice, c->stream));
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_copy_boundary(evofst_ctx *c, void *d_dst) {
+    if (!c || !d_dst) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->stats_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "copy_boundary: pairs mode + run_stats first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = launch_totals_and_carry(c, false);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(d_dst, c->d_carry.p, c->pairs.size() * 4 * 8, hipMemcpyDeviceToDevice, c->stream));
+    return EVOFST_OK;
+}
+
 // ================================================================== compute
 
 extern "C" int evofst_run_counts(evofst_ctx *c) {
@@ -816,9 +862,8 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
         const size_t np = c->pairs.size();
         const int64_t g = c->g;
         c->seg_cap = c->n_sites / g + 2;
-        std::vector<int64_t> fs(np);
-        for (size_t q = 0; q < np; ++q) fs[q] = c->base[q] / g;
-        if ((rc = upload_vec(c, c->d_first_seg, fs))) return rc;
+        if ((rc = ensure(c, c->d_first_seg, np * 8))) return rc;
+        HIPCHK(c, launch_first_seg((const int64_t *)c->d_base.p, g, (int64_t *)c->d_first_seg.p, (int)np, c->stream));
         const size_t seg_elems = (size_t)c->seg_cap * np;
         if ((rc = ensure(c, c->d_seg_num, seg_elems * 8))) return rc;
         if ((rc = ensure(c, c->d_seg_den, seg_elems * 8))) return rc;
@@ -1067,7 +1112,11 @@ static int segment_rows(evofst_ctx *c, std::vector<int64_t> &first, std::vector<
     std::vector<int64_t> tot(np);
     int rc = d2h(c, tot.data(), c->d_incl_totals.p, np);
     if (rc) return rc;
+    if (!c->base_host_valid) {
+        if ((rc = d2h(c, c->base.data(), c->d_base.p, c->base.size()))) return rc;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->base_host_valid = true;
     first.resize(np); rows.resize(np);
     for (size_t q = 0; q < np; ++q) {
         first[q] = c->base[q] / c->g;
@@ -1097,16 +1146,21 @@ extern "C" int evofst_get_segments(evofst_ctx *c, int64_t *first_segment, int64_
     return EVOFST_OK;
 }
 
-static int totals_and_carry(evofst_ctx *c, double *totals, double *carry) {
-    std::vector<int64_t> first, rows;
-    int rc = segment_rows(c, first, rows);
-    if (rc) return rc;
+static int launch_totals_and_carry(evofst_ctx *c, bool want_totals) {
     const size_t np = c->pairs.size();
-    if ((rc = upload_vec(c, c->d_nrows, rows))) return rc;
+    int rc;
     if ((rc = ensure(c, c->d_totals, np * 4 * 8))) return rc;
     if ((rc = ensure(c, c->d_carry, np * 4 * 8))) return rc;
     K2Params p = make_k2(c);
-    HIPCHK(c, launch_totals(p, (const int64_t *)c->d_nrows.p, (double *)c->d_totals.p, (double *)c->d_carry.p, c->stream));
+    HIPCHK(c, launch_totals(p, (const int64_t *)c->d_base.p, (const int64_t *)c->d_incl_totals.p,
+                            want_totals ? (double *)c->d_totals.p : nullptr, (double *)c->d_carry.p, c->stream));
+    return EVOFST_OK;
+}
+
+static int totals_and_carry(evofst_ctx *c, double *totals, double *carry) {
+    const size_t np = c->pairs.size();
+    int rc = launch_totals_and_carry(c, totals != nullptr);
+    if (rc) return rc;
     if ((rc = d2h(c, totals, c->d_totals.p, np * 4))) return rc;
     if ((rc = d2h(c, carry, c->d_carry.p, np * 4))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));

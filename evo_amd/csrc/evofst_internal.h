@@ -112,7 +112,7 @@ struct GlobalParams {
     const int64_t *chunk_used_kept_off;  // [2][n_chunks] used / kept sites before the chunk
     int32_t size, step;
     int32_t tn_max;       // total chromosomes of populationsToUse (reciprocal-table size)
-    int64_t base_kept;    // kept sites that precede this shard
+    const int64_t *base;  // {used, kept} sites that precede this shard (device)
     int32_t halo_n;       // the last halo_n (<= size) of them, oldest first: what the deques hold when the shard starts
     const double *halo_num, *halo_den;   // [halo_n][n_use]
     const int32_t *halo_tag;             // [halo_n] reported as a row's start site while the oldest entry is a halo entry
@@ -160,7 +160,9 @@ hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *off
                        int n_chunks, int n_cols, hipStream_t st);
 hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st);
 hipError_t launch_stitch(const K2Params &p, hipStream_t st);
-hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *totals, double *carry, hipStream_t st);
+hipError_t launch_totals(const K2Params &p, const int64_t *base, const int64_t *incl_totals, double *totals, double *carry,
+                         hipStream_t st);
+hipError_t launch_first_seg(const int64_t *base, int64_t g, int64_t *first_seg, int n, hipStream_t st);
 hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,

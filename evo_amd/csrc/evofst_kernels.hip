@@ -696,17 +696,18 @@ hipError_t launch_stitch(const K2Params &p, hipStream_t st) {
 // Whole-shard sums per pair: complete segments in order, then the carry after the last one.
 // totals[q] = {num, den, k, n_included}; carry[q] = {num, den, k, n_sites} behind the last complete segment.
 // (k = sumKij is a sum of integers < 2^53 held in doubles: exact in any order.)
-__global__ void totals_kernel(K2Params p, const int64_t *__restrict__ n_rows, double *__restrict__ totals,
-                              double *__restrict__ carry) {
+__global__ void totals_kernel(K2Params p, const int64_t *__restrict__ base, const int64_t *__restrict__ incl_totals,
+                              double *__restrict__ totals, double *__restrict__ carry) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= p.n_pairs) return;
     const size_t plane = (size_t)p.n_pairs * p.n_chunks;
     double an = 0.0, ad = 0.0, ak = 0.0;
-    const int64_t rows = n_rows[q];
-    for (int64_t r = 0; r < rows; ++r) {
-        const size_t o = (size_t)r * p.n_pairs + q;
-        an += p.seg_num[o]; ad += p.seg_den[o]; ak += p.seg_k[o];
-    }
+    const int64_t rows = (base[q] + incl_totals[q]) / p.g - base[q] / p.g;   // complete segments of this shard
+    if (totals)
+        for (int64_t r = 0; r < rows; ++r) {
+            const size_t o = (size_t)r * p.n_pairs + q;
+            an += p.seg_num[o]; ad += p.seg_den[o]; ak += p.seg_k[o];
+        }
     int cl = p.n_chunks - 1;
     while (cl >= 0 && p.tail_n[(size_t)cl * p.n_pairs + q].y == 0) --cl;
     double tn = 0.0, td = 0.0, tk = 0.0, cnt = 0.0;
@@ -723,10 +724,23 @@ __global__ void totals_kernel(K2Params p, const int64_t *__restrict__ n_rows, do
     }
 }
 
-hipError_t launch_totals(const K2Params &p, const int64_t *n_rows, double *totals, double *carry, hipStream_t st) {
+hipError_t launch_totals(const K2Params &p, const int64_t *base, const int64_t *incl_totals, double *totals, double *carry,
+                         hipStream_t st) {
     if (p.n_pairs <= 0) return hipSuccess;
     dim3 block(64), grid((p.n_pairs + 63) / 64);
-    hipLaunchKernelGGL(totals_kernel, grid, block, 0, st, p, n_rows, totals, carry);
+    hipLaunchKernelGGL(totals_kernel, grid, block, 0, st, p, base, incl_totals, totals, carry);
+    return hipGetLastError();
+}
+
+// first_segment[q] = base[q] / g on the device (the base offsets may have arrived device-to-device)
+__global__ void first_seg_kernel(const int64_t *__restrict__ base, int64_t g, int64_t *__restrict__ first_seg, int n) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) first_seg[q] = base[q] / g;
+}
+
+hipError_t launch_first_seg(const int64_t *base, int64_t g, int64_t *first_seg, int n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(first_seg_kernel, dim3((n + 255) / 256), dim3(256), 0, st, base, g, first_seg, n);
     return hipGetLastError();
 }
 
@@ -1135,7 +1149,7 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     // ---- where the replay starts: walk back until SIZE kept sites of this shard are found
     int th = t0;
     int need = p.size;
-    const int64_t kept_before = p.chunk_used_kept_off[(size_t)p.n_chunks + c] - p.base_kept;
+    const int64_t kept_before = p.chunk_used_kept_off[(size_t)p.n_chunks + c] - p.base[1];
     if (kept_before < need) need = (int)kept_before;   // the rest is the zero-initialised deque
     int drop = 0;         // kept sites of tile th to ignore (older than the window)
     while (need > 0 && th > 0) {

@@ -156,6 +156,15 @@ int evofst_set_windows(evofst_ctx *ctx, int snp_size, int snp_step);
  * (n_pairs values), or {used, kept} sites preceding it (against-all mode, 2 values). */
 int evofst_set_base_offsets(evofst_ctx *ctx, const int64_t *offsets);
 
+/* Device-side forms of the same exchange, for callers that keep the whole pass on one stream (set the stream
+ * with evofst_set_stream; nothing here waits for the GPU): the offsets are read from / the totals and carries
+ * are written to device memory of the caller (e.g. the tensors of an RCCL all-gather) by asynchronous copies on
+ * the context's stream.  Sizes as in the host forms: n_pairs (pairs mode) or 2 (against-all) int64 values;
+ * evofst_copy_boundary writes what evofst_get_boundary returns, n_pairs x 4 doubles. */
+int evofst_set_base_offsets_device(evofst_ctx *ctx, const void *d_offsets);
+int evofst_copy_included_totals(evofst_ctx *ctx, void *d_dst);
+int evofst_copy_boundary(evofst_ctx *ctx, void *d_dst);
+
 /* Multi-GPU, against-all mode: the last n (<= SIZE) kept sites that precede this shard, oldest first --
  * what the reference's numDeque / denomDeque (evo_FstAgainstAll.cpp:119-122, 237-240) hold when the shard's
  * first site is read: num / den [n][n_use] as evofst_get_global_site_stats returns them on the earlier shards,
