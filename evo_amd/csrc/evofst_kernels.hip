@@ -788,10 +788,18 @@ __global__ __launch_bounds__(256) void gram_popsums_kernel(GramParams p) {
     p.C[(size_t)w * p.P + k] = C;
 }
 
-template <typename CT, bool MISS>
-__global__ __launch_bounds__(256, 1) void gram_kernel(GramParams p) {
-    __shared__ double rcp[2048];
+constexpr int kGramMaskTiles = 4;    // tiles of a window whose masks are staged in LDS for the epilogue (longer windows read HBM)
+
+// TAB (every population has <= 31 chromosomes): the operands of a packed count {c, nm} come from a 1024-entry LDS
+// table {p, q}, {c, F nm}, [c == nm] instead of being derived with ~25 VALU instructions per element.
+template <typename CT, bool MISS, bool TAB>
+__global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
+    __shared__ double rcp[TAB ? 2 : 2048];
+    __shared__ double2 tab_pq[TAB ? 1024 : 1], tab_cf[TAB ? 1024 : 1];
+    __shared__ double tab_fi[TAB ? 1024 : 1];
+    __shared__ uint64_t lmask[kGramMaskTiles][4][128];   // [tile][z|f|nm<2|nm==0][64 row pops, 64 column pops]
     constexpr int EV = 8;                               // sites per lane and step
+    constexpr int NVEC = sizeof(CT) == 2 ? 1 : 2;       // 16-byte vectors per 8 packed counts
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     // block pair (bi <= bj) from the linear index
@@ -801,12 +809,30 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramParams p) {
     const int bj = bi + rem;
     const int r0 = bi * 64 + (wave >> 1) * 32, c0 = bj * 64 + (wave & 1) * 32;
     const bool use_rcp = p.max_n < 2048;
-    if (use_rcp)
-        for (int i = threadIdx.x; i <= p.max_n; i += blockDim.x) rcp[i] = i ? 1.0 / (double)i : 0.0;
-    __syncthreads();
-    if (r0 > c0 + 31 || r0 >= p.P || c0 >= p.P) return;    // below the diagonal or outside: nothing to do (after the barrier)
     const int w = blockIdx.x;
     const int64_t a = p.win_start[p.first_window + w], b = min(p.win_start[p.first_window + w + 1], p.n_sites);
+    const int tw0 = (int)(a >> 6), tw1 = b > a ? (int)((b - 1) >> 6) : tw0 - 1;
+    const bool staged = tw1 - tw0 < kGramMaskTiles;
+    if (TAB) {
+        for (int i = threadIdx.x; i < 1024; i += blockDim.x) {      // entry (nm << 5) | c; impossible ones (c > nm) are 0: entry 1 serves sites outside the window
+            const int c = i & 31, nm = i >> 5;
+            const bool okc = c <= nm && nm <= p.max_n;
+            const double pp = okc && nm ? (double)c / (double)nm : 0.0;
+            tab_pq[i] = make_double2(pp, okc && nm ? 1.0 - pp : 0.0);
+            tab_cf[i] = make_double2(okc ? (double)c : 0.0, okc && c == nm ? (double)nm : 0.0);
+            tab_fi[i] = okc && c == nm ? 1.0 : 0.0;
+        }
+    } else if (use_rcp) {
+        for (int i = threadIdx.x; i <= p.max_n; i += blockDim.x) rcp[i] = i ? 1.0 / (double)i : 0.0;
+    }
+    if (staged)   // K1's masks of the block's 128 populations for the window's tiles
+        for (int i = threadIdx.x; i < (tw1 - tw0 + 1) * 4 * 128; i += blockDim.x) {
+            const int t = i / 512, m = (i >> 7) & 3, x = i & 127;
+            const int pop = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
+            lmask[t][m][x] = pop < p.P ? p.masks[((size_t)(tw0 + t) * 4 + m) * p.P + pop] : ~0ull;
+        }
+    __syncthreads();
+    if (r0 > c0 + 31 || r0 >= p.P || c0 >= p.P) return;    // below the diagonal or outside: nothing to do (after the barrier)
 
     int pop[4];                                          // row tile 0, 1, column tile 0, 1
     pop[0] = r0 + r; pop[1] = r0 + 16 + r; pop[2] = c0 + r; pop[3] = c0 + 16 + r;
@@ -821,7 +847,20 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramParams p) {
         for (int j = 0; j < 2; ++j) { acc_den[i][j] = double4_t{0, 0, 0, 0}; acc_cc[i][j] = double4_t{0, 0, 0, 0}; acc_m[i][j] = double4_t{0, 0, 0, 0}; }
 
     const CT *cb = reinterpret_cast<const CT *>(p.counts);
-    for (int64_t base = a & ~(int64_t)7; base < b; base += 4 * EV) {
+    const int64_t base0 = a & ~(int64_t)7;
+    uint4 nxt[4][NVEC];
+    auto fetch = [&](int64_t base) {                     // the 4 populations' count vectors of this lane's 8 sites
+        const int64_t sv = base + (int64_t)kq * EV;
+        const int t = (int)min(sv >> 6, (int64_t)p.n_tiles - 1), o = (int)(sv & 63);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const CT *src = cb + ((size_t)t * p.P + min(pop[x], p.P - 1)) * kTileSites + o;
+#pragma unroll
+            for (int v = 0; v < NVEC; ++v) nxt[x][v] = reinterpret_cast<const uint4 *>(src)[v];
+        }
+    };
+    if (base0 < b) fetch(base0);
+    for (int64_t base = base0; base < b; base += 4 * EV) {
         const int64_t sv = base + (int64_t)kq * EV;      // this lane's 8 sites (inside one tile)
         const int t = (int)min(sv >> 6, (int64_t)p.n_tiles - 1), o = (int)(sv & 63);
         // sites of the vector that belong to the window and are not skipped
@@ -834,19 +873,17 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramParams p) {
         uint32_t cnt[4][EV];                             // packed counts of the 4 populations
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const int pk = min(pop[x], p.P - 1);
-            const CT *src = cb + ((size_t)t * p.P + pk) * kTileSites + o;
             if (sizeof(CT) == 2) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(src);
-                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t wv[4] = {nxt[x][0].x, nxt[x][0].y, nxt[x][0].z, nxt[x][0].w};
 #pragma unroll
                 for (int e = 0; e < EV; ++e) cnt[x][e] = (wv[e >> 1] >> (16 * (e & 1))) & 0xffffu;
             } else {
-                const uint4 v0 = *reinterpret_cast<const uint4 *>(src), v1 = *reinterpret_cast<const uint4 *>(src + 4);
+                const uint4 v0 = nxt[x][0], v1 = nxt[x][NVEC - 1];
                 cnt[x][0] = v0.x; cnt[x][1] = v0.y; cnt[x][2] = v0.z; cnt[x][3] = v0.w;
                 cnt[x][4] = v1.x; cnt[x][5] = v1.y; cnt[x][6] = v1.z; cnt[x][7] = v1.w;
             }
         }
+        if (base + 4 * EV < b) fetch(base + 4 * EV);     // the next step's vectors travel while this one is contracted
 #pragma unroll
         for (int e = 0; e < EV; ++e) {
             double P_[4], Q_[4], C_[4], FN[4], FM[4];
@@ -854,6 +891,13 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramParams p) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 uint32_t c = cnt[x][e] & CountTraits<CT>::mask, nm = cnt[x][e] >> CountTraits<CT>::shift;
+                if (TAB) {
+                    const uint32_t idx = ok && pop[x] < p.P ? (nm << 5) | c : 1u;
+                    const double2 pq = tab_pq[idx], cf = tab_cf[idx];
+                    P_[x] = pq.x; Q_[x] = pq.y; C_[x] = cf.x;
+                    if (MISS) { FN[x] = cf.y; FM[x] = fma((double)nfull[x], tab_fi[idx], -cf.y); }   // F (n - nm)
+                    continue;
+                }
                 if (!ok || pop[x] >= p.P) { c = 0; nm = 0; }
                 const double dc = (double)c, dn = (double)nm;
                 double pp;
@@ -887,33 +931,45 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramParams p) {
     }
 
     // ---- epilogue: C/D layout col = lane & 15, row = (lane >> 4) + 4 v
-    const int tw0 = (int)(a >> 6), tw1 = b > a ? (int)((b - 1) >> 6) : tw0 - 1;
     const double kNaN = __longlong_as_double(0x7ff8000000000000ll);
+    const size_t wp = (size_t)w * p.P;
+    const int lr0 = (wave >> 1) * 32, lc0 = 64 + (wave & 1) * 32;     // this wave's rows / columns inside lmask
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+        const int pj = c0 + j * 16 + r;
+        const int xj = lc0 + j * 16 + r;
+        const double Uj = pj < p.P ? p.U[wp + pj] : 0.0, Cj = pj < p.P ? p.C[wp + pj] : 0.0;
+        const double nj = pj < p.P ? (double)p.n_full[pj] : 0.0;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int pi = r0 + i * 16 + kq + 4 * v;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int pj = c0 + j * 16 + r;
+            for (int v = 0; v < 4; ++v) {
+                const int pi = r0 + i * 16 + kq + 4 * v;
+                const int xi = lr0 + i * 16 + kq + 4 * v;
                 if (pi < pj && pj < p.P) {
                     uint32_t cnt_in = 0;
                     uint64_t pn = 0, pd = 0;
                     for (int tw = tw0; tw <= tw1; ++tw) {
-                        const uint64_t *mk = p.masks + (size_t)tw * 4 * p.P;
                         uint64_t wm = ~0ull;
                         if (tw == tw0) wm &= ~0ull << (a & 63);
                         if (tw == tw1 && (b & 63)) wm &= ~0ull >> (64 - (b & 63));
-                        const uint64_t incl = ~((mk[pi] & mk[pj]) | (mk[p.P + pi] & mk[p.P + pj])) & wm;
+                        uint64_t zi, zj, fi, fj, b1 = 0, b0 = 0;
+                        if (staged) {
+                            const int t = tw - tw0;
+                            zi = lmask[t][0][xi]; zj = lmask[t][0][xj]; fi = lmask[t][1][xi]; fj = lmask[t][1][xj];
+                            if (MISS) { b1 = lmask[t][2][xi] | lmask[t][2][xj]; b0 = lmask[t][3][xi] | lmask[t][3][xj]; }
+                        } else {
+                            const uint64_t *mk = p.masks + (size_t)tw * 4 * p.P;
+                            zi = mk[pi]; zj = mk[pj]; fi = mk[p.P + pi]; fj = mk[p.P + pj];
+                            if (MISS) { b1 = mk[2 * p.P + pi] | mk[2 * p.P + pj]; b0 = mk[3 * p.P + pi] | mk[3 * p.P + pj]; }
+                        }
+                        const uint64_t incl = ~((zi & zj) | (fi & fj)) & wm;
                         cnt_in += (uint32_t)__popcll(incl);
-                        pn |= (mk[2 * p.P + pi] | mk[2 * p.P + pj]) & incl;
-                        pd |= (mk[3 * p.P + pi] | mk[3 * p.P + pj]) & incl;
+                        pn |= b1 & incl; pd |= b0 & incl;
                     }
-                    const size_t wp = (size_t)w * p.P;
                     const double den = acc_den[i][j][v];
-                    const double num = den - p.U[wp + pi] - p.U[wp + pj];
-                    double kk = (double)p.n_full[pj] * p.C[wp + pi] + (double)p.n_full[pi] * p.C[wp + pj] - 2.0 * acc_cc[i][j][v];
+                    const double num = den - p.U[wp + pi] - Uj;
+                    double kk = nj * p.C[wp + pi] + (double)p.n_full[pi] * Cj - 2.0 * acc_cc[i][j][v];
                     if (MISS) kk -= acc_m[i][j][v];
                     const size_t q = (size_t)pi * (2 * (size_t)p.P - pi - 1) / 2 + (size_t)(pj - pi - 1);
                     const size_t o = (size_t)w * p.n_pairs + q;
@@ -923,7 +979,7 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(GramParams p) {
                     p.out_cnt[o] = (double)cnt_in;
                 }
             }
-        }
+    }
 }
 
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st) {
@@ -938,11 +994,16 @@ hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, h
     const int nblk = (p.P + 63) / 64;
     dim3 grid(p.n_windows, nblk * (nblk + 1) / 2), block(256);
     if (count_bytes == 2) {
-        if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gram_kernel<uint16_t, false>), grid, block, 0, st, p);
+        if (p.max_n <= 31) {
+            if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((gram_kernel<uint16_t, false, true>), grid, block, 0, st, p);
+        } else {
+            if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true, false>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((gram_kernel<uint16_t, false, false>), grid, block, 0, st, p);
+        }
     } else {
-        if (has_missing) hipLaunchKernelGGL((gram_kernel<uint32_t, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gram_kernel<uint32_t, false>), grid, block, 0, st, p);
+        if (has_missing) hipLaunchKernelGGL((gram_kernel<uint32_t, true, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gram_kernel<uint32_t, false, false>), grid, block, 0, st, p);
     }
     return hipGetLastError();
 }
