@@ -176,9 +176,11 @@ int run_scan(evofst_ctx *c) {
         int rc;
         if ((rc = ensure(c, c->d_offsets, (size_t)c->n_chunks * np * 8))) return rc;
         if ((rc = ensure(c, c->d_incl_totals, (size_t)np * 8))) return rc;
+        if ((rc = ensure(c, c->d_first_seg, (size_t)np * 8))) return rc;
         record(c, 1, 0);
         HIPCHK(c, launch_scan((const uint32_t *)c->d_census.p, (const int64_t *)c->d_base.p, (int64_t *)c->d_offsets.p,
-                              (int64_t *)c->d_incl_totals.p, c->n_chunks, np, c->stream));
+                              (int64_t *)c->d_incl_totals.p, c->n_chunks, np, std::max(1, c->g), (int64_t *)c->d_first_seg.p,
+                              c->stream));
         record(c, 1, 1);
     } else if (c->mode == MODE_GLOBAL) {
         int rc;
@@ -186,7 +188,7 @@ int run_scan(evofst_ctx *c) {
         if ((rc = ensure(c, c->d_uk_tot, 2 * 8))) return rc;
         record(c, 1, 0);
         HIPCHK(c, launch_scan((const uint32_t *)c->d_used_kept.p, (const int64_t *)c->d_base.p, (int64_t *)c->d_uk_off.p,
-                              (int64_t *)c->d_uk_tot.p, c->n_chunks, 2, c->stream));
+                              (int64_t *)c->d_uk_tot.p, c->n_chunks, 2, 1, nullptr, c->stream));
         record(c, 1, 1);
     }
     c->offsets_dirty = false;
@@ -746,6 +748,7 @@ extern "C" int evofst_set_windows(evofst_ctx *c, int snp_size, int snp_step) {
     c->snp_size = snp_size; c->snp_step = snp_size > 0 ? snp_step : 0;
     c->g = snp_size > 0 ? std::gcd(snp_size, snp_step) : INT_MAX;
     c->stats_done = false;
+    c->offsets_dirty = true;   // the scan also derives each pair's first segment row from g
     return EVOFST_OK;
 }
 
@@ -862,8 +865,6 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
         const size_t np = c->pairs.size();
         const int64_t g = c->g;
         c->seg_cap = c->n_sites / g + 2;
-        if ((rc = ensure(c, c->d_first_seg, np * 8))) return rc;
-        HIPCHK(c, launch_first_seg((const int64_t *)c->d_base.p, g, (int64_t *)c->d_first_seg.p, (int)np, c->stream));
         const size_t seg_elems = (size_t)c->seg_cap * np;
         if ((rc = ensure(c, c->d_seg_num, seg_elems * 8))) return rc;
         if ((rc = ensure(c, c->d_seg_den, seg_elems * 8))) return rc;
@@ -900,7 +901,7 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
                                      (const int64_t *)c->d_uk_off.p, c->n_chunks, c->chunk_tiles, c->n_tiles, c->snp_size,
                                      c->snp_step, (uint32_t *)c->d_chunk_rows.p, c->stream));
         HIPCHK(c, launch_scan((const uint32_t *)c->d_chunk_rows.p, nullptr, (int64_t *)c->d_row_off.p,
-                              (int64_t *)c->d_row_tot.p, c->n_chunks, 1, c->stream));
+                              (int64_t *)c->d_row_tot.p, c->n_chunks, 1, 1, nullptr, c->stream));
         record(c, 3, 1);
         GlobalParams p = make_global(c);
         record(c, 2, 0);

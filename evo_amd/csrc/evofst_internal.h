@@ -157,12 +157,11 @@ struct SynthParams {
 // launchers (evofst_kernels.hip)
 hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t st);
 hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *offsets, int64_t *totals,
-                       int n_chunks, int n_cols, hipStream_t st);
+                       int n_chunks, int n_cols, int64_t g, int64_t *first_seg, hipStream_t st);
 hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st);
 hipError_t launch_stitch(const K2Params &p, hipStream_t st);
 hipError_t launch_totals(const K2Params &p, const int64_t *base, const int64_t *incl_totals, double *totals, double *carry,
                          hipStream_t st);
-hipError_t launch_first_seg(const int64_t *base, int64_t g, int64_t *first_seg, int n, hipStream_t st);
 hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,

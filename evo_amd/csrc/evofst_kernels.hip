@@ -223,7 +223,8 @@ constexpr int kScanThreads = 1024, kScanPer = 4;
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const uint32_t *__restrict__ census,
                                                             const int64_t *__restrict__ base,
                                                             int64_t *__restrict__ offsets,
-                                                            int64_t *__restrict__ totals, int n_chunks, int n_cols) {
+                                                            int64_t *__restrict__ totals, int n_chunks, int n_cols,
+                                                            int64_t g, int64_t *__restrict__ first_seg) {
     __shared__ uint32_t wsum[kScanThreads / 64];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int q = blockIdx.x;
@@ -260,12 +261,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const uint32_t *__re
         __syncthreads();
     }
     if (threadIdx.x == 0 && totals) totals[q] = carry - b0;
+    if (threadIdx.x == 0 && first_seg) first_seg[q] = b0 / g;    // segment-table row 0 of the pair in this shard
 }
 
 hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *offsets, int64_t *totals,
-                       int n_chunks, int n_cols, hipStream_t st) {
+                       int n_chunks, int n_cols, int64_t g, int64_t *first_seg, hipStream_t st) {
     if (n_cols <= 0 || n_chunks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(scan_kernel, dim3(n_cols), dim3(kScanThreads), 0, st, census, base, offsets, totals, n_chunks, n_cols);
+    hipLaunchKernelGGL(scan_kernel, dim3(n_cols), dim3(kScanThreads), 0, st, census, base, offsets, totals, n_chunks, n_cols,
+                       g, first_seg);
     return hipGetLastError();
 }
 
@@ -732,18 +735,6 @@ hipError_t launch_totals(const K2Params &p, const int64_t *base, const int64_t *
     return hipGetLastError();
 }
 
-// first_segment[q] = base[q] / g on the device (the base offsets may have arrived device-to-device)
-__global__ void first_seg_kernel(const int64_t *__restrict__ base, int64_t g, int64_t *__restrict__ first_seg, int n) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < n) first_seg[q] = base[q] / g;
-}
-
-hipError_t launch_first_seg(const int64_t *base, int64_t g, int64_t *first_seg, int n, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(first_seg_kernel, dim3((n + 255) / 256), dim3(256), 0, st, base, g, first_seg, n);
-    return hipGetLastError();
-}
-
 // =====================================================================================
 // K4: Gram path.  For windows whose membership does not depend on the pair (bp windows, fixed
 // site blocks) the window sums of every pair follow from a few P x P contractions over the
@@ -1115,30 +1106,36 @@ hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int6
 
 // Number of window rows each chunk emits (evo_FstAgainstAll.cpp:238): a kept site emits when
 // (used > SIZE || SIZE == STEP) && used % STEP == 0.  One thread per chunk walks its masks.
-__global__ void global_rows_kernel(const uint64_t *__restrict__ kept_mask, const uint64_t *__restrict__ skip_mask,
-                                   const int64_t *__restrict__ chunk_off, int n_chunks, int chunk_tiles,
-                                   int n_tiles, int size, int step, uint32_t *__restrict__ chunk_rows) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void global_rows_kernel(const uint64_t *__restrict__ kept_mask, const uint64_t *__restrict__ skip_mask,
+                                                          const int64_t *__restrict__ chunk_off, int n_chunks, int chunk_tiles,
+                                                          int n_tiles, int size, int step, uint32_t *__restrict__ chunk_rows) {
+    // one wave per chunk, lane = site of the tile: the site's `used` is the count of unskipped sites up to it
+    const int lane = lane_id();
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
-    int64_t used = chunk_off[c];
+    int64_t used0 = chunk_off[c];
+    uint32_t r0 = (uint32_t)(used0 % step);           // used modulo STEP, carried in 32 bits
     uint32_t rows = 0;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
     const int t0 = c * chunk_tiles, t1 = min(t0 + chunk_tiles, n_tiles);
     for (int t = t0; t < t1; ++t) {
-        const uint64_t km = kept_mask[t], sm = skip_mask[t];
-        for (int s = 0; s < 64; ++s) {
-            if ((sm >> s) & 1ull) continue;
-            ++used;
-            if (((km >> s) & 1ull) && (used > size || size == step) && (used % step == 0)) ++rows;
-        }
+        const uint64_t km = kept_mask[t], ns = ~skip_mask[t];
+        const uint32_t k = (uint32_t)__popcll(ns & below) + 1u;   // rank of this site among the tile's unskipped sites
+        const bool mine = ((ns >> lane) & 1ull) && ((km >> lane) & 1ull);
+        const int64_t used = used0 + k;
+        const bool emit = mine && (used > size || size == step) && ((r0 + k) % (uint32_t)step == 0u);
+        rows += (uint32_t)__popcll(__ballot(emit));
+        const uint32_t n = (uint32_t)__popcll(ns);
+        used0 += n; r0 = (r0 + n) % (uint32_t)step;
     }
-    chunk_rows[c] = rows;
+    if (lane == 0) chunk_rows[c] = rows;
 }
 
 hipError_t launch_global_rows(const uint64_t *kept_mask, const uint64_t *skip_mask, const int64_t *chunk_off,
                               int n_chunks, int chunk_tiles, int n_tiles, int size, int step,
                               uint32_t *chunk_rows, hipStream_t st) {
     if (n_chunks <= 0) return hipSuccess;
-    dim3 block(64), grid((n_chunks + 63) / 64);
+    dim3 block(256), grid((n_chunks + 3) / 4);
     hipLaunchKernelGGL(global_rows_kernel, grid, block, 0, st, kept_mask, skip_mask, chunk_off, n_chunks,
                        chunk_tiles, n_tiles, size, step, chunk_rows);
     return hipGetLastError();
