@@ -47,6 +47,7 @@ SIGNATURES = {
     "evofst_unpack_codes": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _u8p]),
     "evofst_codes_from_vcf_line": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _u8p, C.POINTER(C.c_uint32),
                                              C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
+    "evofst_pack_vcf_lines": (C.c_int, [_vp, C.c_int, C.c_int64, C.POINTER(C.c_char_p), C.c_int, _i32p, C.c_int, _vp, _u8p]),
     "evofst_reserve": (C.c_int, [_vp, C.c_int64]),
     "evofst_alloc_pinned": (_vp, [_vp, C.c_size_t]),
     "evofst_free_pinned": (None, [_vp, _vp]),
@@ -184,6 +185,17 @@ class EvoFst:
         tiles = np.zeros(self.tiles_bytes(S) // 8, np.uint64)
         self._chk(self.L.evofst_pack_codes(self.h, 0, S, _ptr(codes, _u8p), tiles.ctypes.data_as(_vp)))
         return tiles
+
+    def pack_vcf_lines(self, lines, mode, n_vcf_samples, layout_to_vcf=None, n_threads=1):
+        """Parse + pack VCF data lines (bytes objects) into tiles on n_threads host threads -> (tiles, site_flags)."""
+        n = len(lines)
+        arr = (C.c_char_p * n)(*lines)
+        tiles = np.zeros(self.tiles_bytes(n), np.uint8)
+        flags = np.zeros(n, np.uint8)
+        l2v = None if layout_to_vcf is None else np.ascontiguousarray(layout_to_vcf, np.int32)
+        self._chk(self.L.evofst_pack_vcf_lines(self.h, mode, n, arr, n_vcf_samples, _ptr(l2v, _i32p) if l2v is not None else None,
+                                               n_threads, tiles.ctypes.data_as(_vp), _ptr(flags, _u8p)))
+        return tiles, flags
 
     def unpack_codes(self, tiles, n_sites):
         codes = np.empty((n_sites, 2 * self.n_samples), np.uint8)

@@ -24,6 +24,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/evofst.h"
@@ -116,11 +117,20 @@ void x86_nan_sign(std::vector<double> &v) {
 
 // One batch of parsed sites waiting for the device.
 struct Batch {
-    std::vector<uint8_t> codes;   // [n][2*n_virtual]
-    std::vector<uint8_t> flags;
+    std::vector<string> lines;    // the VCF data lines as read
+    std::vector<uint8_t> flags;   // filled by the packer
     std::vector<string> chrom, pos;
     size_t n = 0;
-    void clear() { codes.clear(); flags.clear(); chrom.clear(); pos.clear(); n = 0; }
+    void clear() { lines.clear(); flags.clear(); chrom.clear(); pos.clear(); n = 0; }
+    // keeps the line and its first two columns; the genotype columns are parsed in bulk by Device::load
+    void add(string &line, long long lineNo) {
+        const size_t t1 = line.find('\t');
+        const size_t t2 = t1 == string::npos ? string::npos : line.find('\t', t1 + 1);
+        if (t2 == string::npos) die("malformed VCF line " + numToString(lineNo));
+        chrom.emplace_back(line, 0, t1); pos.emplace_back(line, t1 + 1, t2 - t1 - 1);
+        lines.emplace_back(std::move(line));
+        ++n;
+    }
 };
 
 struct Device {
@@ -130,9 +140,17 @@ struct Device {
         ctx = evofst_create(0);
         if (!ctx) die(string("no usable GPU: ") + evofst_last_error(nullptr));
     }
-    void load(const Batch &b) {
+    // layoutToVcf[k] = genotype column of layout sample k (empty: identity)
+    void load(Batch &b, int mode, int nVcfSamples, const std::vector<int32_t> &layoutToVcf, long long firstLineNo) {
         tiles.resize(evofst_tiles_bytes(ctx, (int64_t)b.n));
-        check(ctx, evofst_pack_codes(ctx, 0, (int64_t)b.n, b.codes.data(), tiles.data()), "pack");
+        b.flags.assign(b.n, 0);
+        std::vector<const char *> ptr(b.n);
+        for (size_t i = 0; i < b.n; ++i) ptr[i] = b.lines[i].c_str();
+        const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        if (evofst_pack_vcf_lines(ctx, mode, (int64_t)b.n, ptr.data(), nVcfSamples, layoutToVcf.empty() ? nullptr : layoutToVcf.data(),
+                                  threads, tiles.data(), b.flags.data()) != EVOFST_OK)
+            die("malformed VCF line among lines " + numToString(firstLineNo) + ".." + numToString(firstLineNo + (long long)b.n - 1) +
+                " (diploid GT fields with single-digit alleles are required)");
         check(ctx, evofst_upload(ctx, (int64_t)b.n, tiles.data(), b.flags.data(), nullptr), "upload");
         check(ctx, evofst_run_counts(ctx), "run_counts");
     }
@@ -236,7 +254,7 @@ int fstMain(int argc, char **argv) {
     Batch batch;
     int nSamples = 0, nVirtual = 0;
     std::vector<size_t> virt;          // virtual sample -> VCF column (set 1 entries, then set 2 entries)
-    std::vector<uint8_t> lineCodes;
+    std::vector<int32_t> virt32;
     std::vector<double> num, den, dxy, het, hetNei, pi;
     std::vector<uint8_t> inc;
     bool haveHeader = false;
@@ -244,7 +262,7 @@ int fstMain(int argc, char **argv) {
     auto flush = [&]() {
         if (batch.n == 0) return;
         const size_t n = batch.n;
-        dev.load(batch);
+        dev.load(batch, EVOFST_MODE_FST, nSamples, virt32, totalVariantNumber - (long long)n + 1);
         num.resize(n); den.resize(n); dxy.resize(n); inc.resize(n);
         het.resize(2 * n); hetNei.resize(2 * n); pi.resize(2 * n);
         check(dev.ctx, evofst_get_site_stats(dev.ctx, 0, (int64_t)n, num.data(), den.data(), dxy.data(), inc.data()), "site_stats");
@@ -350,6 +368,7 @@ int fstMain(int argc, char **argv) {
             for (size_t i : set2Loci) virt.push_back(i);
             for (size_t i : virt) if ((int)i >= nSamples) die("sample index beyond the VCF columns (check the -s file)");
             nVirtual = (int)virt.size();
+            virt32.assign(virt.begin(), virt.end());
             std::vector<int32_t> sp(nVirtual, 1);
             for (size_t i = 0; i < set1Loci.size(); ++i) sp[i] = 0;
             dev.open();
@@ -357,7 +376,6 @@ int fstMain(int argc, char **argv) {
             int32_t pi0 = 0, pj0 = 1;
             check(dev.ctx, evofst_set_pairs(dev.ctx, &pi0, &pj0, 1), "set_pairs");
             check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
-            lineCodes.resize((size_t)2 * nSamples);
             haveHeader = true;
             if (windowSize > 0) {                                    // fst.cpp:507-520
                 if (windowSize == windowStep) {
@@ -377,19 +395,8 @@ int fstMain(int argc, char **argv) {
         }
         if (!haveHeader) die("variant line before the #CHROM header");
         totalVariantNumber++;
-        uint32_t fl = 0;
-        const char *chrom = nullptr, *pos = nullptr;
-        std::vector<char> lb(line.begin(), line.end()); lb.push_back('\0');
-        if (evofst_codes_from_vcf_line(lb.data(), EVOFST_MODE_FST, nSamples, lineCodes.data(), &fl, &chrom, &pos) != EVOFST_OK)
-            die("malformed VCF line " + numToString(totalVariantNumber) + " (diploid GT fields with single-digit alleles are required)");
-        const size_t o = batch.codes.size();
-        batch.codes.resize(o + (size_t)2 * nVirtual);
-        for (int v = 0; v < nVirtual; ++v) {
-            batch.codes[o + 2 * v] = lineCodes[2 * virt[v]];
-            batch.codes[o + 2 * v + 1] = lineCodes[2 * virt[v] + 1];
-        }
-        batch.flags.push_back((uint8_t)fl); batch.chrom.emplace_back(chrom); batch.pos.emplace_back(pos);
-        if (++batch.n == (size_t)kChunkSites) flush();
+        batch.add(line, totalVariantNumber);
+        if (batch.n == (size_t)kChunkSites) flush();
         if (totalVariantNumber % 100000 == 0) std::cerr << totalVariantNumber << " variants processed..." << std::endl;
     }
     flush();
@@ -494,7 +501,7 @@ int FstGlobalMain(int argc, char **argv) {
     auto flush = [&]() {
         if (batch.n == 0) return;
         const size_t n = batch.n;
-        dev.load(batch);
+        dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
         num.resize(nUse * n); den.resize(nUse * n); kept.resize(n);
         check(dev.ctx, evofst_get_global_site_stats(dev.ctx, 0, (int64_t)n, num.data(), den.data(), kept.data()), "global_site_stats");
         x86_nan_sign(num); x86_nan_sign(den);
@@ -532,7 +539,6 @@ int FstGlobalMain(int argc, char **argv) {
         batch.clear();
     };
 
-    std::vector<uint8_t> lineCodes;
     while (vcf.getline(line)) {
         line.erase(std::remove(line.begin(), line.end(), '\r'), line.end());   // :146
         if (line[0] == '#' && line[1] == '#') continue;
@@ -562,21 +568,14 @@ int FstGlobalMain(int argc, char **argv) {
             check(dev.ctx, evofst_set_layout(dev.ctx, nSamples, (int)populations.size(), sp.data()), "set_layout");
             check(dev.ctx, evofst_set_against_all(dev.ctx, use.data(), (int)nUse, setSizes.data()), "set_against_all");
             check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
-            lineCodes.resize((size_t)2 * nSamples);
             haveHeader = true;
             continue;
         }
         if (!haveHeader) die("variant line before the #CHROM header");
         totalVariantNumber++;
         if (totalVariantNumber % 10000 == 0) std::cerr << "Processed " << totalVariantNumber << " variants" << std::endl;
-        uint32_t fl = 0;
-        const char *chrom = nullptr, *pos = nullptr;
-        std::vector<char> lb(line.begin(), line.end()); lb.push_back('\0');
-        if (evofst_codes_from_vcf_line(lb.data(), EVOFST_MODE_GLOBAL, nSamples, lineCodes.data(), &fl, &chrom, &pos) != EVOFST_OK)
-            die("malformed VCF line " + numToString(totalVariantNumber));
-        batch.codes.insert(batch.codes.end(), lineCodes.begin(), lineCodes.end());
-        batch.flags.push_back((uint8_t)fl); batch.chrom.emplace_back(chrom); batch.pos.emplace_back(pos);
-        if (++batch.n == (size_t)kChunkSites) flush();
+        batch.add(line, totalVariantNumber);
+        if (batch.n == (size_t)kChunkSites) flush();
     }
     flush();
     if (dev.ctx) evofst_destroy(dev.ctx);

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 using namespace evofst;
@@ -469,23 +471,26 @@ extern "C" int evofst_unpack_codes(const evofst_ctx *c, int64_t first_site, int6
     return EVOFST_OK;
 }
 
-extern "C" int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, uint8_t *codes, uint32_t *site_flags,
-                                          const char **chrom, const char **pos) {
-    if (!line || !codes || !site_flags || n_samples <= 0) return EVOFST_ERR_ARG;
+namespace {
+
+// One VCF data line -> allele codes of its n_samples genotype columns + site flags, without touching the text.
+// cols[0..1] receive the starts of CHROM and POS, col_len their lengths.
+int parse_vcf_line(const char *line, int mode, int n_samples, uint8_t *codes, uint32_t *site_flags,
+                   const char **cols, size_t *col_len) {
     // columns: CHROM POS ID REF ALT QUAL FILTER INFO FORMAT samples...
-    char *col[9];
-    char *p = line;
+    const char *col[9];
+    size_t len[9];
+    const char *p = line;
     for (int i = 0; i < 9; ++i) {
         col[i] = p;
-        char *t = std::strchr(p, '\t');
+        const char *t = std::strchr(p, '\t');
         if (!t) return EVOFST_ERR_ARG;
-        *t = '\0';
+        len[i] = (size_t)(t - p);
         p = t + 1;
     }
-    if (chrom) *chrom = col[0];
-    if (pos) *pos = col[1];
-    const char *ref = col[3];
-    char *alt = col[4];
+    if (cols) { cols[0] = col[0]; cols[1] = col[1]; col_len[0] = len[0]; col_len[1] = len[1]; }
+    const size_t ref_len = len[3], alt_len = len[4];
+    const char *alt = col[4], *alt_end = col[4] + alt_len;
     uint32_t fl = 0;
     int alt_code = 1, allele_as_missing = -1;
     if (mode == EVOFST_MODE_FST) {
@@ -494,23 +499,23 @@ extern "C" int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, u
         int n_alt = 0, idx = 0;
         bool indel = false;
         const char *a = alt;
-        if (*a != '\0') {
+        if (a != alt_end) {
             for (;;) {
-                const char *e = std::strchr(a, ',');
-                const size_t len = e ? (size_t)(e - a) : std::strlen(a);
+                const char *e = (const char *)std::memchr(a, ',', (size_t)(alt_end - a));
+                const size_t l = e ? (size_t)(e - a) : (size_t)(alt_end - a);
                 ++idx; ++n_alt;
-                if (len == 1 && a[0] == '*') { --n_alt; allele_as_missing = idx; }
-                if (len > 1) indel = true;
+                if (l == 1 && a[0] == '*') { --n_alt; allele_as_missing = idx; }
+                if (l > 1) indel = true;
                 if (!e) break;
                 a = e + 1;
-                if (*a == '\0') break;
+                if (a == alt_end) break;
             }
         }
         if (n_alt == 1 && allele_as_missing == 1) alt_code = 2;
-        if (std::strlen(ref) > 1 || n_alt != 1 || indel) fl |= EVOFST_SITE_SKIP;  // :529-532, :543
+        if (ref_len > 1 || n_alt != 1 || indel) fl |= EVOFST_SITE_SKIP;  // :529-532, :543
     } else {
-        if (std::strlen(ref) > 1 || std::strlen(alt) > 1 || std::strcmp(alt, "*") == 0)
-            fl |= EVOFST_SITE_SKIP;                                               // FstAgainstAll.cpp:185
+        if (ref_len > 1 || alt_len > 1 || (alt_len == 1 && alt[0] == '*'))
+            fl |= EVOFST_SITE_SKIP;                                       // FstAgainstAll.cpp:185
     }
     *site_flags = fl;
     if (fl & EVOFST_SITE_SKIP) {
@@ -535,7 +540,7 @@ extern "C" int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, u
             }
             codes[2 * i + h] = code;
         }
-        char *t = std::strchr(p, '\t');
+        const char *t = std::strchr(p + 3, '\t');
         if (!t) {
             if (i != n_samples - 1) return EVOFST_ERR_ARG;
             break;
@@ -543,6 +548,84 @@ extern "C" int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, u
         p = t + 1;
     }
     return EVOFST_OK;
+}
+
+}  // namespace
+
+extern "C" int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, uint8_t *codes, uint32_t *site_flags,
+                                          const char **chrom, const char **pos) {
+    if (!line || !codes || !site_flags || n_samples <= 0) return EVOFST_ERR_ARG;
+    const char *cols[2];
+    size_t len[2];
+    const int rc = parse_vcf_line(line, mode, n_samples, codes, site_flags, cols, len);
+    if (rc != EVOFST_OK) return rc;
+    // CHROM and POS are handed back as C strings inside the caller's buffer
+    line[(cols[0] - line) + len[0]] = '\0';
+    line[(cols[1] - line) + len[1]] = '\0';
+    if (chrom) *chrom = cols[0];
+    if (pos) *pos = cols[1];
+    return EVOFST_OK;
+}
+
+// K0 in bulk: parse + pack a block of VCF lines on n_threads host threads (a thread owns whole tiles of 64 sites).
+extern "C" int evofst_pack_vcf_lines(const evofst_ctx *c, int mode, int64_t n_lines, const char *const *lines,
+                                     int n_vcf_samples, const int32_t *layout_to_vcf, int n_threads, void *tiles,
+                                     uint8_t *site_flags) {
+    if (!c || !lines || !tiles || !site_flags || n_lines < 0 || n_vcf_samples <= 0) return EVOFST_ERR_ARG;
+    if (c->n_pops == 0) return EVOFST_ERR_STATE;
+    if (mode != EVOFST_MODE_FST && mode != EVOFST_MODE_GLOBAL) return EVOFST_ERR_ARG;
+    // haplotype of the packed layout -> index into a line's code row
+    std::vector<int32_t> src((size_t)c->H);
+    for (int h = 0; h < c->H; ++h) {
+        const int32_t lh = c->src_hap[h];                   // layout sample * 2 + hap
+        const int32_t vs = layout_to_vcf ? layout_to_vcf[lh >> 1] : (lh >> 1);
+        if (vs < 0 || vs >= n_vcf_samples) return EVOFST_ERR_ARG;
+        src[h] = 2 * vs + (lh & 1);
+    }
+    const int64_t n_tiles = (n_lines + kTileSites - 1) / kTileSites;
+    n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(n_threads, 64), n_tiles));
+    std::atomic<int64_t> next{0};
+    std::atomic<int> status{EVOFST_OK};
+    uint64_t *out = (uint64_t *)tiles;
+    const int W = c->W, H = c->H;
+    auto work = [&]() {
+        std::vector<uint8_t> codes((size_t)2 * n_vcf_samples);
+        for (;;) {
+            const int64_t t = next.fetch_add(1);
+            if (t >= n_tiles || status.load() != EVOFST_OK) break;
+            for (int s = 0; s < kTileSites; ++s) {
+                const int64_t site = t * kTileSites + s;
+                uint64_t *tp = out + ((size_t)t * W * kTileSites + (size_t)s) * 2;
+                if (site >= n_lines) {                      // padding sites of the last tile
+                    for (int w = 0; w < W; ++w) { tp[(size_t)w * kTileSites * 2] = 0; tp[(size_t)w * kTileSites * 2 + 1] = 0; }
+                    continue;
+                }
+                uint32_t fl = 0;
+                if (!lines[site] || parse_vcf_line(lines[site], mode, n_vcf_samples, codes.data(), &fl, nullptr, nullptr) != EVOFST_OK) {
+                    status.store(EVOFST_ERR_ARG);
+                    break;
+                }
+                site_flags[site] = (uint8_t)fl;
+                for (int w = 0; w < W; ++w) {
+                    uint64_t alt = 0, miss = 0;
+                    const int b1 = std::min(64, H - w * 64);
+                    const int32_t *sp = src.data() + (size_t)w * 64;
+                    for (int b = 0; b < b1; ++b) {
+                        const uint8_t code = codes[sp[b]];
+                        alt |= (uint64_t)(code == EVOFST_ALT) << b;
+                        miss |= (uint64_t)(code == EVOFST_MISSING) << b;
+                    }
+                    tp[(size_t)w * kTileSites * 2] = alt;
+                    tp[(size_t)w * kTileSites * 2 + 1] = miss;
+                }
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n_threads; ++i) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+    return status.load();
 }
 
 // ================================================================== device data

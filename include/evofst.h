@@ -106,6 +106,15 @@ int evofst_unpack_codes(const evofst_ctx *ctx, int64_t first_site, int64_t n_sit
  * shorter than 3 characters (the reference reads chars [0] and [2] unchecked). */
 int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, uint8_t *codes,
                                uint32_t *site_flags, const char **chrom, const char **pos);
+/* The same for a block of lines, parsed and packed straight into tiles on n_threads host threads (the reference's
+ * per-line split() + char tests, process_vcf_utils.cpp:104-130 and process_vcf_fst.cpp:243-280, are its largest
+ * cost: SURVEY 8a row 1).  lines[i] are NUL-terminated data lines and are not modified; layout_to_vcf[k] = VCF
+ * genotype column (0-based) of sample k of evofst_set_layout (NULL: identity); tiles as evofst_pack_codes writes
+ * them for sites 0 .. n_lines-1 (evofst_tiles_bytes(ctx, n_lines) bytes), site_flags[n_lines].  Returns
+ * EVOFST_ERR_ARG if any line is malformed. */
+int evofst_pack_vcf_lines(const evofst_ctx *ctx, int mode, int64_t n_lines, const char *const *lines,
+                          int n_vcf_samples, const int32_t *layout_to_vcf, int n_threads, void *tiles,
+                          uint8_t *site_flags);
 
 /* ------------------------------------------------------------------ device data */
 
