@@ -1240,44 +1240,65 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     auto vec_at = [&](int t, int j) {
         return *reinterpret_cast<const uint4 *>(cbase + ((size_t)t * p.P + k) * kTileSites + (size_t)j * EPT);
     };
+    // totals {sum alt, sum nm} of the same EPT sites: EPT x 8 bytes, wave-uniform
+    constexpr int TV = EPT / 2;                        // 16-byte vectors of totals per count vector
+    auto tot_at = [&](int t, int j, uint4 (&dst)[TV]) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.totals + (size_t)t * kTileSites + (size_t)j * EPT);
+#pragma unroll
+        for (int x = 0; x < TV; ++x) dst[x] = src[x];
+    };
     uint4 nxt = vec_at(th, 0);
+    uint4 nxt_tot[TV];
+    tot_at(th, 0, nxt_tot);
+    uint32_t urem = (uint32_t)(used % p.step);         // used modulo STEP, carried in 32 bits
     for (int t = th; t < t1; ++t) {
         const uint64_t km = p.kept_mask[t], sm = p.skip_mask[t];
         const bool replay = t < t0;
 #pragma unroll 1
         for (int j = 0; j < VPT; ++j) {
             const uint4 cur = nxt;
+            uint4 cur_tot[TV];
+#pragma unroll
+            for (int x = 0; x < TV; ++x) cur_tot[x] = nxt_tot[x];
             {   // prefetch the next vector of this lane's row (clamped at the end of the chunk)
                 int tn = t, jn = j + 1;
                 if (jn == VPT) { jn = 0; tn = min(t + 1, t1 - 1); }
                 nxt = vec_at(tn, jn);
+                tot_at(tn, jn, nxt_tot);
             }
             const uint32_t kb = (uint32_t)(km >> (j * EPT)) & ((1u << EPT) - 1u);
             const uint32_t sb = (uint32_t)(sm >> (j * EPT)) & ((1u << EPT) - 1u);
             if (kb == 0u) {                       // nothing kept among these sites: only the used counter moves
-                if (!replay) used += EPT - __popc(sb);
+                if (!replay) { const uint32_t n = EPT - __popc(sb); used += n; urem = (urem + n) % (uint32_t)p.step; }
                 continue;
             }
-            const uint64_t lo = (uint64_t)cur.x | ((uint64_t)cur.y << 32), hi = (uint64_t)cur.z | ((uint64_t)cur.w << 32);
+            // 1) the EPT sites' values, independent of each other (no branches: the chains overlap)
+            double numv[EPT], denv[EPT];
+            {
+                const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const uint32_t v = (cw[(e * EB) / 32] >> ((e * EB) % 32)) & (uint32_t)((1ull << EB) - 1ull);
+                    const uint4 tv = cur_tot[e / 2];
+                    const uint32_t Tc = (e & 1) ? tv.z : tv.x, Tn = (e & 1) ? tv.w : tv.y;
+                    global_eval<RCP>(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, Tc, Tn, thr, rcp, numv[e], denv[e]);
+                }
+            }
+            // 2) the deque walk, in site order
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 if ((sb >> e) & 1u) continue;
-                if (!replay) ++used;
+                if (!replay) { ++used; urem = urem + 1 == (uint32_t)p.step ? 0u : urem + 1; }
                 if (!((kb >> e) & 1u)) continue;
                 if (replay && drop > 0) { --drop; continue; }
                 const int site = t * kTileSites + j * EPT + e;
-                const uint2 T = p.totals[site];
-                const uint64_t half = e < EPT / 2 ? lo : hi;
-                const uint32_t v = (uint32_t)(half >> (EB * (e & (EPT / 2 - 1)))) & (uint32_t)((1ull << EB) - 1ull);
                 if (active) {
-                    double num, den;
-                    global_eval<RCP>(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, T.x, T.y, thr, rcp, num, den);
-                    ring_n[(size_t)head * p.n_use + u] = num;
-                    ring_d[(size_t)head * p.n_use + u] = den;
+                    ring_n[(size_t)head * p.n_use + u] = numv[e];
+                    ring_d[(size_t)head * p.n_use + u] = denv[e];
                 }
                 if (threadIdx.x == 0) ring_s[head] = site;
                 head = head + 1 == p.size ? 0 : head + 1;
-                if (!replay && (used > p.size || p.size == p.step) && (used % p.step == 0)) {
+                if (!replay && (used > p.size || p.size == p.step) && urem == 0u) {
                     if (active) {
                         double an = 0.0, ad = 0.0;
                         int idx = head;
