@@ -907,6 +907,8 @@ extern "C" int evofst_run_counts(evofst_ctx *c) {
     int rc;
     if (c->mode == MODE_PAIRS) {
         p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)c->pairs.size();
+        if ((size_t)p.n_pairs * 20 + (size_t)c->n_pops * 128 + (size_t)c->segs.size() * 16 > 140 * 1024)
+            return fail(c, EVOFST_ERR_UNSUPPORTED, "run_counts: too many pairs for the per-chunk census in LDS (use the Gram path: evofst_set_gram)");
         if ((rc = ensure(c, c->d_census, (size_t)c->n_chunks * p.n_pairs * 4))) return rc;
         p.chunk_census = (uint32_t *)c->d_census.p;
         if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 16))) return rc;

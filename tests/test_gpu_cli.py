@@ -138,6 +138,17 @@ def test_cli_fstglobal_outgroup_sorts_first(tmp_path):
     _global_case(tmp_path, np.random.default_rng(9), ["-w", "20,10"], 20, 10, pops=["zeta", "Outgroup", "yak", "xxx", "wolf"])
 
 
+def test_cli_fst_several_device_batches(tmp_path):
+    """70 k sites: the front-end hands the device three batches of 32768 lines; windows and the bp-window
+    table run across the batch edges."""
+    _fst_case(tmp_path, np.random.default_rng(21), ["-w", "50,50", "--physicalWindowSize=5000"], 50, 50, n_sites=70000,
+              n_samples=8, scaffolds=("scaffold_0", "chrB", "chrC"), phys=5000)
+
+
+def test_cli_fstglobal_several_device_batches(tmp_path):
+    _global_case(tmp_path, np.random.default_rng(22), [], 20, 10, n_sites=70000, n_samples=8, pops=["popA", "popB", "popC"])
+
+
 def test_cli_rejects_unknown_command():
     r = subprocess.run([EVO, "stats"], capture_output=True, text=True)
     assert r.returncode != 0 and "Unrecognized command" in r.stderr
