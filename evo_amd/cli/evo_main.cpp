@@ -582,20 +582,149 @@ int FstGlobalMain(int argc, char **argv) {
     return 0;
 }
 
+// ===================================================================================== alleleFreq
+
+namespace afopt { string vcfFile, setsFile, runName = "out"; }
+
+const char *AF_USAGE =
+    "Usage: evo alleleFreq [OPTIONS] INPUT_FILE.vcf POPULATIONS.txt\n"
+    "Calculate the Allele Frequencies per population/species from a VCF \n"
+    "       -h, --help                              display this help and exit\n"
+    "       -n, --run-name                          run-name will be included in the output file name\n\n";
+
+string stripExtension(const string &filename) {                      // process_vcf_utils.cpp:164-171
+    size_t suffixPos = filename.find_last_of('.');
+    return suffixPos == string::npos ? filename : filename.substr(0, suffixPos);
+}
+
+// evo alleleFreq (AFmain, evo_AlleleFeq.cpp:46-166) without --use-genotype-probabilities: the per-population
+// counts come from K1, the frequency is alt / called alleles, or -1 for a population without a called allele.
+int AFmain(int argc, char **argv) {
+    using namespace afopt;
+    static const struct option longopts[] = {{"help", no_argument, NULL, 'h'}, {"run-name", required_argument, NULL, 'n'},
+                                             {"use-genotype-probabilities", no_argument, NULL, 'g'}, {NULL, 0, NULL, 0}};
+    bool dieFlag = false;
+    for (int c; (c = getopt_long(argc, argv, "hn:g", longopts, NULL)) != -1;) {
+        std::istringstream arg(optarg != NULL ? optarg : "");
+        switch (c) {
+            case '?': dieFlag = true; break;
+            case 'n': arg >> runName; break;
+            case 'g': die("--use-genotype-probabilities is not carried by the GPU build");
+            case 'h': std::cout << AF_USAGE; exit(EXIT_SUCCESS);
+        }
+    }
+    if (argc - optind < 2) { std::cerr << "missing arguments\n"; dieFlag = true; }
+    else if (argc - optind > 2) { std::cerr << "too many arguments\n"; dieFlag = true; }
+    if (dieFlag) { std::cout << "\n" << AF_USAGE; exit(EXIT_FAILURE); }
+    vcfFile = argv[optind++]; setsFile = argv[optind++];
+
+    LineReader vcf(vcfFile);
+    std::ifstream setsF(setsFile.c_str());
+    if (!setsF.is_open()) die("could not open " + setsFile);
+    std::map<string, std::vector<string>> popToIDsMap;
+    std::map<string, string> IDsToPopMap;
+    string line;
+    while (getline(setsF, line)) {                                   // AlleleFeq.cpp:62-68
+        std::vector<string> ID_Pop = split(line, '\t');
+        if (ID_Pop.size() < 2) die("POPULATIONS.txt needs two tab-separated columns per line");
+        popToIDsMap[ID_Pop[1]].push_back(ID_Pop[0]);
+        IDsToPopMap[ID_Pop[0]] = ID_Pop[1];
+    }
+    std::vector<string> populations;
+    std::map<string, int> popIndex;
+    for (auto &kv : popToIDsMap) { popIndex[kv.first] = (int)populations.size(); populations.push_back(kv.first); }
+    std::cerr << "There are " << populations.size() << " populations " << std::endl;
+    std::ofstream out((stripExtension(setsFile) + "_" + runName + "_AF" + ".txt").c_str());   // :82
+    if (!out.is_open()) die("could not open the output file");
+
+    const size_t P = populations.size();
+    Device dev;
+    Batch batch;
+    std::vector<string> refs, alts;
+    int nSamples = 0, totalVariantNumber = 0;
+    std::vector<int32_t> altc, nmc;
+    bool haveHeader = false;
+    auto flush = [&]() {
+        if (batch.n == 0) return;
+        const size_t n = batch.n;
+        dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
+        altc.resize(n * P); nmc.resize(n * P);
+        check(dev.ctx, evofst_get_counts(dev.ctx, 0, (int64_t)n, altc.data(), nmc.data()), "get_counts");
+        for (size_t s = 0; s < n; ++s) {
+            if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :124-127
+            out << batch.chrom[s] << "\t" << batch.pos[s] << "\t" << refs[s] << "\t" << alts[s];
+            for (size_t k = 0; k < P; ++k) {                          // utils.cpp:56-58, setAAFs init -1.0 (utils.h:75)
+                double aaf = -1.0;
+                if (nmc[s * P + k] > 0) aaf = (double)altc[s * P + k] / nmc[s * P + k];
+                out << "\t" << aaf;
+            }
+            out << "\n";
+        }
+        batch.clear(); refs.clear(); alts.clear();
+    };
+    while (vcf.getline(line)) {
+        line.erase(std::remove(line.begin(), line.end(), '\r'), line.end());   // :85
+        if (line[0] == '#' && line[1] == '#') continue;
+        if (line[0] == '#' && line[1] == 'C') {
+            std::vector<string> fields = split(line, '\t');
+            std::vector<string> sampleNames(fields.begin() + std::min<size_t>(9, fields.size()), fields.end());
+            nSamples = (int)sampleNames.size();
+            if (nSamples <= 0) die("VCF header has no sample columns");
+            std::vector<int32_t> sp(nSamples, -1);
+            for (int i = 0; i < nSamples; ++i) {
+                auto it = IDsToPopMap.find(sampleNames[i]);
+                if (it != IDsToPopMap.end()) sp[i] = popIndex[it->second];
+            }
+            for (auto &kv : popToIDsMap)                              // :100-109
+                if (locateSet(sampleNames, kv.second).empty()) { std::cerr << "Did not find any samples in the VCF for \"" << kv.first << "\"" << std::endl; exit(EXIT_FAILURE); }
+            for (size_t k = 0; k < P; ++k)
+                if (std::find(sp.begin(), sp.end(), (int32_t)k) == sp.end()) die("population \"" + populations[k] + "\" has no sample column of its own");
+            dev.open();
+            check(dev.ctx, evofst_set_layout(dev.ctx, nSamples, (int)P, sp.data()), "set_layout");
+            check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
+            haveHeader = true;
+            continue;
+        }
+        if (!haveHeader) die("variant line before the #CHROM header");
+        totalVariantNumber++;
+        if (totalVariantNumber == 1) {                                // :114-120
+            out << "chr" << "\t" << "coord" << "\t" << "ref" << "\t" << "alt";
+            for (auto &kv : popToIDsMap) out << "\t" << kv.first;
+            out << "\n";
+        }
+        if (totalVariantNumber % 10000 == 0) std::cerr << "Processed " << totalVariantNumber << " variants" << std::endl;
+        {   // REF and ALT as written (columns 4 and 5)
+            size_t p0 = 0;
+            for (int f = 0; f < 3; ++f) { p0 = line.find('\t', p0); if (p0 == string::npos) die("malformed VCF line " + numToString(totalVariantNumber)); ++p0; }
+            const size_t p1 = line.find('\t', p0);
+            const size_t p2 = p1 == string::npos ? string::npos : line.find('\t', p1 + 1);
+            if (p2 == string::npos) die("malformed VCF line " + numToString(totalVariantNumber));
+            refs.emplace_back(line, p0, p1 - p0); alts.emplace_back(line, p1 + 1, p2 - p1 - 1);
+        }
+        batch.add(line, totalVariantNumber);
+        if (batch.n == (size_t)kChunkSites) flush();
+    }
+    flush();
+    out.flush();
+    if (dev.ctx) evofst_destroy(dev.ctx);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc <= 1) {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal\n";
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq\n";
         return 0;
     }
     string command(argv[1]);
     if (command == "fst") return fstMain(argc - 1, argv + 1);
     if (command == "FstGlobal") return FstGlobalMain(argc - 1, argv + 1);
+    if (command == "alleleFreq") return AFmain(argc - 1, argv + 1);
     if (command == "help" || command == "--help") {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal\n" << FST_USAGE << FSTGLOBAL_USAGE;
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq\n" << FST_USAGE << FSTGLOBAL_USAGE << AF_USAGE;
         return 0;
     }
-    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal)\n";
+    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal, alleleFreq)\n";
     return 1;
 }

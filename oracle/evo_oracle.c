@@ -974,6 +974,124 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
 }
 
 /* ===================================================================== */
+/* `evo alleleFreq [-n] VCF POPS` (AFmain, evo_AlleleFeq.cpp:46-166)     */
+/* without --use-genotype-probabilities.  The reference writes next to   */
+/* the populations file; here the file goes to out_dir under the same    */
+/* base name.                                                            */
+/* ===================================================================== */
+int orc_af_run(const char *vcf_path, const char *pops_path, const char *run_name, const char *out_dir) {
+    lreader vcf;
+    if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
+    FILE *sf = fopen(pops_path, "r");
+    if (!sf) { lr_close(&vcf); return -2; }
+    /* :62-68  popToIDsMap / IDsToPopMap (a later line with the same ID overwrites its pop) */
+    pop_t *pops = NULL; int n_pops = 0, pcap = 0;
+    char **id_names = NULL; char **id_pop = NULL; int n_ids = 0, icap = 0;
+    {
+        char *l = NULL; size_t cap = 0; ssize_t r;
+        while ((r = getline(&l, &cap, sf)) >= 0) {
+            if (r && l[r - 1] == '\n') l[r - 1] = '\0';
+            char *tab = strchr(l, '\t');
+            if (!tab) continue;
+            *tab = '\0';
+            char *id = l, *pn = tab + 1;
+            char *tab2 = strchr(pn, '\t'); if (tab2) *tab2 = '\0';
+            int k = -1;
+            for (int i = 0; i < n_pops; i++) if (strcmp(pops[i].name, pn) == 0) { k = i; break; }
+            if (k < 0) {
+                if (n_pops == pcap) { pcap = pcap ? pcap * 2 : 16; pops = (pop_t *)realloc(pops, sizeof(pop_t) * (size_t)pcap); }
+                k = n_pops++;
+                memset(&pops[k], 0, sizeof(pop_t));
+                pops[k].name = strdup(pn);
+            }
+            pop_t *P = &pops[k];
+            if (P->n_ids == P->cap) { P->cap = P->cap ? P->cap * 2 : 16; P->ids = (char **)realloc(P->ids, sizeof(char *) * (size_t)P->cap); }
+            P->ids[P->n_ids++] = strdup(id);
+            int found = -1;
+            for (int i = 0; i < n_ids; i++) if (strcmp(id_names[i], id) == 0) { found = i; break; }
+            if (found < 0) {
+                if (n_ids == icap) { icap = icap ? icap * 2 : 64; id_names = (char **)realloc(id_names, sizeof(char *) * (size_t)icap); id_pop = (char **)realloc(id_pop, sizeof(char *) * (size_t)icap); }
+                id_names[n_ids] = strdup(id); id_pop[n_ids] = strdup(pn); n_ids++;
+            } else { free(id_pop[found]); id_pop[found] = strdup(pn); }
+        }
+        free(l); fclose(sf);
+    }
+    qsort(pops, (size_t)n_pops, sizeof(pop_t), cmp_pop);    /* std::map order */
+    fprintf(stderr, "There are %d populations \n", n_pops);
+    /* :82 stripExtension(setsFile) + "_" + runName + "_AF.txt" */
+    const char *slash = strrchr(pops_path, '/');
+    char *base = strdup(slash ? slash + 1 : pops_path);
+    { char *dot = strrchr(base, '.'); if (dot) *dot = '\0'; }
+    char name[768];
+    snprintf(name, sizeof name, "%s_%s_AF.txt", base, run_name);
+    free(base);
+    char *op = path_join(out_dir, name); FILE *out = fopen(op, "w"); free(op);
+    if (!out) { lr_close(&vcf); return -3; }
+
+    uint8_t *use_pop = (uint8_t *)calloc((size_t)n_pops + 1, 1);
+    int32_t *sample_pop = NULL; int n_samples = 0;
+    char **fields = NULL; int fcap = 0;
+    int *alt = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1)), *alleles = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1));
+    int *allelesC = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1));
+    double *aaf = (double *)malloc(sizeof(double) * (size_t)(n_pops + 1)), *aafC = (double *)malloc(sizeof(double) * (size_t)(n_pops + 1));
+    int totalVariantNumber = 0, rc = 0;
+    char *line;
+    while ((line = lr_getline(&vcf)) != NULL) {
+        { char *w = line; for (char *r = line; *r; r++) if (*r != '\r') *w++ = *r; *w = '\0'; }   /* :85 */
+        if (line[0] == '#' && line[1] == '#') continue;
+        else if (line[0] == '#' && line[1] == 'C') {
+            char *hdr = strdup(line); char **hf = NULL; int hcap = 0;
+            int nh = split_inplace(hdr, '\t', &hf, &hcap);
+            n_samples = nh - 9; if (n_samples < 0) n_samples = 0;
+            sample_pop = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_samples + 1));
+            for (int i = 0; i < n_samples; i++) {            /* :92-94 */
+                sample_pop[i] = -1;
+                for (int j = 0; j < n_ids; j++)
+                    if (strcmp(id_names[j], hf[9 + i]) == 0) {
+                        for (int k = 0; k < n_pops; k++) if (strcmp(pops[k].name, id_pop[j]) == 0) sample_pop[i] = k;
+                        break;
+                    }
+            }
+            for (int k = 0; k < n_pops; k++) {               /* :97-108 */
+                pops[k].pos = (size_t *)malloc(sizeof(size_t) * (size_t)(pops[k].n_ids + 1));
+                pops[k].n_pos = locate_set(hf + 9, n_samples, pops[k].ids, pops[k].n_ids, pops[k].pos);
+                if (pops[k].n_pos == 0) {
+                    fprintf(stderr, "Did not find any samples in the VCF for \"%s\"\n", pops[k].name);
+                    rc = -4;
+                }
+            }
+            free(hf); free(hdr);
+            if (rc) break;
+        } else {
+            totalVariantNumber++;
+            if (totalVariantNumber == 1) {                   /* :114-120 */
+                fprintf(out, "chr\tcoord\tref\talt");
+                for (int k = 0; k < n_pops; k++) fprintf(out, "\t%s", pops[k].name);
+                fprintf(out, "\n");
+            }
+            int nf = split_inplace(line, '\t', &fields, &fcap);
+            if (nf < 9) continue;
+            if (orc_general_site_flags(fields[3], fields[4]) & ORC_SITE_SKIP) continue;   /* :124-127 */
+            orc_general_counts((const char *const *)(fields + 9), n_samples, sample_pop, n_pops, use_pop,
+                               alt, alleles, aaf, allelesC, aafC);
+            fprintf(out, "%s\t%s\t%s\t%s", fields[0], fields[1], fields[3], fields[4]);
+            for (int k = 0; k < n_pops; k++) fprintf(out, "\t%g", aaf[k]);   /* setAAFs in map order, :149-151 */
+            fprintf(out, "\n");
+        }
+    }
+    fclose(out); lr_close(&vcf);
+    free(fields); free(sample_pop); free(alt); free(alleles); free(allelesC); free(aaf); free(aafC); free(use_pop);
+    for (int k = 0; k < n_pops; k++) {
+        for (int i = 0; i < pops[k].n_ids; i++) free(pops[k].ids[i]);
+        free(pops[k].ids); free(pops[k].pos); free(pops[k].name);
+    }
+    free(pops);
+    for (int i = 0; i < n_ids; i++) { free(id_names[i]); free(id_pop[i]); }
+    free(id_names); free(id_pop);
+    return rc;
+}
+
+/* ===================================================================== */
 /* checker for the kernels' reciprocal-table division (no reference      */
 /* counterpart): counts (c, nm) pairs for which                          */
 /*   q0 = a*r; e = fma(-q0,b,a); q = fma(e,r,q0),  r = RN(1/b)           */

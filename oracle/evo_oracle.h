@@ -177,6 +177,10 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
                       int window_size, int window_step, int fixed_window_size,
                       const char *run_name, const char *out_dir);
 
+/* `evo alleleFreq [-n] VCF POPS` (AFmain, evo_AlleleFeq.cpp:46-166) without -g; the output file
+ * <pops base name>_<run_name>_AF.txt is written into out_dir. */
+int orc_af_run(const char *vcf_path, const char *pops_path, const char *run_name, const char *out_dir);
+
 /* checker for the kernels' reciprocal-table division; returns the number of mismatches */
 long orc_check_rcp_division(int max_n);
 

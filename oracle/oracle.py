@@ -105,6 +105,8 @@ def lib():
         L.orc_fst_run.restype = C.c_int
         L.orc_fst_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                   C.c_double, C.c_char_p, C.c_char_p, _dp]
+        L.orc_af_run.restype = C.c_int
+        L.orc_af_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
         L.orc_fstglobal_run.restype = C.c_int
         L.orc_fstglobal_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                         C.c_char_p, C.c_char_p]
@@ -256,6 +258,12 @@ def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_abo
     if rc != 0:
         raise RuntimeError("orc_fst_run failed: %d" % rc)
     return summ
+
+
+def af_run(vcf, pops, out_dir, run_name="out"):
+    rc = lib().orc_af_run(vcf.encode(), pops.encode(), run_name.encode(), out_dir.encode())
+    if rc != 0:
+        raise RuntimeError("orc_af_run failed: %d" % rc)
 
 
 def fstglobal_run(vcf, pops, out_dir, run_name="", size=20, step=10, fixed=10000):

@@ -149,6 +149,28 @@ def test_cli_fstglobal_several_device_batches(tmp_path):
     _global_case(tmp_path, np.random.default_rng(22), [], 20, 10, n_sites=70000, n_samples=8, pops=["popA", "popB", "popC"])
 
 
+def test_cli_allele_freq(tmp_path):
+    """evo alleleFreq: per-population allele frequencies straight from K1's counts, -1 where a
+    population has no called allele; the file is written next to the populations file, as the reference does."""
+    rng = np.random.default_rng(31)
+    cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
+    cli_dir.mkdir(); orc_dir.mkdir()
+    vcf = str(tmp_path / "in.vcf")
+    names = write_vcf(vcf, rng, 40000, 10, scaffolds=("chr1", "chr2"), crlf=True, miss=0.3)
+    pf = str(cli_dir / "pops.v2.txt")
+    with open(pf, "w") as f:
+        for i, n in enumerate(names):
+            if i != 4:
+                f.write("%s\t%s\n" % (n, ["popB", "Outgroup", "popA"][i % 3]))
+    r = subprocess.run([EVO, "alleleFreq", "-n", "af", vcf, pf], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    O.af_run(vcf, pf, str(orc_dir), run_name="af")
+    got = cli_dir / "pops.v2_af_AF.txt"
+    assert got.exists()
+    assert filecmp.cmp(str(got), str(orc_dir / "pops.v2_af_AF.txt"), shallow=False)
+    assert sum(1 for _ in open(got)) > 30000
+
+
 def test_cli_rejects_unknown_command():
     r = subprocess.run([EVO, "stats"], capture_output=True, text=True)
     assert r.returncode != 0 and "Unrecognized command" in r.stderr
