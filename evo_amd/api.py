@@ -76,6 +76,7 @@ SIGNATURES = {
     "evofst_get_counts": (C.c_int, [_vp, C.c_int64, C.c_int64, _i32p, _i32p]),
     "evofst_get_included_totals": (C.c_int, [_vp, _i64p]),
     "evofst_get_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp, _u8p]),
+    "evofst_get_pbs_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i32p, _dp, _u8p]),
     "evofst_get_pop_site_div": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp]),
     "evofst_max_segments": (C.c_int64, [_vp]),
     "evofst_get_segments": (C.c_int, [_vp, _i64p, _i64p, _dp, _dp, _dp, _i32p]),
@@ -344,6 +345,14 @@ class EvoFst:
         self._chk(self.L.evofst_get_site_stats(self.h, first, n, _ptr(num, _dp), _ptr(den, _dp), _ptr(dxy, _dp),
                                                _ptr(inc, _u8p)))
         return num, den, dxy, inc
+
+    def pbs_site_stats(self, trios, first=0, n=None):
+        """PBS per site: (pbs [T, 3, n], used [T, n]) for trios [T, 3] of population indices."""
+        n = self.n_sites - first if n is None else n
+        tr = np.ascontiguousarray(trios, np.int32).reshape(-1, 3)
+        pbs = np.empty((len(tr), 3, n)); used = np.empty((len(tr), n), np.uint8)
+        self._chk(self.L.evofst_get_pbs_site_stats(self.h, first, n, len(tr), _ptr(tr, _i32p), _ptr(pbs, _dp), _ptr(used, _u8p)))
+        return pbs, used
 
     def pop_site_div(self, first=0, n=None):
         n = self.n_sites - first if n is None else n

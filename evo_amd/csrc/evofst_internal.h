@@ -91,6 +91,16 @@ struct SiteStatParams {
     uint8_t *include;
 };
 
+struct PbsParams {
+    const void *counts;
+    const uint8_t *site_flags;
+    int64_t first_site, n_sites;
+    int32_t P, n_trios;
+    const int32_t *trios;   // [n_trios][3] population indices (device)
+    double *pbs;            // [n_trios][3][n_sites]
+    uint8_t *used;          // [n_trios][n_sites]
+};
+
 struct PopDivParams {
     const void *counts;
     int64_t first_site, n_sites;
@@ -163,6 +173,7 @@ hipError_t launch_stitch(const K2Params &p, hipStream_t st);
 hipError_t launch_totals(const K2Params &p, const int64_t *base, const int64_t *incl_totals, double *totals, double *carry,
                          hipStream_t st);
 hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st);
+hipError_t launch_pbs_sites(const PbsParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,
                                 int32_t *alt, int32_t *nm, hipStream_t st);

@@ -1036,6 +1036,58 @@ __global__ __launch_bounds__(256) void site_stats_kernel(SiteStatParams p) {
     }
 }
 
+// Population branch statistic per site and trio (calculatePBSfromAFs, evo_PBS.cpp:69-98, and the per-site rules of
+// PBSmain, :304-322): lane = site, blockIdx.y walks the trios.  AAF = -1 for a population without a called allele.
+template <typename CT>
+__global__ __launch_bounds__(256) void pbs_site_kernel(PbsParams p) {
+    const int64_t ls = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ls >= p.n_sites) return;
+    const int64_t site = p.first_site + ls;
+    const CT *cp = reinterpret_cast<const CT *>(p.counts) + (size_t)(site >> 6) * p.P * kTileSites + (int)(site & 63);
+    const bool skip = p.site_flags ? ((p.site_flags[site] & 1u) != 0) : false;
+    for (int q = blockIdx.y; q < p.n_trios; q += gridDim.y) {
+        double pf[3], nf[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            const uint32_t v = cp[(size_t)p.trios[3 * q + x] * kTileSites];
+            const int c = (int)(v & CountTraits<CT>::mask), nm = (int)(v >> CountTraits<CT>::shift);
+            pf[x] = nm > 0 ? (double)c / (double)nm : -1.0;                 // utils.cpp:56-58, utils.h:75
+            nf[x] = (double)nm;
+        }
+        const double p1 = pf[0], p2 = pf[1], p3 = pf[2];
+        bool used = !skip && p1 != -1.0 && p2 != -1.0 && p3 != -1.0;        // PBS.cpp:304-309
+        if (used && ((p1 == 0 && p2 == 0 && p3 == 0) || (p1 == 1 && p2 == 1 && p3 == 1))) used = false;   // :311-312
+        double out[3] = {0.0, 0.0, 0.0};
+        if (used) {
+            const double power12 = (p1 - p2) * (p1 - p2), power13 = (p1 - p3) * (p1 - p3), power23 = (p2 - p3) * (p2 - p3);
+            const double fraction1 = (p1 * (1 - p1)) / (nf[0] - 1), fraction2 = (p2 * (1 - p2)) / (nf[1] - 1), fraction3 = (p3 * (1 - p3)) / (nf[2] - 1);
+            const double numerator12 = power12 - fraction1 - fraction2, numerator13 = power13 - fraction1 - fraction3, numerator23 = power23 - fraction2 - fraction3;
+            const double denominator12 = (p1 * (1 - p2)) + (p2 * (1 - p1)), denominator13 = (p1 * (1 - p3)) + (p3 * (1 - p1)), denominator23 = (p2 * (1 - p3)) + (p3 * (1 - p2));
+            double Fst12, Fst13, Fst23;
+            if ((p1 == 0 && p2 == 0) || (p1 == 1 && p2 == 1)) Fst12 = 0.0; else Fst12 = numerator12 / denominator12;
+            if ((p1 == 0 && p3 == 0) || (p1 == 1 && p3 == 1)) Fst13 = 0.0; else Fst13 = numerator13 / denominator13;
+            if ((p2 == 0 && p3 == 0) || (p2 == 1 && p3 == 1)) Fst23 = 0.0; else Fst23 = numerator23 / denominator23;
+            if (Fst12 < 0) Fst12 = 0; if (Fst13 < 0) Fst13 = 0; if (Fst23 < 0) Fst23 = 0;
+            if (Fst12 == 1) Fst12 = 1 - (Fst12 / nf[0]); if (Fst13 == 1) Fst13 = 1 - (Fst13 / nf[0]); if (Fst23 == 1) Fst23 = 1 - (Fst23 / nf[1]);   // :87 (sic)
+            const double T12 = -log(1 - Fst12), T13 = -log(1 - Fst13), T23 = -log(1 - Fst23);
+            out[0] = (T12 + T13 - T23) / 2.0; out[1] = (T12 + T23 - T13) / 2.0; out[2] = (T13 + T23 - T12) / 2.0;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) if (out[x] < 0) out[x] = 0;
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) p.pbs[((size_t)q * 3 + x) * p.n_sites + ls] = out[x];
+        p.used[(size_t)q * p.n_sites + ls] = used ? 1 : 0;
+    }
+}
+
+hipError_t launch_pbs_sites(const PbsParams &p, int count_bytes, hipStream_t st) {
+    if (p.n_sites <= 0 || p.n_trios <= 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((p.n_sites + 255) / 256), (unsigned)min(p.n_trios, 1024));
+    if (count_bytes == 2) hipLaunchKernelGGL((pbs_site_kernel<uint16_t>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((pbs_site_kernel<uint32_t>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st) {
     if (p.n_sites <= 0 || p.n_pairs <= 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((p.n_sites + 255) / 256), (unsigned)min(p.n_pairs, 1024));

@@ -224,6 +224,13 @@ int evofst_get_included_totals(evofst_ctx *ctx, int64_t *totals);
  * calculateFstNumerator / calculateFstDenominator / calculateDxy; include is the site filter. */
 int evofst_get_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *num,
                           double *den, double *dxy, uint8_t *include);
+/* Population branch statistic per site for n_trios population trios (trios[3*t + 0..2] = population indices):
+ * calculatePBSfromAFs (evo_PBS.cpp:69-98) on the allele frequencies of the general counting rules
+ * (EVOFST_MODE_GLOBAL codes), pbs[t][0..2][site]; used[t][site] = 1 where PBSmain counts the site for the trio
+ * (evo_PBS.cpp:304-313: every population has a called allele, not all three frequencies 0 or all 1, site not
+ * skipped), else 0 and the three values are 0.  Any mode, after evofst_run_counts. */
+int evofst_get_pbs_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, int n_trios, const int32_t *trios,
+                              double *pbs, uint8_t *used);
 /* Per-site per-population diversity (getSetHeterozygozities + calculatePiTwoSets,
  * process_vcf_fst.cpp:325-371): arrays [n_pops][n_sites]; any pointer may be NULL. */
 int evofst_get_pop_site_div(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *het,

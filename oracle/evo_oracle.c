@@ -974,6 +974,62 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
 }
 
 /* ===================================================================== */
+/* PBS (evo_PBS.cpp)                                                     */
+/* ===================================================================== */
+/* calculatePBSfromAFs, evo_PBS.cpp:69-98 (pow(x,2) == x*x, see the header) */
+void orc_pbs_from_afs(double p1, double p2, double p3, double n1, double n2, double n3, double *pbs) {
+    double Fst12, Fst13, Fst23;
+    double power12 = (p1 - p2) * (p1 - p2);
+    double power13 = (p1 - p3) * (p1 - p3);
+    double power23 = (p2 - p3) * (p2 - p3);
+    double fraction1 = (p1 * (1 - p1)) / (n1 - 1);
+    double fraction2 = (p2 * (1 - p2)) / (n2 - 1);
+    double fraction3 = (p3 * (1 - p3)) / (n3 - 1);
+    double numerator12 = power12 - fraction1 - fraction2;
+    double numerator13 = power13 - fraction1 - fraction3;
+    double numerator23 = power23 - fraction2 - fraction3;
+    double denominator12 = (p1 * (1 - p2)) + (p2 * (1 - p1));
+    double denominator13 = (p1 * (1 - p3)) + (p3 * (1 - p1));
+    double denominator23 = (p2 * (1 - p3)) + (p3 * (1 - p2));
+    if ((p1 == 0 && p2 == 0) || (p1 == 1 && p2 == 1)) Fst12 = 0.0; else Fst12 = numerator12 / denominator12;
+    if ((p1 == 0 && p3 == 0) || (p1 == 1 && p3 == 1)) Fst13 = 0.0; else Fst13 = numerator13 / denominator13;
+    if ((p2 == 0 && p3 == 0) || (p2 == 1 && p3 == 1)) Fst23 = 0.0; else Fst23 = numerator23 / denominator23;
+    if (Fst12 < 0) Fst12 = 0;
+    if (Fst13 < 0) Fst13 = 0;
+    if (Fst23 < 0) Fst23 = 0;
+    if (Fst12 == 1) Fst12 = 1 - (Fst12 / n1);
+    if (Fst13 == 1) Fst13 = 1 - (Fst13 / n1);      /* :87 divides by p1AlleleCount for 13 and p2AlleleCount for 23 (sic) */
+    if (Fst23 == 1) Fst23 = 1 - (Fst23 / n2);
+    double T12 = -log(1 - Fst12), T13 = -log(1 - Fst13), T23 = -log(1 - Fst23);
+    pbs[0] = (T12 + T13 - T23) / 2.0;
+    pbs[1] = (T12 + T23 - T13) / 2.0;
+    pbs[2] = (T13 + T23 - T12) / 2.0;
+    for (int x = 0; x < 3; x++) if (pbs[x] < 0) pbs[x] = 0;
+}
+
+/* per-site rules of PBSmain (evo_PBS.cpp:304-322) on counts: pbs [n_trios][3][n_sites], used [n_trios][n_sites] */
+void orc_pbs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, int n_pops,
+                        const int32_t *trios, int n_trios, const uint8_t *site_flags, double *pbs, uint8_t *used) {
+    for (int t = 0; t < n_trios; t++)
+        for (int64_t s = 0; s < n_sites; s++) {
+            double p[3], n[3], out[3] = {0, 0, 0};
+            int ok = !(site_flags && (site_flags[s] & ORC_SITE_SKIP));
+            for (int x = 0; x < 3; x++) {
+                int k = trios[3 * t + x];
+                int a = alt[s * n_pops + k], m = nm[s * n_pops + k];
+                p[x] = m > 0 ? (double)a / m : -1.0;
+                n[x] = (double)m;
+                if (p[x] == -1) ok = 0;
+            }
+            if (ok && p[0] == 0 && p[1] == 0 && p[2] == 0) ok = 0;
+            if (ok && p[0] == 1 && p[1] == 1 && p[2] == 1) ok = 0;
+            if (ok) orc_pbs_from_afs(p[0], p[1], p[2], n[0], n[1], n[2], out);
+            for (int x = 0; x < 3; x++) pbs[((size_t)t * 3 + (size_t)x) * (size_t)n_sites + (size_t)s] = out[x];
+            used[(size_t)t * (size_t)n_sites + (size_t)s] = (uint8_t)ok;
+        }
+}
+
+/* ===================================================================== */
 /* `evo alleleFreq [-n] VCF POPS` (AFmain, evo_AlleleFeq.cpp:46-166)     */
 /* without --use-genotype-probabilities.  The reference writes next to   */
 /* the populations file; here the file goes to out_dir under the same    */

@@ -177,6 +177,12 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
                       int window_size, int window_step, int fixed_window_size,
                       const char *run_name, const char *out_dir);
 
+/* calculatePBSfromAFs (evo_PBS.cpp:69-98) and the per-site rules of PBSmain (:304-322) on counts:
+ * pbs [n_trios][3][n_sites], used [n_trios][n_sites].  No reference build or fixture covers these: parity unpinned. */
+void orc_pbs_from_afs(double p1, double p2, double p3, double n1, double n2, double n3, double *pbs);
+void orc_pbs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, int n_pops,
+                        const int32_t *trios, int n_trios, const uint8_t *site_flags, double *pbs, uint8_t *used);
+
 /* `evo alleleFreq [-n] VCF POPS` (AFmain, evo_AlleleFeq.cpp:46-166) without -g; the output file
  * <pops base name>_<run_name>_AF.txt is written into out_dir. */
 int orc_af_run(const char *vcf_path, const char *pops_path, const char *run_name, const char *out_dir);

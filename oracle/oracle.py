@@ -260,6 +260,20 @@ def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_abo
     return summ
 
 
+def pbs_site_stats(alt, nm, trios, site_flags=None):
+    """(pbs [T, 3, S], used [T, S]) from counts [S, P] (evo_PBS.cpp:69-98, 304-322)."""
+    L = lib()
+    alt = np.ascontiguousarray(alt, np.int32); nm = np.ascontiguousarray(nm, np.int32)
+    S, P = alt.shape
+    tr = np.ascontiguousarray(trios, np.int32).reshape(-1, 3)
+    fl = np.ascontiguousarray(site_flags, np.uint8) if site_flags is not None else None
+    pbs = np.empty((len(tr), 3, S)); used = np.empty((len(tr), S), np.uint8)
+    L.orc_pbs_site_stats.restype = None
+    L.orc_pbs_site_stats.argtypes = [_i32p, _i32p, C.c_int64, C.c_int, _i32p, C.c_int, _u8p, _dp, _u8p]
+    L.orc_pbs_site_stats(_p(alt, _i32p), _p(nm, _i32p), S, P, _p(tr, _i32p), len(tr), _p(fl, _u8p), _p(pbs, _dp), _p(used, _u8p))
+    return pbs, used
+
+
 def af_run(vcf, pops, out_dir, run_name="out"):
     rc = lib().orc_af_run(vcf.encode(), pops.encode(), run_name.encode(), out_dir.encode())
     if rc != 0:
