@@ -3,6 +3,8 @@
 //
 //   reference entry points replaced:  fstMain        process_vcf_fst.cpp:936   (VCF mode only)
 //                                     FstGlobalMain  evo_FstAgainstAll.cpp:62
+//                                     AFmain         evo_AlleleFeq.cpp:46
+//                                     PBSmain        evo_PBS.cpp:126
 //
 // Division of labour: the host parses VCF text and packs genotypes (stage K0), the device computes
 // per-site counts and statistics (K1 + per-site kernels), and the host replays the reference's two
@@ -710,21 +712,233 @@ int AFmain(int argc, char **argv) {
     return 0;
 }
 
+// ============================================================================================ PBS
+
+namespace pbsopt {
+string vcfFile, setsFile, triosFile, runName = "";
+int fixedWindowSize = 10000, windowSize = 20, windowStep = 10;
+}
+
+const char *PBS_USAGE =
+    "Usage: evo PBS [OPTIONS] INPUT_FILE.vcf POPULATIONS.txt PBS_trios.txt\n"
+    "Population branch statistic for each trio of populations named in PBS_trios.txt (three tab-separated names per line);\n"
+    "writes POP1_POP2_POP3_PBS_RUN_SIZE_STEP.txt and POP1_POP2_POP3_PBS_RUN_FWsize.txt per trio\n"
+    "       -h, --help                              display this help and exit\n"
+    "       -f, --fixedW size                       fixed (physical) window size (default: 10000)\n"
+    "       -w SIZE,STEP --window=SIZE,STEP         sliding window: SIZE SNPs, moving by STEP (default: 20,10)\n"
+    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n\n";
+
+// Sign of a NaN PBS value as the reference's x86 build writes it ("nan" / "-nan").  A population with a single called
+// allele makes its variance term 0/0, every branch length that uses it NaN, and all three PBS values NaN; the sign
+// that survives depends on WHICH of T12, T13, T23 are NaN (the compiler folds the negations of -log() into the sums).
+// Index: T12 | T13 << 1 | T23 << 2; bit x set = PBS value x is "-nan".  The table is what g++ -O2 makes of
+// evo_PBS.cpp:69-98 on this image; tests/test_oracle.py pins the oracle, sign included, against that build.
+const uint8_t kPbsNanNegative[8] = {0, 4, 3, 0, 7, 4, 3, 0};
+
+// evo PBS (PBSmain, evo_PBS.cpp:126-369) without --annot, --af and -i: per-site PBS of every trio on the device,
+// the sliding and fixed windows replayed on the host in file order.
+int PBSmain(int argc, char **argv) {
+    using namespace pbsopt;
+    static const struct option longopts[] = {{"fixedW", required_argument, NULL, 'f'}, {"window", required_argument, NULL, 'w'},
+                                             {"annot", required_argument, NULL, OPT_UNSUPPORTED}, {"af", required_argument, NULL, OPT_UNSUPPORTED},
+                                             {"allow-indels-and-multiallelics", no_argument, NULL, 'i'},
+                                             {"help", no_argument, NULL, 'h'}, {"run-name", required_argument, NULL, 'n'}, {NULL, 0, NULL, 0}};
+    bool dieFlag = false;
+    std::vector<string> ws;
+    for (int c; (c = getopt_long(argc, argv, "hw:n:f:i", longopts, NULL)) != -1;) {
+        std::istringstream arg(optarg != NULL ? optarg : "");
+        switch (c) {
+            case '?': dieFlag = true; break;
+            case 'f': arg >> fixedWindowSize; break;
+            case 'w':
+                ws = split(arg.str(), ',');
+                if (ws.size() < 2) die("-w needs SIZE,STEP");
+                windowSize = atoi(ws[0].c_str()); windowStep = atoi(ws[1].c_str());
+                break;
+            case 'n': arg >> runName; break;
+            case 'i': die("-i (indels and multiallelics) is not carried by the GPU build");
+            case OPT_UNSUPPORTED: die("--annot and --af are not carried by the GPU build");
+            case 'h': std::cout << PBS_USAGE; exit(EXIT_SUCCESS);
+        }
+    }
+    if (argc - optind < 3) { std::cerr << "missing arguments\n"; dieFlag = true; }
+    else if (argc - optind > 3) { std::cerr << "too many arguments\n"; dieFlag = true; }
+    if (windowSize <= 0 || windowStep <= 0) { std::cerr << "window SIZE and STEP must be positive\n"; dieFlag = true; }
+    if (dieFlag) { std::cout << "\n" << PBS_USAGE; exit(EXIT_FAILURE); }
+    vcfFile = argv[optind++]; setsFile = argv[optind++]; triosFile = argv[optind++];
+
+    LineReader vcf(vcfFile);
+    std::ifstream setsF(setsFile.c_str()), triosF(triosFile.c_str());
+    if (!setsF.is_open()) die("could not open " + setsFile);
+    if (!triosF.is_open()) die("could not open " + triosFile);
+    std::map<string, std::vector<string>> popToIDsMap;
+    std::map<string, string> IDsToPopMap;
+    string line;
+    while (getline(setsF, line)) {                                   // PBS.cpp:148-154
+        std::vector<string> ID_Pop = split(line, '\t');
+        if (ID_Pop.size() < 2) die("POPULATIONS.txt needs two tab-separated columns per line");
+        popToIDsMap[ID_Pop[1]].push_back(ID_Pop[0]);
+        IDsToPopMap[ID_Pop[0]] = ID_Pop[1];
+    }
+    std::vector<string> populations;
+    std::map<string, int> popIndex;
+    for (auto &kv : popToIDsMap) { popIndex[kv.first] = (int)populations.size(); populations.push_back(kv.first); }
+    std::cerr << "There are " << populations.size() << " populations " << std::endl;
+    const size_t P = populations.size();
+
+    std::vector<std::ofstream> outFiles, outFilesFixedWindow;        // :163-183
+    std::vector<int32_t> trios;
+    while (getline(triosF, line)) {
+        std::vector<string> threePops = split(line, '\t');
+        if (threePops.size() != 3) die("PBS_trios.txt needs three tab-separated population names per line");
+        for (const string &name : threePops) {
+            auto it = popIndex.find(name);
+            if (it == popIndex.end()) die("population \"" + name + "\" of PBS_trios.txt is not in " + setsFile);
+            trios.push_back(it->second);
+        }
+        const string stem = threePops[0] + "_" + threePops[1] + "_" + threePops[2] + "_PBS_" + runName;
+        outFiles.emplace_back((stem + "_" + numToString(windowSize) + "_" + numToString(windowStep) + ".txt").c_str());
+        outFilesFixedWindow.emplace_back((stem + "_FW" + numToString(fixedWindowSize) + ".txt").c_str());
+        outFiles.back() << "chr\twStart\twEnd\t" << threePops[0] << "\t" << threePops[1] << "\t" << threePops[2] << std::endl;
+        outFilesFixedWindow.back() << "chr\twStart\twEnd\t" << threePops[0] << "\t" << threePops[1] << "\t" << threePops[2] << "\t"
+                                   << "nFwSNPs1" << "\t" << "nFwSNPs2" << "\t" << "nFwSNPs3" << std::endl;
+    }
+    const size_t T = outFiles.size();
+    if (T == 0) die("no trio in " + triosFile);
+
+    std::deque<double> initDeq(windowSize, 0.0);                     // :186-192
+    std::vector<std::vector<std::deque<double>>> PBSresults(T, std::vector<std::deque<double>>(4, initDeq));
+    std::vector<std::vector<std::vector<double>>> PBSfixedWindowResults(T, std::vector<std::vector<double>>(3));
+    int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
+    std::vector<int> usedVars(T, 0);
+    int totalVariantNumber = 0;
+
+    Device dev;
+    Batch batch;
+    int nSamples = 0;
+    std::vector<double> pbs;
+    std::vector<uint8_t> used;
+    std::vector<int32_t> altc, nmc;
+    bool haveHeader = false;
+
+    auto flush = [&]() {
+        if (batch.n == 0) return;
+        const size_t n = batch.n;
+        dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
+        pbs.resize(T * 3 * n); used.resize(T * n);
+        check(dev.ctx, evofst_get_pbs_site_stats(dev.ctx, 0, (int64_t)n, (int)T, trios.data(), pbs.data(), used.data()), "pbs_site_stats");
+        bool anyNan = false;
+        for (double x : pbs) if (x != x) { anyNan = true; break; }
+        if (anyNan) {                                                // give NaNs the sign the reference prints
+            altc.resize(n * P); nmc.resize(n * P);
+            check(dev.ctx, evofst_get_counts(dev.ctx, 0, (int64_t)n, altc.data(), nmc.data()), "get_counts");
+            auto tNan = [&](size_t s, int a, int b) {
+                const int ca = altc[s * P + a], na = nmc[s * P + a], cb = altc[s * P + b], nb = nmc[s * P + b];
+                if ((ca == 0 && cb == 0) || (ca == na && cb == nb)) return 0;   // Fst forced to 0 (:82-84)
+                return (na == 1 || nb == 1) ? 1 : 0;
+            };
+            for (size_t t = 0; t < T; ++t)
+                for (size_t s = 0; s < n; ++s) {
+                    double *v = &pbs[t * 3 * n + s];
+                    if (v[0] == v[0]) continue;
+                    const int a = trios[3 * t], b = trios[3 * t + 1], c = trios[3 * t + 2];
+                    const int neg = kPbsNanNegative[tNan(s, a, b) | tNan(s, a, c) << 1 | tNan(s, b, c) << 2];
+                    for (int x = 0; x < 3; ++x) v[x * n] = (neg >> x & 1) ? -__builtin_fabs(v[x * n]) : __builtin_fabs(v[x * n]);
+                }
+        }
+        for (size_t s = 0; s < n; ++s) {
+            if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :248-256
+            const string &chr = batch.chrom[s];
+            const string &coord = batch.pos[s];
+            double coordDouble; { std::stringstream ss(coord); ss >> coordDouble; }
+            if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {   // :289-303
+                for (size_t i = 0; i != T; i++) {
+                    std::vector<std::vector<double>> &fw = PBSfixedWindowResults[i];
+                    const int nFwSNPs1 = (int)fw[0].size(), nFwSNPs2 = (int)fw[1].size(), nFwSNPs3 = (int)fw[2].size();
+                    double PBSfw1 = 0; if (nFwSNPs1 > 0) PBSfw1 = vector_average(fw[0]);
+                    double PBSfw2 = 0; if (nFwSNPs2 > 0) PBSfw2 = vector_average(fw[1]);
+                    double PBSfw3 = 0; if (nFwSNPs3 > 0) PBSfw3 = vector_average(fw[2]);
+                    outFilesFixedWindow[i] << chr << "\t" << currentWindowStart << "\t" << currentWindowEnd << "\t" << PBSfw1 << "\t" << PBSfw2
+                                           << "\t" << PBSfw3 << "\t" << nFwSNPs1 << "\t" << nFwSNPs2 << "\t" << nFwSNPs3 << std::endl;
+                    fw[0].clear(); fw[1].clear(); fw[2].clear();
+                }
+                if (coordDouble > currentWindowEnd) { currentWindowStart = currentWindowStart + fixedWindowSize; currentWindowEnd = currentWindowEnd + fixedWindowSize; }
+                else if (coordDouble < currentWindowStart) { currentWindowStart = 0; currentWindowEnd = 0 + fixedWindowSize; }
+            }
+            for (size_t i = 0; i != T; i++) {                        // :309-347
+                if (!used[i * n + s]) continue;
+                usedVars[i]++;
+                std::vector<std::deque<double>> &r = PBSresults[i];
+                for (int x = 0; x < 3; ++x) {
+                    const double v = pbs[(i * 3 + x) * n + s];
+                    r[x].push_back(v); r[x].pop_front();
+                    PBSfixedWindowResults[i][x].push_back(v);
+                }
+                r[3].push_back(coordDouble); r[3].pop_front();
+                if (usedVars[i] > windowSize && (usedVars[i] % windowStep == 0)) {
+                    double av[3];
+                    for (int x = 0; x < 3; ++x) {
+                        double sum = 0;
+                        for (size_t k = 0; k < r[x].size(); k++) sum += r[x][k];
+                        av[x] = (double)sum / (double)r[x].size();
+                    }
+                    outFiles[i] << chr << "\t" << (int)r[3][0] << "\t" << coord << "\t" << av[0] << "\t" << av[1] << "\t" << av[2] << std::endl;
+                }
+            }
+        }
+        batch.clear();
+    };
+
+    while (vcf.getline(line)) {
+        line.erase(std::remove(line.begin(), line.end(), '\r'), line.end());   // :210
+        if (line[0] == '#' && line[1] == '#') continue;
+        if (line[0] == '#' && line[1] == 'C') {
+            std::vector<string> fields = split(line, '\t');
+            std::vector<string> sampleNames(fields.begin() + std::min<size_t>(9, fields.size()), fields.end());
+            nSamples = (int)sampleNames.size();
+            if (nSamples <= 0) die("VCF header has no sample columns");
+            std::vector<int32_t> sp(nSamples, -1);
+            for (int i = 0; i < nSamples; ++i) {                     // :217-219
+                auto it = IDsToPopMap.find(sampleNames[i]);
+                if (it != IDsToPopMap.end()) sp[i] = popIndex[it->second];
+            }
+            for (auto &kv : popToIDsMap)                              // :222-232
+                if (locateSet(sampleNames, kv.second).empty()) { std::cerr << "Did not find any samples in the VCF for \"" << kv.first << "\"" << std::endl; exit(EXIT_FAILURE); }
+            for (size_t k = 0; k < P; ++k)
+                if (std::find(sp.begin(), sp.end(), (int32_t)k) == sp.end()) die("population \"" + populations[k] + "\" has no sample column of its own");
+            dev.open();
+            check(dev.ctx, evofst_set_layout(dev.ctx, nSamples, (int)P, sp.data()), "set_layout");
+            check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
+            haveHeader = true;
+            continue;
+        }
+        if (!haveHeader) die("variant line before the #CHROM header");
+        totalVariantNumber++;
+        if (totalVariantNumber % 10000 == 0) std::cerr << "Processed " << totalVariantNumber << " variants" << std::endl;
+        batch.add(line, totalVariantNumber);
+        if (batch.n == (size_t)kChunkSites) flush();
+    }
+    flush();
+    if (dev.ctx) evofst_destroy(dev.ctx);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc <= 1) {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq\n";
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS\n";
         return 0;
     }
     string command(argv[1]);
     if (command == "fst") return fstMain(argc - 1, argv + 1);
     if (command == "FstGlobal") return FstGlobalMain(argc - 1, argv + 1);
     if (command == "alleleFreq") return AFmain(argc - 1, argv + 1);
+    if (command == "PBS") return PBSmain(argc - 1, argv + 1);
     if (command == "help" || command == "--help") {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq\n" << FST_USAGE << FSTGLOBAL_USAGE << AF_USAGE;
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS\n" << FST_USAGE << FSTGLOBAL_USAGE << AF_USAGE << PBS_USAGE;
         return 0;
     }
-    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal, alleleFreq)\n";
+    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal, alleleFreq, PBS)\n";
     return 1;
 }

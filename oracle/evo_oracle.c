@@ -1029,6 +1029,182 @@ void orc_pbs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, 
         }
 }
 
+/* `evo PBS [-w SIZE,STEP] [-f FW] [-n RUN] VCF POPS TRIOS` (PBSmain, evo_PBS.cpp:125-363) without --annot,
+ * --af and -i.  Output files go to out_dir. */
+int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_path,
+                int windowSize, int windowStep, int fixedWindowSize, const char *run_name, const char *out_dir) {
+    lreader vcf;
+    if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
+    FILE *sf = fopen(pops_path, "r");
+    FILE *tf = fopen(trios_path, "r");
+    if (!sf || !tf) { lr_close(&vcf); return -2; }
+    pop_t *pops = NULL; int n_pops = 0, pcap = 0;
+    char **id_names = NULL; char **id_pop = NULL; int n_ids = 0, icap = 0;
+    {
+        char *l = NULL; size_t cap = 0; ssize_t r;
+        while ((r = getline(&l, &cap, sf)) >= 0) {           /* :148-154 */
+            if (r && l[r - 1] == '\n') l[r - 1] = '\0';
+            char *tab = strchr(l, '\t');
+            if (!tab) continue;
+            *tab = '\0';
+            char *id = l, *pn = tab + 1;
+            char *tab2 = strchr(pn, '\t'); if (tab2) *tab2 = '\0';
+            int k = -1;
+            for (int i = 0; i < n_pops; i++) if (strcmp(pops[i].name, pn) == 0) { k = i; break; }
+            if (k < 0) {
+                if (n_pops == pcap) { pcap = pcap ? pcap * 2 : 16; pops = (pop_t *)realloc(pops, sizeof(pop_t) * (size_t)pcap); }
+                k = n_pops++;
+                memset(&pops[k], 0, sizeof(pop_t));
+                pops[k].name = strdup(pn);
+            }
+            pop_t *P = &pops[k];
+            if (P->n_ids == P->cap) { P->cap = P->cap ? P->cap * 2 : 16; P->ids = (char **)realloc(P->ids, sizeof(char *) * (size_t)P->cap); }
+            P->ids[P->n_ids++] = strdup(id);
+            int found = -1;
+            for (int i = 0; i < n_ids; i++) if (strcmp(id_names[i], id) == 0) { found = i; break; }
+            if (found < 0) {
+                if (n_ids == icap) { icap = icap ? icap * 2 : 64; id_names = (char **)realloc(id_names, sizeof(char *) * (size_t)icap); id_pop = (char **)realloc(id_pop, sizeof(char *) * (size_t)icap); }
+                id_names[n_ids] = strdup(id); id_pop[n_ids] = strdup(pn); n_ids++;
+            } else { free(id_pop[found]); id_pop[found] = strdup(pn); }
+        }
+        free(l); fclose(sf);
+    }
+    qsort(pops, (size_t)n_pops, sizeof(pop_t), cmp_pop);
+    fprintf(stderr, "There are %d populations \n", n_pops);
+    /* :163-186 trios and their output files */
+    int n_trios = 0, tcap = 0; int *trio = NULL; FILE **outW = NULL, **outFW = NULL;
+    int rc = 0;
+    {
+        char *l = NULL; size_t cap = 0; ssize_t r;
+        while ((r = getline(&l, &cap, tf)) >= 0) {
+            if (r && l[r - 1] == '\n') l[r - 1] = '\0';
+            char *a = l, *b = strchr(a, '\t'); if (!b) { rc = -5; break; } *b++ = '\0';
+            char *c3 = strchr(b, '\t'); if (!c3) { rc = -5; break; } *c3++ = '\0';
+            if (strchr(c3, '\t')) { rc = -5; break; }            /* assert(threePops.size() == 3) */
+            if (n_trios == tcap) {
+                tcap = tcap ? tcap * 2 : 8;
+                trio = (int *)realloc(trio, sizeof(int) * 3 * (size_t)tcap);
+                outW = (FILE **)realloc(outW, sizeof(FILE *) * (size_t)tcap); outFW = (FILE **)realloc(outFW, sizeof(FILE *) * (size_t)tcap);
+            }
+            const char *nm3[3] = {a, b, c3};
+            for (int x = 0; x < 3; x++) {
+                int k = -1;
+                for (int i = 0; i < n_pops; i++) if (strcmp(pops[i].name, nm3[x]) == 0) k = i;
+                if (k < 0) rc = -6;                               /* setAAFs.at() would throw */
+                trio[3 * n_trios + x] = k;
+            }
+            char name[1024];
+            snprintf(name, sizeof name, "%s_%s_%s_PBS_%s_%d_%d.txt", a, b, c3, run_name, windowSize, windowStep);
+            char *p1 = path_join(out_dir, name); outW[n_trios] = fopen(p1, "w"); free(p1);
+            snprintf(name, sizeof name, "%s_%s_%s_PBS_%s_FW%d.txt", a, b, c3, run_name, fixedWindowSize);
+            char *p2 = path_join(out_dir, name); outFW[n_trios] = fopen(p2, "w"); free(p2);
+            if (!outW[n_trios] || !outFW[n_trios]) { rc = -3; n_trios++; break; }
+            fprintf(outW[n_trios], "chr\twStart\twEnd\t%s\t%s\t%s\n", a, b, c3);
+            fprintf(outFW[n_trios], "chr\twStart\twEnd\t%s\t%s\t%s\tnFwSNPs1\tnFwSNPs2\tnFwSNPs3\n", a, b, c3);
+            n_trios++;
+        }
+        free(l); fclose(tf);
+    }
+    /* :189-196 per trio: three deques of per-site PBS + one of coordinates, zero-initialised; fixed-window vectors */
+    size_t W = (size_t)(windowSize > 0 ? windowSize : 1);
+    double *dq = (double *)calloc((size_t)(n_trios + 1) * 4 * W, sizeof(double));
+    int *head = (int *)calloc((size_t)n_trios + 1, sizeof(int));
+    dvec *fw = (dvec *)calloc((size_t)(n_trios + 1) * 3, sizeof(dvec));
+    int *usedVars = (int *)calloc((size_t)n_trios + 1, sizeof(int));
+    int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
+    uint8_t *use_pop = (uint8_t *)calloc((size_t)n_pops + 1, 1);
+    int32_t *sample_pop = NULL; int n_samples = 0;
+    char **fields = NULL; int fcap = 0;
+    int *alt = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1)), *alleles = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1));
+    int *allelesC = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1));
+    double *aaf = (double *)malloc(sizeof(double) * (size_t)(n_pops + 1)), *aafC = (double *)malloc(sizeof(double) * (size_t)(n_pops + 1));
+    char *line;
+    while (!rc && (line = lr_getline(&vcf)) != NULL) {
+        { char *w = line; for (char *r = line; *r; r++) if (*r != '\r') *w++ = *r; *w = '\0'; }   /* :215 */
+        if (line[0] == '#' && line[1] == '#') continue;
+        else if (line[0] == '#' && line[1] == 'C') {
+            char *hdr = strdup(line); char **hf = NULL; int hcap = 0;
+            int nh = split_inplace(hdr, '\t', &hf, &hcap);
+            n_samples = nh - 9; if (n_samples < 0) n_samples = 0;
+            sample_pop = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_samples + 1));
+            for (int i = 0; i < n_samples; i++) {
+                sample_pop[i] = -1;
+                for (int j = 0; j < n_ids; j++)
+                    if (strcmp(id_names[j], hf[9 + i]) == 0) {
+                        for (int k = 0; k < n_pops; k++) if (strcmp(pops[k].name, id_pop[j]) == 0) sample_pop[i] = k;
+                        break;
+                    }
+            }
+            for (int k = 0; k < n_pops; k++) {
+                pops[k].pos = (size_t *)malloc(sizeof(size_t) * (size_t)(pops[k].n_ids + 1));
+                pops[k].n_pos = locate_set(hf + 9, n_samples, pops[k].ids, pops[k].n_ids, pops[k].pos);
+                if (pops[k].n_pos == 0) { fprintf(stderr, "Did not find any samples in the VCF for \"%s\"\n", pops[k].name); rc = -4; }
+            }
+            free(hf); free(hdr);
+        } else {
+            int nf = split_inplace(line, '\t', &fields, &fcap);
+            if (nf < 9) continue;
+            const char *chr = fields[0]; const char *coord = fields[1];
+            double coordDouble = strtod(coord, NULL);
+            /* :255-263 only biallelic SNPs (no -i) */
+            if (strcmp(fields[4], "*") == 0 || strlen(fields[3]) > 1 || strlen(fields[4]) > 1) continue;
+            orc_general_counts((const char *const *)(fields + 9), n_samples, sample_pop, n_pops, use_pop,
+                               alt, alleles, aaf, allelesC, aafC);
+            if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {          /* :288-303 */
+                for (int i = 0; i < n_trios; i++) {
+                    dvec *f0 = &fw[3 * i];
+                    int n1 = (int)f0[0].n, n2 = (int)f0[1].n, n3 = (int)f0[2].n;
+                    double a1 = 0, a2 = 0, a3 = 0;
+                    if (n1 > 0) a1 = orc_vector_average(f0[0].v, f0[0].n);
+                    if (n2 > 0) a2 = orc_vector_average(f0[1].v, f0[1].n);
+                    if (n3 > 0) a3 = orc_vector_average(f0[2].v, f0[2].n);
+                    fprintf(outFW[i], "%s\t%d\t%d\t%g\t%g\t%g\t%d\t%d\t%d\n", chr, currentWindowStart, currentWindowEnd, a1, a2, a3, n1, n2, n3);
+                    dv_clear(&f0[0]); dv_clear(&f0[1]); dv_clear(&f0[2]);
+                }
+                if (coordDouble > currentWindowEnd) { currentWindowStart += fixedWindowSize; currentWindowEnd += fixedWindowSize; }
+                else if (coordDouble < currentWindowStart) { currentWindowStart = 0; currentWindowEnd = fixedWindowSize; }
+            }
+            for (int i = 0; i < n_trios; i++) {                                                 /* :307-343 */
+                double p1 = aaf[trio[3 * i]]; if (p1 == -1) continue;
+                double p2 = aaf[trio[3 * i + 1]]; if (p2 == -1) continue;
+                double p3 = aaf[trio[3 * i + 2]]; if (p3 == -1) continue;
+                if (p1 == 0 && p2 == 0 && p3 == 0) continue;
+                if (p1 == 1 && p2 == 1 && p3 == 1) continue;
+                usedVars[i]++;
+                double pbs[3];
+                orc_pbs_from_afs(p1, p2, p3, alleles[trio[3 * i]], alleles[trio[3 * i + 1]], alleles[trio[3 * i + 2]], pbs);
+                double *d = dq + (size_t)i * 4 * W;
+                int h = head[i];
+                d[0 * W + (size_t)h] = pbs[0]; d[1 * W + (size_t)h] = pbs[1]; d[2 * W + (size_t)h] = pbs[2]; d[3 * W + (size_t)h] = coordDouble;
+                head[i] = h = (h + 1) % (int)W;                                                  /* push_back + pop_front */
+                dv_push(&fw[3 * i], pbs[0]); dv_push(&fw[3 * i + 1], pbs[1]); dv_push(&fw[3 * i + 2], pbs[2]);
+                if (usedVars[i] > windowSize && (usedVars[i] % windowStep == 0)) {
+                    double av[3];
+                    for (int x = 0; x < 3; x++) {
+                        double sum = 0;
+                        for (size_t t = 0; t < W; t++) sum += d[(size_t)x * W + (size_t)((h + (int)t) % (int)W)];
+                        av[x] = sum / (double)W;
+                    }
+                    fprintf(outW[i], "%s\t%d\t%s\t%g\t%g\t%g\n", chr, (int)d[3 * W + (size_t)h], coord, av[0], av[1], av[2]);
+                }
+            }
+        }
+    }
+    for (int i = 0; i < n_trios; i++) { if (outW[i]) fclose(outW[i]); if (outFW[i]) fclose(outFW[i]); }
+    for (int i = 0; i < 3 * n_trios; i++) dv_free(&fw[i]);
+    lr_close(&vcf);
+    free(fw); free(dq); free(head); free(usedVars); free(trio); free(outW); free(outFW);
+    free(fields); free(sample_pop); free(alt); free(alleles); free(allelesC); free(aaf); free(aafC); free(use_pop);
+    for (int k = 0; k < n_pops; k++) {
+        for (int i = 0; i < pops[k].n_ids; i++) free(pops[k].ids[i]);
+        free(pops[k].ids); free(pops[k].pos); free(pops[k].name);
+    }
+    free(pops);
+    for (int i = 0; i < n_ids; i++) { free(id_names[i]); free(id_pop[i]); }
+    free(id_names); free(id_pop);
+    return rc;
+}
+
 /* ===================================================================== */
 /* `evo alleleFreq [-n] VCF POPS` (AFmain, evo_AlleleFeq.cpp:46-166)     */
 /* without --use-genotype-probabilities.  The reference writes next to   */

@@ -10,8 +10,14 @@
  *     heterozygosities, allele frequency, vector_average*) is PINNED against
  *     the reference's own inline code: oracle/ref_math_shim.cpp compiles
  *     /root/reference/process_vcf_fst.h + process_vcf_utils.h unmodified into
- *     oracle/_ref/libevo_refmath.so and tests/test_oracle_vs_ref.py checks
+ *     oracle/_ref/libevo_refmath.so and tests/test_oracle.py checks
  *     bit-equality.
+ *   - The PBS per-site math (orc_pbs_from_afs) is PINNED the same way:
+ *     oracle/ref_pbs_shim.cpp compiles /root/reference/evo_PBS.cpp where it
+ *     lies, keeps only calculatePBSfromAFs (everything else is hidden and
+ *     discarded at link time) in oracle/_ref/libevo_refpbs.so, and
+ *     tests/test_oracle.py checks bit-equality, NaN sign included.  The PBS
+ *     window text driver (orc_pbs_run) is a restatement: "parity unpinned".
  *   - The genotype counting code (process_vcf_fst.cpp, process_vcf_utils.cpp)
  *     and the two window state machines live in translation units that need
  *     Boost.Math, which this image lacks; they are therefore UNBUILDABLE here
@@ -182,6 +188,10 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
 void orc_pbs_from_afs(double p1, double p2, double p3, double n1, double n2, double n3, double *pbs);
 void orc_pbs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, int n_pops,
                         const int32_t *trios, int n_trios, const uint8_t *site_flags, double *pbs, uint8_t *used);
+
+/* `evo PBS [-w] [-f] [-n] VCF POPS TRIOS` (PBSmain, evo_PBS.cpp:125-363) without --annot / --af / -i */
+int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_path,
+                int window_size, int window_step, int fixed_window_size, const char *run_name, const char *out_dir);
 
 /* `evo alleleFreq [-n] VCF POPS` (AFmain, evo_AlleleFeq.cpp:46-166) without -g; the output file
  * <pops base name>_<run_name>_AF.txt is written into out_dir. */

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libevo_oracle.so")
 _REF = os.path.join(_HERE, "_ref", "libevo_refmath.so")
+_REF_PBS = os.path.join(_HERE, "_ref", "libevo_refpbs.so")
 
 _dp = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -25,7 +26,7 @@ def build(force=False):
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
             os.path.join(_HERE, "evo_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "libevo_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF)):
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF) or not os.path.exists(_REF_PBS)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -144,6 +145,32 @@ def ref():
         R.ref_build_info.restype = C.c_char_p
         _ref = R
     return _ref
+
+
+_ref_pbs = None
+
+
+def ref_pbs():
+    """The reference's own calculatePBSfromAFs (evo_PBS.cpp:69-98), or None when oracle/_ref was never built."""
+    global _ref_pbs
+    if _ref_pbs is None:
+        build()
+        if not os.path.exists(_REF_PBS):
+            return None
+        R = C.CDLL(_REF_PBS)
+        R.ref_calculatePBSfromAFs.restype = None
+        R.ref_calculatePBSfromAFs.argtypes = [C.c_double] * 6 + [_dp]
+        _ref_pbs = R
+    return _ref_pbs
+
+
+def pbs_from_afs(p1, p2, p3, n1, n2, n3):
+    L = lib()
+    L.orc_pbs_from_afs.restype = None
+    L.orc_pbs_from_afs.argtypes = [C.c_double] * 6 + [_dp]
+    out = (C.c_double * 3)()
+    L.orc_pbs_from_afs(p1, p2, p3, n1, n2, n3, out)
+    return np.array(out[:])
 
 
 # ---------------------------------------------------------------------------
@@ -272,6 +299,15 @@ def pbs_site_stats(alt, nm, trios, site_flags=None):
     L.orc_pbs_site_stats.argtypes = [_i32p, _i32p, C.c_int64, C.c_int, _i32p, C.c_int, _u8p, _dp, _u8p]
     L.orc_pbs_site_stats(_p(alt, _i32p), _p(nm, _i32p), S, P, _p(tr, _i32p), len(tr), _p(fl, _u8p), _p(pbs, _dp), _p(used, _u8p))
     return pbs, used
+
+
+def pbs_run(vcf, pops, trios, out_dir, run_name="", size=20, step=10, fixed=10000):
+    L = lib()
+    L.orc_pbs_run.restype = C.c_int
+    L.orc_pbs_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    rc = L.orc_pbs_run(vcf.encode(), pops.encode(), trios.encode(), size, step, fixed, run_name.encode(), out_dir.encode())
+    if rc != 0:
+        raise RuntimeError("orc_pbs_run failed: %d" % rc)
 
 
 def af_run(vcf, pops, out_dir, run_name="out"):

@@ -1,5 +1,5 @@
 """GPU, end to end: the `evo` CLI front-end (evo_amd/cli/evo -> libevofst.so -> HIP kernels) writes the
-same bytes as the oracle's restatement of `evo fst` / `evo FstGlobal` on small seeded VCFs.
+same bytes as the oracle's restatement of `evo fst` / `evo FstGlobal` / `evo alleleFreq` / `evo PBS` on small seeded VCFs.
 
 The expected files come from the CPU oracle (oracle/evo_oracle.c text drivers); beyond the behaviours
 recorded in tests/golden/survey_known_answers.json the text level is "parity unpinned" (the reference
@@ -169,6 +169,47 @@ def test_cli_allele_freq(tmp_path):
     assert got.exists()
     assert filecmp.cmp(str(got), str(orc_dir / "pops.v2_af_AF.txt"), shallow=False)
     assert sum(1 for _ in open(got)) > 30000
+
+
+def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25):
+    vcf = str(tmp_path / "in.vcf")
+    names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=miss)
+    pf, tf = str(tmp_path / "pops.txt"), str(tmp_path / "trios.txt")
+    pops = ["popC", "popA", "popD", "popB"]
+    with open(pf, "w") as f:
+        f.write("%s\tsolo\n" % names[0])                             # one sample: half calls leave a single allele
+        f.write("%s\tduo\n%s\tduo\n" % (names[1], names[2]))
+        for i, n in enumerate(names[3:]):
+            if i % 9 != 8:
+                f.write("%s\t%s\n" % (n, pops[i % 4]))
+        f.write("GHOST\tpopA\n")
+    open(tf, "w").write("popA\tpopB\tpopC\nsolo\tpopA\tpopB\npopA\tsolo\tduo\npopD\tduo\tsolo\npopC\tpopB\tpopA\nduo\tsolo\tduo\n")
+    cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
+    cli_dir.mkdir(); orc_dir.mkdir()
+    r = subprocess.run([EVO, "PBS", "-n", "p"] + args + [vcf, pf, tf], cwd=str(cli_dir), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    O.pbs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step, fixed=fixed)
+    _same_files(str(cli_dir), str(orc_dir))
+    return cli_dir
+
+
+def test_cli_pbs_default(tmp_path):
+    """evo PBS: per-site PBS of six trios from the device, windows replayed on the host.  The solo
+    population makes NaN rows ("nan" and "-nan", as the x86 build of the reference signs them)."""
+    d = _pbs_case(tmp_path, np.random.default_rng(41), [], 20, 10)
+    assert len(os.listdir(d)) == 12
+    text = (d / "solo_popA_popB_PBS_p_20_10.txt").read_text() + (d / "popD_duo_solo_PBS_p_20_10.txt").read_text()
+    assert "\tnan" in text and "\t-nan" in text
+    assert sum(1 for _ in open(d / "popA_popB_popC_PBS_p_20_10.txt")) > 100
+
+
+def test_cli_pbs_windows_fixed_crlf(tmp_path):
+    _pbs_case(tmp_path, np.random.default_rng(42), ["-w", "7,3", "-f", "2500"], 7, 3, fixed=2500, crlf=True, miss=0.1)
+
+
+def test_cli_pbs_several_device_batches(tmp_path):
+    _pbs_case(tmp_path, np.random.default_rng(43), ["--window=50,25", "--fixedW", "20000"], 50, 25, fixed=20000, n_sites=70000,
+              n_samples=12, miss=0.15)
 
 
 def test_cli_rejects_unknown_command():

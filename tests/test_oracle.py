@@ -122,6 +122,37 @@ def test_general_ctor_order_and_init():
     assert a.value == -1.0 and b.value == -1.0
 
 
+@pytest.mark.skipif(O.ref_pbs() is None, reason="oracle/_ref not built (no /root/reference here)")
+def test_pbs_bit_equal_to_reference():
+    """orc_pbs_from_afs vs the reference's own calculatePBSfromAFs (evo_PBS.cpp:69-98) compiled from
+    /root/reference, on every triple of (alt, called) counts up to 7 alleles -- this includes single-allele
+    populations (0/0 in the variance term), fixed differences (Fst == 1) and the NaN sign that reaches the text."""
+    R = O.ref_pbs()
+    L = O.lib()
+    L.orc_pbs_from_afs.restype = None
+    L.orc_pbs_from_afs.argtypes = [C.c_double] * 6 + [O._dp]
+    pn = [(c / n, float(n)) for n in range(1, 8) for c in range(n + 1)]
+    a = (C.c_double * 3)(); b = (C.c_double * 3)()
+    got = np.empty((len(pn) ** 3, 3)); want = np.empty_like(got)
+    k = 0
+    for p1, n1 in pn:
+        for p2, n2 in pn:
+            for p3, n3 in pn:
+                R.ref_calculatePBSfromAFs(p1, p2, p3, n1, n2, n3, a)
+                L.orc_pbs_from_afs(p1, p2, p3, n1, n2, n3, b)
+                want[k] = a[:]; got[k] = b[:]; k += 1
+    assert_same_bits(got, want, "PBS")
+    assert (np.signbit(got) == np.signbit(want)).all()       # also the sign of a NaN: it is printed
+    assert np.isnan(want).any() and (want > 0).any()
+    rng = np.random.default_rng(5)
+    for _ in range(20000):                                   # larger populations
+        n = rng.integers(2, 400, 3)
+        c = [int(rng.integers(0, x + 1)) for x in n]
+        args = [c[0] / n[0], c[1] / n[1], c[2] / n[2], float(n[0]), float(n[1]), float(n[2])]
+        R.ref_calculatePBSfromAFs(*args, a); L.orc_pbs_from_afs(*args, b)
+        assert_same_bits(b[:], a[:], "PBS %r" % (args,))
+
+
 def test_rcp_division_identity():
     """The kernels' reciprocal-table quotient is bit-identical to IEEE division on the whole domain."""
     assert O.lib().orc_check_rcp_division(2047) == 0
