@@ -77,6 +77,7 @@ SIGNATURES = {
     "evofst_get_included_totals": (C.c_int, [_vp, _i64p]),
     "evofst_get_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp, _u8p]),
     "evofst_get_pbs_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i32p, _dp, _u8p]),
+    "evofst_get_abs_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i32p, _dp, _u8p]),
     "evofst_get_pop_site_div": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp]),
     "evofst_max_segments": (C.c_int64, [_vp]),
     "evofst_get_segments": (C.c_int, [_vp, _i64p, _i64p, _dp, _dp, _dp, _i32p]),
@@ -353,6 +354,14 @@ class EvoFst:
         pbs = np.empty((len(tr), 3, n)); used = np.empty((len(tr), n), np.uint8)
         self._chk(self.L.evofst_get_pbs_site_stats(self.h, first, n, len(tr), _ptr(tr, _i32p), _ptr(pbs, _dp), _ptr(used, _u8p)))
         return pbs, used
+
+    def abs_site_stats(self, quartets, first=0, n=None):
+        """ABS per site: (abs [T, 2, n] = {ABS, ABSalt}, used [T, n]) for quartets [T, 4] of population indices W, X, Y, Z."""
+        n = self.n_sites - first if n is None else n
+        qt = np.ascontiguousarray(quartets, np.int32).reshape(-1, 4)
+        out = np.empty((len(qt), 2, n)); used = np.empty((len(qt), n), np.uint8)
+        self._chk(self.L.evofst_get_abs_site_stats(self.h, first, n, len(qt), _ptr(qt, _i32p), _ptr(out, _dp), _ptr(used, _u8p)))
+        return out, used
 
     def pop_site_div(self, first=0, n=None):
         n = self.n_sites - first if n is None else n

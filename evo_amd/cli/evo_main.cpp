@@ -5,6 +5,7 @@
 //                                     FstGlobalMain  evo_FstAgainstAll.cpp:62
 //                                     AFmain         evo_AlleleFeq.cpp:46
 //                                     PBSmain        evo_PBS.cpp:126
+//                                     ABSmain        evo_ABS.cpp:109
 //
 // Division of labour: the host parses VCF text and packs genotypes (stage K0), the device computes
 // per-site counts and statistics (K1 + per-site kernels), and the host replays the reference's two
@@ -712,10 +713,10 @@ int AFmain(int argc, char **argv) {
     return 0;
 }
 
-// ============================================================================================ PBS
+// ====================================================================================== PBS, ABS
 
-namespace pbsopt {
-string vcfFile, setsFile, triosFile, runName = "";
+namespace bopt {
+string vcfFile, setsFile, tuplesFile, runName = "";
 int fixedWindowSize = 10000, windowSize = 20, windowStep = 10;
 }
 
@@ -728,24 +729,42 @@ const char *PBS_USAGE =
     "       -w SIZE,STEP --window=SIZE,STEP         sliding window: SIZE SNPs, moving by STEP (default: 20,10)\n"
     "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n\n";
 
-// Sign of a NaN PBS value as the reference's x86 build writes it ("nan" / "-nan").  A population with a single called
-// allele makes its variance term 0/0, every branch length that uses it NaN, and all three PBS values NaN; the sign
-// that survives depends on WHICH of T12, T13, T23 are NaN (the compiler folds the negations of -log() into the sums).
-// Index: T12 | T13 << 1 | T23 << 2; bit x set = PBS value x is "-nan".  The table is what g++ -O2 makes of
-// evo_PBS.cpp:69-98 on this image; tests/test_oracle.py pins the oracle, sign included, against that build.
-const uint8_t kPbsNanNegative[8] = {0, 4, 3, 0, 7, 4, 3, 0};
+const char *ABS_USAGE =
+    "Usage: evo ABS [OPTIONS] INPUT_FILE.vcf POPULATIONS.txt ABS_quartets.txt\n"
+    "Ancestral branch statistic for each quartet POP_W POP_X POP_Y POP_Z named in ABS_quartets.txt (four tab-separated\n"
+    "names per line); writes POPW_POPX_POPY_POPZ_ABS_RUN_SIZE_STEP.txt per quartet\n"
+    "       -h, --help                              display this help and exit\n"
+    "       -w SIZE,STEP --window=SIZE,STEP         sliding window: SIZE SNPs, moving by STEP (default: 20,10)\n"
+    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n\n";
 
-// evo PBS (PBSmain, evo_PBS.cpp:126-369) without --annot, --af and -i: per-site PBS of every trio on the device,
-// the sliding and fixed windows replayed on the host in file order.
-int PBSmain(int argc, char **argv) {
-    using namespace pbsopt;
+// Sign of a NaN value as the reference's x86 build writes it ("nan" / "-nan").  A population with a single called
+// allele makes its variance term 0/0 and every branch length T = -log(1 - Fst) that uses it NaN; which sign reaches the
+// output depends on WHICH branch lengths are NaN (the compiler folds the negations of -log() into the sums, and an x86
+// addition keeps its first NaN operand).  The tables are what g++ -O2 makes of evo_PBS.cpp:69-98 and evo_ABS.cpp:58-106
+// on this image; tests/test_oracle.py pins the oracle, sign included, against those builds, and the CLI tests compare
+// this program's text with the oracle's.
+//   PBS  index: T12 | T13 << 1 | T23 << 2;                                   bit x set = value x is "-nan"
+//   ABS  index: TWX | TWY << 1 | TWZ << 2 | TXY << 3 | TXZ << 4 | TYZ << 5;  bit 0 = ABS, bit 1 = ABSalt
+const uint8_t kPbsNanNegative[8] = {0, 4, 3, 0, 7, 4, 3, 0};
+const uint8_t kAbsNanNegative[64] = {0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 3, 2, 0, 0, 0, 0,
+                                     3, 0, 3, 0, 1, 0, 0, 0, 3, 2, 3, 0, 1, 0, 1, 0, 3, 0, 3, 0, 1, 0, 1, 0, 0, 2, 3, 2, 1, 0, 1, 0};
+
+// evo PBS (PBSmain, evo_PBS.cpp:126-369, without --annot, --af and -i) and evo ABS (ABSmain, evo_ABS.cpp:109-293,
+// without --annot): the reference's two mains are one loop over a different per-site statistic.  Per-site values of
+// every trio / quartet come from the device; the sliding windows (and, for PBS, the fixed windows) are replayed on the
+// host in file order.  Line citations are PBSmain's unless marked.
+int branchMain(const int arity, int argc, char **argv) {
+    using namespace bopt;
+    const bool pbsMode = arity == 3;
+    const int nVal = pbsMode ? 3 : 2;
+    const char *usage = pbsMode ? PBS_USAGE : ABS_USAGE;
     static const struct option longopts[] = {{"fixedW", required_argument, NULL, 'f'}, {"window", required_argument, NULL, 'w'},
                                              {"annot", required_argument, NULL, OPT_UNSUPPORTED}, {"af", required_argument, NULL, OPT_UNSUPPORTED},
                                              {"allow-indels-and-multiallelics", no_argument, NULL, 'i'},
                                              {"help", no_argument, NULL, 'h'}, {"run-name", required_argument, NULL, 'n'}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
     std::vector<string> ws;
-    for (int c; (c = getopt_long(argc, argv, "hw:n:f:i", longopts, NULL)) != -1;) {
+    for (int c; (c = getopt_long(argc, argv, pbsMode ? "hw:n:f:i" : "hw:n:", pbsMode ? longopts : longopts + 1, NULL)) != -1;) {
         std::istringstream arg(optarg != NULL ? optarg : "");
         switch (c) {
             case '?': dieFlag = true; break;
@@ -756,25 +775,25 @@ int PBSmain(int argc, char **argv) {
                 windowSize = atoi(ws[0].c_str()); windowStep = atoi(ws[1].c_str());
                 break;
             case 'n': arg >> runName; break;
-            case 'i': die("-i (indels and multiallelics) is not carried by the GPU build");
+            case 'i': if (!pbsMode) { dieFlag = true; break; } die("-i (indels and multiallelics) is not carried by the GPU build");
             case OPT_UNSUPPORTED: die("--annot and --af are not carried by the GPU build");
-            case 'h': std::cout << PBS_USAGE; exit(EXIT_SUCCESS);
+            case 'h': std::cout << usage; exit(EXIT_SUCCESS);
         }
     }
     if (argc - optind < 3) { std::cerr << "missing arguments\n"; dieFlag = true; }
     else if (argc - optind > 3) { std::cerr << "too many arguments\n"; dieFlag = true; }
     if (windowSize <= 0 || windowStep <= 0) { std::cerr << "window SIZE and STEP must be positive\n"; dieFlag = true; }
-    if (dieFlag) { std::cout << "\n" << PBS_USAGE; exit(EXIT_FAILURE); }
-    vcfFile = argv[optind++]; setsFile = argv[optind++]; triosFile = argv[optind++];
+    if (dieFlag) { std::cout << "\n" << usage; exit(EXIT_FAILURE); }
+    vcfFile = argv[optind++]; setsFile = argv[optind++]; tuplesFile = argv[optind++];
 
     LineReader vcf(vcfFile);
-    std::ifstream setsF(setsFile.c_str()), triosF(triosFile.c_str());
+    std::ifstream setsF(setsFile.c_str()), tuplesF(tuplesFile.c_str());
     if (!setsF.is_open()) die("could not open " + setsFile);
-    if (!triosF.is_open()) die("could not open " + triosFile);
+    if (!tuplesF.is_open()) die("could not open " + tuplesFile);
     std::map<string, std::vector<string>> popToIDsMap;
     std::map<string, string> IDsToPopMap;
     string line;
-    while (getline(setsF, line)) {                                   // PBS.cpp:148-154
+    while (getline(setsF, line)) {                                   // :148-154
         std::vector<string> ID_Pop = split(line, '\t');
         if (ID_Pop.size() < 2) die("POPULATIONS.txt needs two tab-separated columns per line");
         popToIDsMap[ID_Pop[1]].push_back(ID_Pop[0]);
@@ -786,29 +805,36 @@ int PBSmain(int argc, char **argv) {
     std::cerr << "There are " << populations.size() << " populations " << std::endl;
     const size_t P = populations.size();
 
-    std::vector<std::ofstream> outFiles, outFilesFixedWindow;        // :163-183
-    std::vector<int32_t> trios;
-    while (getline(triosF, line)) {
-        std::vector<string> threePops = split(line, '\t');
-        if (threePops.size() != 3) die("PBS_trios.txt needs three tab-separated population names per line");
-        for (const string &name : threePops) {
+    std::vector<std::ofstream> outFiles, outFilesFixedWindow;        // :163-183, ABS.cpp:146-156
+    std::vector<int32_t> tuples;
+    while (getline(tuplesF, line)) {
+        std::vector<string> names = split(line, '\t');
+        if ((int)names.size() != arity)
+            die(string(pbsMode ? "PBS_trios.txt needs three" : "ABS_quartets.txt needs four") + " tab-separated population names per line");
+        string stem;
+        for (const string &name : names) {
             auto it = popIndex.find(name);
-            if (it == popIndex.end()) die("population \"" + name + "\" of PBS_trios.txt is not in " + setsFile);
-            trios.push_back(it->second);
+            if (it == popIndex.end()) die("population \"" + name + "\" of " + tuplesFile + " is not in " + setsFile);
+            tuples.push_back(it->second);
+            stem += name + "_";
         }
-        const string stem = threePops[0] + "_" + threePops[1] + "_" + threePops[2] + "_PBS_" + runName;
+        stem += string(pbsMode ? "PBS_" : "ABS_") + runName;
         outFiles.emplace_back((stem + "_" + numToString(windowSize) + "_" + numToString(windowStep) + ".txt").c_str());
-        outFilesFixedWindow.emplace_back((stem + "_FW" + numToString(fixedWindowSize) + ".txt").c_str());
-        outFiles.back() << "chr\twStart\twEnd\t" << threePops[0] << "\t" << threePops[1] << "\t" << threePops[2] << std::endl;
-        outFilesFixedWindow.back() << "chr\twStart\twEnd\t" << threePops[0] << "\t" << threePops[1] << "\t" << threePops[2] << "\t"
-                                   << "nFwSNPs1" << "\t" << "nFwSNPs2" << "\t" << "nFwSNPs3" << std::endl;
+        if (pbsMode) {
+            outFilesFixedWindow.emplace_back((stem + "_FW" + numToString(fixedWindowSize) + ".txt").c_str());
+            outFiles.back() << "chr\twStart\twEnd\t" << names[0] << "\t" << names[1] << "\t" << names[2] << std::endl;
+            outFilesFixedWindow.back() << "chr\twStart\twEnd\t" << names[0] << "\t" << names[1] << "\t" << names[2] << "\t"
+                                       << "nFwSNPs1" << "\t" << "nFwSNPs2" << "\t" << "nFwSNPs3" << std::endl;
+        } else {
+            outFiles.back() << "chr\tpos1\tpos2\tABS\tABSalt" << std::endl;
+        }
     }
     const size_t T = outFiles.size();
-    if (T == 0) die("no trio in " + triosFile);
+    if (T == 0) die("no line in " + tuplesFile);
 
-    std::deque<double> initDeq(windowSize, 0.0);                     // :186-192
-    std::vector<std::vector<std::deque<double>>> PBSresults(T, std::vector<std::deque<double>>(4, initDeq));
-    std::vector<std::vector<std::vector<double>>> PBSfixedWindowResults(T, std::vector<std::vector<double>>(3));
+    std::deque<double> initDeq(windowSize, 0.0);                     // :186-192: nVal value deques + one of coordinates
+    std::vector<std::vector<std::deque<double>>> results(T, std::vector<std::deque<double>>(nVal + 1, initDeq));
+    std::vector<std::vector<std::vector<double>>> fixedWindowResults(T, std::vector<std::vector<double>>(3));
     int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
     std::vector<int> usedVars(T, 0);
     int totalVariantNumber = 0;
@@ -816,7 +842,7 @@ int PBSmain(int argc, char **argv) {
     Device dev;
     Batch batch;
     int nSamples = 0;
-    std::vector<double> pbs;
+    std::vector<double> val;
     std::vector<uint8_t> used;
     std::vector<int32_t> altc, nmc;
     bool haveHeader = false;
@@ -825,35 +851,52 @@ int PBSmain(int argc, char **argv) {
         if (batch.n == 0) return;
         const size_t n = batch.n;
         dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
-        pbs.resize(T * 3 * n); used.resize(T * n);
-        check(dev.ctx, evofst_get_pbs_site_stats(dev.ctx, 0, (int64_t)n, (int)T, trios.data(), pbs.data(), used.data()), "pbs_site_stats");
+        val.resize(T * nVal * n); used.resize(T * n);
+        if (pbsMode) check(dev.ctx, evofst_get_pbs_site_stats(dev.ctx, 0, (int64_t)n, (int)T, tuples.data(), val.data(), used.data()), "pbs_site_stats");
+        else check(dev.ctx, evofst_get_abs_site_stats(dev.ctx, 0, (int64_t)n, (int)T, tuples.data(), val.data(), used.data()), "abs_site_stats");
         bool anyNan = false;
-        for (double x : pbs) if (x != x) { anyNan = true; break; }
+        for (double x : val) if (x != x) { anyNan = true; break; }
         if (anyNan) {                                                // give NaNs the sign the reference prints
             altc.resize(n * P); nmc.resize(n * P);
             check(dev.ctx, evofst_get_counts(dev.ctx, 0, (int64_t)n, altc.data(), nmc.data()), "get_counts");
-            auto tNan = [&](size_t s, int a, int b) {
+            // is T = -log(1 - Fst) of populations a, b NaN, when na1 / nb1 say whether the two variance terms the
+            // reference subtracts for this pair come from a single-allele population
+            auto tNan = [&](size_t s, int a, int b, bool na1, bool nb1) {
                 const int ca = altc[s * P + a], na = nmc[s * P + a], cb = altc[s * P + b], nb = nmc[s * P + b];
-                if ((ca == 0 && cb == 0) || (ca == na && cb == nb)) return 0;   // Fst forced to 0 (:82-84)
-                return (na == 1 || nb == 1) ? 1 : 0;
+                if ((ca == 0 && cb == 0) || (ca == na && cb == nb)) return 0;   // Fst forced to 0 (:82-84, ABS.cpp:77-82)
+                return (na1 || nb1) ? 1 : 0;
             };
             for (size_t t = 0; t < T; ++t)
                 for (size_t s = 0; s < n; ++s) {
-                    double *v = &pbs[t * 3 * n + s];
-                    if (v[0] == v[0]) continue;
-                    const int a = trios[3 * t], b = trios[3 * t + 1], c = trios[3 * t + 2];
-                    const int neg = kPbsNanNegative[tNan(s, a, b) | tNan(s, a, c) << 1 | tNan(s, b, c) << 2];
-                    for (int x = 0; x < 3; ++x) v[x * n] = (neg >> x & 1) ? -__builtin_fabs(v[x * n]) : __builtin_fabs(v[x * n]);
+                    double *v = &val[t * nVal * n + s];
+                    bool any = false;
+                    for (int x = 0; x < nVal; ++x) any |= v[x * n] != v[x * n];
+                    if (!any) continue;
+                    const int32_t *q = &tuples[arity * t];
+                    bool one[4];
+                    for (int x = 0; x < arity; ++x) one[x] = nmc[s * P + q[x]] == 1;
+                    int neg;
+                    if (pbsMode) {
+                        neg = kPbsNanNegative[tNan(s, q[0], q[1], one[0], one[1]) | tNan(s, q[0], q[2], one[0], one[2]) << 1 |
+                                              tNan(s, q[1], q[2], one[1], one[2]) << 2];
+                    } else {
+                        // ABS.cpp:66: W's pairs subtract X's variance term and X's pairs subtract W's
+                        const bool fW = one[1], fX = one[0], fY = one[2], fZ = one[3];
+                        neg = kAbsNanNegative[tNan(s, q[0], q[1], fW, fX) | tNan(s, q[0], q[2], fW, fY) << 1 | tNan(s, q[0], q[3], fW, fZ) << 2 |
+                                              tNan(s, q[1], q[2], fX, fY) << 3 | tNan(s, q[1], q[3], fX, fZ) << 4 | tNan(s, q[2], q[3], fY, fZ) << 5];
+                    }
+                    for (int x = 0; x < nVal; ++x)
+                        if (v[x * n] != v[x * n]) v[x * n] = (neg >> x & 1) ? -__builtin_fabs(v[x * n]) : __builtin_fabs(v[x * n]);
                 }
         }
         for (size_t s = 0; s < n; ++s) {
-            if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :248-256
+            if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :248-256, ABS.cpp:217-221
             const string &chr = batch.chrom[s];
             const string &coord = batch.pos[s];
             double coordDouble; { std::stringstream ss(coord); ss >> coordDouble; }
-            if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {   // :289-303
+            if (pbsMode && (coordDouble > currentWindowEnd || coordDouble < currentWindowStart)) {   // :289-303 (PBS only)
                 for (size_t i = 0; i != T; i++) {
-                    std::vector<std::vector<double>> &fw = PBSfixedWindowResults[i];
+                    std::vector<std::vector<double>> &fw = fixedWindowResults[i];
                     const int nFwSNPs1 = (int)fw[0].size(), nFwSNPs2 = (int)fw[1].size(), nFwSNPs3 = (int)fw[2].size();
                     double PBSfw1 = 0; if (nFwSNPs1 > 0) PBSfw1 = vector_average(fw[0]);
                     double PBSfw2 = 0; if (nFwSNPs2 > 0) PBSfw2 = vector_average(fw[1]);
@@ -865,24 +908,25 @@ int PBSmain(int argc, char **argv) {
                 if (coordDouble > currentWindowEnd) { currentWindowStart = currentWindowStart + fixedWindowSize; currentWindowEnd = currentWindowEnd + fixedWindowSize; }
                 else if (coordDouble < currentWindowStart) { currentWindowStart = 0; currentWindowEnd = 0 + fixedWindowSize; }
             }
-            for (size_t i = 0; i != T; i++) {                        // :309-347
+            for (size_t i = 0; i != T; i++) {                        // :309-347, ABS.cpp:244-278
                 if (!used[i * n + s]) continue;
                 usedVars[i]++;
-                std::vector<std::deque<double>> &r = PBSresults[i];
-                for (int x = 0; x < 3; ++x) {
-                    const double v = pbs[(i * 3 + x) * n + s];
+                std::vector<std::deque<double>> &r = results[i];
+                for (int x = 0; x < nVal; ++x) {
+                    const double v = val[(i * nVal + x) * n + s];
                     r[x].push_back(v); r[x].pop_front();
-                    PBSfixedWindowResults[i][x].push_back(v);
+                    if (pbsMode) fixedWindowResults[i][x].push_back(v);
                 }
-                r[3].push_back(coordDouble); r[3].pop_front();
+                r[nVal].push_back(coordDouble); r[nVal].pop_front();
                 if (usedVars[i] > windowSize && (usedVars[i] % windowStep == 0)) {
                     double av[3];
-                    for (int x = 0; x < 3; ++x) {
+                    for (int x = 0; x < nVal; ++x) {
                         double sum = 0;
                         for (size_t k = 0; k < r[x].size(); k++) sum += r[x][k];
                         av[x] = (double)sum / (double)r[x].size();
                     }
-                    outFiles[i] << chr << "\t" << (int)r[3][0] << "\t" << coord << "\t" << av[0] << "\t" << av[1] << "\t" << av[2] << std::endl;
+                    if (pbsMode) outFiles[i] << chr << "\t" << (int)r[3][0] << "\t" << coord << "\t" << av[0] << "\t" << av[1] << "\t" << av[2] << std::endl;
+                    else outFiles[i] << chr << "\t" << r[2][0] << "\t" << coord << "\t" << av[0] << "\t" << av[1] << std::endl;   // ABS.cpp:275: a double
                 }
             }
         }
@@ -927,18 +971,19 @@ int PBSmain(int argc, char **argv) {
 
 int main(int argc, char **argv) {
     if (argc <= 1) {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS\n";
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS\n";
         return 0;
     }
     string command(argv[1]);
     if (command == "fst") return fstMain(argc - 1, argv + 1);
     if (command == "FstGlobal") return FstGlobalMain(argc - 1, argv + 1);
     if (command == "alleleFreq") return AFmain(argc - 1, argv + 1);
-    if (command == "PBS") return PBSmain(argc - 1, argv + 1);
+    if (command == "PBS") return branchMain(3, argc - 1, argv + 1);
+    if (command == "ABS") return branchMain(4, argc - 1, argv + 1);
     if (command == "help" || command == "--help") {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS\n" << FST_USAGE << FSTGLOBAL_USAGE << AF_USAGE << PBS_USAGE;
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS\n" << FST_USAGE << FSTGLOBAL_USAGE << AF_USAGE << PBS_USAGE << ABS_USAGE;
         return 0;
     }
-    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal, alleleFreq, PBS)\n";
+    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal, alleleFreq, PBS, ABS)\n";
     return 1;
 }

@@ -1157,37 +1157,50 @@ extern "C" int evofst_get_site_stats(evofst_ctx *c, int64_t first_site, int64_t 
     return EVOFST_OK;
 }
 
-extern "C" int evofst_get_pbs_site_stats(evofst_ctx *c, int64_t first_site, int64_t n_sites, int n_trios, const int32_t *trios,
-                                         double *pbs, uint8_t *used) {
-    if (!c || !trios || !pbs || !used || n_trios <= 0) return EVOFST_ERR_ARG;
+namespace {
+// PBS (arity 3, 3 values per site) and ABS (arity 4, 2 values) share the staging: population tuples up, values down
+int branch_site_stats(evofst_ctx *c, const char *what, int arity, int n_out, int64_t first_site, int64_t n_sites, int n_sets,
+                      const int32_t *sets, double *out, uint8_t *used) {
+    if (!c || !sets || !out || !used || n_sets <= 0) return EVOFST_ERR_ARG;
     NEED_GPU(c);
-    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "get_pbs_site_stats: run_counts first");
+    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, std::string(what) + ": run_counts first");
     int rc = check_range(c, first_site, n_sites);
     if (rc) return rc;
-    for (int i = 0; i < 3 * n_trios; ++i)
-        if (trios[i] < 0 || trios[i] >= c->n_pops) return fail(c, EVOFST_ERR_ARG, "get_pbs_site_stats: population index out of range");
+    for (int i = 0; i < arity * n_sets; ++i)
+        if (sets[i] < 0 || sets[i] >= c->n_pops) return fail(c, EVOFST_ERR_ARG, std::string(what) + ": population index out of range");
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf b[3];
     PbsParams p{};
     p.counts = c->d_counts.p; p.site_flags = c->have_flags ? c->flags : nullptr;
-    p.first_site = first_site; p.n_sites = n_sites; p.P = c->n_pops; p.n_trios = n_trios;
-    const size_t n = (size_t)n_trios * n_sites;
-    rc = ensure(c, b[0], (size_t)n_trios * 3 * 4);
-    if (!rc) rc = ensure(c, b[1], n * 3 * 8);
+    p.first_site = first_site; p.n_sites = n_sites; p.P = c->n_pops; p.n_trios = n_sets;
+    const size_t n = (size_t)n_sets * n_sites, set_bytes = (size_t)n_sets * arity * sizeof(int32_t);
+    rc = ensure(c, b[0], set_bytes);
+    if (!rc) rc = ensure(c, b[1], n * n_out * sizeof(double));
     if (!rc) rc = ensure(c, b[2], n);
     hipError_t e = hipSuccess;
     if (!rc) {
         p.trios = (const int32_t *)b[0].p; p.pbs = (double *)b[1].p; p.used = (uint8_t *)b[2].p;
-        e = hipMemcpyAsync(b[0].p, trios, (size_t)n_trios * 3 * 4, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = launch_pbs_sites(p, c->count_bytes, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(pbs, b[1].p, n * 3 * 8, hipMemcpyDeviceToHost, c->stream);
+        e = hipMemcpyAsync(b[0].p, sets, set_bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = arity == 3 ? launch_pbs_sites(p, c->count_bytes, c->stream) : launch_abs_sites(p, c->count_bytes, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out, b[1].p, n * n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(used, b[2].p, n, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
     for (auto &x : b) release(x);
     if (rc) return rc;
-    if (e != hipSuccess) return hip_fail(c, e, "get_pbs_site_stats");
+    if (e != hipSuccess) return hip_fail(c, e, what);
     return EVOFST_OK;
+}
+}  // namespace
+
+extern "C" int evofst_get_pbs_site_stats(evofst_ctx *c, int64_t first_site, int64_t n_sites, int n_trios, const int32_t *trios,
+                                         double *pbs, uint8_t *used) {
+    return branch_site_stats(c, "get_pbs_site_stats", 3, 3, first_site, n_sites, n_trios, trios, pbs, used);
+}
+
+extern "C" int evofst_get_abs_site_stats(evofst_ctx *c, int64_t first_site, int64_t n_sites, int n_quartets, const int32_t *quartets,
+                                         double *abs_out, uint8_t *used) {
+    return branch_site_stats(c, "get_abs_site_stats", 4, 2, first_site, n_sites, n_quartets, quartets, abs_out, used);
 }
 
 extern "C" int evofst_get_pop_site_div(evofst_ctx *c, int64_t first_site, int64_t n_sites, double *het, double *het_nei,

@@ -174,6 +174,7 @@ hipError_t launch_totals(const K2Params &p, const int64_t *base, const int64_t *
                          hipStream_t st);
 hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_pbs_sites(const PbsParams &p, int count_bytes, hipStream_t st);
+hipError_t launch_abs_sites(const PbsParams &p, int count_bytes, hipStream_t st);   // trios = [n][4], pbs = [n][2][n_sites]
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,
                                 int32_t *alt, int32_t *nm, hipStream_t st);

@@ -1080,6 +1080,75 @@ __global__ __launch_bounds__(256) void pbs_site_kernel(PbsParams p) {
     }
 }
 
+// Hudson Fst of one population pair as calculateABSfromAFs forms it (evo_ABS.cpp:63-91); fa, fb = the two variance
+// terms the reference subtracts for this pair
+__device__ __forceinline__ double abs_pair_fst(double pa, double pb, double fa, double fb, double na, double nb) {
+    const double power = (pa - pb) * (pa - pb);
+    const double numerator = power - fa - fb;
+    const double denominator = (pa * (1 - pb)) + (pb * (1 - pa));
+    double Fst;
+    if ((pa == 0 && pb == 0) || (pa == 1 && pb == 1)) Fst = 0.0; else Fst = numerator / denominator;
+    if (Fst < 0) Fst = 0;
+    if (Fst == 1) Fst = 1 - (Fst / ((na + nb) / 2.0));
+    return Fst;
+}
+
+// Ancestral branch statistic per site and quartet W, X, Y, Z (calculateABSfromAFs, evo_ABS.cpp:58-106, and the
+// per-site rules of ABSmain, :243-262): lane = site, blockIdx.y walks the quartets; out[q][0] = ABS, out[q][1] = ABSalt.
+// PbsParams is reused: trios = [n][4] population indices, pbs = [n][2][n_sites].
+template <typename CT>
+__global__ __launch_bounds__(256) void abs_site_kernel(PbsParams p) {
+    const int64_t ls = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ls >= p.n_sites) return;
+    const int64_t site = p.first_site + ls;
+    const CT *cp = reinterpret_cast<const CT *>(p.counts) + (size_t)(site >> 6) * p.P * kTileSites + (int)(site & 63);
+    const bool skip = p.site_flags ? ((p.site_flags[site] & 1u) != 0) : false;
+    for (int q = blockIdx.y; q < p.n_trios; q += gridDim.y) {
+        double pf[4], nf[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const uint32_t v = cp[(size_t)p.trios[4 * q + x] * kTileSites];
+            const int c = (int)(v & CountTraits<CT>::mask), nm = (int)(v >> CountTraits<CT>::shift);
+            pf[x] = nm > 0 ? (double)c / (double)nm : -1.0;
+            nf[x] = (double)nm;
+        }
+        const double pW = pf[0], pX = pf[1], pY = pf[2], pZ = pf[3];
+        bool used = !skip && pW != -1.0 && pX != -1.0 && pY != -1.0 && pZ != -1.0;                        // ABS.cpp:245-252
+        if (used && ((pW == 0 && pX == 0 && pY == 0 && pZ == 0) || (pW == 1 && pX == 1 && pY == 1 && pZ == 1))) used = false;   // :254-255
+        double ABSmain = 0.0, ABSalt = 0.0;
+        if (used) {
+            // :66 (sic) the variable named fractionX holds W's term and fractionW holds X's
+            const double fractionX = (pW * (1 - pW)) / (nf[0] - 1), fractionW = (pX * (1 - pX)) / (nf[1] - 1);
+            const double fractionY = (pY * (1 - pY)) / (nf[2] - 1), fractionZ = (pZ * (1 - pZ)) / (nf[3] - 1);
+            const double TWX = -log(1 - abs_pair_fst(pW, pX, fractionW, fractionX, nf[0], nf[1]));
+            const double TWY = -log(1 - abs_pair_fst(pW, pY, fractionW, fractionY, nf[0], nf[2]));
+            const double TWZ = -log(1 - abs_pair_fst(pW, pZ, fractionW, fractionZ, nf[0], nf[3]));
+            const double TXY = -log(1 - abs_pair_fst(pX, pY, fractionX, fractionY, nf[1], nf[2]));
+            const double TXZ = -log(1 - abs_pair_fst(pX, pZ, fractionX, fractionZ, nf[1], nf[3]));
+            const double TYZ = -log(1 - abs_pair_fst(pY, pZ, fractionY, fractionZ, nf[2], nf[3]));
+            const double TWYTXZ = TWY + TXZ, TWZTXY = TWZ + TXY, TWXTYZ = TWX + TYZ;
+            const double twoMax = (TWYTXZ >= TWZTXY) ? TWYTXZ : TWZTXY;                                      // :95
+            ABSalt = (twoMax - TWXTYZ) / 2.0;
+            double threeMax, threeMin;                                                                     // :97-100
+            if (TWYTXZ >= TWZTXY && TWYTXZ >= TWXTYZ) { threeMax = TWYTXZ; threeMin = (TWZTXY <= TWXTYZ) ? TWZTXY : TWXTYZ; }
+            else if (TWZTXY >= TWYTXZ && TWZTXY >= TWXTYZ) { threeMax = TWZTXY; threeMin = (TWYTXZ <= TWXTYZ) ? TWYTXZ : TWXTYZ; }
+            else { threeMax = TWXTYZ; threeMin = (TWYTXZ <= TWZTXY) ? TWYTXZ : TWZTXY; }
+            ABSmain = (threeMax - threeMin) / 2.0;
+        }
+        p.pbs[((size_t)q * 2 + 0) * p.n_sites + ls] = ABSmain;
+        p.pbs[((size_t)q * 2 + 1) * p.n_sites + ls] = ABSalt;
+        p.used[(size_t)q * p.n_sites + ls] = used ? 1 : 0;
+    }
+}
+
+hipError_t launch_abs_sites(const PbsParams &p, int count_bytes, hipStream_t st) {
+    if (p.n_sites <= 0 || p.n_trios <= 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((p.n_sites + 255) / 256), (unsigned)min(p.n_trios, 1024));
+    if (count_bytes == 2) hipLaunchKernelGGL((abs_site_kernel<uint16_t>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((abs_site_kernel<uint32_t>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_pbs_sites(const PbsParams &p, int count_bytes, hipStream_t st) {
     if (p.n_sites <= 0 || p.n_trios <= 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((p.n_sites + 255) / 256), (unsigned)min(p.n_trios, 1024));

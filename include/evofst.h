@@ -231,6 +231,12 @@ int evofst_get_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, 
  * skipped), else 0 and the three values are 0.  Any mode, after evofst_run_counts. */
 int evofst_get_pbs_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, int n_trios, const int32_t *trios,
                               double *pbs, uint8_t *used);
+/* Ancestral branch statistic per site for n_quartets population quartets W, X, Y, Z (quartets[4*t + 0..3] = population
+ * indices): calculateABSfromAFs (evo_ABS.cpp:58-106, including the swapped variance terms of :66) on the same allele
+ * frequencies, abs_out[t][0][site] = ABS, abs_out[t][1][site] = ABSalt; used[t][site] = 1 where ABSmain counts the site
+ * for the quartet (evo_ABS.cpp:243-256), else 0 and both values are 0.  Any mode, after evofst_run_counts. */
+int evofst_get_abs_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, int n_quartets, const int32_t *quartets,
+                              double *abs_out, uint8_t *used);
 /* Per-site per-population diversity (getSetHeterozygozities + calculatePiTwoSets,
  * process_vcf_fst.cpp:325-371): arrays [n_pops][n_sites]; any pointer may be NULL. */
 int evofst_get_pop_site_div(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *het,

@@ -1029,10 +1029,76 @@ void orc_pbs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, 
         }
 }
 
+/* ===================================================================== */
+/* ABS (evo_ABS.cpp)                                                     */
+/* ===================================================================== */
+/* Hudson Fst of one population pair as calculateABSfromAFs forms it (evo_ABS.cpp:63-91): fa, fb are the two
+ * variance terms the reference subtracts for this pair (see the note on their naming in orc_abs_from_afs) */
+static double abs_pair_fst(double pa, double pb, double fa, double fb, double na, double nb) {
+    double power = (pa - pb) * (pa - pb);
+    double numerator = power - fa - fb;
+    double denominator = (pa * (1 - pb)) + (pb * (1 - pa));
+    double Fst;
+    if ((pa == 0 && pb == 0) || (pa == 1 && pb == 1)) Fst = 0.0; else Fst = numerator / denominator;
+    if (Fst < 0) Fst = 0;
+    if (Fst == 1) Fst = 1 - (Fst / ((na + nb) / 2.0));
+    return Fst;
+}
+
+/* calculateABSfromAFs, evo_ABS.cpp:58-106.  abs_out[0] = ABS, abs_out[1] = ABSalt.
+ * Quirk kept (:66): the variable called fractionX holds W's term pW(1-pW)/(nW-1) and fractionW holds X's, so
+ * every pair with W subtracts X's term in W's place and every pair with X subtracts W's (WX itself is unaffected). */
+void orc_abs_from_afs(double pW, double pX, double pY, double pZ, double nW, double nX, double nY, double nZ, double *abs_out) {
+    double fractionX = (pW * (1 - pW)) / (nW - 1), fractionW = (pX * (1 - pX)) / (nX - 1);
+    double fractionY = (pY * (1 - pY)) / (nY - 1), fractionZ = (pZ * (1 - pZ)) / (nZ - 1);
+    double FstWX = abs_pair_fst(pW, pX, fractionW, fractionX, nW, nX);
+    double FstWY = abs_pair_fst(pW, pY, fractionW, fractionY, nW, nY);
+    double FstWZ = abs_pair_fst(pW, pZ, fractionW, fractionZ, nW, nZ);
+    double FstXY = abs_pair_fst(pX, pY, fractionX, fractionY, nX, nY);
+    double FstXZ = abs_pair_fst(pX, pZ, fractionX, fractionZ, nX, nZ);
+    double FstYZ = abs_pair_fst(pY, pZ, fractionY, fractionZ, nY, nZ);
+    double TWX = -log(1 - FstWX), TWY = -log(1 - FstWY), TWZ = -log(1 - FstWZ);
+    double TXY = -log(1 - FstXY), TXZ = -log(1 - FstXZ), TYZ = -log(1 - FstYZ);
+    double TWYTXZ = TWY + TXZ, TWZTXY = TWZ + TXY, TWXTYZ = TWX + TYZ;
+    double twoMax = (TWYTXZ >= TWZTXY) ? TWYTXZ : TWZTXY;
+    double ABSalt = (twoMax - TWXTYZ) / 2.0;
+    double threeMax, threeMin;
+    if (TWYTXZ >= TWZTXY && TWYTXZ >= TWXTYZ) { threeMax = TWYTXZ; threeMin = (TWZTXY <= TWXTYZ) ? TWZTXY : TWXTYZ; }
+    else if (TWZTXY >= TWYTXZ && TWZTXY >= TWXTYZ) { threeMax = TWZTXY; threeMin = (TWYTXZ <= TWXTYZ) ? TWYTXZ : TWXTYZ; }
+    else { threeMax = TWXTYZ; threeMin = (TWYTXZ <= TWZTXY) ? TWYTXZ : TWZTXY; }
+    abs_out[0] = (threeMax - threeMin) / 2.0;
+    abs_out[1] = ABSalt;
+}
+
+/* per-site rules of ABSmain (evo_ABS.cpp:243-262) on counts: abs [n_quartets][2][n_sites], used [n_quartets][n_sites] */
+void orc_abs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, int n_pops,
+                        const int32_t *quartets, int n_quartets, const uint8_t *site_flags, double *abs_out, uint8_t *used) {
+    for (int t = 0; t < n_quartets; t++)
+        for (int64_t s = 0; s < n_sites; s++) {
+            double p[4], n[4], out[2] = {0, 0};
+            int ok = !(site_flags && (site_flags[s] & ORC_SITE_SKIP));
+            for (int x = 0; x < 4; x++) {
+                int k = quartets[4 * t + x];
+                int a = alt[s * n_pops + k], m = nm[s * n_pops + k];
+                p[x] = m > 0 ? (double)a / m : -1.0;
+                n[x] = (double)m;
+                if (p[x] == -1) ok = 0;
+            }
+            if (ok && p[0] == 0 && p[1] == 0 && p[2] == 0 && p[3] == 0) ok = 0;
+            if (ok && p[0] == 1 && p[1] == 1 && p[2] == 1 && p[3] == 1) ok = 0;
+            if (ok) orc_abs_from_afs(p[0], p[1], p[2], p[3], n[0], n[1], n[2], n[3], out);
+            for (int x = 0; x < 2; x++) abs_out[((size_t)t * 2 + (size_t)x) * (size_t)n_sites + (size_t)s] = out[x];
+            used[(size_t)t * (size_t)n_sites + (size_t)s] = (uint8_t)ok;
+        }
+}
+
 /* `evo PBS [-w SIZE,STEP] [-f FW] [-n RUN] VCF POPS TRIOS` (PBSmain, evo_PBS.cpp:125-363) without --annot,
- * --af and -i.  Output files go to out_dir. */
-int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_path,
-                int windowSize, int windowStep, int fixedWindowSize, const char *run_name, const char *out_dir) {
+ * --af and -i, and `evo ABS [-w SIZE,STEP] [-n RUN] VCF POPS QUARTETS` (ABSmain, evo_ABS.cpp:109-293) without --annot.
+ * The two mains are the same loop over a different statistic (arity 3 with fixed windows, arity 4 without); the
+ * citations below are PBSmain's, ABSmain's lines are noted where the behaviour differs.  Output files go to out_dir. */
+static int branch_run(int arity, const char *vcf_path, const char *pops_path, const char *trios_path,
+                      int windowSize, int windowStep, int fixedWindowSize, const char *run_name, const char *out_dir) {
+    const int nval = arity == 3 ? 3 : 2;                         /* values per site: PBS x3, or ABS and ABSalt */
     lreader vcf;
     if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
     FILE *sf = fopen(pops_path, "r");
@@ -1078,29 +1144,37 @@ int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_p
         char *l = NULL; size_t cap = 0; ssize_t r;
         while ((r = getline(&l, &cap, tf)) >= 0) {
             if (r && l[r - 1] == '\n') l[r - 1] = '\0';
-            char *a = l, *b = strchr(a, '\t'); if (!b) { rc = -5; break; } *b++ = '\0';
-            char *c3 = strchr(b, '\t'); if (!c3) { rc = -5; break; } *c3++ = '\0';
-            if (strchr(c3, '\t')) { rc = -5; break; }            /* assert(threePops.size() == 3) */
+            char *nm4[4] = {l, NULL, NULL, NULL};
+            int nf = 1;
+            for (char *q = l; *q; q++) if (*q == '\t') { *q = '\0'; if (nf < 4) nm4[nf] = q + 1; nf++; }
+            if (nf != arity) { rc = -5; break; }                  /* assert(threePops.size() == 3) / fourPops == 4 */
             if (n_trios == tcap) {
                 tcap = tcap ? tcap * 2 : 8;
-                trio = (int *)realloc(trio, sizeof(int) * 3 * (size_t)tcap);
+                trio = (int *)realloc(trio, sizeof(int) * 4 * (size_t)tcap);
                 outW = (FILE **)realloc(outW, sizeof(FILE *) * (size_t)tcap); outFW = (FILE **)realloc(outFW, sizeof(FILE *) * (size_t)tcap);
             }
-            const char *nm3[3] = {a, b, c3};
-            for (int x = 0; x < 3; x++) {
+            for (int x = 0; x < arity; x++) {
                 int k = -1;
-                for (int i = 0; i < n_pops; i++) if (strcmp(pops[i].name, nm3[x]) == 0) k = i;
+                for (int i = 0; i < n_pops; i++) if (strcmp(pops[i].name, nm4[x]) == 0) k = i;
                 if (k < 0) rc = -6;                               /* setAAFs.at() would throw */
-                trio[3 * n_trios + x] = k;
+                trio[4 * n_trios + x] = k;
             }
             char name[1024];
-            snprintf(name, sizeof name, "%s_%s_%s_PBS_%s_%d_%d.txt", a, b, c3, run_name, windowSize, windowStep);
-            char *p1 = path_join(out_dir, name); outW[n_trios] = fopen(p1, "w"); free(p1);
-            snprintf(name, sizeof name, "%s_%s_%s_PBS_%s_FW%d.txt", a, b, c3, run_name, fixedWindowSize);
-            char *p2 = path_join(out_dir, name); outFW[n_trios] = fopen(p2, "w"); free(p2);
-            if (!outW[n_trios] || !outFW[n_trios]) { rc = -3; n_trios++; break; }
-            fprintf(outW[n_trios], "chr\twStart\twEnd\t%s\t%s\t%s\n", a, b, c3);
-            fprintf(outFW[n_trios], "chr\twStart\twEnd\t%s\t%s\t%s\tnFwSNPs1\tnFwSNPs2\tnFwSNPs3\n", a, b, c3);
+            outFW[n_trios] = NULL;
+            if (arity == 3) {
+                snprintf(name, sizeof name, "%s_%s_%s_PBS_%s_%d_%d.txt", nm4[0], nm4[1], nm4[2], run_name, windowSize, windowStep);
+                char *p1 = path_join(out_dir, name); outW[n_trios] = fopen(p1, "w"); free(p1);
+                snprintf(name, sizeof name, "%s_%s_%s_PBS_%s_FW%d.txt", nm4[0], nm4[1], nm4[2], run_name, fixedWindowSize);
+                char *p2 = path_join(out_dir, name); outFW[n_trios] = fopen(p2, "w"); free(p2);
+                if (!outW[n_trios] || !outFW[n_trios]) { rc = -3; n_trios++; break; }
+                fprintf(outW[n_trios], "chr\twStart\twEnd\t%s\t%s\t%s\n", nm4[0], nm4[1], nm4[2]);
+                fprintf(outFW[n_trios], "chr\twStart\twEnd\t%s\t%s\t%s\tnFwSNPs1\tnFwSNPs2\tnFwSNPs3\n", nm4[0], nm4[1], nm4[2]);
+            } else {                                              /* ABS.cpp:153-154 */
+                snprintf(name, sizeof name, "%s_%s_%s_%s_ABS_%s_%d_%d.txt", nm4[0], nm4[1], nm4[2], nm4[3], run_name, windowSize, windowStep);
+                char *p1 = path_join(out_dir, name); outW[n_trios] = fopen(p1, "w"); free(p1);
+                if (!outW[n_trios]) { rc = -3; n_trios++; break; }
+                fprintf(outW[n_trios], "chr\tpos1\tpos2\tABS\tABSalt\n");
+            }
             n_trios++;
         }
         free(l); fclose(tf);
@@ -1150,7 +1224,7 @@ int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_p
             if (strcmp(fields[4], "*") == 0 || strlen(fields[3]) > 1 || strlen(fields[4]) > 1) continue;
             orc_general_counts((const char *const *)(fields + 9), n_samples, sample_pop, n_pops, use_pop,
                                alt, alleles, aaf, allelesC, aafC);
-            if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {          /* :288-303 */
+            if (arity == 3 && (coordDouble > currentWindowEnd || coordDouble < currentWindowStart)) {   /* :288-303; ABS has no fixed windows */
                 for (int i = 0; i < n_trios; i++) {
                     dvec *f0 = &fw[3 * i];
                     int n1 = (int)f0[0].n, n2 = (int)f0[1].n, n3 = (int)f0[2].n;
@@ -1164,28 +1238,35 @@ int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_p
                 if (coordDouble > currentWindowEnd) { currentWindowStart += fixedWindowSize; currentWindowEnd += fixedWindowSize; }
                 else if (coordDouble < currentWindowStart) { currentWindowStart = 0; currentWindowEnd = fixedWindowSize; }
             }
-            for (int i = 0; i < n_trios; i++) {                                                 /* :307-343 */
-                double p1 = aaf[trio[3 * i]]; if (p1 == -1) continue;
-                double p2 = aaf[trio[3 * i + 1]]; if (p2 == -1) continue;
-                double p3 = aaf[trio[3 * i + 2]]; if (p3 == -1) continue;
-                if (p1 == 0 && p2 == 0 && p3 == 0) continue;
-                if (p1 == 1 && p2 == 1 && p3 == 1) continue;
+            for (int i = 0; i < n_trios; i++) {                                                 /* :307-343, ABS.cpp:243-277 */
+                double pq[4], nq[4];
+                int ok = 1, all0 = 1, all1 = 1;
+                for (int x = 0; x < arity && ok; x++) {
+                    pq[x] = aaf[trio[4 * i + x]]; nq[x] = alleles[trio[4 * i + x]];
+                    if (pq[x] == -1) ok = 0;
+                    if (pq[x] != 0) all0 = 0;
+                    if (pq[x] != 1) all1 = 0;
+                }
+                if (!ok || all0 || all1) continue;
                 usedVars[i]++;
-                double pbs[3];
-                orc_pbs_from_afs(p1, p2, p3, alleles[trio[3 * i]], alleles[trio[3 * i + 1]], alleles[trio[3 * i + 2]], pbs);
+                double val[3];
+                if (arity == 3) orc_pbs_from_afs(pq[0], pq[1], pq[2], nq[0], nq[1], nq[2], val);
+                else orc_abs_from_afs(pq[0], pq[1], pq[2], pq[3], nq[0], nq[1], nq[2], nq[3], val);
                 double *d = dq + (size_t)i * 4 * W;
                 int h = head[i];
-                d[0 * W + (size_t)h] = pbs[0]; d[1 * W + (size_t)h] = pbs[1]; d[2 * W + (size_t)h] = pbs[2]; d[3 * W + (size_t)h] = coordDouble;
+                for (int x = 0; x < nval; x++) d[(size_t)x * W + (size_t)h] = val[x];
+                d[3 * W + (size_t)h] = coordDouble;
                 head[i] = h = (h + 1) % (int)W;                                                  /* push_back + pop_front */
-                dv_push(&fw[3 * i], pbs[0]); dv_push(&fw[3 * i + 1], pbs[1]); dv_push(&fw[3 * i + 2], pbs[2]);
+                if (arity == 3) for (int x = 0; x < 3; x++) dv_push(&fw[3 * i + x], val[x]);
                 if (usedVars[i] > windowSize && (usedVars[i] % windowStep == 0)) {
                     double av[3];
-                    for (int x = 0; x < 3; x++) {
+                    for (int x = 0; x < nval; x++) {
                         double sum = 0;
                         for (size_t t = 0; t < W; t++) sum += d[(size_t)x * W + (size_t)((h + (int)t) % (int)W)];
                         av[x] = sum / (double)W;
                     }
-                    fprintf(outW[i], "%s\t%d\t%s\t%g\t%g\t%g\n", chr, (int)d[3 * W + (size_t)h], coord, av[0], av[1], av[2]);
+                    if (arity == 3) fprintf(outW[i], "%s\t%d\t%s\t%g\t%g\t%g\n", chr, (int)d[3 * W + (size_t)h], coord, av[0], av[1], av[2]);
+                    else fprintf(outW[i], "%s\t%g\t%s\t%g\t%g\n", chr, d[3 * W + (size_t)h], coord, av[0], av[1]);   /* ABS.cpp:275: the coordinate stays a double */
                 }
             }
         }
@@ -1203,6 +1284,16 @@ int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_p
     for (int i = 0; i < n_ids; i++) { free(id_names[i]); free(id_pop[i]); }
     free(id_names); free(id_pop);
     return rc;
+}
+
+int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_path,
+                int windowSize, int windowStep, int fixedWindowSize, const char *run_name, const char *out_dir) {
+    return branch_run(3, vcf_path, pops_path, trios_path, windowSize, windowStep, fixedWindowSize, run_name, out_dir);
+}
+
+int orc_abs_run(const char *vcf_path, const char *pops_path, const char *quartets_path,
+                int windowSize, int windowStep, const char *run_name, const char *out_dir) {
+    return branch_run(4, vcf_path, pops_path, quartets_path, windowSize, windowStep, 10000, run_name, out_dir);
 }
 
 /* ===================================================================== */

@@ -12,12 +12,14 @@
  *     /root/reference/process_vcf_fst.h + process_vcf_utils.h unmodified into
  *     oracle/_ref/libevo_refmath.so and tests/test_oracle.py checks
  *     bit-equality.
- *   - The PBS per-site math (orc_pbs_from_afs) is PINNED the same way:
- *     oracle/ref_pbs_shim.cpp compiles /root/reference/evo_PBS.cpp where it
- *     lies, keeps only calculatePBSfromAFs (everything else is hidden and
- *     discarded at link time) in oracle/_ref/libevo_refpbs.so, and
- *     tests/test_oracle.py checks bit-equality, NaN sign included.  The PBS
- *     window text driver (orc_pbs_run) is a restatement: "parity unpinned".
+ *   - The PBS / ABS per-site math (orc_pbs_from_afs, orc_abs_from_afs) is
+ *     PINNED the same way: oracle/ref_pbs_shim.cpp / ref_abs_shim.cpp compile
+ *     /root/reference/evo_PBS.cpp / evo_ABS.cpp where they lie, keep only
+ *     calculatePBSfromAFs / calculateABSfromAFs (everything else is hidden
+ *     and discarded at link time) in oracle/_ref/libevo_refpbs.so /
+ *     libevo_refabs.so, and tests/test_oracle.py checks bit-equality, NaN
+ *     sign included.  The window text drivers (orc_pbs_run, orc_abs_run)
+ *     are restatements: "parity unpinned".
  *   - The genotype counting code (process_vcf_fst.cpp, process_vcf_utils.cpp)
  *     and the two window state machines live in translation units that need
  *     Boost.Math, which this image lacks; they are therefore UNBUILDABLE here
@@ -189,9 +191,17 @@ void orc_pbs_from_afs(double p1, double p2, double p3, double n1, double n2, dou
 void orc_pbs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, int n_pops,
                         const int32_t *trios, int n_trios, const uint8_t *site_flags, double *pbs, uint8_t *used);
 
+/* calculateABSfromAFs (evo_ABS.cpp:58-106; abs_out = {ABS, ABSalt}) and the per-site rules of ABSmain (:243-262) on
+ * counts: abs [n_quartets][2][n_sites], used [n_quartets][n_sites] */
+void orc_abs_from_afs(double pW, double pX, double pY, double pZ, double nW, double nX, double nY, double nZ, double *abs_out);
+void orc_abs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, int n_pops,
+                        const int32_t *quartets, int n_quartets, const uint8_t *site_flags, double *abs_out, uint8_t *used);
 /* `evo PBS [-w] [-f] [-n] VCF POPS TRIOS` (PBSmain, evo_PBS.cpp:125-363) without --annot / --af / -i */
 int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_path,
                 int window_size, int window_step, int fixed_window_size, const char *run_name, const char *out_dir);
+/* `evo ABS [-w] [-n] VCF POPS QUARTETS` (ABSmain, evo_ABS.cpp:109-293) without --annot */
+int orc_abs_run(const char *vcf_path, const char *pops_path, const char *quartets_path,
+                int windowSize, int windowStep, const char *run_name, const char *out_dir);
 
 /* `evo alleleFreq [-n] VCF POPS` (AFmain, evo_AlleleFeq.cpp:46-166) without -g; the output file
  * <pops base name>_<run_name>_AF.txt is written into out_dir. */

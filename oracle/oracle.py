@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libevo_oracle.so")
 _REF = os.path.join(_HERE, "_ref", "libevo_refmath.so")
 _REF_PBS = os.path.join(_HERE, "_ref", "libevo_refpbs.so")
+_REF_ABS = os.path.join(_HERE, "_ref", "libevo_refabs.so")
 
 _dp = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -26,7 +27,8 @@ def build(force=False):
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
             os.path.join(_HERE, "evo_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "libevo_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF) or not os.path.exists(_REF_PBS)):
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF) or not os.path.exists(_REF_PBS)
+                                             or not os.path.exists(_REF_ABS)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -162,6 +164,46 @@ def ref_pbs():
         R.ref_calculatePBSfromAFs.argtypes = [C.c_double] * 6 + [_dp]
         _ref_pbs = R
     return _ref_pbs
+
+
+_ref_abs = None
+
+
+def ref_abs():
+    """The reference's own calculateABSfromAFs (evo_ABS.cpp:58-106), or None when oracle/_ref was never built."""
+    global _ref_abs
+    if _ref_abs is None:
+        build()
+        if not os.path.exists(_REF_ABS):
+            return None
+        R = C.CDLL(_REF_ABS)
+        R.ref_calculateABSfromAFs.restype = None
+        R.ref_calculateABSfromAFs.argtypes = [C.c_double] * 8 + [_dp]
+        _ref_abs = R
+    return _ref_abs
+
+
+def abs_from_afs(pW, pX, pY, pZ, nW, nX, nY, nZ):
+    L = lib()
+    L.orc_abs_from_afs.restype = None
+    L.orc_abs_from_afs.argtypes = [C.c_double] * 8 + [_dp]
+    out = (C.c_double * 2)()
+    L.orc_abs_from_afs(pW, pX, pY, pZ, nW, nX, nY, nZ, out)
+    return np.array(out[:])
+
+
+def abs_site_stats(alt, nm, quartets, site_flags=None):
+    """(abs [T, 2, S], used [T, S]) from counts [S, P] (evo_ABS.cpp:58-106, 243-262)."""
+    L = lib()
+    alt = np.ascontiguousarray(alt, np.int32); nm = np.ascontiguousarray(nm, np.int32)
+    S, P = alt.shape
+    qt = np.ascontiguousarray(quartets, np.int32).reshape(-1, 4)
+    fl = np.ascontiguousarray(site_flags, np.uint8) if site_flags is not None else None
+    out = np.empty((len(qt), 2, S)); used = np.empty((len(qt), S), np.uint8)
+    L.orc_abs_site_stats.restype = None
+    L.orc_abs_site_stats.argtypes = [_i32p, _i32p, C.c_int64, C.c_int, _i32p, C.c_int, _u8p, _dp, _u8p]
+    L.orc_abs_site_stats(_p(alt, _i32p), _p(nm, _i32p), S, P, _p(qt, _i32p), len(qt), _p(fl, _u8p), _p(out, _dp), _p(used, _u8p))
+    return out, used
 
 
 def pbs_from_afs(p1, p2, p3, n1, n2, n3):
@@ -308,6 +350,15 @@ def pbs_run(vcf, pops, trios, out_dir, run_name="", size=20, step=10, fixed=1000
     rc = L.orc_pbs_run(vcf.encode(), pops.encode(), trios.encode(), size, step, fixed, run_name.encode(), out_dir.encode())
     if rc != 0:
         raise RuntimeError("orc_pbs_run failed: %d" % rc)
+
+
+def abs_run(vcf, pops, quartets, out_dir, run_name="", size=20, step=10):
+    L = lib()
+    L.orc_abs_run.restype = C.c_int
+    L.orc_abs_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    rc = L.orc_abs_run(vcf.encode(), pops.encode(), quartets.encode(), size, step, run_name.encode(), out_dir.encode())
+    if rc != 0:
+        raise RuntimeError("orc_abs_run failed: %d" % rc)
 
 
 def af_run(vcf, pops, out_dir, run_name="out"):

@@ -171,7 +171,7 @@ def test_cli_allele_freq(tmp_path):
     assert sum(1 for _ in open(got)) > 30000
 
 
-def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25):
+def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25, quartets=False):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=miss)
     pf, tf = str(tmp_path / "pops.txt"), str(tmp_path / "trios.txt")
@@ -183,12 +183,20 @@ def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samp
             if i % 9 != 8:
                 f.write("%s\t%s\n" % (n, pops[i % 4]))
         f.write("GHOST\tpopA\n")
-    open(tf, "w").write("popA\tpopB\tpopC\nsolo\tpopA\tpopB\npopA\tsolo\tduo\npopD\tduo\tsolo\npopC\tpopB\tpopA\nduo\tsolo\tduo\n")
+    if quartets:
+        open(tf, "w").write("popA\tpopB\tpopC\tpopD\nsolo\tpopA\tpopB\tduo\npopA\tsolo\tduo\tpopC\npopD\tduo\tsolo\tpopB\n"
+                            "popC\tpopB\tpopA\tsolo\nduo\tsolo\tduo\tpopA\npopD\tpopC\tpopB\tpopA\n")
+    else:
+        open(tf, "w").write("popA\tpopB\tpopC\nsolo\tpopA\tpopB\npopA\tsolo\tduo\npopD\tduo\tsolo\npopC\tpopB\tpopA\nduo\tsolo\tduo\n")
     cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
     cli_dir.mkdir(); orc_dir.mkdir()
-    r = subprocess.run([EVO, "PBS", "-n", "p"] + args + [vcf, pf, tf], cwd=str(cli_dir), capture_output=True, text=True, timeout=120)
+    r = subprocess.run([EVO, "ABS" if quartets else "PBS", "-n", "p"] + args + [vcf, pf, tf], cwd=str(cli_dir), capture_output=True,
+                       text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
-    O.pbs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step, fixed=fixed)
+    if quartets:
+        O.abs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step)
+    else:
+        O.pbs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step, fixed=fixed)
     _same_files(str(cli_dir), str(orc_dir))
     return cli_dir
 
@@ -210,6 +218,20 @@ def test_cli_pbs_windows_fixed_crlf(tmp_path):
 def test_cli_pbs_several_device_batches(tmp_path):
     _pbs_case(tmp_path, np.random.default_rng(43), ["--window=50,25", "--fixedW", "20000"], 50, 25, fixed=20000, n_sites=70000,
               n_samples=12, miss=0.15)
+
+
+def test_cli_abs_default(tmp_path):
+    """evo ABS (SURVEY 8f-2): per-site ABS / ABSalt of seven quartets from the device, windows replayed on the host;
+    the solo population makes NaN rows of either sign, and quartets where only T_WY or T_XZ is NaN stay finite."""
+    d = _pbs_case(tmp_path, np.random.default_rng(51), [], 20, 10, quartets=True)
+    assert len(os.listdir(d)) == 7
+    text = "".join((d / n).read_text() for n in os.listdir(d))
+    assert "\tnan" in text and "\t-nan" in text
+    assert sum(1 for _ in open(d / "popA_popB_popC_popD_ABS_p_20_10.txt")) > 100
+
+
+def test_cli_abs_windows_crlf_batches(tmp_path):
+    _pbs_case(tmp_path, np.random.default_rng(52), ["-w", "9,4"], 9, 4, crlf=True, miss=0.12, n_sites=40000, n_samples=14, quartets=True)
 
 
 def test_cli_rejects_unknown_command():

@@ -153,6 +153,38 @@ def test_pbs_bit_equal_to_reference():
         assert_same_bits(b[:], a[:], "PBS %r" % (args,))
 
 
+@pytest.mark.skipif(O.ref_abs() is None, reason="oracle/_ref not built (no /root/reference here)")
+def test_abs_bit_equal_to_reference():
+    """orc_abs_from_afs vs the reference's own calculateABSfromAFs (evo_ABS.cpp:58-106) compiled from /root/reference:
+    every quadruple of (alt, called) counts up to 3 alleles (single-allele populations, fixed differences, the swapped
+    variance terms of :66, NaN signs) and random larger ones."""
+    R = O.ref_abs()
+    L = O.lib()
+    L.orc_abs_from_afs.restype = None
+    L.orc_abs_from_afs.argtypes = [C.c_double] * 8 + [O._dp]
+    pn = [(c / n, float(n)) for n in range(1, 4) for c in range(n + 1)]
+    a = (C.c_double * 2)(); b = (C.c_double * 2)()
+    got = np.empty((len(pn) ** 4, 2)); want = np.empty_like(got)
+    k = 0
+    for pw, nw in pn:
+        for px, nx in pn:
+            for py, ny in pn:
+                for pz, nz in pn:
+                    R.ref_calculateABSfromAFs(pw, px, py, pz, nw, nx, ny, nz, a)
+                    L.orc_abs_from_afs(pw, px, py, pz, nw, nx, ny, nz, b)
+                    want[k] = a[:]; got[k] = b[:]; k += 1
+    assert_same_bits(got, want, "ABS")
+    assert (np.signbit(got) == np.signbit(want)).all()
+    assert np.isnan(want).any() and (want > 0).any() and (want < 0).any()
+    rng = np.random.default_rng(6)
+    for _ in range(20000):
+        n = rng.integers(2, 300, 4)
+        c = [int(rng.integers(0, x + 1)) for x in n]
+        args = [c[i] / n[i] for i in range(4)] + [float(x) for x in n]
+        R.ref_calculateABSfromAFs(*args, a); L.orc_abs_from_afs(*args, b)
+        assert_same_bits(b[:], a[:], "ABS %r" % (args,))
+
+
 def test_rcp_division_identity():
     """The kernels' reciprocal-table quotient is bit-identical to IEEE division on the whole domain."""
     assert O.lib().orc_check_rcp_division(2047) == 0
