@@ -78,6 +78,8 @@ SIGNATURES = {
     "evofst_get_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp, _u8p]),
     "evofst_get_pbs_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i32p, _dp, _u8p]),
     "evofst_get_abs_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i32p, _dp, _u8p]),
+    "evofst_get_dist_windows": (C.c_int, [_vp, C.c_int, _i64p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _dp, _i32p, _i32p,
+                                          _i32p, _i32p]),
     "evofst_get_pop_site_div": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp]),
     "evofst_max_segments": (C.c_int64, [_vp]),
     "evofst_get_segments": (C.c_int, [_vp, _i64p, _i64p, _dp, _dp, _dp, _i32p]),
@@ -362,6 +364,22 @@ class EvoFst:
         out = np.empty((len(qt), 2, n)); used = np.empty((len(qt), n), np.uint8)
         self._chk(self.L.evofst_get_abs_site_stats(self.h, first, n, len(qt), _ptr(qt, _i32p), _ptr(out, _dp), _ptr(used, _u8p)))
         return out, used
+
+    def dist_windows(self, win_off, out_idx, in_idx, carry=None):
+        """Outgroup-to-ingroup dxy per window [win_off[w], win_off[w+1]) -> dict(sum, nsnp, miss [W, O, I], used, missing
+        [W, O]); carry = the same dict for one window (shapes [O, I] / [O]) whose running values window 0 continues."""
+        wo = np.ascontiguousarray(win_off, np.int64)
+        oi = np.ascontiguousarray(out_idx, np.int32); ii = np.ascontiguousarray(in_idx, np.int32)
+        W, O, I = len(wo) - 1, len(oi), len(ii)
+        r = dict(sum=np.zeros((W, O, I)), nsnp=np.zeros((W, O, I), np.int32), miss=np.zeros((W, O, I), np.int32),
+                 used=np.zeros((W, O), np.int32), missing=np.zeros((W, O), np.int32))
+        if carry is not None:
+            for k in r:
+                r[k][0] = carry[k]
+        self._chk(self.L.evofst_get_dist_windows(self.h, W, _ptr(wo, _i64p), O, _ptr(oi, _i32p), I, _ptr(ii, _i32p),
+                                                 0 if carry is None else 1, _ptr(r["sum"], _dp), _ptr(r["nsnp"], _i32p),
+                                                 _ptr(r["miss"], _i32p), _ptr(r["used"], _i32p), _ptr(r["missing"], _i32p)))
+        return r
 
     def pop_site_div(self, first=0, n=None):
         n = self.n_sites - first if n is None else n

@@ -6,6 +6,7 @@
 //                                     AFmain         evo_AlleleFeq.cpp:46
 //                                     PBSmain        evo_PBS.cpp:126
 //                                     ABSmain        evo_ABS.cpp:109
+//                                     DistOutMain    evo_distanceToOutgroups.cpp:68
 //
 // Division of labour: the host parses VCF text and packs genotypes (stage K0), the device computes
 // per-site counts and statistics (K1 + per-site kernels), and the host replays the reference's two
@@ -18,6 +19,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -967,11 +969,198 @@ int branchMain(const int arity, int argc, char **argv) {
     return 0;
 }
 
+// ================================================================================== DistOutgroups
+
+namespace dopt {
+string vcfFile, setsFile, outgroupFile, ingroupFile, runName = "";
+int fixedWindowSize = 10000;
+}
+
+const char *DISTOUT_USAGE =
+    "Usage: evo DistOutgroups [OPTIONS] INPUT_FILE.vcf POPULATIONS.txt OUTGROUPS.txt INGROUPS.txt\n"
+    "Mean genetic distance (dxy) between each outgroup population (one name per line in OUTGROUPS.txt) and each ingroup\n"
+    "population (one per line in INGROUPS.txt) in fixed windows; writes OUTGROUP_DIST_RUN_FWsize.txt per outgroup\n"
+    "       -h, --help                              display this help and exit\n"
+    "       -f, --fixedW size                       fixed (physical) window size (default: 10000)\n"
+    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n\n";
+
+// evo DistOutgroups (DistOutMain, evo_distanceToOutgroups.cpp:68-306) without -i and --accessibleGenomeBED.  The host
+// replays the fixed-window state machine on the coordinates alone to find where rows are emitted, the device adds up
+// the per-site dxy of every (outgroup, ingroup) pair between two emissions in site order, the host turns the sums
+// into rows.  A window left open at the end of a device batch is continued by the next batch (carry_first).
+int DistOutMain(int argc, char **argv) {
+    using namespace dopt;
+    static const struct option longopts[] = {{"fixedW", required_argument, NULL, 'f'}, {"help", no_argument, NULL, 'h'},
+                                             {"run-name", required_argument, NULL, 'n'},
+                                             {"allow-indels-and-multiallelics", no_argument, NULL, 'i'},
+                                             {"accessibleGenomeBED", required_argument, NULL, OPT_UNSUPPORTED}, {NULL, 0, NULL, 0}};
+    bool dieFlag = false;
+    for (int c; (c = getopt_long(argc, argv, "hn:f:i", longopts, NULL)) != -1;) {
+        std::istringstream arg(optarg != NULL ? optarg : "");
+        switch (c) {
+            case '?': dieFlag = true; break;
+            case 'f': arg >> fixedWindowSize; break;
+            case 'n': arg >> runName; break;
+            case 'i': die("-i (indels and multiallelics) is not carried by the GPU build");
+            case OPT_UNSUPPORTED: die("--accessibleGenomeBED is not carried by the GPU build");
+            case 'h': std::cout << DISTOUT_USAGE; exit(EXIT_SUCCESS);
+        }
+    }
+    if (argc - optind < 4) { std::cerr << "missing arguments\n"; dieFlag = true; }
+    else if (argc - optind > 4) { std::cerr << "too many arguments\n"; dieFlag = true; }
+    if (dieFlag) { std::cout << "\n" << DISTOUT_USAGE; exit(EXIT_FAILURE); }
+    vcfFile = argv[optind++]; setsFile = argv[optind++]; outgroupFile = argv[optind++]; ingroupFile = argv[optind++];
+
+    LineReader vcf(vcfFile);
+    std::ifstream setsF(setsFile.c_str()), outgroupF(outgroupFile.c_str()), ingroupF(ingroupFile.c_str());
+    if (!setsF.is_open()) die("could not open " + setsFile);
+    if (!outgroupF.is_open()) die("could not open " + outgroupFile);
+    if (!ingroupF.is_open()) die("could not open " + ingroupFile);
+    std::map<string, std::vector<string>> popToIDsMap;
+    std::map<string, string> IDsToPopMap;
+    string line;
+    while (getline(setsF, line)) {                                   // :88-94
+        std::vector<string> ID_Pop = split(line, '\t');
+        if (ID_Pop.size() < 2) die("POPULATIONS.txt needs two tab-separated columns per line");
+        popToIDsMap[ID_Pop[1]].push_back(ID_Pop[0]);
+        IDsToPopMap[ID_Pop[0]] = ID_Pop[1];
+    }
+    std::vector<string> populations, ingroups, outgroups;
+    std::map<string, int> popIndex;
+    for (auto &kv : popToIDsMap) { popIndex[kv.first] = (int)populations.size(); populations.push_back(kv.first); }
+    std::cerr << "There are " << populations.size() << " populations " << std::endl;
+    const size_t P = populations.size();
+    auto indexOf = [&](const string &name, const string &file) {
+        auto it = popIndex.find(name);
+        if (it == popIndex.end()) die("population \"" + name + "\" of " + file + " is not in " + setsFile);
+        return (int32_t)it->second;
+    };
+    std::vector<int32_t> inIdx, outIdx;
+    while (getline(ingroupF, line)) { ingroups.push_back(line); inIdx.push_back(indexOf(line, ingroupFile)); }   // :104-106
+    std::vector<std::ofstream> outFilesFixedWindow;                  // :109-117
+    auto printRow = [](std::ofstream &f, const auto &v) {            // print_vector, process_vcf_utils.h:338-347
+        for (size_t k = 0; k < v.size(); k++) {
+            if (k == v.size() - 1) f << v[k] << std::endl;
+            else f << v[k] << '\t';
+        }
+    };
+    while (getline(outgroupF, line)) {
+        outIdx.push_back(indexOf(line, outgroupFile));
+        outFilesFixedWindow.emplace_back((line + "_DIST_" + runName + "_FW" + numToString(fixedWindowSize) + ".txt").c_str());
+        outFilesFixedWindow.back() << "chr\twStart\twEnd\tSNPs_used\tSNPs_missing\tAccessibleSizeBP" << "\t";
+        printRow(outFilesFixedWindow.back(), ingroups);
+        outgroups.push_back(line);
+    }
+    const size_t nOut = outgroups.size(), nIn = ingroups.size();
+    if (nOut == 0) die("no outgroup in " + outgroupFile);
+
+    int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
+    int totalVariantNumber = 0;
+    Device dev;
+    Batch batch;
+    int nSamples = 0;
+    bool haveHeader = false;
+    struct Emission { int64_t site; string chr; int wStart, wEnd; };
+    std::vector<Emission> rows;
+    std::vector<int64_t> winOff;
+    std::vector<double> sum, carrySum(nOut * nIn, 0.0), averaged(nIn);
+    std::vector<int32_t> nsnp, miss, usedV, missingV, carryNsnp(nOut * nIn, 0), carryMiss(nOut * nIn, 0), carryUsed(nOut, 0), carryMissing(nOut, 0);
+
+    auto flush = [&]() {
+        if (batch.n == 0) return;
+        const size_t n = batch.n;
+        dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
+        rows.clear();
+        for (size_t s = 0; s < n; ++s) {                             // the state machine of :221-269 on coordinates alone
+            if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :194-202
+            double coordDouble; { std::stringstream ss(batch.pos[s]); ss >> coordDouble; }
+            if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {
+                rows.push_back(Emission{(int64_t)s, batch.chrom[s], currentWindowStart, currentWindowEnd});
+                if (coordDouble > currentWindowEnd) { currentWindowStart = currentWindowStart + fixedWindowSize; currentWindowEnd = currentWindowEnd + fixedWindowSize; }
+                else if (coordDouble < currentWindowStart) { currentWindowStart = 0; currentWindowEnd = 0 + fixedWindowSize; }
+            }
+        }
+        const size_t W = rows.size() + 1;                            // the last one stays open
+        winOff.assign(1, 0);
+        for (const Emission &e : rows) winOff.push_back(e.site);
+        winOff.push_back((int64_t)n);
+        sum.assign(W * nOut * nIn, 0.0); nsnp.assign(W * nOut * nIn, 0); miss.assign(W * nOut * nIn, 0);
+        usedV.assign(W * nOut, 0); missingV.assign(W * nOut, 0);
+        std::copy(carrySum.begin(), carrySum.end(), sum.begin()); std::copy(carryNsnp.begin(), carryNsnp.end(), nsnp.begin());
+        std::copy(carryMiss.begin(), carryMiss.end(), miss.begin());
+        std::copy(carryUsed.begin(), carryUsed.end(), usedV.begin()); std::copy(carryMissing.begin(), carryMissing.end(), missingV.begin());
+        check(dev.ctx, evofst_get_dist_windows(dev.ctx, (int)W, winOff.data(), (int)nOut, outIdx.data(), (int)nIn, inIdx.data(), 1,
+                                               sum.data(), nsnp.data(), miss.data(), usedV.data(), missingV.data()), "get_dist_windows");
+        for (size_t w = 0; w + 1 < W; ++w) {
+            const int accessibleInThisWindow = fixedWindowSize;      // :223 (no BED file)
+            for (size_t i = 0; i != nOut; i++) {                     // :232-254
+                for (size_t j = 0; j != nIn; j++) {
+                    const size_t o = (w * nOut + i) * nIn + j;
+                    const int nSNPs = nsnp[o], md = miss[o];
+                    if (nSNPs > 0) {
+                        double missingProportion = (double)md / (nSNPs + md);
+                        if (missingProportion > 0.5) averaged[j] = NAN;
+                        else {
+                            averaged[j] = (double)sum[o] / (double)accessibleInThisWindow;     // vector_average_withRegion
+                            double nonMissingProportion = (double)nSNPs / (nSNPs + md);
+                            double scalingFactor = 1 + (missingProportion / nonMissingProportion);
+                            averaged[j] = averaged[j] * scalingFactor;
+                        }
+                    } else averaged[j] = NAN;
+                }
+                outFilesFixedWindow[i] << rows[w].chr << "\t" << rows[w].wStart << "\t" << rows[w].wEnd << "\t" << usedV[w * nOut + i] << "\t"
+                                       << missingV[w * nOut + i] << "\t" << accessibleInThisWindow << "\t";
+                printRow(outFilesFixedWindow[i], averaged);
+            }
+        }
+        const size_t last = W - 1;
+        std::copy(sum.begin() + last * nOut * nIn, sum.end(), carrySum.begin());
+        std::copy(nsnp.begin() + last * nOut * nIn, nsnp.end(), carryNsnp.begin());
+        std::copy(miss.begin() + last * nOut * nIn, miss.end(), carryMiss.begin());
+        std::copy(usedV.begin() + last * nOut, usedV.end(), carryUsed.begin());
+        std::copy(missingV.begin() + last * nOut, missingV.end(), carryMissing.begin());
+        batch.clear();
+    };
+
+    while (vcf.getline(line)) {
+        line.erase(std::remove(line.begin(), line.end(), '\r'), line.end());   // :156
+        if (line[0] == '#' && line[1] == '#') continue;
+        if (line[0] == '#' && line[1] == 'C') {
+            std::vector<string> fields = split(line, '\t');
+            std::vector<string> sampleNames(fields.begin() + std::min<size_t>(9, fields.size()), fields.end());
+            nSamples = (int)sampleNames.size();
+            if (nSamples <= 0) die("VCF header has no sample columns");
+            std::vector<int32_t> sp(nSamples, -1);
+            for (int i = 0; i < nSamples; ++i) {                     // :163-165
+                auto it = IDsToPopMap.find(sampleNames[i]);
+                if (it != IDsToPopMap.end()) sp[i] = popIndex[it->second];
+            }
+            for (auto &kv : popToIDsMap)                              // :168-178
+                if (locateSet(sampleNames, kv.second).empty()) { std::cerr << "Did not find any samples in the VCF for \"" << kv.first << "\"" << std::endl; exit(EXIT_FAILURE); }
+            for (size_t k = 0; k < P; ++k)
+                if (std::find(sp.begin(), sp.end(), (int32_t)k) == sp.end()) die("population \"" + populations[k] + "\" has no sample column of its own");
+            dev.open();
+            check(dev.ctx, evofst_set_layout(dev.ctx, nSamples, (int)P, sp.data()), "set_layout");
+            check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
+            haveHeader = true;
+            continue;
+        }
+        if (!haveHeader) die("variant line before the #CHROM header");
+        totalVariantNumber++;
+        if (totalVariantNumber % 10000 == 0) std::cerr << "Processed " << totalVariantNumber << " variants" << std::endl;
+        batch.add(line, totalVariantNumber);
+        if (batch.n == (size_t)kChunkSites) flush();
+    }
+    flush();                                                         // the window open at the end is never written (:298)
+    if (dev.ctx) evofst_destroy(dev.ctx);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc <= 1) {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS\n";
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS  DistOutgroups\n";
         return 0;
     }
     string command(argv[1]);
@@ -980,10 +1169,11 @@ int main(int argc, char **argv) {
     if (command == "alleleFreq") return AFmain(argc - 1, argv + 1);
     if (command == "PBS") return branchMain(3, argc - 1, argv + 1);
     if (command == "ABS") return branchMain(4, argc - 1, argv + 1);
+    if (command == "DistOutgroups") return DistOutMain(argc - 1, argv + 1);
     if (command == "help" || command == "--help") {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS\n" << FST_USAGE << FSTGLOBAL_USAGE << AF_USAGE << PBS_USAGE << ABS_USAGE;
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS  DistOutgroups\n" << FST_USAGE << FSTGLOBAL_USAGE << AF_USAGE << PBS_USAGE << ABS_USAGE << DISTOUT_USAGE;
         return 0;
     }
-    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal, alleleFreq, PBS, ABS)\n";
+    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal, alleleFreq, PBS, ABS, DistOutgroups)\n";
     return 1;
 }

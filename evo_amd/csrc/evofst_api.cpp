@@ -1203,6 +1203,61 @@ extern "C" int evofst_get_abs_site_stats(evofst_ctx *c, int64_t first_site, int6
     return branch_site_stats(c, "get_abs_site_stats", 4, 2, first_site, n_sites, n_quartets, quartets, abs_out, used);
 }
 
+extern "C" int evofst_get_dist_windows(evofst_ctx *c, int n_windows, const int64_t *win_off, int n_out, const int32_t *out_idx,
+                                      int n_in, const int32_t *in_idx, int carry_first, double *sum, int32_t *nsnp, int32_t *miss,
+                                      int32_t *used, int32_t *missing) {
+    if (!c || !win_off || !out_idx || !used || !missing || n_windows <= 0 || n_out <= 0 || n_in < 0) return EVOFST_ERR_ARG;
+    if (n_in > 0 && (!in_idx || !sum || !nsnp || !miss)) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "get_dist_windows: run_counts first");
+    if (win_off[0] < 0 || win_off[n_windows] > c->n_sites) return fail(c, EVOFST_ERR_ARG, "get_dist_windows: window offsets out of bounds");
+    for (int w = 0; w < n_windows; ++w)
+        if (win_off[w] > win_off[w + 1]) return fail(c, EVOFST_ERR_ARG, "get_dist_windows: window offsets must not decrease");
+    for (int i = 0; i < n_out; ++i)
+        if (out_idx[i] < 0 || out_idx[i] >= c->n_pops) return fail(c, EVOFST_ERR_ARG, "get_dist_windows: population index out of range");
+    for (int j = 0; j < n_in; ++j)
+        if (in_idx[j] < 0 || in_idx[j] >= c->n_pops) return fail(c, EVOFST_ERR_ARG, "get_dist_windows: population index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nw = (size_t)n_windows * n_out, nwj = nw * (size_t)n_in;
+    // one staging block: sum | win_off | nsnp | miss | used | missing | out_idx | in_idx  (8-byte items first)
+    const size_t o_sum = 0, o_off = o_sum + nwj * 8, o_nsnp = o_off + ((size_t)n_windows + 1) * 8, o_miss = o_nsnp + nwj * 4,
+                 o_used = o_miss + nwj * 4, o_missing = o_used + nw * 4, o_out = o_missing + nw * 4, o_in = o_out + (size_t)n_out * 4,
+                 total = o_in + (size_t)n_in * 4;
+    DevBuf b;
+    int rc = ensure(c, b, total);
+    if (rc) return rc;
+    char *d = (char *)b.p;
+    DistParams p{};
+    p.counts = c->d_counts.p; p.site_flags = c->have_flags ? c->flags : nullptr;
+    p.win_off = (const int64_t *)(d + o_off); p.P = c->n_pops; p.n_windows = n_windows; p.n_out = n_out; p.n_in = n_in;
+    p.carry_first = carry_first ? 1 : 0;
+    p.out_idx = (const int32_t *)(d + o_out); p.in_idx = (const int32_t *)(d + o_in);
+    p.sum = (double *)(d + o_sum); p.nsnp = (int32_t *)(d + o_nsnp); p.miss = (int32_t *)(d + o_miss);
+    p.used = (int32_t *)(d + o_used); p.missing = (int32_t *)(d + o_missing);
+    hipError_t e = hipMemcpyAsync(d + o_off, win_off, ((size_t)n_windows + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_out, out_idx, (size_t)n_out * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n_in) e = hipMemcpyAsync(d + o_in, in_idx, (size_t)n_in * 4, hipMemcpyHostToDevice, c->stream);
+    if (carry_first) {   // the running values of window 0
+        const size_t r = (size_t)n_out * n_in;
+        if (e == hipSuccess && r) e = hipMemcpyAsync(d + o_sum, sum, r * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && r) e = hipMemcpyAsync(d + o_nsnp, nsnp, r * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && r) e = hipMemcpyAsync(d + o_miss, miss, r * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d + o_used, used, (size_t)n_out * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d + o_missing, missing, (size_t)n_out * 4, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = launch_dist_windows(p, c->count_bytes, c->stream);
+    if (e == hipSuccess && nwj) e = hipMemcpyAsync(sum, d + o_sum, nwj * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && nwj) e = hipMemcpyAsync(nsnp, d + o_nsnp, nwj * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && nwj) e = hipMemcpyAsync(miss, d + o_miss, nwj * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(used, d + o_used, nw * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(missing, d + o_missing, nw * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    else (void)hipStreamSynchronize(c->stream);
+    release(b);
+    if (e != hipSuccess) return hip_fail(c, e, "get_dist_windows");
+    return EVOFST_OK;
+}
+
 extern "C" int evofst_get_pop_site_div(evofst_ctx *c, int64_t first_site, int64_t n_sites, double *het, double *het_nei,
                                        double *pi) {
     if (!c) return EVOFST_ERR_ARG;

@@ -101,6 +101,19 @@ struct PbsParams {
     uint8_t *used;          // [n_trios][n_sites]
 };
 
+// windowed outgroup-to-ingroup dxy (DistOutMain, evo_distanceToOutgroups.cpp:274-294)
+struct DistParams {
+    const void *counts;
+    const uint8_t *site_flags;
+    const int64_t *win_off;     // [n_windows + 1] site offsets (device)
+    int32_t P, n_windows, n_out, n_in, carry_first;
+    const int32_t *out_idx;     // [n_out] population indices (device)
+    const int32_t *in_idx;      // [n_in]
+    double *sum;                // [n_windows][n_out][n_in]
+    int32_t *nsnp, *miss;       // [n_windows][n_out][n_in]
+    int32_t *used, *missing;    // [n_windows][n_out]
+};
+
 struct PopDivParams {
     const void *counts;
     int64_t first_site, n_sites;
@@ -175,6 +188,7 @@ hipError_t launch_totals(const K2Params &p, const int64_t *base, const int64_t *
 hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_pbs_sites(const PbsParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_abs_sites(const PbsParams &p, int count_bytes, hipStream_t st);   // trios = [n][4], pbs = [n][2][n_sites]
+hipError_t launch_dist_windows(const DistParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,
                                 int32_t *alt, int32_t *nm, hipStream_t st);

@@ -237,6 +237,18 @@ int evofst_get_pbs_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sit
  * for the quartet (evo_ABS.cpp:243-256), else 0 and both values are 0.  Any mode, after evofst_run_counts. */
 int evofst_get_abs_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, int n_quartets, const int32_t *quartets,
                               double *abs_out, uint8_t *used);
+/* Outgroup-to-ingroup dxy in caller-cut windows: what DistOutMain (evo_distanceToOutgroups.cpp:274-294, DxyPerSNPfromAFs
+ * :62-65) accumulates between two emissions of its fixed-window state machine.  Window w covers sites
+ * [win_off[w], win_off[w+1]) of the uploaded shard (n_windows + 1 non-decreasing offsets); skipped sites do not count.
+ * Per window and outgroup i (arrays [n_windows][n_out]): used = sites where the outgroup has a called allele,
+ * missing = sites where it has none.  Per window, outgroup and ingroup j (arrays [n_windows][n_out][n_in]):
+ * sum = the per-site dxy AFout(1-AFin) + AFin(1-AFout) added up in site order (bit-identical to the reference's
+ * sequential sum), nsnp = the sites in that sum, miss = used sites where the ingroup has no called allele.
+ * carry_first != 0: on entry the entries of window 0 hold the running values of a window begun in an earlier shard,
+ * and are continued.  Any mode, after evofst_run_counts. */
+int evofst_get_dist_windows(evofst_ctx *ctx, int n_windows, const int64_t *win_off, int n_out, const int32_t *out_idx,
+                            int n_in, const int32_t *in_idx, int carry_first, double *sum, int32_t *nsnp, int32_t *miss,
+                            int32_t *used, int32_t *missing);
 /* Per-site per-population diversity (getSetHeterozygozities + calculatePiTwoSets,
  * process_vcf_fst.cpp:325-371): arrays [n_pops][n_sites]; any pointer may be NULL. */
 int evofst_get_pop_site_div(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *het,

@@ -1439,3 +1439,248 @@ long orc_check_rcp_division(int max_n) {
     }
     return bad;
 }
+
+/* ===================================================================== */
+/* DistOutgroups (evo_distanceToOutgroups.cpp)                           */
+/* ===================================================================== */
+/* the populations file and the header mapping every GeneralSetCounts driver starts with, for the drivers below */
+typedef struct {
+    pop_t *pops; int n_pops;                 /* sorted by name: std::map order */
+    char **id_names, **id_pop; int n_ids;    /* IDsToPopMap (a later line with the same ID overwrites its population) */
+} popfile_t;
+
+static int popfile_read(const char *path, popfile_t *pf) {
+    memset(pf, 0, sizeof *pf);
+    FILE *sf = fopen(path, "r");
+    if (!sf) return -2;
+    int pcap = 0, icap = 0;
+    char *l = NULL; size_t cap = 0; ssize_t r;
+    while ((r = getline(&l, &cap, sf)) >= 0) {
+        if (r && l[r - 1] == '\n') l[r - 1] = '\0';
+        char *tab = strchr(l, '\t');
+        if (!tab) continue;
+        *tab = '\0';
+        char *id = l, *pn = tab + 1;
+        char *tab2 = strchr(pn, '\t'); if (tab2) *tab2 = '\0';
+        int k = -1;
+        for (int i = 0; i < pf->n_pops; i++) if (strcmp(pf->pops[i].name, pn) == 0) { k = i; break; }
+        if (k < 0) {
+            if (pf->n_pops == pcap) { pcap = pcap ? pcap * 2 : 16; pf->pops = (pop_t *)realloc(pf->pops, sizeof(pop_t) * (size_t)pcap); }
+            k = pf->n_pops++;
+            memset(&pf->pops[k], 0, sizeof(pop_t));
+            pf->pops[k].name = strdup(pn);
+        }
+        pop_t *P = &pf->pops[k];
+        if (P->n_ids == P->cap) { P->cap = P->cap ? P->cap * 2 : 16; P->ids = (char **)realloc(P->ids, sizeof(char *) * (size_t)P->cap); }
+        P->ids[P->n_ids++] = strdup(id);
+        int found = -1;
+        for (int i = 0; i < pf->n_ids; i++) if (strcmp(pf->id_names[i], id) == 0) { found = i; break; }
+        if (found < 0) {
+            if (pf->n_ids == icap) {
+                icap = icap ? icap * 2 : 64;
+                pf->id_names = (char **)realloc(pf->id_names, sizeof(char *) * (size_t)icap);
+                pf->id_pop = (char **)realloc(pf->id_pop, sizeof(char *) * (size_t)icap);
+            }
+            pf->id_names[pf->n_ids] = strdup(id); pf->id_pop[pf->n_ids] = strdup(pn); pf->n_ids++;
+        } else { free(pf->id_pop[found]); pf->id_pop[found] = strdup(pn); }
+    }
+    free(l); fclose(sf);
+    qsort(pf->pops, (size_t)pf->n_pops, sizeof(pop_t), cmp_pop);
+    return 0;
+}
+
+/* #CHROM line -> population of every genotype column (posToPopMap) and the columns of every population
+ * (popToPosMap); returns the number of genotype columns, *rc = -4 if a population has no column */
+static int popfile_map_header(popfile_t *pf, const char *line, int32_t **sample_pop, int *rc) {
+    char *hdr = strdup(line); char **hf = NULL; int hcap = 0;
+    int nh = split_inplace(hdr, '\t', &hf, &hcap);
+    int n_samples = nh - 9; if (n_samples < 0) n_samples = 0;
+    *sample_pop = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_samples + 1));
+    for (int i = 0; i < n_samples; i++) {
+        (*sample_pop)[i] = -1;
+        for (int j = 0; j < pf->n_ids; j++)
+            if (strcmp(pf->id_names[j], hf[9 + i]) == 0) {
+                for (int k = 0; k < pf->n_pops; k++) if (strcmp(pf->pops[k].name, pf->id_pop[j]) == 0) (*sample_pop)[i] = k;
+                break;
+            }
+    }
+    for (int k = 0; k < pf->n_pops; k++) {
+        pf->pops[k].pos = (size_t *)malloc(sizeof(size_t) * (size_t)(pf->pops[k].n_ids + 1));
+        pf->pops[k].n_pos = locate_set(hf + 9, n_samples, pf->pops[k].ids, pf->pops[k].n_ids, pf->pops[k].pos);
+        if (pf->pops[k].n_pos == 0) { fprintf(stderr, "Did not find any samples in the VCF for \"%s\"\n", pf->pops[k].name); *rc = -4; }
+    }
+    free(hf); free(hdr);
+    return n_samples;
+}
+
+static void popfile_free(popfile_t *pf) {
+    for (int k = 0; k < pf->n_pops; k++) {
+        for (int i = 0; i < pf->pops[k].n_ids; i++) free(pf->pops[k].ids[i]);
+        free(pf->pops[k].ids); free(pf->pops[k].pos); free(pf->pops[k].name);
+    }
+    free(pf->pops);
+    for (int i = 0; i < pf->n_ids; i++) { free(pf->id_names[i]); free(pf->id_pop[i]); }
+    free(pf->id_names); free(pf->id_pop);
+}
+
+/* lines of a file as they are (getline without any trimming, evo_distanceToOutgroups.cpp:104-117) */
+static char **read_lines(const char *path, int *n) {
+    *n = 0;
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    char **out = NULL; int capn = 0;
+    char *l = NULL; size_t cap = 0; ssize_t r;
+    while ((r = getline(&l, &cap, f)) >= 0) {
+        if (r && l[r - 1] == '\n') l[r - 1] = '\0';
+        if (*n == capn) { capn = capn ? capn * 2 : 16; out = (char **)realloc(out, sizeof(char *) * (size_t)capn); }
+        out[(*n)++] = strdup(l);
+    }
+    free(l); fclose(f);
+    if (!out) out = (char **)calloc(1, sizeof(char *));
+    return out;
+}
+
+/* DxyPerSNPfromAFs, evo_distanceToOutgroups.cpp:62-65 */
+double orc_dxy_from_afs(double AF1, double AF2) { return AF1 * (1 - AF2) + AF2 * (1 - AF1); }
+
+/* The accumulation of DistOutMain (evo_distanceToOutgroups.cpp:274-294) between two window emissions, on counts:
+ * window w covers sites [win_off[w], win_off[w+1]); per window and outgroup i: used / missing site counts
+ * ([n_windows][n_out]); per window, outgroup and ingroup j ([n_windows][n_out][n_in]): the sum of the per-site dxy in
+ * site order, the number of sites in it, and the number of sites where only the ingroup is missing.
+ * carry_first != 0: the entries of window 0 hold the running values of a window begun earlier and are continued. */
+void orc_dist_windows(const int32_t *alt, const int32_t *nm, int n_pops, const uint8_t *site_flags,
+                      const int64_t *win_off, int n_windows, const int32_t *out_idx, int n_out, const int32_t *in_idx, int n_in,
+                      int carry_first, double *sum, int32_t *nsnp, int32_t *miss, int32_t *used, int32_t *missing_vars) {
+    for (int w = 0; w < n_windows; w++)
+        for (int i = 0; i < n_out; i++) {
+            size_t wi = (size_t)w * (size_t)n_out + (size_t)i;
+            if (!(carry_first && w == 0)) {
+                used[wi] = 0; missing_vars[wi] = 0;
+                for (int j = 0; j < n_in; j++) { sum[wi * (size_t)n_in + (size_t)j] = 0; nsnp[wi * (size_t)n_in + (size_t)j] = 0; miss[wi * (size_t)n_in + (size_t)j] = 0; }
+            }
+            for (int64_t s = win_off[w]; s < win_off[w + 1]; s++) {
+                if (site_flags && (site_flags[s] & ORC_SITE_SKIP)) continue;
+                int mo = nm[s * n_pops + out_idx[i]];
+                if (mo == 0) { missing_vars[wi]++; continue; }                 /* AFout == -1, :278-282 */
+                used[wi]++;
+                double AFout = (double)alt[s * n_pops + out_idx[i]] / mo;
+                for (int j = 0; j < n_in; j++) {
+                    int mi = nm[s * n_pops + in_idx[j]];
+                    size_t o = wi * (size_t)n_in + (size_t)j;
+                    if (mi != 0) { sum[o] += orc_dxy_from_afs(AFout, (double)alt[s * n_pops + in_idx[j]] / mi); nsnp[o]++; }
+                    else miss[o]++;
+                }
+            }
+        }
+}
+
+/* `evo DistOutgroups [-f FW] [-n RUN] VCF POPS OUTGROUPS INGROUPS` (DistOutMain, evo_distanceToOutgroups.cpp:68-306)
+ * without -i and --accessibleGenomeBED.  Output files go to out_dir. */
+int orc_distout_run(const char *vcf_path, const char *pops_path, const char *outgroups_path, const char *ingroups_path,
+                    int fixedWindowSize, const char *run_name, const char *out_dir) {
+    lreader vcf;
+    if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
+    popfile_t pf;
+    int rc = popfile_read(pops_path, &pf);
+    if (rc) { lr_close(&vcf); return rc; }
+    fprintf(stderr, "There are %d populations \n", pf.n_pops);
+    int n_in = 0, n_out = 0;
+    char **ingroups = read_lines(ingroups_path, &n_in);                      /* :104-106 */
+    char **outgroups = read_lines(outgroups_path, &n_out);                   /* :110-117 */
+    if (!ingroups || !outgroups) { lr_close(&vcf); popfile_free(&pf); return -2; }
+    FILE **outFW = (FILE **)calloc((size_t)n_out + 1, sizeof(FILE *));
+    int *out_k = (int *)malloc(sizeof(int) * (size_t)(n_out + 1)), *in_k = (int *)malloc(sizeof(int) * (size_t)(n_in + 1));
+    for (int i = 0; i < n_out; i++) {
+        char name[1024];
+        snprintf(name, sizeof name, "%s_DIST_%s_FW%d.txt", outgroups[i], run_name, fixedWindowSize);
+        char *pth = path_join(out_dir, name); outFW[i] = fopen(pth, "w"); free(pth);
+        if (!outFW[i]) { rc = -3; break; }
+        fprintf(outFW[i], "chr\twStart\twEnd\tSNPs_used\tSNPs_missing\tAccessibleSizeBP\t");
+        for (int j = 0; j < n_in; j++) fprintf(outFW[i], "%s%s", ingroups[j], j == n_in - 1 ? "\n" : "\t");   /* print_vector */
+        out_k[i] = -1;
+        for (int k = 0; k < pf.n_pops; k++) if (strcmp(pf.pops[k].name, outgroups[i]) == 0) out_k[i] = k;
+        if (out_k[i] < 0) rc = -6;                                           /* setAAFs.at() would throw */
+    }
+    for (int j = 0; j < n_in; j++) {
+        in_k[j] = -1;
+        for (int k = 0; k < pf.n_pops; k++) if (strcmp(pf.pops[k].name, ingroups[j]) == 0) in_k[j] = k;
+        if (in_k[j] < 0 && n_out > 0) rc = -6;
+    }
+    /* :133-149 */
+    dvec *perSNP = (dvec *)calloc((size_t)(n_out * n_in) + 1, sizeof(dvec));
+    int *missingDist = (int *)calloc((size_t)(n_out * n_in) + 1, sizeof(int));
+    double *averaged = (double *)calloc((size_t)(n_out * n_in) + 1, sizeof(double));
+    int *usedVars = (int *)calloc((size_t)n_out + 1, sizeof(int)), *missingVars = (int *)calloc((size_t)n_out + 1, sizeof(int));
+    int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
+    int n_pops = pf.n_pops;
+    uint8_t *use_pop = (uint8_t *)calloc((size_t)n_pops + 1, 1);
+    int32_t *sample_pop = NULL; int n_samples = 0;
+    char **fields = NULL; int fcap = 0;
+    int *alt = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1)), *alleles = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1));
+    int *allelesC = (int *)malloc(sizeof(int) * (size_t)(n_pops + 1));
+    double *aaf = (double *)malloc(sizeof(double) * (size_t)(n_pops + 1)), *aafC = (double *)malloc(sizeof(double) * (size_t)(n_pops + 1));
+    char *line;
+    while (!rc && (line = lr_getline(&vcf)) != NULL) {
+        { char *w = line; for (char *r = line; *r; r++) if (*r != '\r') *w++ = *r; *w = '\0'; }   /* :156 */
+        if (line[0] == '#' && line[1] == '#') continue;
+        else if (line[0] == '#' && line[1] == 'C') {
+            n_samples = popfile_map_header(&pf, line, &sample_pop, &rc);
+        } else {
+            int nf = split_inplace(line, '\t', &fields, &fcap);
+            if (nf < 9) continue;
+            const char *chr = fields[0];
+            double coordDouble = strtod(fields[1], NULL);
+            if (strcmp(fields[4], "*") == 0 || strlen(fields[3]) > 1 || strlen(fields[4]) > 1) continue;   /* :194-202 */
+            orc_general_counts((const char *const *)(fields + 9), n_samples, sample_pop, n_pops, use_pop,
+                               alt, alleles, aaf, allelesC, aafC);
+            if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {                    /* :221-269 */
+                int accessibleInThisWindow = fixedWindowSize;
+                for (int i = 0; i < n_out; i++) {
+                    for (int j = 0; j < n_in; j++) {
+                        dvec *v = &perSNP[i * n_in + j];
+                        int nSNPs = (int)v->n, md = missingDist[i * n_in + j];
+                        if (nSNPs > 0) {
+                            double missingProportion = (double)md / (nSNPs + md);
+                            if (missingProportion > 0.5) averaged[i * n_in + j] = NAN;
+                            else {
+                                double a = orc_vector_average_with_region(v->v, v->n, accessibleInThisWindow);
+                                double nonMissingProportion = (double)nSNPs / (nSNPs + md);
+                                double scalingFactor = 1 + (missingProportion / nonMissingProportion);
+                                averaged[i * n_in + j] = a * scalingFactor;
+                            }
+                        } else averaged[i * n_in + j] = NAN;
+                        dv_clear(v);
+                    }
+                    fprintf(outFW[i], "%s\t%d\t%d\t%d\t%d\t%d\t", chr, currentWindowStart, currentWindowEnd, usedVars[i], missingVars[i], accessibleInThisWindow);
+                    for (int j = 0; j < n_in; j++) fprintf(outFW[i], "%g%s", averaged[i * n_in + j], j == n_in - 1 ? "\n" : "\t");
+                }
+                for (int i = 0; i < n_out; i++) {
+                    usedVars[i] = 0; missingVars[i] = 0;
+                    for (int j = 0; j < n_in; j++) missingDist[i * n_in + j] = 0;
+                }
+                if (coordDouble > currentWindowEnd) { currentWindowStart += fixedWindowSize; currentWindowEnd += fixedWindowSize; }
+                else if (coordDouble < currentWindowStart) { currentWindowStart = 0; currentWindowEnd = fixedWindowSize; }
+            }
+            for (int i = 0; i < n_out; i++) {                                                            /* :274-294 */
+                double AFout = aaf[out_k[i]];
+                if (AFout == -1) { missingVars[i]++; continue; }
+                usedVars[i]++;
+                for (int j = 0; j < n_in; j++) {
+                    double AFin = aaf[in_k[j]];
+                    if (AFin != -1) dv_push(&perSNP[i * n_in + j], orc_dxy_from_afs(AFout, AFin));
+                    else missingDist[i * n_in + j]++;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < n_out; i++) if (outFW[i]) fclose(outFW[i]);
+    for (int i = 0; i < n_out * n_in; i++) dv_free(&perSNP[i]);
+    lr_close(&vcf);
+    free(perSNP); free(missingDist); free(averaged); free(usedVars); free(missingVars); free(outFW); free(out_k); free(in_k);
+    free(fields); free(sample_pop); free(alt); free(alleles); free(allelesC); free(aaf); free(aafC); free(use_pop);
+    for (int i = 0; i < n_in; i++) free(ingroups[i]);
+    for (int i = 0; i < n_out; i++) free(outgroups[i]);
+    free(ingroups); free(outgroups);
+    popfile_free(&pf);
+    return rc;
+}

@@ -210,6 +210,16 @@ int orc_af_run(const char *vcf_path, const char *pops_path, const char *run_name
 /* checker for the kernels' reciprocal-table division; returns the number of mismatches */
 long orc_check_rcp_division(int max_n);
 
+/* DistOutgroups (evo_distanceToOutgroups.cpp): DxyPerSNPfromAFs (:62-65); the accumulation of DistOutMain between two
+ * window emissions (:274-294) on counts (see evo_oracle.c for the array shapes); and the text driver
+ * `evo DistOutgroups [-f] [-n] VCF POPS OUTGROUPS INGROUPS` (:68-306) without -i / --accessibleGenomeBED */
+double orc_dxy_from_afs(double AF1, double AF2);
+void orc_dist_windows(const int32_t *alt, const int32_t *nm, int n_pops, const uint8_t *site_flags,
+                      const int64_t *win_off, int n_windows, const int32_t *out_idx, int n_out, const int32_t *in_idx, int n_in,
+                      int carry_first, double *sum, int32_t *nsnp, int32_t *miss, int32_t *used, int32_t *missing_vars);
+int orc_distout_run(const char *vcf_path, const char *pops_path, const char *outgroups_path, const char *ingroups_path,
+                    int fixedWindowSize, const char *run_name, const char *out_dir);
+
 #ifdef __cplusplus
 }
 #endif

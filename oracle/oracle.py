@@ -361,6 +361,39 @@ def abs_run(vcf, pops, quartets, out_dir, run_name="", size=20, step=10):
         raise RuntimeError("orc_abs_run failed: %d" % rc)
 
 
+def dist_windows(alt, nm, win_off, out_idx, in_idx, site_flags=None, carry=None):
+    """DistOutMain's accumulation per window (evo_distanceToOutgroups.cpp:274-294) from counts [S, P]."""
+    L = lib()
+    alt = np.ascontiguousarray(alt, np.int32); nm = np.ascontiguousarray(nm, np.int32)
+    S, P = alt.shape
+    wo = np.ascontiguousarray(win_off, np.int64)
+    oi = np.ascontiguousarray(out_idx, np.int32); ii = np.ascontiguousarray(in_idx, np.int32)
+    W, O, I = len(wo) - 1, len(oi), len(ii)
+    fl = np.ascontiguousarray(site_flags, np.uint8) if site_flags is not None else None
+    r = dict(sum=np.zeros((W, O, I)), nsnp=np.zeros((W, O, I), np.int32), miss=np.zeros((W, O, I), np.int32),
+             used=np.zeros((W, O), np.int32), missing=np.zeros((W, O), np.int32))
+    if carry is not None:
+        for k in r:
+            r[k][0] = carry[k]
+    L.orc_dist_windows.restype = None
+    L.orc_dist_windows.argtypes = [_i32p, _i32p, C.c_int, _u8p, _i64p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, C.c_int,
+                                   _dp, _i32p, _i32p, _i32p, _i32p]
+    L.orc_dist_windows(_p(alt, _i32p), _p(nm, _i32p), P, _p(fl, _u8p), _p(wo, _i64p), W, _p(oi, _i32p), O, _p(ii, _i32p), I,
+                       0 if carry is None else 1, _p(r["sum"], _dp), _p(r["nsnp"], _i32p), _p(r["miss"], _i32p),
+                       _p(r["used"], _i32p), _p(r["missing"], _i32p))
+    return r
+
+
+def distout_run(vcf, pops, outgroups, ingroups, out_dir, run_name="", fixed=10000):
+    L = lib()
+    L.orc_distout_run.restype = C.c_int
+    L.orc_distout_run.argtypes = [C.c_char_p] * 4 + [C.c_int, C.c_char_p, C.c_char_p]
+    rc = L.orc_distout_run(vcf.encode(), pops.encode(), outgroups.encode(), ingroups.encode(), fixed, run_name.encode(),
+                           out_dir.encode())
+    if rc != 0:
+        raise RuntimeError("orc_distout_run failed: %d" % rc)
+
+
 def af_run(vcf, pops, out_dir, run_name="out"):
     rc = lib().orc_af_run(vcf.encode(), pops.encode(), run_name.encode(), out_dir.encode())
     if rc != 0:

@@ -234,6 +234,43 @@ def test_cli_abs_windows_crlf_batches(tmp_path):
     _pbs_case(tmp_path, np.random.default_rng(52), ["-w", "9,4"], 9, 4, crlf=True, miss=0.12, n_sites=40000, n_samples=14, quartets=True)
 
 
+def _dist_case(tmp_path, rng, args, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.3):
+    vcf = str(tmp_path / "in.vcf")
+    names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=miss)
+    pf, of, inf = str(tmp_path / "pops.txt"), str(tmp_path / "outgroups.txt"), str(tmp_path / "ingroups.txt")
+    pops = ["popC", "popA", "popD", "popB"]
+    with open(pf, "w") as f:
+        f.write("%s\tsolo\n" % names[0])                             # one sample: often entirely missing
+        f.write("%s\tout2\n%s\tout2\n" % (names[1], names[2]))
+        for i, n in enumerate(names[3:]):
+            if i % 9 != 8:
+                f.write("%s\t%s\n" % (n, pops[i % 4]))
+    open(of, "w").write("solo\nout2\npopA\n")
+    open(inf, "w").write("popA\npopB\npopC\nsolo\npopD\n")
+    cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
+    cli_dir.mkdir(); orc_dir.mkdir()
+    r = subprocess.run([EVO, "DistOutgroups", "-n", "d"] + args + [vcf, pf, of, inf], cwd=str(cli_dir), capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    O.distout_run(vcf, pf, of, inf, str(orc_dir), run_name="d", fixed=fixed)
+    _same_files(str(cli_dir), str(orc_dir))
+    return cli_dir
+
+
+def test_cli_distoutgroups_default(tmp_path):
+    """evo DistOutgroups: windowed dxy of 3 outgroups x 5 ingroups; the device adds up in site order, so
+    the rows match the oracle's to the last printed digit; windows with too much missing data print nan."""
+    d = _dist_case(tmp_path, np.random.default_rng(61), [])
+    assert len(os.listdir(d)) == 3
+    rows = (d / "solo_DIST_d_FW10000.txt").read_text().splitlines()
+    assert len(rows) > 30 and all(r.split("\t")[5] == "10000" for r in rows[1:])
+
+
+def test_cli_distoutgroups_small_windows_crlf_batches(tmp_path):
+    d = _dist_case(tmp_path, np.random.default_rng(62), ["-f", "2000"], fixed=2000, n_sites=70000, n_samples=12, crlf=True, miss=0.4)
+    assert "\tnan" in (d / "out2_DIST_d_FW2000.txt").read_text()       # windows where an ingroup is mostly missing
+
+
 def test_cli_rejects_unknown_command():
     r = subprocess.run([EVO, "stats"], capture_output=True, text=True)
     assert r.returncode != 0 and "Unrecognized command" in r.stderr

@@ -185,6 +185,36 @@ def test_abs_bit_equal_to_reference():
         assert_same_bits(b[:], a[:], "ABS %r" % (args,))
 
 
+def test_dist_windows_against_numpy():
+    """orc_dist_windows (evo_distanceToOutgroups.cpp:274-294) against a direct numpy evaluation, incl. carry."""
+    rng = np.random.default_rng(9)
+    S, P = 3000, 6
+    nm = rng.integers(0, 9, (S, P)).astype(np.int32)
+    nm[rng.random((S, P)) < 0.2] = 0
+    alt = (rng.random((S, P)) * (nm + 1)).astype(np.int32).clip(0, nm)
+    fl = (rng.random(S) < 0.1).astype(np.uint8)
+    wo = np.array([0, 0, 500, 1700, 1700, S], np.int64)
+    oi, ii = [0, 5], [1, 2, 5]
+    r = O.dist_windows(alt, nm, wo, oi, ii, fl)
+    with np.errstate(all="ignore"):
+        af = alt / nm
+    for w in range(len(wo) - 1):
+        sl = slice(wo[w], wo[w + 1])
+        keep = fl[sl] == 0
+        for a, o in enumerate(oi):
+            has_o = keep & (nm[sl, o] > 0)
+            assert r["used"][w, a] == has_o.sum() and r["missing"][w, a] == (keep & (nm[sl, o] == 0)).sum()
+            for b, j in enumerate(ii):
+                both = has_o & (nm[sl, j] > 0)
+                assert r["nsnp"][w, a, b] == both.sum() and r["miss"][w, a, b] == (has_o & (nm[sl, j] == 0)).sum()
+                d = af[sl, o][both] * (1 - af[sl, j][both]) + af[sl, j][both] * (1 - af[sl, o][both])
+                assert abs(r["sum"][w, a, b] - d.sum()) <= 1e-12 * max(1.0, d.sum())
+    first = O.dist_windows(alt[:1000], nm[:1000], [0, 0, 500, 1000], oi, ii, fl[:1000])
+    rest = O.dist_windows(alt[1000:], nm[1000:], [0, 700, 700, S - 1000], oi, ii, fl[1000:], carry={k: v[-1] for k, v in first.items()})
+    for k in r:
+        assert np.array_equal(np.concatenate([first[k][:-1], rest[k]]), r[k]), k     # bit-identical, sums included
+
+
 def test_rcp_division_identity():
     """The kernels' reciprocal-table quotient is bit-identical to IEEE division on the whole domain."""
     assert O.lib().orc_check_rcp_division(2047) == 0
