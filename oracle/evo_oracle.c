@@ -1684,3 +1684,249 @@ int orc_distout_run(const char *vcf_path, const char *pops_path, const char *out
     popfile_free(&pf);
     return rc;
 }
+
+/* ===================================================================== */
+/* stats --diff-matrix (process_vcf_stats.cpp, process_vcf_stats_functions.cpp) */
+/* ===================================================================== */
+/* getThisVariantCountsSimple, process_vcf_utils.cpp:358-408, for the fields the difference matrices read.
+ * genotypes = the n genotype columns.  randomisePhase (:387) only swaps the two alleles of an unphased individual;
+ * every consumer restated here is symmetric in them, so it is left out.  haps[2n], ind_with_variant[n], missing[n]. */
+void orc_stats_variant_counts(const char *alt_field, const char *const *genotypes, int n,
+                              int *ind_with_variant, int *haps, uint8_t *missing, int *is_multiallelic) {
+    /* split(fields[4], ','): a trailing empty field is dropped, an empty string gives no field */
+    int numAltAlleles = 0; const char *last = alt_field; size_t last_len = 0;
+    {
+        const char *a = alt_field;
+        if (*a) for (;;) {
+            const char *e = strchr(a, ',');
+            size_t l = e ? (size_t)(e - a) : strlen(a);
+            numAltAlleles++; last = a; last_len = l;
+            if (!e) break;
+            a = e + 1;
+            if (!*a) break;
+        }
+    }
+    int alleleAsMissing = -1, multi = 0;
+    if (numAltAlleles > 1) {                                           /* :369-381 */
+        if (last_len == 1 && last[0] == '*') { alleleAsMissing = numAltAlleles; if ((numAltAlleles - 1) > 1) multi = 1; }
+        else multi = 1;
+    }
+    for (int i = 0; i < n; i++) {
+        char v1 = genotypes[i][0], v2 = genotypes[i][2];
+        int v1int = v1 - '0', v2int = v2 - '0';
+        ind_with_variant[i] = 0; haps[2 * i] = 0; haps[2 * i + 1] = 0; missing[i] = 0;
+        if (v1 == '.' || v2 == '.' || v1int == alleleAsMissing || v2int == alleleAsMissing) missing[i] = 1;
+        else { haps[2 * i] = v1int; haps[2 * i + 1] = v2int; }
+        if (!multi) {                                                  /* :397-406 */
+            if (v1 == '1') ind_with_variant[i]++;
+            if (v2 == '1') ind_with_variant[i]++;
+        }
+    }
+    *is_multiallelic = multi;
+}
+
+static const double ORC_DIFF_BOTH_HETS_ME = 0.5, ORC_DIFF_BOTH_HETS_RICHARD = (2.0 / 3.0), ORC_DIFF_HOM_ME = 1,
+                    ORC_DIFF_HOM_RICHARD = (2.0 / 3.0), ORC_DIFF_HOM_HET = 0.5;   /* stats_functions.cpp:12-16 */
+
+/* diffs_between_individuals (stats_functions.cpp:180-232) and diffs_between_individuals_with_multialleleics
+ * (:235-281), literally, over S sites: all matrices are n x n row-major and are ADDED to (bootstrap copies may be
+ * NULL).  ind_with_variant [S][n], haps [S][2n], missing [S][n], multi [S]. */
+void orc_indiv_diffs(int n, int64_t S, const int *ind_with_variant, const int *haps, const uint8_t *missing, const uint8_t *multi,
+                     double *diffs, double *diffs_me, double *diffs_me_bootstrap, double *hets_vs_homs,
+                     int *pairwise_missingness, int *pairwise_missingness_bootstrap) {
+    for (int64_t s = 0; s < S; s++) {
+        const int *iv = ind_with_variant + s * n, *hp = haps + s * 2 * n;
+        const uint8_t *ms = missing + s * n;
+        for (int i = 0; i < n; i++) {
+            for (int j = 0; j <= i; j++) {
+                size_t o = (size_t)i * (size_t)n + (size_t)j;
+                if (ms[i] || ms[j]) {
+                    pairwise_missingness[o]++;
+                    if (pairwise_missingness_bootstrap) pairwise_missingness_bootstrap[o]++;
+                    continue;
+                }
+                if (!multi[s]) {
+                    int ind_i = iv[i], ind_j = iv[j];
+                    if (j < i) {
+                        double r, me;
+                        if (ind_i == 1 && ind_j == 1) { r = ORC_DIFF_BOTH_HETS_RICHARD; me = ORC_DIFF_BOTH_HETS_ME; hets_vs_homs[o]++; }
+                        else if ((ind_i == 2 && ind_j == 0) || (ind_i == 0 && ind_j == 2)) {
+                            r = ORC_DIFF_HOM_RICHARD; me = ORC_DIFF_HOM_ME; hets_vs_homs[(size_t)j * (size_t)n + (size_t)i]++;
+                        } else if ((ind_i == 2 && ind_j == 1) || (ind_i == 1 && ind_j == 2) || (ind_i == 0 && ind_j == 1) || (ind_i == 1 && ind_j == 0)) {
+                            r = ORC_DIFF_HOM_HET; me = ORC_DIFF_HOM_HET;
+                        } else { r = 0; me = 0; }
+                        diffs[o] = diffs[o] + r;
+                        diffs_me[o] = diffs_me[o] + me;
+                        if (diffs_me_bootstrap) diffs_me_bootstrap[o] = diffs_me_bootstrap[o] + me;
+                    } else if (ind_i == 1) {
+                        diffs[o]++; diffs_me[o]++;
+                        if (diffs_me_bootstrap) diffs_me_bootstrap[o]++;
+                    }
+                } else {
+                    int ind_i = hp[2 * i], ind_i2 = hp[2 * i + 1], ind_j = hp[2 * j], ind_j2 = hp[2 * j + 1];
+                    if (j < i) {
+                        double totalD = 0; const double numComparisons = 4;
+                        if (ind_i != ind_j) totalD++;
+                        if (ind_i != ind_j2) totalD++;
+                        if (ind_i2 != ind_j) totalD++;
+                        if (ind_i2 != ind_j2) totalD++;
+                        double me = totalD / numComparisons;
+                        diffs_me[o] = diffs_me[o] + me;
+                        if (diffs_me_bootstrap) diffs_me_bootstrap[o] = diffs_me_bootstrap[o] + me;
+                    } else if (ind_i != ind_i2) {
+                        diffs_me[o]++;
+                        if (diffs_me_bootstrap) diffs_me_bootstrap[o]++;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* The same sites as five counts per pair j <= i (triangular index i(i+1)/2 + j), which is what the device returns:
+ * hh both heterozygous (diagonal: heterozygous), hd opposite homozygotes, oh one homozygous one heterozygous -- all
+ * three on bi-allelic sites; ms either individual missing (any site); d4 differing allele comparisons, of 4 per
+ * multi-allelic site (diagonal: sites where the individual's own two alleles differ).  Counts are ADDED to. */
+void orc_indiv_diff_counts(int n, int64_t S, const int *ind_with_variant, const int *haps, const uint8_t *missing, const uint8_t *multi,
+                           int32_t *hh, int32_t *hd, int32_t *oh, int32_t *ms_out, int32_t *d4) {
+    for (int64_t s = 0; s < S; s++) {
+        const int *iv = ind_with_variant + s * n, *hp = haps + s * 2 * n;
+        const uint8_t *ms = missing + s * n;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j <= i; j++) {
+                size_t o = (size_t)i * ((size_t)i + 1) / 2 + (size_t)j;
+                if (ms[i] || ms[j]) { ms_out[o]++; continue; }
+                if (!multi[s]) {
+                    int a = iv[i], b = iv[j];
+                    if (j == i) { if (a == 1) hh[o]++; }
+                    else if (a == 1 && b == 1) hh[o]++;
+                    else if ((a == 2 && b == 0) || (a == 0 && b == 2)) hd[o]++;
+                    else if ((a == 1) != (b == 1)) oh[o]++;
+                } else if (j == i) { if (hp[2 * i] != hp[2 * i + 1]) d4[o]++; }
+                else d4[o] += (hp[2 * i] != hp[2 * j]) + (hp[2 * i] != hp[2 * j + 1]) + (hp[2 * i + 1] != hp[2 * j]) + (hp[2 * i + 1] != hp[2 * j + 1]);
+            }
+    }
+}
+
+static void print_matrix_d(FILE *f, const double *m, int n, int precision) {      /* print_matrix, utils.h:326-335 */
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) fprintf(f, "%.*g%s", precision, m[(size_t)i * (size_t)n + (size_t)j], j == n - 1 ? "\n" : "\t");
+}
+
+/* `evo stats --diff-matrix [--block-bootstrap=B] [--numAccessibleBP=A] VCF` (statsMain, process_vcf_stats.cpp:98-355,
+ * the bDiffs and bDoBootstrap parts; B = 0: no bootstrap, A < 0: no scaling).  The four matrix files go to out_dir
+ * under the VCF's base name, the bootstrap replicates too (the reference writes those next to the VCF). */
+int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAccessibleBP, const char *out_dir) {
+    lreader vcf;
+    if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
+    /* fileRoot = stripExtension(fileName), fileNoPath = stripPath(fileRoot) (:103, :328) */
+    char *root = strdup(vcf_path);
+    { char *dot = strrchr(root, '.'); if (dot) *dot = '\0'; }
+    const char *slash = strrchr(root, '/');
+    const char *noPath = slash ? slash + 1 : root;
+    int n = 0, totalVariantNumber = 0, bootstrapBlockNum = 0, rc = 0;
+    char **names = NULL;
+    double *diffs = NULL, *diffs_me = NULL, *hvh = NULL, *boot = NULL, **bootBlocks = NULL;
+    int *miss = NULL, *bootMiss = NULL, **bootMissBlocks = NULL;
+    int *iv = NULL, *hp = NULL; uint8_t *ms = NULL;
+    char **fields = NULL; int fcap = 0;
+    char *line;
+    while ((line = lr_getline(&vcf)) != NULL) {
+        if (line[0] == '#' && line[1] == '#') continue;
+        else if (line[0] == '#' && line[1] == 'C') {
+            int nf = split_inplace(line, '\t', &fields, &fcap);
+            n = nf - 9; if (n < 0) n = 0;
+            names = (char **)malloc(sizeof(char *) * (size_t)(n + 1));
+            for (int i = 0; i < n; i++) names[i] = strdup(fields[9 + i]);
+            size_t nn = (size_t)n * (size_t)n + 1;
+            diffs = (double *)calloc(nn, sizeof(double)); diffs_me = (double *)calloc(nn, sizeof(double));
+            hvh = (double *)calloc(nn, sizeof(double)); boot = (double *)calloc(nn, sizeof(double));
+            miss = (int *)calloc(nn, sizeof(int)); bootMiss = (int *)calloc(nn, sizeof(int));
+            iv = (int *)malloc(sizeof(int) * (size_t)(n + 1)); hp = (int *)malloc(sizeof(int) * (size_t)(2 * n + 2));
+            ms = (uint8_t *)malloc((size_t)n + 1);
+        } else {
+            if (!names) { rc = -5; break; }
+            totalVariantNumber++;
+            int nf = split_inplace(line, '\t', &fields, &fcap);
+            if (nf < 9 + n) { rc = -5; break; }
+            int multi = 0;
+            orc_stats_variant_counts(fields[4], (const char *const *)(fields + 9), n, iv, hp, ms, &multi);
+            uint8_t m8 = (uint8_t)multi;
+            orc_indiv_diffs(n, 1, iv, hp, ms, &m8, diffs, diffs_me, boot, hvh, miss, bootMiss);
+            if (bootstrapBlockSize > 0 && totalVariantNumber % bootstrapBlockSize == 0) {              /* :265-275 */
+                size_t nn = (size_t)n * (size_t)n;
+                bootBlocks = (double **)realloc(bootBlocks, sizeof(double *) * (size_t)(bootstrapBlockNum + 1));
+                bootMissBlocks = (int **)realloc(bootMissBlocks, sizeof(int *) * (size_t)(bootstrapBlockNum + 1));
+                bootBlocks[bootstrapBlockNum] = (double *)malloc(sizeof(double) * (nn + 1));
+                bootMissBlocks[bootstrapBlockNum] = (int *)malloc(sizeof(int) * (nn + 1));
+                memcpy(bootBlocks[bootstrapBlockNum], boot, sizeof(double) * nn);
+                memcpy(bootMissBlocks[bootstrapBlockNum], bootMiss, sizeof(int) * nn);
+                memset(boot, 0, sizeof(double) * nn); memset(bootMiss, 0, sizeof(int) * nn);
+                bootstrapBlockNum++;
+            }
+        }
+    }
+    if (!rc && !names) rc = -5;
+    if (!rc) {
+        size_t nn = (size_t)n * (size_t)n;
+        if (numAccessibleBP > -1) for (size_t k = 0; k < nn; k++) diffs_me[k] = (double)diffs_me[k] / numAccessibleBP;   /* :286-293 */
+        if (bootstrapBlockSize > 0) {                                                                   /* :296-325 */
+            srand(1);                                        /* the reference never seeds: a fresh process starts from 1 */
+            const int n_bootstrap_replicates = 100;
+            double *rep = (double *)malloc(sizeof(double) * (nn + 1)), *repMiss = (double *)malloc(sizeof(double) * (nn + 1));
+            for (int r = 0; r < n_bootstrap_replicates; r++) {
+                char name[1024];
+                snprintf(name, sizeof name, "%sboot.%d.txt", noPath, r);
+                char *pth = path_join(out_dir, name); FILE *f = fopen(pth, "w"); free(pth);
+                if (!f) { rc = -3; break; }
+                for (size_t k = 0; k < nn; k++) { rep[k] = 0; repMiss[k] = 0; }
+                for (int b = 0; b < bootstrapBlockNum; b++) {
+                    int block = rand() % bootstrapBlockNum;
+                    for (size_t k = 0; k < nn; k++) { rep[k] = rep[k] + bootBlocks[block][k]; repMiss[k] = repMiss[k] + bootMissBlocks[block][k]; }
+                }
+                int totalSitesBootstrap = bootstrapBlockNum * bootstrapBlockSize;
+                for (size_t k = 0; k < nn; k++) {
+                    double proportionUsed = 1 - (repMiss[k] / totalSitesBootstrap);
+                    rep[k] = rep[k] / proportionUsed;
+                }
+                for (int i = 0; i < n; i++) fprintf(f, "%s%s", names[i], i == n - 1 ? "\n" : "\t");
+                print_matrix_d(f, rep, n, 6);
+                fclose(f);
+            }
+            free(rep); free(repMiss);
+        }
+        for (int i = 0; i < n; i++)                          /* finalize_diffs_Hets_vs_Homs_proportions, utils.cpp:1148-1155 */
+            for (int j = 0; j < i; j++) {
+                hvh[(size_t)i * (size_t)n + (size_t)j] = hvh[(size_t)i * (size_t)n + (size_t)j] / hvh[(size_t)j * (size_t)n + (size_t)i];
+                hvh[(size_t)j * (size_t)n + (size_t)i] = 0;
+            }
+        /* print_pairwise_diff_stats, print_routines.cpp:74-120 */
+        const char *suffix[4] = {".diff_matrix.txt", ".diff_me_matrix.txt", ".hets_over_homs_matrix.txt", ".parwiseMissingness.txt"};
+        FILE *f[4] = {NULL, NULL, NULL, NULL};
+        for (int k = 0; k < 4; k++) {
+            char name[1024];
+            snprintf(name, sizeof name, "%s%s", noPath, suffix[k]);
+            char *pth = path_join(out_dir, name); f[k] = fopen(pth, "w"); free(pth);
+            if (!f[k]) rc = -3;
+        }
+        if (!rc) {
+            fprintf(f[0], "# Input file:%s.vcf\n# Total number of segragating variant sites in this sample:%d\n# Richard's scoring scheme\n", noPath, totalVariantNumber);
+            fprintf(f[1], "# Input file:%s.vcf\n# Total number of segragating variant sites in this sample: %d\n# Homozygous difference = 1, one homozygous, another heterozygous = 0.5\n", noPath, totalVariantNumber);
+            fprintf(f[2], "# Input file:%s.vcf\n# number of sites both individuals hets/number of sites individuals have a homozygous difference; i.e. num(1/0::1/0)/num(1/1::0/0)\n# For a free mixing population, we expect this number ~2; for fully separated species ~0\n", noPath);
+            fprintf(f[3], "# Input file:%s.vcf\n# Total number of segragating variant sites in this sample: %d\n# Pairwise missingness:\n", noPath, totalVariantNumber);
+            for (int k = 0; k < 4; k++) for (int i = 0; i < n; i++) fprintf(f[k], "%s%s", names[i], i == n - 1 ? "\n" : "\t");
+            print_matrix_d(f[0], diffs, n, 6);
+            print_matrix_d(f[1], diffs_me, n, 10);                                  /* precision(10), :114 */
+            print_matrix_d(f[2], hvh, n, 6);
+            for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) fprintf(f[3], "%d%s", miss[(size_t)i * (size_t)n + (size_t)j], j == n - 1 ? "\n" : "\t");
+        }
+        for (int k = 0; k < 4; k++) if (f[k]) fclose(f[k]);
+    }
+    for (int b = 0; b < bootstrapBlockNum; b++) { free(bootBlocks[b]); free(bootMissBlocks[b]); }
+    free(bootBlocks); free(bootMissBlocks);
+    for (int i = 0; names && i < n; i++) free(names[i]);
+    free(names); free(diffs); free(diffs_me); free(hvh); free(boot); free(miss); free(bootMiss); free(iv); free(hp); free(ms);
+    free(fields); free(root);
+    lr_close(&vcf);
+    return rc;
+}

@@ -220,6 +220,19 @@ void orc_dist_windows(const int32_t *alt, const int32_t *nm, int n_pops, const u
 int orc_distout_run(const char *vcf_path, const char *pops_path, const char *outgroups_path, const char *ingroups_path,
                     int fixedWindowSize, const char *run_name, const char *out_dir);
 
+/* stats --diff-matrix: getThisVariantCountsSimple (process_vcf_utils.cpp:358-408), the two per-site matrix updates
+ * (process_vcf_stats_functions.cpp:180-281) literally, the same as five counts per pair (what the device returns), and
+ * the text driver for `evo stats --diff-matrix [--block-bootstrap=B] [--numAccessibleBP=A] VCF`
+ * (process_vcf_stats.cpp:98-355).  Array shapes: see evo_oracle.c. */
+void orc_stats_variant_counts(const char *alt_field, const char *const *genotypes, int n,
+                              int *ind_with_variant, int *haps, uint8_t *missing, int *is_multiallelic);
+void orc_indiv_diffs(int n, int64_t S, const int *ind_with_variant, const int *haps, const uint8_t *missing, const uint8_t *multi,
+                     double *diffs, double *diffs_me, double *diffs_me_bootstrap, double *hets_vs_homs,
+                     int *pairwise_missingness, int *pairwise_missingness_bootstrap);
+void orc_indiv_diff_counts(int n, int64_t S, const int *ind_with_variant, const int *haps, const uint8_t *missing, const uint8_t *multi,
+                           int32_t *hh, int32_t *hd, int32_t *oh, int32_t *ms_out, int32_t *d4);
+int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAccessibleBP, const char *out_dir);
+
 #ifdef __cplusplus
 }
 #endif

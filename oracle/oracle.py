@@ -14,6 +14,7 @@ _LIB = os.path.join(_HERE, "libevo_oracle.so")
 _REF = os.path.join(_HERE, "_ref", "libevo_refmath.so")
 _REF_PBS = os.path.join(_HERE, "_ref", "libevo_refpbs.so")
 _REF_ABS = os.path.join(_HERE, "_ref", "libevo_refabs.so")
+_REF_DIFFS = os.path.join(_HERE, "_ref", "libevo_refdiffs.so")
 
 _dp = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -28,7 +29,7 @@ def build(force=False):
             os.path.join(_HERE, "evo_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "libevo_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF) or not os.path.exists(_REF_PBS)
-                                             or not os.path.exists(_REF_ABS)):
+                                             or not os.path.exists(_REF_ABS) or not os.path.exists(_REF_DIFFS)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -204,6 +205,97 @@ def abs_site_stats(alt, nm, quartets, site_flags=None):
     L.orc_abs_site_stats.argtypes = [_i32p, _i32p, C.c_int64, C.c_int, _i32p, C.c_int, _u8p, _dp, _u8p]
     L.orc_abs_site_stats(_p(alt, _i32p), _p(nm, _i32p), S, P, _p(qt, _i32p), len(qt), _p(fl, _u8p), _p(out, _dp), _p(used, _u8p))
     return out, used
+
+
+_ref_diffs = None
+_u8p_ = C.POINTER(C.c_uint8)
+
+
+def ref_diffs():
+    """The reference's own diffs_between_individuals[_with_multialleleics] (process_vcf_stats_functions.cpp:180-281),
+    or None when oracle/_ref was never built."""
+    global _ref_diffs
+    if _ref_diffs is None:
+        build()
+        if not os.path.exists(_REF_DIFFS):
+            return None
+        R = C.CDLL(_REF_DIFFS)
+        R.ref_indiv_diffs.restype = None
+        R.ref_indiv_diffs.argtypes = [C.c_int, C.c_long, _ip, _ip, _u8p_, _u8p_, _dp, _dp, _dp, _dp, _ip, _ip]
+        _ref_diffs = R
+    return _ref_diffs
+
+
+def _diff_inputs(iv, haps, missing, multi):
+    iv = np.ascontiguousarray(iv, np.intc); haps = np.ascontiguousarray(haps, np.intc)
+    missing = np.ascontiguousarray(missing, np.uint8); multi = np.ascontiguousarray(multi, np.uint8)
+    S, n = iv.shape
+    assert haps.shape == (S, 2 * n) and missing.shape == (S, n) and multi.shape == (S,)
+    return iv, haps, missing, multi, S, n
+
+
+def indiv_diffs(iv, haps, missing, multi, use_reference=False):
+    """Literal per-site matrix updates -> dict(diffs, diffs_me, boot, hets_vs_homs [n, n] doubles, miss, boot_miss ints)."""
+    iv, haps, missing, multi, S, n = _diff_inputs(iv, haps, missing, multi)
+    r = dict(diffs=np.zeros((n, n)), diffs_me=np.zeros((n, n)), boot=np.zeros((n, n)), hets_vs_homs=np.zeros((n, n)),
+             miss=np.zeros((n, n), np.intc), boot_miss=np.zeros((n, n), np.intc))
+    args = [n, S, _p(iv, _ip), _p(haps, _ip), _p(missing, _u8p), _p(multi, _u8p), _p(r["diffs"], _dp), _p(r["diffs_me"], _dp),
+            _p(r["boot"], _dp), _p(r["hets_vs_homs"], _dp), _p(r["miss"], _ip), _p(r["boot_miss"], _ip)]
+    if use_reference:
+        ref_diffs().ref_indiv_diffs(*args)
+    else:
+        L = lib()
+        L.orc_indiv_diffs.restype = None
+        L.orc_indiv_diffs.argtypes = [C.c_int, C.c_int64, _ip, _ip, _u8p, _u8p, _dp, _dp, _dp, _dp, _ip, _ip]
+        L.orc_indiv_diffs(*args)
+    return r
+
+
+def indiv_diff_counts(iv, haps, missing, multi):
+    """The same sites as five counts per pair j <= i (triangular index): dict(hh, hd, oh, ms, d4) of int32 [n(n+1)/2]."""
+    iv, haps, missing, multi, S, n = _diff_inputs(iv, haps, missing, multi)
+    T = n * (n + 1) // 2
+    r = {k: np.zeros(T, np.int32) for k in ("hh", "hd", "oh", "ms", "d4")}
+    L = lib()
+    L.orc_indiv_diff_counts.restype = None
+    L.orc_indiv_diff_counts.argtypes = [C.c_int, C.c_int64, _ip, _ip, _u8p, _u8p] + [_i32p] * 5
+    L.orc_indiv_diff_counts(n, S, _p(iv, _ip), _p(haps, _ip), _p(missing, _u8p), _p(multi, _u8p),
+                            *[_p(r[k], _i32p) for k in ("hh", "hd", "oh", "ms", "d4")])
+    return r
+
+
+def matrices_from_diff_counts(c, n):
+    """Compose the reference's four matrices from the five counts (the closed form the CLI uses)."""
+    D = np.zeros((n, n)); Dme = np.zeros((n, n)); H = np.zeros((n, n)); M = np.zeros((n, n), np.intc)
+    i, j = np.tril_indices(n)
+    o = i * (i + 1) // 2 + j
+    off = j < i
+    hh, hd, oh, ms, d4 = (c[k][o].astype(np.float64) for k in ("hh", "hd", "oh", "ms", "d4"))
+    D[i, j] = np.where(off, (2.0 / 3.0) * hh + (2.0 / 3.0) * hd + 0.5 * oh, hh)
+    Dme[i, j] = np.where(off, 0.5 * hh + hd + 0.5 * oh + d4 / 4.0, hh + d4)
+    H[i[off], j[off]] = hh[off]; H[j[off], i[off]] = hd[off]
+    M[i, j] = ms
+    return dict(diffs=D, diffs_me=Dme, hets_vs_homs=H, miss=M)
+
+
+def stats_variant_counts(alt_field, genotypes):
+    L = lib()
+    n = len(genotypes)
+    g = (C.c_char_p * n)(*[s.encode() for s in genotypes])
+    iv = np.zeros(n, np.intc); hp = np.zeros(2 * n, np.intc); ms = np.zeros(n, np.uint8); multi = C.c_int(0)
+    L.orc_stats_variant_counts.restype = None
+    L.orc_stats_variant_counts.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, _ip, _ip, _u8p, C.POINTER(C.c_int)]
+    L.orc_stats_variant_counts(alt_field.encode(), g, n, _p(iv, _ip), _p(hp, _ip), _p(ms, _u8p), C.byref(multi))
+    return iv, hp, ms, multi.value
+
+
+def stats_diffs_run(vcf, out_dir, block=0, accessible=-1):
+    L = lib()
+    L.orc_stats_diffs_run.restype = C.c_int
+    L.orc_stats_diffs_run.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+    rc = L.orc_stats_diffs_run(vcf.encode(), block, accessible, out_dir.encode())
+    if rc != 0:
+        raise RuntimeError("orc_stats_diffs_run failed: %d" % rc)
 
 
 def pbs_from_afs(p1, p2, p3, n1, n2, n3):

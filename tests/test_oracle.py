@@ -215,6 +215,62 @@ def test_dist_windows_against_numpy():
         assert np.array_equal(np.concatenate([first[k][:-1], rest[k]]), r[k]), k     # bit-identical, sums included
 
 
+def _random_diff_sites(rng, S, n, miss=0.15, multi=0.1):
+    iv = rng.integers(0, 3, (S, n))
+    haps = rng.integers(0, 4, (S, 2 * n))
+    missing = (rng.random((S, n)) < miss).astype(np.uint8)
+    mul = (rng.random(S) < multi).astype(np.uint8)
+    return iv, haps, missing, mul
+
+
+@pytest.mark.skipif(O.ref_diffs() is None, reason="oracle/_ref not built (no /root/reference here)")
+def test_indiv_diffs_bit_equal_to_reference():
+    """orc_indiv_diffs vs the reference's own diffs_between_individuals / ..._with_multialleleics
+    (process_vcf_stats_functions.cpp:180-281) compiled from /root/reference: all six matrices, bit for bit (the 2/3
+    weights are added up in site order in both)."""
+    rng = np.random.default_rng(12)
+    for S, n in ((1500, 9), (400, 23)):
+        args = _random_diff_sites(rng, S, n)
+        a = O.indiv_diffs(*args, use_reference=True)
+        b = O.indiv_diffs(*args)
+        for k in a:
+            if a[k].dtype == np.float64:
+                assert_same_bits(b[k], a[k], k)
+            else:
+                assert np.array_equal(a[k], b[k]), k
+        assert a["diffs"].sum() > 0 and a["hets_vs_homs"][np.triu_indices(n, 1)].sum() > 0 and a["miss"].sum() > 0
+
+
+def test_indiv_diff_counts_compose_the_matrices():
+    """The five counts per pair give back the literal matrices: diffs_me, hets/homs and missingness exactly (all terms
+    are multiples of 1/4), Richard's matrix to 1e-12 (its 2/3 weights are rounded site by site in the reference)."""
+    rng = np.random.default_rng(13)
+    S, n = 3000, 17
+    args = _random_diff_sites(rng, S, n)
+    lit = O.indiv_diffs(*args)
+    comp = O.matrices_from_diff_counts(O.indiv_diff_counts(*args), n)
+    assert np.array_equal(lit["diffs_me"], comp["diffs_me"])
+    assert np.array_equal(lit["hets_vs_homs"], comp["hets_vs_homs"])
+    assert np.array_equal(lit["miss"], comp["miss"])
+    assert np.allclose(lit["diffs"], comp["diffs"], rtol=1e-12, atol=0)
+
+
+def test_stats_variant_counts_rules():
+    """getThisVariantCountsSimple (process_vcf_utils.cpp:358-408): '*' last among two ALTs is a missing allele and the
+    site stays bi-allelic; '*' first, or three ALTs, make it multi-allelic; a half call is a missing individual."""
+    g = ["0/1:9", "1|1:3", "./1:0", "2/0:1", "0/0:5"]
+    iv, hp, ms, multi = O.stats_variant_counts("G", g)
+    assert multi == 0 and list(iv) == [1, 2, 1, 0, 0] and list(ms) == [0, 0, 1, 0, 0] and list(hp[6:8]) == [2, 0]
+    iv, hp, ms, multi = O.stats_variant_counts("G,*", g)
+    assert multi == 0 and list(ms) == [0, 0, 1, 1, 0] and list(iv) == [1, 2, 1, 0, 0]
+    iv, hp, ms, multi = O.stats_variant_counts("*,G", g)
+    assert multi == 1 and list(ms) == [0, 0, 1, 0, 0] and list(iv) == [0] * 5 and list(hp[:4]) == [0, 1, 1, 1]
+    iv, hp, ms, multi = O.stats_variant_counts("G,T,*", g)
+    assert multi == 1 and list(ms) == [0, 0, 1, 0, 0]
+    iv, hp, ms, multi = O.stats_variant_counts("G,T,*", ["3/0", "0/2"])
+    assert multi == 1 and list(ms) == [1, 0] and list(hp) == [0, 0, 0, 2]
+
+
 def test_rcp_division_identity():
     """The kernels' reciprocal-table quotient is bit-identical to IEEE division on the whole domain."""
     assert O.lib().orc_check_rcp_division(2047) == 0
