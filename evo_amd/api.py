@@ -78,6 +78,9 @@ SIGNATURES = {
     "evofst_get_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp, _u8p]),
     "evofst_get_pbs_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i32p, _dp, _u8p]),
     "evofst_get_abs_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i32p, _dp, _u8p]),
+    "evofst_alleles_from_vcf_line": (C.c_int, [C.c_char_p, C.c_int, _u8p]),
+    "evofst_set_multiallelic": (C.c_int, [_vp, C.c_int64, _i64p, _u8p]),
+    "evofst_get_indiv_diffs": (C.c_int, [_vp, C.c_int, _i64p, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "evofst_get_dist_windows": (C.c_int, [_vp, C.c_int, _i64p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _dp, _i32p, _i32p,
                                           _i32p, _i32p]),
     "evofst_get_pop_site_div": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp]),
@@ -131,6 +134,16 @@ def codes_from_vcf_line(line, mode, n_samples):
     if rc != 0:
         raise EvoFstError(rc, "malformed VCF line")
     return codes, fl.value, chrom.value.decode(), pos.value.decode()
+
+
+def alleles_from_vcf_line(line, n_samples):
+    """Allele numbers of one (multi-allelic) VCF data line as `evo stats` reads them -> uint8 [2N], 255 = missing."""
+    L = load_library()
+    out = np.empty(2 * n_samples, np.uint8)
+    rc = L.evofst_alleles_from_vcf_line(line.encode() if isinstance(line, str) else line, n_samples, _ptr(out, _u8p))
+    if rc != 0:
+        raise EvoFstError(rc, "malformed VCF line")
+    return out
 
 
 class EvoFst:
@@ -379,6 +392,21 @@ class EvoFst:
         self._chk(self.L.evofst_get_dist_windows(self.h, W, _ptr(wo, _i64p), O, _ptr(oi, _i32p), I, _ptr(ii, _i32p),
                                                  0 if carry is None else 1, _ptr(r["sum"], _dp), _ptr(r["nsnp"], _i32p),
                                                  _ptr(r["miss"], _i32p), _ptr(r["used"], _i32p), _ptr(r["missing"], _i32p)))
+        return r
+
+    def set_multiallelic(self, site_index, alleles):
+        """Multi-allelic sites of the uploaded shard: ascending site indices, alleles uint8 [n, 2 * n_samples] (255 = missing)."""
+        si = np.ascontiguousarray(site_index, np.int64)
+        al = np.ascontiguousarray(alleles, np.uint8).reshape(len(si), -1)
+        self._chk(self.L.evofst_set_multiallelic(self.h, len(si), _ptr(si, _i64p), _ptr(al, _u8p)))
+
+    def indiv_diffs(self, block_off):
+        """Five counts per block and pair j <= i of layout individuals -> dict(hh, hd, oh, ms, d4) int32 [B, n(n+1)/2]."""
+        bo = np.ascontiguousarray(block_off, np.int64)
+        B = len(bo) - 1
+        n = self.geometry().n_haplotypes // 2
+        r = {k: np.zeros((B, n * (n + 1) // 2), np.int32) for k in ("hh", "hd", "oh", "ms", "d4")}
+        self._chk(self.L.evofst_get_indiv_diffs(self.h, B, _ptr(bo, _i64p), *[_ptr(r[k], _i32p) for k in ("hh", "hd", "oh", "ms", "d4")]))
         return r
 
     def pop_site_div(self, first=0, n=None):

@@ -61,6 +61,8 @@ struct evofst_ctx {
     int64_t cap_sites = 0, n_sites = 0;
     int n_tiles = 0, chunk_tiles = 0, n_chunks = 0;
     DevBuf d_tiles, d_flags, d_pos, d_counts;
+    DevBuf d_planes, d_multi_site, d_multi_alleles;   // per-individual differences
+    int64_t n_multi = 0;
     const void *tiles = nullptr;  // d_tiles.p or an attached pointer
     const uint8_t *flags = nullptr;
     const int32_t *pos = nullptr;
@@ -308,7 +310,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
                       &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_halo_num, &c->d_halo_den, &c->d_halo_tag, &c->d_gU, &c->d_gC, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_carry,
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
-                      &c->d_row_num, &c->d_row_den};
+                      &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles};
     for (DevBuf *b : bufs) release(*b);
     for (auto &pair : c->ev)
         for (auto &e : pair)
@@ -473,6 +475,33 @@ extern "C" int evofst_unpack_codes(const evofst_ctx *c, int64_t first_site, int6
 
 namespace {
 
+// ALT column as `evo stats` reads it (getThisVariantCountsSimple, process_vcf_utils.cpp:365-381): returns the allele
+// number that stands for "missing" (-1: none) and adds SKIP | MULTI to *fl for a multi-allelic site.  split() drops a
+// trailing empty field and yields no field for an empty string (process_vcf_utils.cpp:104-110).
+int stats_missing_allele(const char *alt, const char *alt_end, uint32_t *fl) {
+    int n_alt = 0;
+    const char *last = alt;
+    size_t last_len = 0;
+    const char *a = alt;
+    if (a != alt_end) {
+        for (;;) {
+            const char *e = (const char *)std::memchr(a, ',', (size_t)(alt_end - a));
+            ++n_alt; last = a; last_len = e ? (size_t)(e - a) : (size_t)(alt_end - a);
+            if (!e) break;
+            a = e + 1;
+            if (a == alt_end) break;
+        }
+    }
+    int miss_allele = -1;
+    bool multi = false;
+    if (n_alt > 1) {
+        if (last_len == 1 && last[0] == '*') { miss_allele = n_alt; multi = (n_alt - 1) > 1; }
+        else multi = true;
+    }
+    if (multi) *fl |= EVOFST_SITE_SKIP | EVOFST_SITE_MULTI;
+    return miss_allele;
+}
+
 // One VCF data line -> allele codes of its n_samples genotype columns + site flags, without touching the text.
 // cols[0..1] receive the starts of CHROM and POS, col_len their lengths.
 int parse_vcf_line(const char *line, int mode, int n_samples, uint8_t *codes, uint32_t *site_flags,
@@ -513,6 +542,11 @@ int parse_vcf_line(const char *line, int mode, int n_samples, uint8_t *codes, ui
         }
         if (n_alt == 1 && allele_as_missing == 1) alt_code = 2;
         if (ref_len > 1 || n_alt != 1 || indel) fl |= EVOFST_SITE_SKIP;  // :529-532, :543
+    } else if (mode == EVOFST_MODE_STATS) {
+        // ALT parse of getThisVariantCountsSimple (process_vcf_utils.cpp:365-381): a '*' that comes last among
+        // several ALT alleles is a missing allele; more than one real ALT allele makes the site multi-allelic
+        const int miss_allele = stats_missing_allele(alt, alt_end, &fl);
+        allele_as_missing = miss_allele;
     } else {
         if (ref_len > 1 || alt_len > 1 || (alt_len == 1 && alt[0] == '*'))
             fl |= EVOFST_SITE_SKIP;                                       // FstAgainstAll.cpp:185
@@ -535,6 +569,11 @@ int parse_vcf_line(const char *line, int mode, int n_samples, uint8_t *codes, ui
                 if (v == alt_code) code = EVOFST_ALT;
                 else if (ch == '.' || v == allele_as_missing) code = EVOFST_MISSING;
                 else code = EVOFST_REF;
+            } else if (mode == EVOFST_MODE_STATS) {
+                // utils.cpp:386-405: either allele '.' or the missing allele -> the individual is missing; '1' counts
+                const char c0 = p[0], c2 = p[2];
+                if (c0 == '.' || c2 == '.' || c0 - '0' == allele_as_missing || c2 - '0' == allele_as_missing) code = EVOFST_MISSING;
+                else code = ch == '1' ? EVOFST_ALT : EVOFST_REF;
             } else {
                 code = ch == '1' ? EVOFST_ALT : (ch == '0' ? EVOFST_REF : EVOFST_MISSING);
             }
@@ -573,7 +612,7 @@ extern "C" int evofst_pack_vcf_lines(const evofst_ctx *c, int mode, int64_t n_li
                                      uint8_t *site_flags) {
     if (!c || !lines || !tiles || !site_flags || n_lines < 0 || n_vcf_samples <= 0) return EVOFST_ERR_ARG;
     if (c->n_pops == 0) return EVOFST_ERR_STATE;
-    if (mode != EVOFST_MODE_FST && mode != EVOFST_MODE_GLOBAL) return EVOFST_ERR_ARG;
+    if (mode != EVOFST_MODE_FST && mode != EVOFST_MODE_GLOBAL && mode != EVOFST_MODE_STATS) return EVOFST_ERR_ARG;
     // haplotype of the packed layout -> index into a line's code row
     std::vector<int32_t> src((size_t)c->H);
     for (int h = 0; h < c->H; ++h) {
@@ -664,6 +703,7 @@ static int begin_data(evofst_ctx *c, int64_t n_sites) {
     HIPCHK(c, hipSetDevice(c->device));
     c->counts_done = c->stats_done = false;
     c->offsets_dirty = true;
+    c->n_multi = 0;
     return EVOFST_OK;
 }
 
@@ -1255,6 +1295,112 @@ extern "C" int evofst_get_dist_windows(evofst_ctx *c, int n_windows, const int64
     else (void)hipStreamSynchronize(c->stream);
     release(b);
     if (e != hipSuccess) return hip_fail(c, e, "get_dist_windows");
+    return EVOFST_OK;
+}
+
+// Allele numbers of one multi-allelic line as `evo stats` reads them (process_vcf_utils.cpp:385-395)
+extern "C" int evofst_alleles_from_vcf_line(const char *line, int n_samples, uint8_t *alleles) {
+    if (!line || !alleles || n_samples <= 0) return EVOFST_ERR_ARG;
+    const char *col[9];
+    size_t len[9];
+    const char *p = line;
+    for (int i = 0; i < 9; ++i) {
+        col[i] = p;
+        const char *t = std::strchr(p, '\t');
+        if (!t) return EVOFST_ERR_ARG;
+        len[i] = (size_t)(t - p);
+        p = t + 1;
+    }
+    uint32_t fl = 0;
+    const int miss_allele = stats_missing_allele(col[4], col[4] + len[4], &fl);
+    for (int i = 0; i < n_samples; ++i) {
+        if (p[0] == '\0' || p[0] == '\t' || p[1] == '\0' || p[1] == '\t' || p[2] == '\0' || p[2] == '\t') return EVOFST_ERR_ARG;
+        const char c0 = p[0], c2 = p[2];
+        const int v1 = c0 - '0', v2 = c2 - '0';
+        if (c0 == '.' || c2 == '.' || v1 == miss_allele || v2 == miss_allele) { alleles[2 * i] = 255; alleles[2 * i + 1] = 255; }
+        else {
+            if (v1 < 0 || v1 > 254 || v2 < 0 || v2 > 254) return EVOFST_ERR_ARG;
+            alleles[2 * i] = (uint8_t)v1; alleles[2 * i + 1] = (uint8_t)v2;
+        }
+        const char *t = std::strchr(p + 3, '\t');
+        if (!t) {
+            if (i != n_samples - 1) return EVOFST_ERR_ARG;
+            break;
+        }
+        p = t + 1;
+    }
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_set_multiallelic(evofst_ctx *c, int64_t n_multi, const int64_t *site_index, const uint8_t *alleles) {
+    if (!c || n_multi < 0 || (n_multi > 0 && (!site_index || !alleles))) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_sites <= 0) return fail(c, EVOFST_ERR_STATE, "set_multiallelic: upload first");
+    for (int64_t k = 0; k < n_multi; ++k)
+        if (site_index[k] < 0 || site_index[k] >= c->n_sites || (k && site_index[k] <= site_index[k - 1]))
+            return fail(c, EVOFST_ERR_ARG, "set_multiallelic: site indices must ascend inside the shard");
+    c->n_multi = 0;
+    if (n_multi == 0) return EVOFST_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // from VCF sample order to the layout's individual order (dropped samples leave)
+    const int n_ind = c->H / 2;
+    std::vector<uint8_t> lay((size_t)n_multi * n_ind * 2);
+    for (int64_t k = 0; k < n_multi; ++k)
+        for (int h = 0; h < c->H; ++h) lay[(size_t)k * c->H + h] = alleles[(size_t)k * 2 * c->n_samples + c->src_hap[h]];
+    int rc = ensure(c, c->d_multi_site, (size_t)n_multi * 8);
+    if (!rc) rc = ensure(c, c->d_multi_alleles, lay.size());
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_multi_site.p, site_index, (size_t)n_multi * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_multi_alleles.p, lay.data(), lay.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // lay goes out of scope
+    c->n_multi = n_multi;
+    return EVOFST_OK;
+}
+
+extern "C" int evofst_get_indiv_diffs(evofst_ctx *c, int n_blocks, const int64_t *block_off, int32_t *hh, int32_t *hd, int32_t *oh,
+                                     int32_t *ms, int32_t *d4) {
+    if (!c || !block_off || !hh || !hd || !oh || !ms || !d4 || n_blocks <= 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_sites <= 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "get_indiv_diffs: upload first");
+    if (n_blocks > 65535) return fail(c, EVOFST_ERR_UNSUPPORTED, "get_indiv_diffs: at most 65535 blocks per call");
+    if (block_off[0] < 0 || block_off[n_blocks] > c->n_sites) return fail(c, EVOFST_ERR_ARG, "get_indiv_diffs: block offsets out of bounds");
+    for (int b = 0; b < n_blocks; ++b)
+        if (block_off[b] > block_off[b + 1]) return fail(c, EVOFST_ERR_ARG, "get_indiv_diffs: block offsets must not decrease");
+    HIPCHK(c, hipSetDevice(c->device));
+    IndivParams p{};
+    p.tiles = (const ulonglong2 *)c->tiles; p.site_flags = c->have_flags ? c->flags : nullptr;
+    p.n_sites = c->n_sites; p.W = c->W; p.n_tiles = n_tiles_of(c->n_sites); p.n_ind = c->H / 2;
+    p.n_blocks = n_blocks;
+    const int nb16 = (p.n_ind + 15) / 16;
+    p.n_pair_blocks = nb16 * (nb16 + 1) / 2;
+    p.T = (int64_t)p.n_ind * (p.n_ind + 1) / 2;
+    p.n_multi = c->n_multi;
+    p.multi_site = (const int64_t *)c->d_multi_site.p; p.multi_alleles = (const uint8_t *)c->d_multi_alleles.p;
+    const size_t out_n = (size_t)n_blocks * (size_t)p.T;
+    int rc = ensure(c, c->d_planes, (size_t)p.n_tiles * p.n_ind * 32);
+    DevBuf b;
+    const size_t off_bytes = ((size_t)n_blocks + 1) * 8;
+    if (!rc) rc = ensure(c, b, off_bytes + out_n * 5 * 4);
+    if (rc) { release(b); return rc; }
+    char *d = (char *)b.p;
+    p.planes = (uint64_t *)c->d_planes.p;
+    p.block_off = (const int64_t *)d;
+    int32_t *o = (int32_t *)(d + off_bytes);
+    p.hh = o; p.hd = o + out_n; p.oh = o + 2 * out_n; p.ms = o + 3 * out_n; p.d4 = o + 4 * out_n;
+    hipError_t e = hipMemcpyAsync(d, block_off, off_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_indiv_planes(p, c->stream);
+    if (e == hipSuccess) e = launch_indiv_pairs(p, c->stream);
+    if (e == hipSuccess) {
+        if (p.n_multi > 0) e = launch_indiv_multi(p, c->stream);
+        else e = hipMemsetAsync(p.d4, 0, out_n * 4, c->stream);
+    }
+    int32_t *host[5] = {hh, hd, oh, ms, d4};
+    for (int k = 0; k < 5 && e == hipSuccess; ++k)
+        e = hipMemcpyAsync(host[k], o + (size_t)k * out_n, out_n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    else (void)hipStreamSynchronize(c->stream);
+    release(b);
+    if (e != hipSuccess) return hip_fail(c, e, "get_indiv_diffs");
     return EVOFST_OK;
 }
 

@@ -114,6 +114,22 @@ struct DistParams {
     int32_t *used, *missing;    // [n_windows][n_out]
 };
 
+// per-individual pairwise differences (process_vcf_stats_functions.cpp:180-281)
+struct IndivParams {
+    const ulonglong2 *tiles;
+    const uint8_t *site_flags;
+    int64_t n_sites;
+    int32_t W, n_tiles, n_ind;       // n_ind = layout individuals (H / 2)
+    uint64_t *planes;                // [n_tiles][n_ind][4] = {het, hom-alt, hom-ref, missing} bits over the tile's sites
+    const int64_t *block_off;        // [n_blocks + 1] site offsets
+    int32_t n_blocks, n_pair_blocks; // pair blocks: 16 x 16 individuals on or below the diagonal
+    int64_t T;                       // n_ind (n_ind + 1) / 2
+    int32_t *hh, *hd, *oh, *ms, *d4; // [n_blocks][T]
+    const int64_t *multi_site;       // [n_multi] site index of the multi-allelic sites, ascending
+    const uint8_t *multi_alleles;    // [n_multi][n_ind][2], 255 = missing individual
+    int64_t n_multi;
+};
+
 struct PopDivParams {
     const void *counts;
     int64_t first_site, n_sites;
@@ -189,6 +205,9 @@ hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream
 hipError_t launch_pbs_sites(const PbsParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_abs_sites(const PbsParams &p, int count_bytes, hipStream_t st);   // trios = [n][4], pbs = [n][2][n_sites]
 hipError_t launch_dist_windows(const DistParams &p, int count_bytes, hipStream_t st);
+hipError_t launch_indiv_planes(const IndivParams &p, hipStream_t st);
+hipError_t launch_indiv_pairs(const IndivParams &p, hipStream_t st);
+hipError_t launch_indiv_multi(const IndivParams &p, hipStream_t st);
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,
                                 int32_t *alt, int32_t *nm, hipStream_t st);

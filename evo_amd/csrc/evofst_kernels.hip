@@ -1222,6 +1222,131 @@ hipError_t launch_dist_windows(const DistParams &p, int count_bytes, hipStream_t
     return hipGetLastError();
 }
 
+// =====================================================================================
+// Per-individual pairwise differences (diffs_between_individuals[_with_multialleleics],
+// process_vcf_stats_functions.cpp:180-281).  Three kernels:
+//   indiv_planes  tiles (site-major: one word = 64 haplotypes of a site) -> per individual and tile four 64-bit planes
+//                 over the tile's sites {heterozygous, hom-alt, hom-ref, missing}; a 64 x 64 bit transpose by ballots
+//   indiv_pairs   thread = pair j <= i, walks the tiles of a site block: the reference's if-chain becomes ANDs and
+//                 popcounts of the planes, 64 sites at a time
+//   indiv_multi   thread = pair, walks the (rare) multi-allelic sites of the block on their allele codes
+// =====================================================================================
+__global__ __launch_bounds__(256) void indiv_planes_kernel(IndivParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (tile, word)
+    if (item >= (int64_t)p.n_tiles * p.W) return;
+    const int t = (int)(item / p.W), w = (int)(item % p.W);
+    const int64_t site = (int64_t)t * kTileSites + lane;
+    const bool valid = site < p.n_sites && !(p.site_flags && (p.site_flags[site < p.n_sites ? site : 0] & 1u));
+    ulonglong2 v = p.tiles[((size_t)t * p.W + w) * kTileSites + lane];
+    if (!valid) v = make_ulonglong2(0, 0);
+    const uint64_t incl = __builtin_amdgcn_ballot_w64(valid);
+    // lane b of the result holds, for haplotype 64 w + b, one bit per site of the tile
+    uint64_t ta = 0, tm = 0;
+    const bool any_missing = __builtin_amdgcn_ballot_w64(v.y != 0) != 0;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64((v.x >> b) & 1ull);
+        if (lane == b) ta = m;
+    }
+    if (any_missing) {
+#pragma unroll 8
+        for (int b = 0; b < 64; ++b) {
+            const uint64_t m = __builtin_amdgcn_ballot_w64((v.y >> b) & 1ull);
+            if (lane == b) tm = m;
+        }
+    }
+    const uint64_t pa = __shfl_xor(ta, 1), pm = __shfl_xor(tm, 1);   // the individual's other haplotype
+    const int d = (w * 64 + lane) >> 1;
+    if ((lane & 1) == 0 && d < p.n_ind) {
+        const uint64_t miss = (tm | pm) & incl;
+        const uint64_t het = (ta ^ pa) & ~miss & incl, alt = ta & pa & ~miss & incl;
+        const uint64_t ref = incl & ~(het | alt | miss);
+        ulonglong2 *o = reinterpret_cast<ulonglong2 *>(p.planes + ((size_t)t * p.n_ind + d) * 4);
+        o[0] = make_ulonglong2(het, alt);
+        o[1] = make_ulonglong2(ref, miss);
+    }
+}
+
+// pair block pb -> (bi, bj), bj <= bi, in row-major order of the lower triangle
+__device__ __forceinline__ void pair_block_of(int pb, int &bi, int &bj) {
+    int r = (int)((sqrtf(8.0f * (float)pb + 1.0f) - 1.0f) * 0.5f);
+    while ((r + 1) * (r + 2) / 2 <= pb) ++r;
+    while (r * (r + 1) / 2 > pb) --r;
+    bi = r; bj = pb - r * (r + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void indiv_pair_kernel(IndivParams p) {
+    int bi, bj;
+    pair_block_of((int)blockIdx.x, bi, bj);
+    const int i = bi * 16 + (int)(threadIdx.x >> 4), j = bj * 16 + (int)(threadIdx.x & 15);
+    const int b = blockIdx.y;
+    const int64_t s0 = p.block_off[b], s1 = p.block_off[b + 1];
+    if (i >= p.n_ind || j > i) return;
+    int hh = 0, hd = 0, oh = 0, ms = 0;
+    if (s1 > s0) {
+        const int t0 = (int)(s0 >> 6), t1 = (int)((s1 - 1) >> 6);
+        for (int t = t0; t <= t1; ++t) {
+            // the sites of this tile that belong to the block
+            const int64_t base = (int64_t)t << 6;
+            const int lo = (int)(s0 > base ? s0 - base : 0), hi = (int)(s1 - base < 64 ? s1 - base : 64);
+            const uint64_t tmask = (hi == 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+            const ulonglong2 *pi = reinterpret_cast<const ulonglong2 *>(p.planes + ((size_t)t * p.n_ind + i) * 4);
+            const ulonglong2 *pj = reinterpret_cast<const ulonglong2 *>(p.planes + ((size_t)t * p.n_ind + j) * 4);
+            const ulonglong2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
+            const uint64_t Hi = i0.x & tmask, Ai = i0.y & tmask, Ri = i1.x & tmask, Mi = i1.y;
+            const uint64_t Hj = j0.x, Aj = j0.y, Rj = j1.x, Mj = j1.y;
+            hh += __popcll(Hi & Hj);                                         // :201 both heterozygous (j == i: heterozygous, :222)
+            hd += __popcll((Ai & Rj) | (Ri & Aj));                           // :205 opposite homozygotes
+            oh += __popcll((Hi & (Rj | Aj)) | ((Ri | Ai) & Hj));             // :211 one homozygous, one heterozygous
+            ms += __popcll((Mi | Mj) & tmask);                               // :186-197 either one missing
+        }
+    }
+    const size_t o = (size_t)b * p.T + (size_t)i * (i + 1) / 2 + j;
+    p.hh[o] = hh; p.hd[o] = hd; p.oh[o] = oh; p.ms[o] = ms;
+}
+
+// multi-allelic sites (:235-281): adds its missing pairs to ms (the pair kernel has already written it), writes d4
+__global__ __launch_bounds__(256) void indiv_multi_kernel(IndivParams p) {
+    int bi, bj;
+    pair_block_of((int)blockIdx.x, bi, bj);
+    const int i = bi * 16 + (int)(threadIdx.x >> 4), j = bj * 16 + (int)(threadIdx.x & 15);
+    const int b = blockIdx.y;
+    if (i >= p.n_ind || j > i) return;
+    const int64_t s0 = p.block_off[b], s1 = p.block_off[b + 1];
+    // first multi-allelic site at or after s0
+    int64_t lo = 0, hi = p.n_multi;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (p.multi_site[mid] < s0) lo = mid + 1; else hi = mid; }
+    int d4 = 0, ms = 0;
+    for (int64_t k = lo; k < p.n_multi && p.multi_site[k] < s1; ++k) {
+        const uint8_t *a = p.multi_alleles + ((size_t)k * p.n_ind) * 2;
+        const int i1 = a[2 * i], i2 = a[2 * i + 1], j1 = a[2 * j], j2 = a[2 * j + 1];
+        if (i1 == 255 || j1 == 255) { ++ms; continue; }
+        if (j < i) d4 += (i1 != j1) + (i1 != j2) + (i2 != j1) + (i2 != j2);  // :257-260
+        else d4 += (i1 != i2);                                              // :272
+    }
+    const size_t o = (size_t)b * p.T + (size_t)i * (i + 1) / 2 + j;
+    p.d4[o] = d4;
+    if (ms) p.ms[o] += ms;
+}
+
+hipError_t launch_indiv_planes(const IndivParams &p, hipStream_t st) {
+    const int64_t items = (int64_t)p.n_tiles * p.W;
+    if (items <= 0) return hipSuccess;
+    hipLaunchKernelGGL(indiv_planes_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+hipError_t launch_indiv_pairs(const IndivParams &p, hipStream_t st) {
+    if (p.n_blocks <= 0 || p.n_pair_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(indiv_pair_kernel, dim3((unsigned)p.n_pair_blocks, (unsigned)p.n_blocks), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+hipError_t launch_indiv_multi(const IndivParams &p, hipStream_t st) {
+    if (p.n_blocks <= 0 || p.n_pair_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(indiv_multi_kernel, dim3((unsigned)p.n_pair_blocks, (unsigned)p.n_blocks), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_site_stats(const SiteStatParams &p, int count_bytes, hipStream_t st) {
     if (p.n_sites <= 0 || p.n_pairs <= 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((p.n_sites + 255) / 256), (unsigned)min(p.n_pairs, 1024));

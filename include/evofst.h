@@ -47,10 +47,15 @@ extern "C" {
 
 /* site flags */
 #define EVOFST_SITE_SKIP 1u /* site fails the REF/ALT filters of the mode in use */
+#define EVOFST_SITE_MULTI 2u /* EVOFST_MODE_STATS: multi-allelic site (always together with SKIP: its genotypes travel as
+                              * allele numbers through evofst_set_multiallelic, not in the tiles) */
 
 /* genotype-text interpretation, evofst_codes_from_vcf_line() */
 #define EVOFST_MODE_FST 0    /* `evo fst` rules   (process_vcf_fst.cpp:222-280, 529-532) */
 #define EVOFST_MODE_GLOBAL 1 /* `evo FstGlobal`   (process_vcf_utils.cpp:62-83, evo_FstAgainstAll.cpp:184-188) */
+#define EVOFST_MODE_STATS 2  /* `evo stats`       (getThisVariantCountsSimple, process_vcf_utils.cpp:358-408): an individual
+                              * with a '.' or the missing allele in either position is missing as a whole (both haplotypes
+                              * EVOFST_MISSING); ALT = the character '1'; no REF/ALT length filter */
 
 typedef struct evofst_ctx evofst_ctx;
 
@@ -249,6 +254,26 @@ int evofst_get_abs_site_stats(evofst_ctx *ctx, int64_t first_site, int64_t n_sit
 int evofst_get_dist_windows(evofst_ctx *ctx, int n_windows, const int64_t *win_off, int n_out, const int32_t *out_idx,
                             int n_in, const int32_t *in_idx, int carry_first, double *sum, int32_t *nsnp, int32_t *miss,
                             int32_t *used, int32_t *missing);
+/* Per-individual pairwise differences: diffs_between_individuals and diffs_between_individuals_with_multialleleics
+ * (process_vcf_stats_functions.cpp:180-281), as driven by statsMain (process_vcf_stats.cpp:257-263), as five counts
+ * per pair of individuals j <= i and per caller-cut block of sites (the reference's bootstrap blocks,
+ * process_vcf_stats.cpp:265-275; one block = the whole shard gives the totals).  Individuals are those of the layout, in
+ * layout order (set_layout with one population keeps the VCF order); tiles packed with EVOFST_MODE_STATS.
+ *   evofst_alleles_from_vcf_line: allele numbers of one multi-allelic line (flag EVOFST_SITE_MULTI from the packer),
+ *       alleles[2 * n_samples], 255 255 = individual missing;
+ *   evofst_set_multiallelic: the multi-allelic sites of the uploaded shard (ascending shard-relative site indices,
+ *       alleles [n_multi][2 * n_samples] in VCF sample order); forgotten by the next upload;
+ *   evofst_get_indiv_diffs: block b covers sites [block_off[b], block_off[b+1]); arrays [n_blocks][n_ind (n_ind + 1) / 2],
+ *       pair (i, j) at i (i + 1) / 2 + j.  On bi-allelic sites: hh = both heterozygous (j == i: heterozygous),
+ *       hd = opposite homozygotes, oh = one homozygous and one heterozygous; ms = either one missing (all sites);
+ *       d4 = on multi-allelic sites, the allele comparisons that differ, of 4 per site (j == i: sites where the
+ *       individual's own two alleles differ).  The reference's matrices follow exactly:
+ *       diffs_me = hh / 2 + hd + oh / 2 + d4 / 4 (diagonal hh + d4), hets-vs-homs = hh below and hd above the diagonal,
+ *       missingness = ms; Richard's matrix = 2/3 hh + 2/3 hd + oh / 2 (diagonal hh). */
+int evofst_alleles_from_vcf_line(const char *line, int n_samples, uint8_t *alleles);
+int evofst_set_multiallelic(evofst_ctx *ctx, int64_t n_multi, const int64_t *site_index, const uint8_t *alleles);
+int evofst_get_indiv_diffs(evofst_ctx *ctx, int n_blocks, const int64_t *block_off, int32_t *hh, int32_t *hd, int32_t *oh,
+                           int32_t *ms, int32_t *d4);
 /* Per-site per-population diversity (getSetHeterozygozities + calculatePiTwoSets,
  * process_vcf_fst.cpp:325-371): arrays [n_pops][n_sites]; any pointer may be NULL. */
 int evofst_get_pop_site_div(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *het,
