@@ -79,6 +79,7 @@ SIGNATURES = {
     "evofst_get_pbs_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i32p, _dp, _u8p]),
     "evofst_get_abs_site_stats": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, _i32p, _dp, _u8p]),
     "evofst_alleles_from_vcf_line": (C.c_int, [C.c_char_p, C.c_int, _u8p]),
+    "evofst_stats_phase_draws": (C.c_int, [C.c_int64, C.POINTER(C.c_char_p), C.c_int, C.c_int, _i64p]),
     "evofst_set_multiallelic": (C.c_int, [_vp, C.c_int64, _i64p, _u8p]),
     "evofst_get_indiv_diffs": (C.c_int, [_vp, C.c_int, _i64p, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "evofst_get_dist_windows": (C.c_int, [_vp, C.c_int, _i64p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _dp, _i32p, _i32p,

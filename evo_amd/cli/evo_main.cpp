@@ -7,6 +7,7 @@
 //                                     PBSmain        evo_PBS.cpp:126
 //                                     ABSmain        evo_ABS.cpp:109
 //                                     DistOutMain    evo_distanceToOutgroups.cpp:68
+//                                     statsMain      process_vcf_stats.cpp:98     (--diff-matrix only)
 //
 // Division of labour: the host parses VCF text and packs genotypes (stage K0), the device computes
 // per-site counts and statistics (K1 + per-site kernels), and the host replays the reference's two
@@ -1156,11 +1157,260 @@ int DistOutMain(int argc, char **argv) {
     return 0;
 }
 
+// ========================================================================================== stats
+
+namespace sopt {
+string vcfFile;
+int bootstrapBlockSize = 1000, numAccessibleBP = -1;
+bool bDiffs = false, bDoBootstrap = false;
+const int n_bootstrap_replicates = 100;
+}
+
+const char *STATS_USAGE =
+    "Usage: evo stats [OPTIONS] INPUT_FILE.vcf\n"
+    "Pairwise difference statistics between the individuals of a VCF (GPU build: --diff-matrix only)\n"
+    "       -h, --help                              display this help and exit\n"
+    "       --diff-matrix                           writes FILE.diff_matrix.txt, FILE.diff_me_matrix.txt,\n"
+    "                                               FILE.hets_over_homs_matrix.txt and FILE.parwiseMissingness.txt\n"
+    "       --block-bootstrap=BLOCKSIZE             also 100 bootstrap replicates of the diff_me matrix, resampling blocks of\n"
+    "                                               BLOCKSIZE variants with replacement (written next to the VCF)\n"
+    "       --numAccessibleBP=NUM                   divide the diff_me matrix by the number of accessible base pairs\n\n";
+
+enum { OPT_DIFF_MATRIX = 64, OPT_BLOCK_BOOTSTRAP, OPT_NUM_ACCESSIBLE };
+
+string stripPath(const string &filename) {                           // process_vcf_utils.cpp:153-160
+    size_t slashPos = filename.find_last_of('/');
+    return slashPos == string::npos ? filename : filename.substr(slashPos + 1);
+}
+
+// evo stats --diff-matrix (statsMain, process_vcf_stats.cpp:98-355: the bDiffs and bDoBootstrap parts).  The device
+// returns, per bootstrap block and pair of individuals, the five counts the reference's per-site if-chains
+// (process_vcf_stats_functions.cpp:180-281) reduce to; every matrix the reference prints follows from them.  All
+// weights of the diff_me matrix are multiples of 1/4, so it is exact; Richard's matrix adds up 2/3 site by site in the
+// reference and is a product here (equal to ~1e-13 relative, printed with 6 digits).
+int statsMain(int argc, char **argv) {
+    using namespace sopt;
+    static const struct option longopts[] = {
+        {"help", no_argument, NULL, 'h'}, {"diff-matrix", no_argument, NULL, OPT_DIFF_MATRIX},
+        {"block-bootstrap", required_argument, NULL, OPT_BLOCK_BOOTSTRAP}, {"numAccessibleBP", required_argument, NULL, OPT_NUM_ACCESSIBLE},
+        {"ind-file", required_argument, NULL, OPT_UNSUPPORTED}, {"pop-file", required_argument, NULL, OPT_UNSUPPORTED},
+        {"hets-per-individual", no_argument, NULL, OPT_UNSUPPORTED}, {"doubleton-distribution", no_argument, NULL, OPT_UNSUPPORTED},
+        {"diff-matrix-h1", no_argument, NULL, OPT_UNSUPPORTED}, {"diff-matrix-allH", no_argument, NULL, OPT_UNSUPPORTED},
+        {"private-variants", no_argument, NULL, OPT_UNSUPPORTED}, {"accessibleGenomeBED", required_argument, NULL, OPT_UNSUPPORTED},
+        {"accessibleGenBedWindow", required_argument, NULL, OPT_UNSUPPORTED}, {NULL, 0, NULL, 0}};
+    bool dieFlag = false;
+    for (int c; (c = getopt_long(argc, argv, "h", longopts, NULL)) != -1;) {
+        std::istringstream arg(optarg != NULL ? optarg : "");
+        switch (c) {
+            case '?': dieFlag = true; break;
+            case OPT_DIFF_MATRIX: bDiffs = true; break;
+            case OPT_BLOCK_BOOTSTRAP: arg >> bootstrapBlockSize; bDoBootstrap = true; break;
+            case OPT_NUM_ACCESSIBLE: arg >> numAccessibleBP; break;
+            case OPT_UNSUPPORTED: die("of `evo stats` the GPU build carries --diff-matrix, --block-bootstrap and --numAccessibleBP only");
+            case 'h': std::cout << STATS_USAGE; exit(EXIT_SUCCESS);
+        }
+    }
+    if (argc - optind < 1) { std::cerr << "missing arguments\n"; dieFlag = true; }
+    else if (argc - optind > 1) { std::cerr << "too many arguments\n"; dieFlag = true; }
+    if (!bDiffs) { std::cerr << "Which statistics should the program calculate?\n"; dieFlag = true; }
+    if (bDoBootstrap && bootstrapBlockSize <= 0) { std::cerr << "the bootstrap BLOCKSIZE must be positive\n"; dieFlag = true; }
+    if (dieFlag) { std::cout << "\n" << STATS_USAGE; exit(EXIT_FAILURE); }
+    vcfFile = argv[optind++];
+
+    const string fileRoot = stripExtension(vcfFile);                 // :103
+    std::cerr << "Calculating statistics from: " << vcfFile << std::endl;
+    LineReader vcf(vcfFile);
+    std::vector<string> sampleNames;
+    int numSamples = 0, totalVariantNumber = 0;
+    long long phaseDraws = 0;                                        // rand() draws the reference has made by the end of the file
+    size_t T = 0;                                                    // pairs j <= i
+    std::vector<int64_t> hh, hd, oh, ms, d4;                         // totals per pair
+    std::vector<int32_t> openMe4, openMs;                            // the bootstrap block being filled (:220-221)
+    std::vector<std::vector<int32_t>> blockMe4, blockMs;             // finished blocks (:266-267), diff_me in quarters
+    Device dev;
+    Batch batch;
+    bool haveHeader = false;
+    std::vector<int32_t> bhh, bhd, boh, bms, bd4;
+    std::vector<int64_t> multiSite, blockOff;
+    std::vector<uint8_t> multiAlleles;
+
+    // diff_me of one pair in quarters: off the diagonal hh / 2 + hd + oh / 2 + d4 / 4, on it hh + d4 (:218-226, :269-274)
+    auto me4 = [](bool diag, int64_t a_hh, int64_t a_hd, int64_t a_oh, int64_t a_d4) {
+        return diag ? 4 * (a_hh + a_d4) : 2 * a_hh + 4 * a_hd + 2 * a_oh + a_d4;
+    };
+    std::vector<uint8_t> isDiag;
+
+    auto flush = [&]() {
+        if (batch.n == 0) return;
+        const size_t n = batch.n;
+        const long long g0 = totalVariantNumber - (long long)n;      // variants before this batch
+        dev.tiles.resize(evofst_tiles_bytes(dev.ctx, (int64_t)n));
+        batch.flags.assign(n, 0);
+        std::vector<const char *> ptr(n);
+        for (size_t i = 0; i < n; ++i) ptr[i] = batch.lines[i].c_str();
+        const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        if (evofst_pack_vcf_lines(dev.ctx, EVOFST_MODE_STATS, (int64_t)n, ptr.data(), numSamples, nullptr, threads, dev.tiles.data(),
+                                  batch.flags.data()) != EVOFST_OK)
+            die("malformed VCF line among lines " + numToString(g0 + 1) + ".." + numToString(g0 + (long long)n) +
+                " (diploid GT fields with single-digit alleles are required)");
+        check(dev.ctx, evofst_upload(dev.ctx, (int64_t)n, dev.tiles.data(), batch.flags.data(), nullptr), "upload");
+        if (bDoBootstrap) {
+            int64_t draws = 0;
+            if (evofst_stats_phase_draws((int64_t)n, ptr.data(), numSamples, threads, &draws) != EVOFST_OK) die("malformed VCF line");
+            phaseDraws += draws;
+        }
+        multiSite.clear(); multiAlleles.clear();
+        for (size_t s = 0; s < n; ++s)
+            if (batch.flags[s] & EVOFST_SITE_MULTI) {
+                multiSite.push_back((int64_t)s);
+                multiAlleles.resize(multiSite.size() * 2 * (size_t)numSamples);
+                if (evofst_alleles_from_vcf_line(ptr[s], numSamples, &multiAlleles[(multiSite.size() - 1) * 2 * (size_t)numSamples]) != EVOFST_OK)
+                    die("malformed VCF line " + numToString(g0 + (long long)s + 1));
+            }
+        check(dev.ctx, evofst_set_multiallelic(dev.ctx, (int64_t)multiSite.size(), multiSite.data(), multiAlleles.data()), "set_multiallelic");
+        // blocks end after every variant whose number is a multiple of the block size (:265); without the bootstrap
+        // the batch is one block
+        blockOff.assign(1, 0);
+        if (bDoBootstrap)
+            for (long long k = g0 / bootstrapBlockSize + 1; k * bootstrapBlockSize < g0 + (long long)n; ++k)
+                blockOff.push_back(k * bootstrapBlockSize - g0);
+        blockOff.push_back((int64_t)n);
+        const bool lastCloses = bDoBootstrap && (g0 + (long long)n) % bootstrapBlockSize == 0;
+        const size_t nBlocks = blockOff.size() - 1;
+        const size_t perCall = std::max<size_t>(1, std::min<size_t>(65535, ((size_t)64 << 20) / (T * 20)));
+        for (size_t b0 = 0; b0 < nBlocks; b0 += perCall) {
+            const size_t nb = std::min(perCall, nBlocks - b0);
+            bhh.resize(nb * T); bhd.resize(nb * T); boh.resize(nb * T); bms.resize(nb * T); bd4.resize(nb * T);
+            check(dev.ctx, evofst_get_indiv_diffs(dev.ctx, (int)nb, &blockOff[b0], bhh.data(), bhd.data(), boh.data(), bms.data(), bd4.data()),
+                  "get_indiv_diffs");
+            for (size_t b = 0; b < nb; ++b) {
+                const int32_t *a = &bhh[b * T], *d = &bhd[b * T], *o = &boh[b * T], *m = &bms[b * T], *q = &bd4[b * T];
+                for (size_t k = 0; k < T; ++k) { hh[k] += a[k]; hd[k] += d[k]; oh[k] += o[k]; ms[k] += m[k]; d4[k] += q[k]; }
+                if (!bDoBootstrap) continue;
+                for (size_t k = 0; k < T; ++k) { openMe4[k] += (int32_t)me4(isDiag[k], a[k], d[k], o[k], q[k]); openMs[k] += m[k]; }
+                const bool closes = (b0 + b + 1 < nBlocks) || lastCloses;
+                if (closes) {
+                    blockMe4.push_back(openMe4); blockMs.push_back(openMs);
+                    std::fill(openMe4.begin(), openMe4.end(), 0); std::fill(openMs.begin(), openMs.end(), 0);
+                }
+            }
+        }
+        batch.clear();
+    };
+
+    string line;
+    while (vcf.getline(line)) {                                      // :188 (no \r handling in this sub-program)
+        if (line[0] == '#' && line[1] == '#') continue;
+        if (line[0] == '#' && line[1] == 'C') {
+            std::vector<string> fields = split(line, '\t');
+            for (size_t i = 9; i < fields.size(); i++) sampleNames.push_back(fields[i]);   // :196-199
+            numSamples = (int)sampleNames.size();
+            if (numSamples <= 0) die("VCF header has no sample columns");
+            std::cerr << "Number of chromosomes: " << numSamples * 2 << std::endl;
+            T = (size_t)numSamples * ((size_t)numSamples + 1) / 2;
+            hh.assign(T, 0); hd.assign(T, 0); oh.assign(T, 0); ms.assign(T, 0); d4.assign(T, 0);
+            isDiag.assign(T, 0);
+            for (size_t i = 0; i < (size_t)numSamples; ++i) isDiag[i * (i + 1) / 2 + i] = 1;
+            if (bDoBootstrap) { openMe4.assign(T, 0); openMs.assign(T, 0); }
+            std::vector<int32_t> sp(numSamples, 0);                  // one population: the layout keeps the VCF order
+            dev.open();
+            check(dev.ctx, evofst_set_layout(dev.ctx, numSamples, 1, sp.data()), "set_layout");
+            check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
+            haveHeader = true;
+            continue;
+        }
+        if (!haveHeader) die("variant line before the #CHROM header");
+        totalVariantNumber++;
+        if (totalVariantNumber % 100000 == 0) std::cerr << "Processed " << totalVariantNumber << " variants" << std::endl;
+        batch.add(line, totalVariantNumber);
+        if (batch.n == (size_t)kChunkSites) flush();
+    }
+    flush();
+    if (!haveHeader) die("no #CHROM header in " + vcfFile);
+    const size_t N = (size_t)numSamples;
+    auto tri = [](size_t i, size_t j) { return i * (i + 1) / 2 + j; };
+
+    if (bDoBootstrap) {                                              // :296-325
+        const int nBlocks = (int)blockMe4.size();
+        // the reference never seeds rand(), and has drawn from it once per unphased heterozygous genotype while
+        // reading (randomisePhase, process_vcf_utils.cpp:268-276): start the block picks at the same place of the stream
+        srand(1);
+        for (long long k = 0; k < phaseDraws; ++k) (void)rand();
+        std::vector<double> rep(N * N), repMiss(N * N);
+        for (int r = 0; r < n_bootstrap_replicates; r++) {
+            std::ofstream bootOut((fileRoot + "boot." + numToString(r) + ".txt").c_str());
+            std::fill(rep.begin(), rep.end(), 0.0); std::fill(repMiss.begin(), repMiss.end(), 0.0);
+            for (int b = 0; b < nBlocks; b++) {
+                const int block = rand() % nBlocks;
+                for (size_t i = 0; i < N; i++)
+                    for (size_t j = 0; j <= i; j++) {
+                        rep[i * N + j] = rep[i * N + j] + blockMe4[block][tri(i, j)] / 4.0;
+                        repMiss[i * N + j] = repMiss[i * N + j] + blockMs[block][tri(i, j)];
+                    }
+            }
+            const int totalSitesBootstrap = nBlocks * bootstrapBlockSize;
+            for (size_t k = 0; k < N * N; k++) {
+                const double proportionUsed = 1 - (repMiss[k] / totalSitesBootstrap);
+                rep[k] = rep[k] / proportionUsed;
+            }
+            for (size_t i = 0; i < N; i++) bootOut << sampleNames[i] << (i == N - 1 ? "" : "\t");
+            bootOut << std::endl;
+            for (size_t i = 0; i < N; i++) {
+                for (size_t j = 0; j < N; j++) { bootOut << rep[i * N + j]; if (j != N - 1) bootOut << "\t"; }
+                bootOut << std::endl;
+            }
+        }
+    }
+
+    // print_pairwise_diff_stats (process_vcf_print_routines.cpp:74-120) after finalize_diffs_Hets_vs_Homs_proportions
+    const string fileNoPath = stripPath(fileRoot);                   // :328
+    std::ofstream diffOut((fileNoPath + ".diff_matrix.txt").c_str()), diffMeOut((fileNoPath + ".diff_me_matrix.txt").c_str()),
+        hetHomOut((fileNoPath + ".hets_over_homs_matrix.txt").c_str()), pairMisOut((fileNoPath + ".parwiseMissingness.txt").c_str());
+    diffOut << "# Input file:" << fileNoPath << ".vcf" << std::endl;
+    diffOut << "# Total number of segragating variant sites in this sample:" << totalVariantNumber << std::endl;
+    diffOut << "# Richard's scoring scheme" << std::endl;
+    diffMeOut << "# Input file:" << fileNoPath << ".vcf" << std::endl;
+    diffMeOut << "# Total number of segragating variant sites in this sample: " << totalVariantNumber << std::endl;
+    diffMeOut << "# Homozygous difference = 1, one homozygous, another heterozygous = 0.5" << std::endl;
+    hetHomOut << "# Input file:" << fileNoPath << ".vcf" << std::endl;
+    hetHomOut << "# number of sites both individuals hets/number of sites individuals have a homozygous difference; i.e. num(1/0::1/0)/num(1/1::0/0)" << std::endl;
+    hetHomOut << "# For a free mixing population, we expect this number ~2; for fully separated species ~0" << std::endl;
+    pairMisOut << "# Input file:" << fileNoPath << ".vcf" << std::endl;
+    pairMisOut << "# Total number of segragating variant sites in this sample: " << totalVariantNumber << std::endl;
+    pairMisOut << "# Pairwise missingness:" << std::endl;
+    for (std::ofstream *f : {&diffOut, &diffMeOut, &hetHomOut, &pairMisOut}) {
+        for (size_t i = 0; i < N; i++) *f << sampleNames[i] << (i == N - 1 ? "" : "\t");
+        *f << std::endl;
+    }
+    diffMeOut.precision(10);
+    for (size_t i = 0; i < N; i++)
+        for (size_t j = 0; j < N; j++) {
+            double richard = 0, me = 0, hetHom = 0;
+            long long mis = 0;
+            if (j <= i) {
+                const size_t k = tri(i, j);
+                if (j < i) {
+                    richard = (2.0 / 3.0) * (double)hh[k] + (2.0 / 3.0) * (double)hd[k] + 0.5 * (double)oh[k];
+                    hetHom = (double)hh[k] / (double)hd[k];          // utils.cpp:1151
+                } else richard = (double)hh[k];
+                me = (double)me4(j == i, hh[k], hd[k], oh[k], d4[k]) / 4.0;
+                if (numAccessibleBP > -1) me = (double)me / numAccessibleBP;                 // :286-293
+                mis = ms[k];
+            } else if (numAccessibleBP > -1) me = 0.0 / numAccessibleBP;
+            const char *sep = j == N - 1 ? "\n" : "\t";
+            diffOut << richard; diffMeOut << me; hetHomOut << hetHom; pairMisOut << mis;
+            if (j == N - 1) { diffOut << std::endl; diffMeOut << std::endl; hetHomOut << std::endl; pairMisOut << std::endl; }
+            else { diffOut << sep; diffMeOut << sep; hetHomOut << sep; pairMisOut << sep; }
+        }
+    if (dev.ctx) evofst_destroy(dev.ctx);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc <= 1) {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS  DistOutgroups\n";
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS  DistOutgroups  stats\n";
         return 0;
     }
     string command(argv[1]);
@@ -1170,10 +1420,11 @@ int main(int argc, char **argv) {
     if (command == "PBS") return branchMain(3, argc - 1, argv + 1);
     if (command == "ABS") return branchMain(4, argc - 1, argv + 1);
     if (command == "DistOutgroups") return DistOutMain(argc - 1, argv + 1);
+    if (command == "stats") return statsMain(argc - 1, argv + 1);
     if (command == "help" || command == "--help") {
-        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS  DistOutgroups\n" << FST_USAGE << FSTGLOBAL_USAGE << AF_USAGE << PBS_USAGE << ABS_USAGE << DISTOUT_USAGE;
+        std::cout << "evo (MI355X build): commands  fst  FstGlobal  alleleFreq  PBS  ABS  DistOutgroups  stats\n" << FST_USAGE << FSTGLOBAL_USAGE << AF_USAGE << PBS_USAGE << ABS_USAGE << DISTOUT_USAGE << STATS_USAGE;
         return 0;
     }
-    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal, alleleFreq, PBS, ABS, DistOutgroups)\n";
+    std::cerr << "Unrecognized command: " << command << " (this build carries only the Fst / dxy path: fst, FstGlobal, alleleFreq, PBS, ABS, DistOutgroups, stats --diff-matrix)\n";
     return 1;
 }

@@ -1332,6 +1332,45 @@ extern "C" int evofst_alleles_from_vcf_line(const char *line, int n_samples, uin
     return EVOFST_OK;
 }
 
+// How many times getThisVariantCountsSimple draws from rand() on these lines: once per genotype whose two allele
+// characters differ, on lines whose first genotype is not written with '|' (process_vcf_utils.cpp:384-387, 268-276)
+extern "C" int evofst_stats_phase_draws(int64_t n_lines, const char *const *lines, int n_samples, int n_threads, int64_t *draws) {
+    if (!lines || !draws || n_lines < 0 || n_samples <= 0) return EVOFST_ERR_ARG;
+    n_threads = std::max(1, std::min(n_threads, 64));
+    std::vector<int64_t> part((size_t)n_threads, 0);
+    std::vector<int> bad((size_t)n_threads, 0);
+    auto work = [&](int tid) {
+        int64_t acc = 0;
+        for (int64_t l = tid; l < n_lines; l += n_threads) {
+            const char *p = lines[l];
+            for (int i = 0; i < 9 && p; ++i) { p = std::strchr(p, '\t'); if (p) ++p; }
+            if (!p) { bad[tid] = 1; return; }
+            if (p[0] == '\0' || p[1] == '|') continue;
+            for (int i = 0; i < n_samples; ++i) {
+                if (p[0] == '\0' || p[0] == '\t' || p[1] == '\0' || p[1] == '\t' || p[2] == '\0' || p[2] == '\t') { bad[tid] = 1; return; }
+                acc += p[0] != p[2];
+                const char *t = std::strchr(p + 3, '\t');
+                if (!t) {
+                    if (i != n_samples - 1) { bad[tid] = 1; return; }
+                    break;
+                }
+                p = t + 1;
+            }
+        }
+        part[tid] = acc;
+    };
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        for (auto &t : th) t.join();
+    }
+    int64_t total = 0;
+    for (int t = 0; t < n_threads; ++t) { if (bad[t]) return EVOFST_ERR_ARG; total += part[t]; }
+    *draws = total;
+    return EVOFST_OK;
+}
+
 extern "C" int evofst_set_multiallelic(evofst_ctx *c, int64_t n_multi, const int64_t *site_index, const uint8_t *alleles) {
     if (!c || n_multi < 0 || (n_multi > 0 && (!site_index || !alleles))) return EVOFST_ERR_ARG;
     NEED_GPU(c);

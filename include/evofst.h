@@ -271,6 +271,12 @@ int evofst_get_dist_windows(evofst_ctx *ctx, int n_windows, const int64_t *win_o
  *       diffs_me = hh / 2 + hd + oh / 2 + d4 / 4 (diagonal hh + d4), hets-vs-homs = hh below and hd above the diagonal,
  *       missingness = ms; Richard's matrix = 2/3 hh + 2/3 hd + oh / 2 (diagonal hh). */
 int evofst_alleles_from_vcf_line(const char *line, int n_samples, uint8_t *alleles);
+/* Host only: the number of rand() draws getThisVariantCountsSimple makes on these lines (randomisePhase,
+ * process_vcf_utils.cpp:268-276, 384-387: one per genotype whose two allele characters differ, on lines whose first
+ * genotype is not phased).  The draws do not change any statistic of this path, but they move the C library's random
+ * stream from which statsMain then picks its bootstrap blocks (process_vcf_stats.cpp:302); a caller that wants the
+ * reference's replicates advances rand() by this many draws first. */
+int evofst_stats_phase_draws(int64_t n_lines, const char *const *lines, int n_samples, int n_threads, int64_t *draws);
 int evofst_set_multiallelic(evofst_ctx *ctx, int64_t n_multi, const int64_t *site_index, const uint8_t *alleles);
 int evofst_get_indiv_diffs(evofst_ctx *ctx, int n_blocks, const int64_t *block_off, int32_t *hh, int32_t *hd, int32_t *oh,
                            int32_t *ms, int32_t *d4);

@@ -1825,6 +1825,7 @@ int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAcc
     const char *slash = strrchr(root, '/');
     const char *noPath = slash ? slash + 1 : root;
     int n = 0, totalVariantNumber = 0, bootstrapBlockNum = 0, rc = 0;
+    long long phaseDraws = 0;
     char **names = NULL;
     double *diffs = NULL, *diffs_me = NULL, *hvh = NULL, *boot = NULL, **bootBlocks = NULL;
     int *miss = NULL, *bootMiss = NULL, **bootMissBlocks = NULL;
@@ -1851,6 +1852,8 @@ int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAcc
             if (nf < 9 + n) { rc = -5; break; }
             int multi = 0;
             orc_stats_variant_counts(fields[4], (const char *const *)(fields + 9), n, iv, hp, ms, &multi);
+            if (n > 0 && fields[9][1] != '|')                       /* utils.cpp:384-387: randomisePhase draws from rand() */
+                for (int i = 0; i < n; i++) if (fields[9 + i][0] != fields[9 + i][2]) phaseDraws++;
             uint8_t m8 = (uint8_t)multi;
             orc_indiv_diffs(n, 1, iv, hp, ms, &m8, diffs, diffs_me, boot, hvh, miss, bootMiss);
             if (bootstrapBlockSize > 0 && totalVariantNumber % bootstrapBlockSize == 0) {              /* :265-275 */
@@ -1871,7 +1874,10 @@ int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAcc
         size_t nn = (size_t)n * (size_t)n;
         if (numAccessibleBP > -1) for (size_t k = 0; k < nn; k++) diffs_me[k] = (double)diffs_me[k] / numAccessibleBP;   /* :286-293 */
         if (bootstrapBlockSize > 0) {                                                                   /* :296-325 */
-            srand(1);                                        /* the reference never seeds: a fresh process starts from 1 */
+            /* the reference never seeds (a fresh process starts from 1) and randomisePhase (utils.cpp:268-276) has
+             * drawn once per unphased genotype with two different allele characters by now */
+            srand(1);
+            for (long long k = 0; k < phaseDraws; k++) (void)rand();
             const int n_bootstrap_replicates = 100;
             double *rep = (double *)malloc(sizeof(double) * (nn + 1)), *repMiss = (double *)malloc(sizeof(double) * (nn + 1));
             for (int r = 0; r < n_bootstrap_replicates; r++) {

@@ -271,6 +271,46 @@ def test_cli_distoutgroups_small_windows_crlf_batches(tmp_path):
     assert "\tnan" in (d / "out2_DIST_d_FW2000.txt").read_text()       # windows where an ingroup is mostly missing
 
 
+def _stats_case(tmp_path, rng, args, block=0, accessible=-1, n_sites=3000, n_samples=19, crlf=False, miss=0.1):
+    vdir = tmp_path / "data"
+    vdir.mkdir()
+    vcf = str(vdir / "cohort.v1.vcf")
+    write_vcf(vcf, rng, n_sites, n_samples, crlf=crlf, miss=miss)
+    cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
+    cli_dir.mkdir(); orc_dir.mkdir()
+    r = subprocess.run([EVO, "stats", "--diff-matrix"] + args + [vcf], cwd=str(cli_dir), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for f in os.listdir(vdir):                                        # the bootstrap replicates land next to the VCF
+        if "boot." in f:
+            shutil.move(str(vdir / f), str(cli_dir / f))
+    O.stats_diffs_run(vcf, str(orc_dir), block=block, accessible=accessible)
+    _same_files(str(cli_dir), str(orc_dir))
+    return cli_dir
+
+
+def test_cli_stats_diff_matrix(tmp_path):
+    """evo stats --diff-matrix: the four matrix files from the device's five counts per pair; multi-allelic
+    lines, '*' alleles, half calls, indels (this sub-program filters nothing) are all in the input."""
+    d = _stats_case(tmp_path, np.random.default_rng(71), [])
+    assert sorted(os.listdir(d)) == ["cohort.v1.diff_matrix.txt", "cohort.v1.diff_me_matrix.txt",
+                                     "cohort.v1.hets_over_homs_matrix.txt", "cohort.v1.parwiseMissingness.txt"]
+    rows = (d / "cohort.v1.diff_me_matrix.txt").read_text().splitlines()
+    assert len(rows) == 3 + 1 + 19 and rows[-1].split("\t")[0] not in ("0", "")
+
+
+def test_cli_stats_bootstrap_across_batches(tmp_path):
+    """Blocks of 700 variants over 70 k lines (three device batches; blocks straddle the batch edges), 100 replicates
+    drawn with the C library's unseeded rand() as the reference does, and --numAccessibleBP."""
+    d = _stats_case(tmp_path, np.random.default_rng(72), ["--block-bootstrap=700", "--numAccessibleBP=12345"], block=700, accessible=12345,
+                    n_sites=70000, n_samples=9, crlf=True, miss=0.05)
+    assert len(os.listdir(d)) == 104
+
+
+def test_cli_stats_bootstrap_without_a_full_block(tmp_path):
+    d = _stats_case(tmp_path, np.random.default_rng(73), ["--block-bootstrap=5000"], block=5000, n_sites=800, n_samples=5)
+    assert "nan" in (d / "cohort.v1boot.0.txt").read_text()
+
+
 def test_cli_rejects_unknown_command():
-    r = subprocess.run([EVO, "stats"], capture_output=True, text=True)
+    r = subprocess.run([EVO, "getCodingSeq"], capture_output=True, text=True)
     assert r.returncode != 0 and "Unrecognized command" in r.stderr
