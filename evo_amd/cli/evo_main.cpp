@@ -1268,12 +1268,13 @@ int statsMain(int argc, char **argv) {
                     die("malformed VCF line " + numToString(g0 + (long long)s + 1));
             }
         check(dev.ctx, evofst_set_multiallelic(dev.ctx, (int64_t)multiSite.size(), multiSite.data(), multiAlleles.data()), "set_multiallelic");
-        // blocks end after every variant whose number is a multiple of the block size (:265); without the bootstrap
-        // the batch is one block
+        // blocks end after every variant whose number is a multiple of the block size (:265)
         blockOff.assign(1, 0);
         if (bDoBootstrap)
             for (long long k = g0 / bootstrapBlockSize + 1; k * bootstrapBlockSize < g0 + (long long)n; ++k)
                 blockOff.push_back(k * bootstrapBlockSize - g0);
+        else                                                         // only totals wanted: cut the batch so that the chip fills
+            for (int64_t k = 4096; k < (int64_t)n; k += 4096) blockOff.push_back(k);
         blockOff.push_back((int64_t)n);
         const bool lastCloses = bDoBootstrap && (g0 + (long long)n) % bootstrapBlockSize == 0;
         const size_t nBlocks = blockOff.size() - 1;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the SURVEY 8(f) consumer kernels on the cfg2 shard shape (200 samples, 10 populations, missing 2 %):
-PBS and ABS per site, outgroup-to-ingroup dxy per window.  Wall time of the C-ABI call (staging + kernel + copy back
+PBS and ABS per site, outgroup-to-ingroup dxy per window, per-individual pairwise differences (200 x 201 / 2 pairs).  Wall time of the C-ABI call (staging + kernel + copy back
 to pageable host memory); run under `rocprofv3 --kernel-trace --stats` for the kernels' own durations.
 python3 tools/f_rows_bench.py [n_sites]"""
 import itertools, os, sys, time
@@ -35,3 +35,6 @@ timed("pbs_site_stats", lambda: e.pbs_site_stats(trios), S * len(trios), "site*t
 timed("abs_site_stats", lambda: e.abs_site_stats(quartets), S * len(quartets), "site*quartet", S * len(quartets) * 17)
 timed("dist_windows", lambda: e.dist_windows(wo, out_idx, in_idx), S * len(out_idx) * len(in_idx), "site*pair",
       (len(wo) - 1) * len(out_idx) * (len(in_idx) * 16 + 8))
+blocks = np.arange(0, S + 1, 4096, dtype=np.int64)
+timed("indiv_diffs", lambda: e.indiv_diffs(blocks), S * (N * (N + 1) // 2), "site*pair", (len(blocks) - 1) * (N * (N + 1) // 2) * 20)
+timed("indiv_diffs 1 block", lambda: e.indiv_diffs([0, S]), S * (N * (N + 1) // 2), "site*pair", (N * (N + 1) // 2) * 20)
