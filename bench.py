@@ -268,12 +268,20 @@ def main():
         out["cpu_baseline"] = {"value": v, "unit": "site*pair/s", "cores": 1, "kind": "port",
                                "sample": "first %d sites of the same workload, oracle/evo_oracle.c closed-form "
                                          "restatement on allele codes (counts + per-site stats + windows), %.1f s" % (cs, secs)}
+    if multi and cfg["mode"] == "pairs" and rank == 0:
+        # sanity of the device-side exchange: the gathered carries equal what the host getter returns (reported, and
+        # said loudly on stderr, rather than raised: the timing above is valid either way)
+        try:
+            own = t_allc.view(world, nq, 4)[rank].cpu().numpy()
+            ok = bool(np.array_equal(own, e.boundary(), equal_nan=True))
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            print("bench.py: exchange check could not run: %r" % (ex,), file=sys.stderr)
+        out["config"]["exchange_check"] = ok
+        if not ok:
+            print("bench.py: device-side boundary copy differs from evofst_get_boundary", file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
-    if multi and cfg["mode"] == "pairs" and rank == 0:
-        # sanity of the device-side exchange: the gathered carries equal what the host getter returns
-        own = t_allc.view(world, nq, 4)[rank].cpu().numpy()
-        assert np.array_equal(own, e.boundary(), equal_nan=True), "device-side boundary copy differs from evofst_get_boundary"
     e.close()
     if multi:
         dist.destroy_process_group()
