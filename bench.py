@@ -35,6 +35,8 @@ CONFIGS = {
     "cfg5s": dict(sites=2_500_000, samples=5000, pops=500, mode="gram", size=100, step=100, miss=0.15,
                   label="synthetic 2.5M-site shard (1/8 of 20M) x 5000 samples, 500 pops (124,750 pairs), 15% missing, "
                         "Gram path (FP64 MFMA) over fixed 100-site windows"),
+    "cfg5s_w1000": dict(sites=2_500_000, samples=5000, pops=500, mode="gram", size=1000, step=1000, miss=0.15,
+                        label="cfg5s with 1000-site windows (diagnostic: prologue / epilogue amortised over 10x the sites)"),
 }
 HBM_PEAK_GBS = 8000.0
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevofst.so")
+LIB_PATH = os.environ.get("EVOFST_LIBRARY") or os.path.join(_HERE, "libevofst.so")   # EVOFST_LIBRARY: a developer build to test against
 
 EVOFST_OK = 0
 ERR_ARG, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4, -5

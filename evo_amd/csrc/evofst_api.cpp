@@ -1072,6 +1072,7 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p;
     p.n_pairs = np;
     p.out_num = (double *)c->d_gnum.p; p.out_den = (double *)c->d_gden.p; p.out_k = (double *)c->d_gk.p; p.out_cnt = (double *)c->d_gcnt.p;
+    if (const char *e = getenv("EVOFST_DEBUG_GRAM")) p.debug = atoi(e);
     record(c, 2, 0);
     HIPCHK(c, launch_gram(p, c->count_bytes, c->gram_missing != 0, c->stream));
     record(c, 2, 1);

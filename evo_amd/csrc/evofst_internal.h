@@ -180,6 +180,7 @@ struct GramParams {
     double *U, *C;               // [n_windows][P] per-population sums of t + h and of c over the window
     int64_t n_pairs;             // P (P - 1) / 2, pair (i < j) at i (2P - i - 1) / 2 + j - i - 1
     double *out_num, *out_den, *out_k, *out_cnt;   // [n_windows][n_pairs]
+    int32_t debug;               // EVOFST_DEBUG_GRAM (timing experiments): 1 no contraction loop, 2 no epilogue, 4 no popsums
 };
 
 struct SynthParams {

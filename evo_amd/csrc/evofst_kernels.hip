@@ -758,13 +758,17 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 template <typename CT>
 __global__ __launch_bounds__(256) void gram_popsums_kernel(GramParams p) {
+    // one wave per (window, population): lanes stride over the window's sites, then a wave reduction.  (One block per
+    // window with a wave walking every 4th population was tried: 12 ms instead of 5 on the cfg5 shard -- a chain of
+    // dependent load latencies per wave.)
     const int w = blockIdx.x;
-    const int k = blockIdx.y * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= p.P) return;
+    const int lane = lane_id();
     const int64_t a = p.win_start[p.first_window + w], b = min(p.win_start[p.first_window + w + 1], p.n_sites);
     double U = 0.0, C = 0.0;
     const CT *cb = reinterpret_cast<const CT *>(p.counts);
-    for (int64_t s = a; s < b; ++s) {
+    for (int64_t s = a + lane; s < b; s += 64) {
         const int t = (int)(s >> 6), o = (int)(s & 63);
         if ((p.skip_mask[t] >> o) & 1ull) continue;
         const uint32_t v = cb[((size_t)t * p.P + k) * kTileSites + o];
@@ -775,10 +779,18 @@ __global__ __launch_bounds__(256) void gram_popsums_kernel(GramParams p) {
         U += tt + hh;
         C += (double)c;
     }
-    p.U[(size_t)w * p.P + k] = U;
-    p.C[(size_t)w * p.P + k] = C;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { U += __shfl_xor(U, d); C += __shfl_xor(C, d); }
+    if (lane == 0) {
+        p.U[(size_t)w * p.P + k] = U;
+        p.C[(size_t)w * p.P + k] = C;
+    }
 }
 
+#ifndef EVOFST_GRAM_WPB
+#define EVOFST_GRAM_WPB 8
+#endif
+constexpr int kGramWPB = EVOFST_GRAM_WPB;   // windows per block
 constexpr int kGramMaskTiles = 4;    // tiles of a window whose masks are staged in LDS for the epilogue (longer windows read HBM)
 
 // TAB (every population has <= 31 chromosomes): the operands of a packed count {c, nm} come from a 1024-entry LDS
@@ -800,10 +812,6 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     const int bj = bi + rem;
     const int r0 = bi * 64 + (wave >> 1) * 32, c0 = bj * 64 + (wave & 1) * 32;
     const bool use_rcp = p.max_n < 2048;
-    const int w = blockIdx.x;
-    const int64_t a = p.win_start[p.first_window + w], b = min(p.win_start[p.first_window + w + 1], p.n_sites);
-    const int tw0 = (int)(a >> 6), tw1 = b > a ? (int)((b - 1) >> 6) : tw0 - 1;
-    const bool staged = tw1 - tw0 < kGramMaskTiles;
     if (TAB) {
         for (int i = threadIdx.x; i < 1024; i += blockDim.x) {      // entry (nm << 5) | c; impossible ones (c > nm) are 0: entry 1 serves sites outside the window
             const int c = i & 31, nm = i >> 5;
@@ -816,20 +824,73 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     } else if (use_rcp) {
         for (int i = threadIdx.x; i <= p.max_n; i += blockDim.x) rcp[i] = i ? 1.0 / (double)i : 0.0;
     }
-    if (staged)   // K1's masks of the block's 128 populations for the window's tiles
-        for (int i = threadIdx.x; i < (tw1 - tw0 + 1) * 4 * 128; i += blockDim.x) {
-            const int t = i / 512, m = (i >> 7) & 3, x = i & 127;
-            const int pop = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
-            lmask[t][m][x] = pop < p.P ? p.masks[((size_t)(tw0 + t) * 4 + m) * p.P + pop] : ~0ull;
-        }
-    __syncthreads();
-    if (r0 > c0 + 31 || r0 >= p.P || c0 >= p.P) return;    // below the diagonal or outside: nothing to do (after the barrier)
-
+    const bool idle = r0 > c0 + 31 || r0 >= p.P || c0 >= p.P;   // a wave below the diagonal or outside: only joins the barriers
     int pop[4];                                          // row tile 0, 1, column tile 0, 1
     pop[0] = r0 + r; pop[1] = r0 + 16 + r; pop[2] = c0 + r; pop[3] = c0 + 16 + r;
     uint32_t nfull[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) nfull[x] = pop[x] < p.P ? (uint32_t)p.n_full[pop[x]] : 0u;
+    const CT *cb = reinterpret_cast<const CT *>(p.counts);
+    const double kNaN = __longlong_as_double(0x7ff8000000000000ll);
+
+    // a block works through kGramWPB consecutive windows: the tables above are built once for all of them
+    for (int wi = 0; wi < kGramWPB; ++wi) {
+    const int w = blockIdx.x * kGramWPB + wi;
+    if (w >= p.n_windows) break;
+    const int64_t a = p.win_start[p.first_window + w], b = min(p.win_start[p.first_window + w + 1], p.n_sites);
+    const int tw0 = (int)(a >> 6), tw1 = b > a ? (int)((b - 1) >> 6) : tw0 - 1;
+    // K1's masks of the block's 128 populations for ng tiles from tile tg on
+    auto stage_masks = [&](int tg, int ng) {
+        for (int i = threadIdx.x; i < ng * 4 * 128; i += blockDim.x) {
+            const int t = i / 512, m = (i >> 7) & 3, x = i & 127;
+            const int pop = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
+            lmask[t][m][x] = pop < p.P ? p.masks[((size_t)(tg + t) * 4 + m) * p.P + pop] : ~0ull;
+        }
+    };
+    if (wi) __syncthreads();                             // the previous window's epilogue is done with lmask
+    stage_masks(tw0, min(kGramMaskTiles, tw1 - tw0 + 1));
+    __syncthreads();
+
+    // included sites and NaN poison of every pair from K1's masks, kGramMaskTiles tiles at a time through LDS.  The
+    // first group is counted here, before the contraction (18 registers carried through it are cheaper than counting
+    // with the 96 accumulator registers live); longer windows do their other groups after it.
+    const int lr0 = (wave >> 1) * 32, lc0 = 64 + (wave & 1) * 32;     // this wave's rows / columns inside lmask
+    uint32_t cnt_in[2][2][4];
+    uint32_t poison_n = 0, poison_d = 0;                              // bit (j * 2 + i) * 4 + v
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cnt_in[j][i][v] = 0;
+    auto count_group = [&](int tg, int ng) {
+        for (int t = 0; t < ng; ++t) {
+            const int tw = tg + t;
+            uint64_t wm = ~0ull;
+            if (tw == tw0) wm &= ~0ull << (a & 63);
+            if (tw == tw1 && (b & 63)) wm &= ~0ull >> (64 - (b & 63));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int xj = lc0 + j * 16 + r;
+                const uint64_t zj = lmask[t][0][xj], fj = lmask[t][1][xj];
+                const uint64_t b1j = MISS ? lmask[t][2][xj] : 0ull, b0j = MISS ? lmask[t][3][xj] : 0ull;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int xi = lr0 + i * 16 + kq + 4 * v;
+                        const uint64_t incl = ~((lmask[t][0][xi] & zj) | (lmask[t][1][xi] & fj)) & wm;
+                        cnt_in[j][i][v] += (uint32_t)__popcll(incl);
+                        if (MISS) {
+                            const uint32_t bit = 1u << ((j * 2 + i) * 4 + v);
+                            if ((lmask[t][2][xi] | b1j) & incl) poison_n |= bit;
+                            if ((lmask[t][3][xi] | b0j) & incl) poison_d |= bit;
+                        }
+                    }
+            }
+        }
+    };
+    if (!idle && !(p.debug & 2)) count_group(tw0, min(kGramMaskTiles, tw1 - tw0 + 1));
 
     double4_t acc_den[2][2], acc_cc[2][2], acc_m[2][2];
 #pragma unroll
@@ -837,7 +898,6 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc_den[i][j] = double4_t{0, 0, 0, 0}; acc_cc[i][j] = double4_t{0, 0, 0, 0}; acc_m[i][j] = double4_t{0, 0, 0, 0}; }
 
-    const CT *cb = reinterpret_cast<const CT *>(p.counts);
     const int64_t base0 = a & ~(int64_t)7;
     uint4 nxt[4][NVEC];
     auto fetch = [&](int64_t base) {                     // the 4 populations' count vectors of this lane's 8 sites
@@ -850,8 +910,9 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
             for (int v = 0; v < NVEC; ++v) nxt[x][v] = reinterpret_cast<const uint4 *>(src)[v];
         }
     };
-    if (base0 < b) fetch(base0);
-    for (int64_t base = base0; base < b; base += 4 * EV) {
+    const int64_t bend = (idle || (p.debug & 1)) ? base0 : b;        // an idle wave contracts nothing and writes nothing
+    if (base0 < bend) fetch(base0);
+    for (int64_t base = base0; base < bend; base += 4 * EV) {
         const int64_t sv = base + (int64_t)kq * EV;      // this lane's 8 sites (inside one tile)
         const int t = (int)min(sv >> 6, (int64_t)p.n_tiles - 1), o = (int)(sv & 63);
         // sites of the vector that belong to the window and are not skipped
@@ -922,13 +983,23 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     }
 
     // ---- epilogue: C/D layout col = lane & 15, row = (lane >> 4) + 4 v
-    const double kNaN = __longlong_as_double(0x7ff8000000000000ll);
+    if (p.debug & 2) {                                   // timing experiment: keep the accumulators alive, nothing else
+        double s = 0;
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 4; ++v) s += acc_den[i][j][v] + acc_cc[i][j][v] + acc_m[i][j][v];
+        if (s == 1.2345e-300) p.out_num[0] = s;
+        continue;
+    }
+    for (int tg = tw0 + kGramMaskTiles; tg <= tw1; tg += kGramMaskTiles) {   // windows longer than one group of tiles
+        const int ng = min(kGramMaskTiles, tw1 - tg + 1);
+        __syncthreads();
+        stage_masks(tg, ng);
+        __syncthreads();
+        if (!idle) count_group(tg, ng);
+    }
     const size_t wp = (size_t)w * p.P;
-    const int lr0 = (wave >> 1) * 32, lc0 = 64 + (wave & 1) * 32;     // this wave's rows / columns inside lmask
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pj = c0 + j * 16 + r;
-        const int xj = lc0 + j * 16 + r;
         const double Uj = pj < p.P ? p.U[wp + pj] : 0.0, Cj = pj < p.P ? p.C[wp + pj] : 0.0;
         const double nj = pj < p.P ? (double)p.n_full[pj] : 0.0;
 #pragma unroll
@@ -936,54 +1007,35 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int pi = r0 + i * 16 + kq + 4 * v;
-                const int xi = lr0 + i * 16 + kq + 4 * v;
                 if (pi < pj && pj < p.P) {
-                    uint32_t cnt_in = 0;
-                    uint64_t pn = 0, pd = 0;
-                    for (int tw = tw0; tw <= tw1; ++tw) {
-                        uint64_t wm = ~0ull;
-                        if (tw == tw0) wm &= ~0ull << (a & 63);
-                        if (tw == tw1 && (b & 63)) wm &= ~0ull >> (64 - (b & 63));
-                        uint64_t zi, zj, fi, fj, b1 = 0, b0 = 0;
-                        if (staged) {
-                            const int t = tw - tw0;
-                            zi = lmask[t][0][xi]; zj = lmask[t][0][xj]; fi = lmask[t][1][xi]; fj = lmask[t][1][xj];
-                            if (MISS) { b1 = lmask[t][2][xi] | lmask[t][2][xj]; b0 = lmask[t][3][xi] | lmask[t][3][xj]; }
-                        } else {
-                            const uint64_t *mk = p.masks + (size_t)tw * 4 * p.P;
-                            zi = mk[pi]; zj = mk[pj]; fi = mk[p.P + pi]; fj = mk[p.P + pj];
-                            if (MISS) { b1 = mk[2 * p.P + pi] | mk[2 * p.P + pj]; b0 = mk[3 * p.P + pi] | mk[3 * p.P + pj]; }
-                        }
-                        const uint64_t incl = ~((zi & zj) | (fi & fj)) & wm;
-                        cnt_in += (uint32_t)__popcll(incl);
-                        pn |= b1 & incl; pd |= b0 & incl;
-                    }
+                    const uint32_t bit = 1u << ((j * 2 + i) * 4 + v);
                     const double den = acc_den[i][j][v];
                     const double num = den - p.U[wp + pi] - Uj;
                     double kk = nj * p.C[wp + pi] + (double)p.n_full[pi] * Cj - 2.0 * acc_cc[i][j][v];
                     if (MISS) kk -= acc_m[i][j][v];
                     const size_t q = (size_t)pi * (2 * (size_t)p.P - pi - 1) / 2 + (size_t)(pj - pi - 1);
                     const size_t o = (size_t)w * p.n_pairs + q;
-                    p.out_num[o] = pn ? kNaN : num;
-                    p.out_den[o] = pd ? kNaN : den;
+                    p.out_num[o] = (poison_n & bit) ? kNaN : num;
+                    p.out_den[o] = (poison_d & bit) ? kNaN : den;
                     p.out_k[o] = kk;
-                    p.out_cnt[o] = (double)cnt_in;
+                    p.out_cnt[o] = (double)cnt_in[j][i][v];
                 }
             }
     }
+    }   // windows of this block
 }
 
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st) {
     if (p.n_windows <= 0 || p.P < 2) return hipSuccess;
-    {
-        dim3 grid(p.n_windows, (p.P + 255) / 256), block(256);
+    if (!(p.debug & 4)) {
+        dim3 grid(p.n_windows, (p.P + 3) / 4), block(256);
         if (count_bytes == 2) hipLaunchKernelGGL((gram_popsums_kernel<uint16_t>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gram_popsums_kernel<uint32_t>), grid, block, 0, st, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     const int nblk = (p.P + 63) / 64;
-    dim3 grid(p.n_windows, nblk * (nblk + 1) / 2), block(256);
+    dim3 grid((p.n_windows + kGramWPB - 1) / kGramWPB, nblk * (nblk + 1) / 2), block(256);
     if (count_bytes == 2) {
         if (p.max_n <= 31) {
             if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true, true>), grid, block, 0, st, p);
