@@ -940,6 +940,9 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         for (int e = 0; e < EV; ++e) {
             double P_[4], Q_[4], C_[4], FN[4], FM[4];
             const bool ok = (valid >> e) & 1u;
+            // a site index no lane of the wave has inside the window (the ragged ends of a window): all operands would be
+            // zero, so the 12 or 20 MFMAs of this index are skipped -- exact, and ~6 % of the work with 100-site windows
+            if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 uint32_t c = cnt[x][e] & CountTraits<CT>::mask, nm = cnt[x][e] >> CountTraits<CT>::shift;
