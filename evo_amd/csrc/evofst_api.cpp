@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <numeric>
+#include <stdexcept>
 #include <string>
 #include <atomic>
 #include <thread>
@@ -94,6 +96,18 @@ namespace {
 int fail(evofst_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
     return code;
+}
+// No C++ exception leaves the C ABI: every `int` entry point is a function-try-block that ends here.
+int abi_exception(evofst_ctx *c) {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(c, EVOFST_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(c, EVOFST_ERR_STATE, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(c, EVOFST_ERR_STATE, "internal error: unknown exception");
+    }
 }
 int hip_fail(evofst_ctx *c, hipError_t e, const char *what) {
     return fail(c, EVOFST_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -322,7 +336,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
 extern "C" const char *evofst_last_error(const evofst_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 extern "C" const char *evofst_version(void) { return "evofst 0.1 (gfx950)"; }
 
-extern "C" int evofst_set_stream(evofst_ctx *c, void *hip_stream) {
+extern "C" int evofst_set_stream(evofst_ctx *c, void *hip_stream) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -330,11 +344,13 @@ extern "C" int evofst_set_stream(evofst_ctx *c, void *hip_stream) {
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 // ================================================================== layout
 
-extern "C" int evofst_set_layout(evofst_ctx *c, int n_samples, int n_pops, const int32_t *sample_pop) {
+extern "C" int evofst_set_layout(evofst_ctx *c, int n_samples, int n_pops, const int32_t *sample_pop) try {
     if (!c) return EVOFST_ERR_ARG;
     if (n_samples <= 0 || n_pops <= 0 || !sample_pop) return fail(c, EVOFST_ERR_ARG, "set_layout: bad arguments");
     if (n_pops > EVOFST_MAX_POPS) return fail(c, EVOFST_ERR_UNSUPPORTED, "set_layout: too many populations");
@@ -393,21 +409,27 @@ extern "C" int evofst_set_layout(evofst_ctx *c, int n_samples, int n_pops, const
     c->cap_sites = 0; c->n_sites = 0;
     if (c->host_only) return EVOFST_OK;
     return upload_layout(c);
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_get_geometry(const evofst_ctx *c, evofst_geometry *out) {
+extern "C" int evofst_get_geometry(const evofst_ctx *c, evofst_geometry *out) try {
     if (!c || !out) return EVOFST_ERR_ARG;
     if (c->n_pops == 0) return EVOFST_ERR_STATE;
     out->n_samples = c->n_samples; out->n_pops = c->n_pops; out->n_haplotypes = c->H;
     out->words_per_site = c->W; out->tile_sites = kTileSites; out->count_bytes = c->count_bytes;
     out->tile_bytes = (int64_t)c->W * kTileSites * 16;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(nullptr);
 }
 
-extern "C" int evofst_get_pop_chroms(const evofst_ctx *c, int32_t *n_full) {
+extern "C" int evofst_get_pop_chroms(const evofst_ctx *c, int32_t *n_full) try {
     if (!c || !n_full) return EVOFST_ERR_ARG;
     std::copy(c->n_full.begin(), c->n_full.end(), n_full);
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(nullptr);
 }
 
 // ================================================================== host packer (K0)
@@ -418,7 +440,7 @@ extern "C" size_t evofst_tiles_bytes(const evofst_ctx *c, int64_t n_sites) {
 }
 
 extern "C" int evofst_pack_codes(const evofst_ctx *c, int64_t first_site, int64_t n_sites, const uint8_t *codes,
-                                 void *tiles) {
+                                 void *tiles) try {
     if (!c || !codes || !tiles || first_site < 0 || n_sites < 0) return EVOFST_ERR_ARG;
     if (c->n_pops == 0) return EVOFST_ERR_STATE;
     uint64_t *out = (uint64_t *)tiles;
@@ -448,10 +470,12 @@ extern "C" int evofst_pack_codes(const evofst_ctx *c, int64_t first_site, int64_
         for (int w = 0; w < W; ++w) { tp[(size_t)w * kTileSites * 2] = 0; tp[(size_t)w * kTileSites * 2 + 1] = 0; }
     }
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(nullptr);
 }
 
 extern "C" int evofst_unpack_codes(const evofst_ctx *c, int64_t first_site, int64_t n_sites, const void *tiles,
-                                   uint8_t *codes) {
+                                   uint8_t *codes) try {
     if (!c || !codes || !tiles || first_site < 0 || n_sites < 0) return EVOFST_ERR_ARG;
     if (c->n_pops == 0) return EVOFST_ERR_STATE;
     const uint64_t *in = (const uint64_t *)tiles;
@@ -471,6 +495,8 @@ extern "C" int evofst_unpack_codes(const evofst_ctx *c, int64_t first_site, int6
         }
     }
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(nullptr);
 }
 
 namespace {
@@ -592,7 +618,7 @@ int parse_vcf_line(const char *line, int mode, int n_samples, uint8_t *codes, ui
 }  // namespace
 
 extern "C" int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, uint8_t *codes, uint32_t *site_flags,
-                                          const char **chrom, const char **pos) {
+                                          const char **chrom, const char **pos) try {
     if (!line || !codes || !site_flags || n_samples <= 0) return EVOFST_ERR_ARG;
     const char *cols[2];
     size_t len[2];
@@ -604,12 +630,14 @@ extern "C" int evofst_codes_from_vcf_line(char *line, int mode, int n_samples, u
     if (chrom) *chrom = cols[0];
     if (pos) *pos = cols[1];
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(nullptr);
 }
 
 // K0 in bulk: parse + pack a block of VCF lines on n_threads host threads (a thread owns whole tiles of 64 sites).
 extern "C" int evofst_pack_vcf_lines(const evofst_ctx *c, int mode, int64_t n_lines, const char *const *lines,
                                      int n_vcf_samples, const int32_t *layout_to_vcf, int n_threads, void *tiles,
-                                     uint8_t *site_flags) {
+                                     uint8_t *site_flags) try {
     if (!c || !lines || !tiles || !site_flags || n_lines < 0 || n_vcf_samples <= 0) return EVOFST_ERR_ARG;
     if (c->n_pops == 0) return EVOFST_ERR_STATE;
     if (mode != EVOFST_MODE_FST && mode != EVOFST_MODE_GLOBAL && mode != EVOFST_MODE_STATS) return EVOFST_ERR_ARG;
@@ -627,8 +655,9 @@ extern "C" int evofst_pack_vcf_lines(const evofst_ctx *c, int mode, int64_t n_li
     std::atomic<int> status{EVOFST_OK};
     uint64_t *out = (uint64_t *)tiles;
     const int W = c->W, H = c->H;
-    auto work = [&]() {
-        std::vector<uint8_t> codes((size_t)2 * n_vcf_samples);
+    auto work = [&]() noexcept {
+        std::vector<uint8_t> codes;
+        try { codes.resize((size_t)2 * n_vcf_samples); } catch (...) { status.store(EVOFST_ERR_NOMEM); return; }
         for (;;) {
             const int64_t t = next.fetch_add(1);
             if (t >= n_tiles || status.load() != EVOFST_OK) break;
@@ -661,15 +690,20 @@ extern "C" int evofst_pack_vcf_lines(const evofst_ctx *c, int mode, int64_t n_li
         }
     };
     std::vector<std::thread> th;
-    for (int i = 1; i < n_threads; ++i) th.emplace_back(work);
+    th.reserve((size_t)n_threads);
+    for (int i = 1; i < n_threads; ++i) {
+        try { th.emplace_back(work); } catch (...) { break; }   // fewer threads than asked for: the work queue does not care
+    }
     work();
     for (auto &x : th) x.join();
     return status.load();
+} catch (...) {
+    return abi_exception(nullptr);
 }
 
 // ================================================================== device data
 
-extern "C" int evofst_reserve(evofst_ctx *c, int64_t max_sites) {
+extern "C" int evofst_reserve(evofst_ctx *c, int64_t max_sites) try {
     if (!c || max_sites <= 0) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->n_pops == 0) return fail(c, EVOFST_ERR_STATE, "reserve: set_layout first");
@@ -682,6 +716,8 @@ extern "C" int evofst_reserve(evofst_ctx *c, int64_t max_sites) {
     if ((rc = ensure(c, c->d_counts, nt * c->n_pops * kTileSites * c->count_bytes))) return rc;
     c->cap_sites = (int64_t)nt * kTileSites;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" void *evofst_alloc_pinned(evofst_ctx *c, size_t bytes) {
@@ -708,7 +744,7 @@ static int begin_data(evofst_ctx *c, int64_t n_sites) {
 }
 
 extern "C" int evofst_upload(evofst_ctx *c, int64_t n_sites, const void *tiles, const uint8_t *site_flags,
-                             const int32_t *pos) {
+                             const int32_t *pos) try {
     if (!c || !tiles) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     int rc = begin_data(c, n_sites);
@@ -724,10 +760,12 @@ extern "C" int evofst_upload(evofst_ctx *c, int64_t n_sites, const void *tiles, 
     if (pos) HIPCHK(c, hipMemcpyAsync(c->d_pos.p, pos, (size_t)n_sites * 4, hipMemcpyHostToDevice, c->stream));
     c->pos = (const int32_t *)c->d_pos.p;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int evofst_attach_device(evofst_ctx *c, int64_t n_sites, const void *d_tiles, const uint8_t *d_site_flags,
-                                    const int32_t *d_pos) {
+                                    const int32_t *d_pos) try {
     if (!c || !d_tiles) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     int rc = begin_data(c, n_sites);
@@ -739,10 +777,12 @@ extern "C" int evofst_attach_device(evofst_ctx *c, int64_t n_sites, const void *
     c->flags = d_site_flags; c->have_flags = d_site_flags != nullptr;
     c->pos = d_pos; c->have_pos = d_pos != nullptr;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int evofst_synth(evofst_ctx *c, int64_t n_sites, int64_t first_site_global, uint64_t seed,
-                            double missing_rate) {
+                            double missing_rate) try {
     if (!c || missing_rate < 0.0 || missing_rate >= 1.0) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     int rc = begin_data(c, n_sites);
@@ -761,9 +801,11 @@ extern "C" int evofst_synth(evofst_ctx *c, int64_t n_sites, int64_t first_site_g
     c->flags = nullptr; c->have_flags = false;
     c->pos = (const int32_t *)c->d_pos.p; c->have_pos = true;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_download_tiles(evofst_ctx *c, void *tiles) {
+extern "C" int evofst_download_tiles(evofst_ctx *c, void *tiles) try {
     if (!c || !tiles) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->n_sites == 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "no data on the device");
@@ -771,11 +813,13 @@ extern "C" int evofst_download_tiles(evofst_ctx *c, void *tiles) {
     HIPCHK(c, hipMemcpyAsync(tiles, c->tiles, evofst_tiles_bytes(c, c->n_sites), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 // ================================================================== modes
 
-extern "C" int evofst_set_pairs(evofst_ctx *c, const int32_t *pair_i, const int32_t *pair_j, int n_pairs) {
+extern "C" int evofst_set_pairs(evofst_ctx *c, const int32_t *pair_i, const int32_t *pair_j, int n_pairs) try {
     if (!c || n_pairs < 0) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->n_pops == 0) return fail(c, EVOFST_ERR_STATE, "set_pairs: set_layout first");
@@ -800,9 +844,11 @@ extern "C" int evofst_set_pairs(evofst_ctx *c, const int32_t *pair_i, const int3
     if ((rc = upload_vec(c, c->d_pairs, c->pairs))) return rc;
     c->counts_done = c->stats_done = false;
     return set_base_internal(c, nullptr);
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_set_against_all(evofst_ctx *c, const int32_t *use_pops, int n_use, const int64_t *set_sizes) {
+extern "C" int evofst_set_against_all(evofst_ctx *c, const int32_t *use_pops, int n_use, const int64_t *set_sizes) try {
     if (!c || !use_pops || !set_sizes || n_use <= 0) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->n_pops == 0) return fail(c, EVOFST_ERR_STATE, "set_against_all: set_layout first");
@@ -822,9 +868,11 @@ extern "C" int evofst_set_against_all(evofst_ctx *c, const int32_t *use_pops, in
     if ((rc = upload_vec(c, c->d_thr, c->thresholds))) return rc;
     c->counts_done = c->stats_done = false;
     return set_base_internal(c, nullptr);
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_set_global_halo(evofst_ctx *c, int n, const int32_t *tag, const double *num, const double *den) {
+extern "C" int evofst_set_global_halo(evofst_ctx *c, int n, const int32_t *tag, const double *num, const double *den) try {
     if (!c || n < 0) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->mode != MODE_GLOBAL) return fail(c, EVOFST_ERR_STATE, "set_global_halo: against-all mode first");
@@ -839,9 +887,11 @@ extern "C" int evofst_set_global_halo(evofst_ctx *c, int n, const int32_t *tag, 
     if ((rc = upload_vec(c, c->d_halo_tag, std::vector<int32_t>(tag, tag + n)))) return rc;
     if ((rc = upload_vec(c, c->d_halo_num, std::vector<double>(num, num + (size_t)n * nu)))) return rc;
     return upload_vec(c, c->d_halo_den, std::vector<double>(den, den + (size_t)n * nu));
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_set_gram(evofst_ctx *c) {
+extern "C" int evofst_set_gram(evofst_ctx *c) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->n_pops < 2) return fail(c, EVOFST_ERR_STATE, "set_gram: set_layout with at least two populations first");
@@ -853,9 +903,11 @@ extern "C" int evofst_set_gram(evofst_ctx *c) {
     c->counts_done = c->stats_done = false;
     c->gram_missing = -1;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_set_site_windows(evofst_ctx *c, const int64_t *win_start, int64_t n_windows) {
+extern "C" int evofst_set_site_windows(evofst_ctx *c, const int64_t *win_start, int64_t n_windows) try {
     if (!c || !win_start || n_windows <= 0) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     for (int64_t w = 0; w < n_windows; ++w)
@@ -863,9 +915,11 @@ extern "C" int evofst_set_site_windows(evofst_ctx *c, const int64_t *win_start, 
     HIPCHK(c, hipSetDevice(c->device));
     c->win_start.assign(win_start, win_start + n_windows + 1);
     return upload_vec(c, c->d_win, c->win_start);
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_set_windows(evofst_ctx *c, int snp_size, int snp_step) {
+extern "C" int evofst_set_windows(evofst_ctx *c, int snp_size, int snp_step) try {
     if (!c) return EVOFST_ERR_ARG;
     if (snp_size < 0 || (snp_size > 0 && snp_step <= 0)) return fail(c, EVOFST_ERR_ARG, "set_windows: bad size/step");
     c->snp_size = snp_size; c->snp_step = snp_size > 0 ? snp_step : 0;
@@ -873,21 +927,25 @@ extern "C" int evofst_set_windows(evofst_ctx *c, int snp_size, int snp_step) {
     c->stats_done = false;
     c->offsets_dirty = true;   // the scan also derives each pair's first segment row from g
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_set_base_offsets(evofst_ctx *c, const int64_t *offsets) {
+extern "C" int evofst_set_base_offsets(evofst_ctx *c, const int64_t *offsets) try {
     if (!c || !offsets) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->mode == MODE_COUNTS) return fail(c, EVOFST_ERR_STATE, "set_base_offsets: choose a mode first");
     HIPCHK(c, hipSetDevice(c->device));
     return set_base_internal(c, offsets);
+} catch (...) {
+    return abi_exception(c);
 }
 
 static int launch_totals_and_carry(evofst_ctx *c, bool want_totals);
 
 // Device-side forms of the multi-GPU exchange: nothing here waits for the GPU, so a pass over a shard stays one
 // stream of kernels, copies and collectives (bench.py, N > 1).
-extern "C" int evofst_set_base_offsets_device(evofst_ctx *c, const void *d_offsets) {
+extern "C" int evofst_set_base_offsets_device(evofst_ctx *c, const void *d_offsets) try {
     if (!c || !d_offsets) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->mode != MODE_PAIRS && c->mode != MODE_GLOBAL) return fail(c, EVOFST_ERR_STATE, "set_base_offsets_device: choose a mode first");
@@ -901,9 +959,11 @@ extern "C" int evofst_set_base_offsets_device(evofst_ctx *c, const void *d_offse
     c->offsets_dirty = true;
     c->stats_done = false;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_copy_included_totals(evofst_ctx *c, void *d_dst) {
+extern "C" int evofst_copy_included_totals(evofst_ctx *c, void *d_dst) try {
     if (!c || !d_dst) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->counts_done || (c->mode != MODE_PAIRS && c->mode != MODE_GLOBAL)) return fail(c, EVOFST_ERR_STATE, "copy_included_totals: run_counts in a mode first");
@@ -914,9 +974,11 @@ extern "C" int evofst_copy_included_totals(evofst_ctx *c, void *d_dst) {
     const size_t n = c->mode == MODE_PAIRS ? c->pairs.size() : 2;
     HIPCHK(c, hipMemcpyAsync(d_dst, src, n * 8, hipMemcpyDeviceToDevice, c->stream));
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_copy_boundary(evofst_ctx *c, void *d_dst) {
+extern "C" int evofst_copy_boundary(evofst_ctx *c, void *d_dst) try {
     if (!c || !d_dst) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->stats_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "copy_boundary: pairs mode + run_stats first");
@@ -925,11 +987,13 @@ extern "C" int evofst_copy_boundary(evofst_ctx *c, void *d_dst) {
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(d_dst, c->d_carry.p, c->pairs.size() * 4 * 8, hipMemcpyDeviceToDevice, c->stream));
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 // ================================================================== compute
 
-extern "C" int evofst_run_counts(evofst_ctx *c) {
+extern "C" int evofst_run_counts(evofst_ctx *c) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->n_sites == 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "run_counts: no data");
@@ -975,9 +1039,11 @@ extern "C" int evofst_run_counts(evofst_ctx *c) {
     c->counts_done = true; c->stats_done = false;
     if (c->mode != MODE_COUNTS && c->mode != MODE_GRAM && (rc = run_scan(c))) return rc;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_run_stats(evofst_ctx *c) {
+extern "C" int evofst_run_stats(evofst_ctx *c) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "run_stats: run_counts first");
@@ -1035,9 +1101,11 @@ extern "C" int evofst_run_stats(evofst_ctx *c) {
     }
     c->stats_done = true;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_windows) {
+extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_windows) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->mode != MODE_GRAM || !c->counts_done) return fail(c, EVOFST_ERR_STATE, "run_gram: set_gram + run_counts first");
@@ -1078,9 +1146,11 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     record(c, 2, 1);
     c->gram_windows = n_windows;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_get_gram(evofst_ctx *c, double *sum_num, double *sum_den, double *sum_dxy_k, double *n_included) {
+extern "C" int evofst_get_gram(evofst_ctx *c, double *sum_num, double *sum_den, double *sum_dxy_k, double *n_included) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->mode != MODE_GRAM || c->gram_windows <= 0) return fail(c, EVOFST_ERR_STATE, "get_gram: run_gram first");
@@ -1091,29 +1161,37 @@ extern "C" int evofst_get_gram(evofst_ctx *c, double *sum_num, double *sum_den, 
         (rc = d2h(c, sum_dxy_k, c->d_gk.p, n)) || (rc = d2h(c, n_included, c->d_gcnt.p, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_run(evofst_ctx *c) {
+extern "C" int evofst_run(evofst_ctx *c) try {
     int rc = evofst_run_counts(c);
     if (rc) return rc;
     return evofst_run_stats(c);
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_sync(evofst_ctx *c) {
+extern "C" int evofst_sync(evofst_ctx *c) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_set_profiling(evofst_ctx *c, int enabled) {
+extern "C" int evofst_set_profiling(evofst_ctx *c, int enabled) try {
     if (!c) return EVOFST_ERR_ARG;
     c->profiling = enabled != 0;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_get_kernel_ms(evofst_ctx *c, int which, float *ms) {
+extern "C" int evofst_get_kernel_ms(evofst_ctx *c, int which, float *ms) try {
     if (!c || !ms || which < 0 || which >= kNumKernels) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->ev_valid[which]) return fail(c, EVOFST_ERR_STATE, "get_kernel_ms: kernel was not profiled");
@@ -1121,6 +1199,8 @@ extern "C" int evofst_get_kernel_ms(evofst_ctx *c, int which, float *ms) {
     HIPCHK(c, hipEventSynchronize(c->ev[which][1]));
     HIPCHK(c, hipEventElapsedTime(ms, c->ev[which][0], c->ev[which][1]));
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 // ================================================================== results
@@ -1130,7 +1210,7 @@ static int check_range(evofst_ctx *c, int64_t first, int64_t n) {
     return EVOFST_OK;
 }
 
-extern "C" int evofst_get_counts(evofst_ctx *c, int64_t first_site, int64_t n_sites, int32_t *alt, int32_t *nm) {
+extern "C" int evofst_get_counts(evofst_ctx *c, int64_t first_site, int64_t n_sites, int32_t *alt, int32_t *nm) try {
     if (!c || !alt || !nm) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "get_counts: run_counts first");
@@ -1148,9 +1228,11 @@ extern "C" int evofst_get_counts(evofst_ctx *c, int64_t first_site, int64_t n_si
     release(da); release(dn);
     if (e != hipSuccess) return hip_fail(c, e, "get_counts");
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_get_included_totals(evofst_ctx *c, int64_t *totals) {
+extern "C" int evofst_get_included_totals(evofst_ctx *c, int64_t *totals) try {
     if (!c || !totals) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->counts_done || c->mode == MODE_COUNTS) return fail(c, EVOFST_ERR_STATE, "get_included_totals: run_counts in a mode first");
@@ -1161,10 +1243,12 @@ extern "C" int evofst_get_included_totals(evofst_ctx *c, int64_t *totals) {
     else { if ((rc = d2h(c, totals, c->d_uk_tot.p, 2))) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int evofst_get_site_stats(evofst_ctx *c, int64_t first_site, int64_t n_sites, double *num, double *den,
-                                     double *dxy, uint8_t *include) {
+                                     double *dxy, uint8_t *include) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->counts_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_site_stats: pairs mode + run_counts first");
@@ -1196,6 +1280,8 @@ extern "C" int evofst_get_site_stats(evofst_ctx *c, int64_t first_site, int64_t 
     if (rc) return rc;
     if (e != hipSuccess) return hip_fail(c, e, "get_site_stats");
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 namespace {
@@ -1235,18 +1321,22 @@ int branch_site_stats(evofst_ctx *c, const char *what, int arity, int n_out, int
 }  // namespace
 
 extern "C" int evofst_get_pbs_site_stats(evofst_ctx *c, int64_t first_site, int64_t n_sites, int n_trios, const int32_t *trios,
-                                         double *pbs, uint8_t *used) {
+                                         double *pbs, uint8_t *used) try {
     return branch_site_stats(c, "get_pbs_site_stats", 3, 3, first_site, n_sites, n_trios, trios, pbs, used);
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int evofst_get_abs_site_stats(evofst_ctx *c, int64_t first_site, int64_t n_sites, int n_quartets, const int32_t *quartets,
-                                         double *abs_out, uint8_t *used) {
+                                         double *abs_out, uint8_t *used) try {
     return branch_site_stats(c, "get_abs_site_stats", 4, 2, first_site, n_sites, n_quartets, quartets, abs_out, used);
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int evofst_get_dist_windows(evofst_ctx *c, int n_windows, const int64_t *win_off, int n_out, const int32_t *out_idx,
                                       int n_in, const int32_t *in_idx, int carry_first, double *sum, int32_t *nsnp, int32_t *miss,
-                                      int32_t *used, int32_t *missing) {
+                                      int32_t *used, int32_t *missing) try {
     if (!c || !win_off || !out_idx || !used || !missing || n_windows <= 0 || n_out <= 0 || n_in < 0) return EVOFST_ERR_ARG;
     if (n_in > 0 && (!in_idx || !sum || !nsnp || !miss)) return EVOFST_ERR_ARG;
     NEED_GPU(c);
@@ -1297,10 +1387,12 @@ extern "C" int evofst_get_dist_windows(evofst_ctx *c, int n_windows, const int64
     release(b);
     if (e != hipSuccess) return hip_fail(c, e, "get_dist_windows");
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 // Allele numbers of one multi-allelic line as `evo stats` reads them (process_vcf_utils.cpp:385-395)
-extern "C" int evofst_alleles_from_vcf_line(const char *line, int n_samples, uint8_t *alleles) {
+extern "C" int evofst_alleles_from_vcf_line(const char *line, int n_samples, uint8_t *alleles) try {
     if (!line || !alleles || n_samples <= 0) return EVOFST_ERR_ARG;
     const char *col[9];
     size_t len[9];
@@ -1331,11 +1423,13 @@ extern "C" int evofst_alleles_from_vcf_line(const char *line, int n_samples, uin
         p = t + 1;
     }
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(nullptr);
 }
 
 // How many times getThisVariantCountsSimple draws from rand() on these lines: once per genotype whose two allele
 // characters differ, on lines whose first genotype is not written with '|' (process_vcf_utils.cpp:384-387, 268-276)
-extern "C" int evofst_stats_phase_draws(int64_t n_lines, const char *const *lines, int n_samples, int n_threads, int64_t *draws) {
+extern "C" int evofst_stats_phase_draws(int64_t n_lines, const char *const *lines, int n_samples, int n_threads, int64_t *draws) try {
     if (!lines || !draws || n_lines < 0 || n_samples <= 0) return EVOFST_ERR_ARG;
     n_threads = std::max(1, std::min(n_threads, 64));
     std::vector<int64_t> part((size_t)n_threads, 0);
@@ -1363,16 +1457,23 @@ extern "C" int evofst_stats_phase_draws(int64_t n_lines, const char *const *line
     if (n_threads == 1) work(0);
     else {
         std::vector<std::thread> th;
-        for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        th.reserve((size_t)n_threads);
+        int started = 0;
+        for (; started < n_threads - 1; ++started) {
+            try { th.emplace_back(work, started); } catch (...) { break; }
+        }
+        for (int t = started; t < n_threads; ++t) work(t);       // the strides no thread took run here
         for (auto &t : th) t.join();
     }
     int64_t total = 0;
     for (int t = 0; t < n_threads; ++t) { if (bad[t]) return EVOFST_ERR_ARG; total += part[t]; }
     *draws = total;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(nullptr);
 }
 
-extern "C" int evofst_set_multiallelic(evofst_ctx *c, int64_t n_multi, const int64_t *site_index, const uint8_t *alleles) {
+extern "C" int evofst_set_multiallelic(evofst_ctx *c, int64_t n_multi, const int64_t *site_index, const uint8_t *alleles) try {
     if (!c || n_multi < 0 || (n_multi > 0 && (!site_index || !alleles))) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->n_sites <= 0) return fail(c, EVOFST_ERR_STATE, "set_multiallelic: upload first");
@@ -1395,10 +1496,12 @@ extern "C" int evofst_set_multiallelic(evofst_ctx *c, int64_t n_multi, const int
     HIPCHK(c, hipStreamSynchronize(c->stream));   // lay goes out of scope
     c->n_multi = n_multi;
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int evofst_get_indiv_diffs(evofst_ctx *c, int n_blocks, const int64_t *block_off, int32_t *hh, int32_t *hd, int32_t *oh,
-                                     int32_t *ms, int32_t *d4) {
+                                     int32_t *ms, int32_t *d4) try {
     if (!c || !block_off || !hh || !hd || !oh || !ms || !d4 || n_blocks <= 0) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (c->n_sites <= 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "get_indiv_diffs: upload first");
@@ -1442,10 +1545,12 @@ extern "C" int evofst_get_indiv_diffs(evofst_ctx *c, int n_blocks, const int64_t
     release(b);
     if (e != hipSuccess) return hip_fail(c, e, "get_indiv_diffs");
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int evofst_get_pop_site_div(evofst_ctx *c, int64_t first_site, int64_t n_sites, double *het, double *het_nei,
-                                       double *pi) {
+                                       double *pi) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "get_pop_site_div: run_counts first");
@@ -1473,6 +1578,8 @@ extern "C" int evofst_get_pop_site_div(evofst_ctx *c, int64_t first_site, int64_
     if (rc) return rc;
     if (e != hipSuccess) return hip_fail(c, e, "get_pop_site_div");
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int64_t evofst_max_segments(evofst_ctx *c) {
@@ -1499,7 +1606,7 @@ static int segment_rows(evofst_ctx *c, std::vector<int64_t> &first, std::vector<
 }
 
 extern "C" int evofst_get_segments(evofst_ctx *c, int64_t *first_segment, int64_t *n_segments, double *sum_num,
-                                   double *sum_den, double *sum_dxy_k, int32_t *end_site) {
+                                   double *sum_den, double *sum_dxy_k, int32_t *end_site) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->stats_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_segments: pairs mode + run_stats first");
@@ -1517,6 +1624,8 @@ extern "C" int evofst_get_segments(evofst_ctx *c, int64_t *first_segment, int64_
     if ((rc = d2h(c, end_site, c->d_seg_end.p, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 static int launch_totals_and_carry(evofst_ctx *c, bool want_totals) {
@@ -1540,24 +1649,28 @@ static int totals_and_carry(evofst_ctx *c, double *totals, double *carry) {
     return EVOFST_OK;
 }
 
-extern "C" int evofst_get_boundary(evofst_ctx *c, double *carry_out) {
+extern "C" int evofst_get_boundary(evofst_ctx *c, double *carry_out) try {
     if (!c || !carry_out) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->stats_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_boundary: pairs mode + run_stats first");
     HIPCHK(c, hipSetDevice(c->device));
     return totals_and_carry(c, nullptr, carry_out);
+} catch (...) {
+    return abi_exception(c);
 }
 
-extern "C" int evofst_get_totals(evofst_ctx *c, double *totals) {
+extern "C" int evofst_get_totals(evofst_ctx *c, double *totals) try {
     if (!c || !totals) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->stats_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_totals: pairs mode + run_stats first");
     HIPCHK(c, hipSetDevice(c->device));
     return totals_and_carry(c, totals, nullptr);
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int evofst_get_global_site_stats(evofst_ctx *c, int64_t first_site, int64_t n_sites, double *num, double *den,
-                                            uint8_t *kept) {
+                                            uint8_t *kept) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->counts_done || c->mode != MODE_GLOBAL) return fail(c, EVOFST_ERR_STATE, "get_global_site_stats: against-all mode + run_counts first");
@@ -1585,6 +1698,8 @@ extern "C" int evofst_get_global_site_stats(evofst_ctx *c, int64_t first_site, i
     if (rc) return rc;
     if (e != hipSuccess) return hip_fail(c, e, "get_global_site_stats");
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
 
 extern "C" int64_t evofst_max_global_rows(evofst_ctx *c) {
@@ -1593,7 +1708,7 @@ extern "C" int64_t evofst_max_global_rows(evofst_ctx *c) {
 }
 
 extern "C" int evofst_get_global_windows(evofst_ctx *c, int64_t *n_rows, int32_t *start_site, int32_t *end_site,
-                                         double *mean_num, double *mean_den) {
+                                         double *mean_num, double *mean_den) try {
     if (!c || !n_rows) return EVOFST_ERR_ARG;
     NEED_GPU(c);
     if (!c->stats_done || c->mode != MODE_GLOBAL) return fail(c, EVOFST_ERR_STATE, "get_global_windows: against-all mode + run_stats first");
@@ -1610,4 +1725,6 @@ extern "C" int evofst_get_global_windows(evofst_ctx *c, int64_t *n_rows, int32_t
     if ((rc = d2h(c, mean_den, c->d_row_den.p, (size_t)rows * nu))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
 }
