@@ -1331,32 +1331,51 @@ __device__ __forceinline__ void pair_block_of(int pb, int &bi, int &bj) {
     bi = r; bj = pb - r * (r + 1) / 2;
 }
 
+constexpr int kIndivStage = 16;   // tiles staged in LDS at a time by the pair kernel
+
 __global__ __launch_bounds__(256) void indiv_pair_kernel(IndivParams p) {
+    // planes of the block's 16 row individuals and 16 column individuals for kIndivStage tiles: every plane is read
+    // by 16 threads, so it comes from global memory once per block and from LDS after that
+    __shared__ ulonglong2 sp[kIndivStage][2][16][2];       // [tile][rows | columns][individual][{het, alt} | {ref, miss}]
     int bi, bj;
     pair_block_of((int)blockIdx.x, bi, bj);
-    const int i = bi * 16 + (int)(threadIdx.x >> 4), j = bj * 16 + (int)(threadIdx.x & 15);
+    const int ty = (int)(threadIdx.x >> 4), tx = (int)(threadIdx.x & 15);
+    const int i = bi * 16 + ty, j = bj * 16 + tx;
     const int b = blockIdx.y;
     const int64_t s0 = p.block_off[b], s1 = p.block_off[b + 1];
-    if (i >= p.n_ind || j > i) return;
+    const bool act = i < p.n_ind && j <= i;
     int hh = 0, hd = 0, oh = 0, ms = 0;
     if (s1 > s0) {
         const int t0 = (int)(s0 >> 6), t1 = (int)((s1 - 1) >> 6);
-        for (int t = t0; t <= t1; ++t) {
-            // the sites of this tile that belong to the block
-            const int64_t base = (int64_t)t << 6;
-            const int lo = (int)(s0 > base ? s0 - base : 0), hi = (int)(s1 - base < 64 ? s1 - base : 64);
-            const uint64_t tmask = (hi == 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-            const ulonglong2 *pi = reinterpret_cast<const ulonglong2 *>(p.planes + ((size_t)t * p.n_ind + i) * 4);
-            const ulonglong2 *pj = reinterpret_cast<const ulonglong2 *>(p.planes + ((size_t)t * p.n_ind + j) * 4);
-            const ulonglong2 i0 = pi[0], i1 = pi[1], j0 = pj[0], j1 = pj[1];
-            const uint64_t Hi = i0.x & tmask, Ai = i0.y & tmask, Ri = i1.x & tmask, Mi = i1.y;
-            const uint64_t Hj = j0.x, Aj = j0.y, Rj = j1.x, Mj = j1.y;
-            hh += __popcll(Hi & Hj);                                         // :201 both heterozygous (j == i: heterozygous, :222)
-            hd += __popcll((Ai & Rj) | (Ri & Aj));                           // :205 opposite homozygotes
-            oh += __popcll((Hi & (Rj | Aj)) | ((Ri | Ai) & Hj));             // :211 one homozygous, one heterozygous
-            ms += __popcll((Mi | Mj) & tmask);                               // :186-197 either one missing
+        for (int tb = t0; tb <= t1; tb += kIndivStage) {
+            const int nt = min(kIndivStage, t1 - tb + 1);
+            if (tb != t0) __syncthreads();
+            // nt tiles x 32 individuals x 2 vectors of 16 bytes
+            for (int x = threadIdx.x; x < nt * 64; x += 256) {
+                const int t = x >> 6, side = (x >> 5) & 1, ind = (x >> 1) & 15, half = x & 1;
+                const int d = (side ? bj : bi) * 16 + ind;
+                sp[t][side][ind][half] = d < p.n_ind
+                    ? reinterpret_cast<const ulonglong2 *>(p.planes + ((size_t)(tb + t) * p.n_ind + d) * 4)[half]
+                    : make_ulonglong2(0, 0);
+            }
+            __syncthreads();
+            if (act)
+                for (int t = 0; t < nt; ++t) {
+                    // the sites of this tile that belong to the block
+                    const int64_t base = (int64_t)(tb + t) << 6;
+                    const int lo = (int)(s0 > base ? s0 - base : 0), hi = (int)(s1 - base < 64 ? s1 - base : 64);
+                    const uint64_t tmask = (hi == 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                    const ulonglong2 i0 = sp[t][0][ty][0], i1 = sp[t][0][ty][1], j0 = sp[t][1][tx][0], j1 = sp[t][1][tx][1];
+                    const uint64_t Hi = i0.x & tmask, Ai = i0.y & tmask, Ri = i1.x & tmask, Mi = i1.y;
+                    const uint64_t Hj = j0.x, Aj = j0.y, Rj = j1.x, Mj = j1.y;
+                    hh += __popcll(Hi & Hj);                                         // :201 both heterozygous (j == i: heterozygous, :222)
+                    hd += __popcll((Ai & Rj) | (Ri & Aj));                           // :205 opposite homozygotes
+                    oh += __popcll((Hi & (Rj | Aj)) | ((Ri | Ai) & Hj));             // :211 one homozygous, one heterozygous
+                    ms += __popcll((Mi | Mj) & tmask);                               // :186-197 either one missing
+                }
         }
     }
+    if (!act) return;
     const size_t o = (size_t)b * p.T + (size_t)i * (i + 1) / 2 + j;
     p.hh[o] = hh; p.hd[o] = hd; p.oh[o] = oh; p.ms[o] = ms;
 }
