@@ -71,7 +71,7 @@ struct evofst_ctx {
     bool have_flags = false, have_pos = false;
 
     // pairs-mode work buffers
-    DevBuf d_census, d_offsets, d_incl_totals, d_seg_num, d_seg_den, d_seg_k, d_seg_end, d_zf, d_irr,
+    DevBuf d_census, d_offsets, d_incl_totals, d_seg_rows, d_seg_num, d_seg_den, d_seg_k, d_seg_end, d_zf, d_irr,
         d_tail, d_tail_n, d_carry, d_win, d_halo_num, d_halo_den, d_halo_tag, d_gU, d_gC, d_gnum, d_gden, d_gk, d_gcnt,
         d_nrows, d_totals;
     int64_t seg_cap = 0;
@@ -240,9 +240,7 @@ K2Params make_k2(evofst_ctx *c) {
     p.chunk_offsets = (const int64_t *)c->d_offsets.p;
     p.first_segment = (const int64_t *)c->d_first_seg.p;
     p.g = c->g; p.seg_cap = c->seg_cap;
-    p.seg_num = (double *)c->d_seg_num.p; p.seg_den = (double *)c->d_seg_den.p;
-    p.seg_k = (double *)c->d_seg_k.p;
-    p.seg_end = (int32_t *)c->d_seg_end.p;
+    p.seg_rows = (SegRow *)c->d_seg_rows.p;
     p.zf_masks = (const uint64_t *)c->d_zf.p; p.irr_mask = (const uint64_t *)c->d_irr.p; p.skip_mask = (const uint64_t *)c->d_skip.p;
     p.tail = (double *)c->d_tail.p;
     p.tail_n = (int4 *)c->d_tail_n.p;
@@ -320,7 +318,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->d_segs, &c->d_wss, &c->d_nfull, &c->d_pairs, &c->d_use, &c->d_thr, &c->d_base, &c->d_first_seg,
                       &c->d_tiles, &c->d_flags, &c->d_pos, &c->d_counts, &c->d_census, &c->d_offsets, &c->d_incl_totals,
-                      &c->d_seg_num, &c->d_seg_den, &c->d_seg_k, &c->d_seg_end, &c->d_zf, &c->d_irr,
+                      &c->d_seg_rows, &c->d_seg_num, &c->d_seg_den, &c->d_seg_k, &c->d_seg_end, &c->d_zf, &c->d_irr,
                       &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_halo_num, &c->d_halo_den, &c->d_halo_tag, &c->d_gU, &c->d_gC, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_carry,
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
@@ -1057,10 +1055,7 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
         const int64_t g = c->g;
         c->seg_cap = c->n_sites / g + 2;
         const size_t seg_elems = (size_t)c->seg_cap * np;
-        if ((rc = ensure(c, c->d_seg_num, seg_elems * 8))) return rc;
-        if ((rc = ensure(c, c->d_seg_den, seg_elems * 8))) return rc;
-        if ((rc = ensure(c, c->d_seg_k, seg_elems * 8))) return rc;
-        if ((rc = ensure(c, c->d_seg_end, seg_elems * 4))) return rc;
+        if ((rc = ensure(c, c->d_seg_rows, seg_elems * sizeof(SegRow)))) return rc;
         const size_t cq = (size_t)c->n_chunks * np;
         if ((rc = ensure(c, c->d_tail, cq * 3 * 8))) return rc;
         if ((rc = ensure(c, c->d_tail_n, cq * 16))) return rc;
@@ -1618,6 +1613,14 @@ extern "C" int evofst_get_segments(evofst_ctx *c, int64_t *first_segment, int64_
     if (first_segment) std::copy(first.begin(), first.end(), first_segment);
     if (n_segments) std::copy(rows.begin(), rows.end(), n_segments);
     const size_t n = (size_t)c->seg_cap * np;
+    // the device keeps one 32-byte row per segment and pair; the getter hands out the four arrays
+    if (sum_num && (rc = ensure(c, c->d_seg_num, n * 8))) return rc;
+    if (sum_den && (rc = ensure(c, c->d_seg_den, n * 8))) return rc;
+    if (sum_dxy_k && (rc = ensure(c, c->d_seg_k, n * 8))) return rc;
+    if (end_site && (rc = ensure(c, c->d_seg_end, n * 4))) return rc;
+    HIPCHK(c, launch_unpack_segments((const SegRow *)c->d_seg_rows.p, n, sum_num ? (double *)c->d_seg_num.p : nullptr,
+                                     sum_den ? (double *)c->d_seg_den.p : nullptr, sum_dxy_k ? (double *)c->d_seg_k.p : nullptr,
+                                     end_site ? (int32_t *)c->d_seg_end.p : nullptr, c->stream));
     if ((rc = d2h(c, sum_num, c->d_seg_num.p, n))) return rc;
     if ((rc = d2h(c, sum_den, c->d_seg_den.p, n))) return rc;
     if ((rc = d2h(c, sum_dxy_k, c->d_seg_k.p, n))) return rc;

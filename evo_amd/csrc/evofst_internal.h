@@ -55,6 +55,10 @@ struct K1Params {
     uint32_t *chunk_used_kept;  // [2][n_chunks]
 };
 
+// one segment of one pair: sums of the Fst numerators / denominators, sum of sumKij (dxy numerators; integers, exact),
+// site of the last included site of the segment
+struct __align__(32) SegRow { double num, den, k; int32_t end, pad; };
+
 struct K2Params {
     const void *counts;
     const uint8_t *site_flags;
@@ -70,9 +74,8 @@ struct K2Params {
     const int64_t *first_segment;  // [n_pairs]
     int32_t g;
     int64_t seg_cap;
-    double *seg_num, *seg_den;     // [seg_cap][n_pairs] sums of the Fst numerators / denominators
-    double *seg_k;                 // [seg_cap][n_pairs] sum of sumKij (dxy numerators; integers, exact)
-    int32_t *seg_end;              // [seg_cap][n_pairs] site of the last included site of the segment
+    SegRow *seg_rows;              // [seg_cap][n_pairs]: a lane writes the four values of a segment as one 32-byte
+                                   // sector (four separate arrays made four partial-line writes of it)
     const uint64_t *zf_masks, *irr_mask, *skip_mask;   // from K1
     // chunk-boundary partials, planes [chunk][pair] (a wave writes contiguous rows)
     double *tail;                  // [3][n_chunks][n_pairs] {num, den, k} after the last completed segment
@@ -209,6 +212,7 @@ hipError_t launch_dist_windows(const DistParams &p, int count_bytes, hipStream_t
 hipError_t launch_indiv_planes(const IndivParams &p, hipStream_t st);
 hipError_t launch_indiv_pairs(const IndivParams &p, hipStream_t st);
 hipError_t launch_indiv_multi(const IndivParams &p, hipStream_t st);
+hipError_t launch_unpack_segments(const SegRow *rows, size_t n, double *num, double *den, double *k, int32_t *end, hipStream_t st);
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,
                                 int32_t *alt, int32_t *nm, hipStream_t st);

@@ -567,10 +567,16 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
                 const double cumN = cD - H, cumD = cD + T;
                 // sumKij (fst.cpp:299-321) of the segment, exact: differences are taken modulo 2^32 / 2^64
                 const uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC);
-                p.seg_num[orow] = cbn != prevBn ? kNaN : cumN - prevN;
-                p.seg_den[orow] = cbd != prevBd ? kNaN : cumD - prevD;
-                p.seg_k[orow] = (double)kk;
-                p.seg_end[orow] = st * kSub + b;
+                SegRow row;
+                row.num = cbn != prevBn ? kNaN : cumN - prevN;
+                row.den = cbd != prevBd ? kNaN : cumD - prevD;
+                row.k = (double)kk;
+                row.end = st * kSub + b; row.pad = 0;
+                {   // two 16-byte stores into one 32-byte sector
+                    uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(&row);
+                    dst[0] = src[0]; dst[1] = src[1];
+                }
                 prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevBn = cbn; prevBd = cbd;
                 ++nflush;
                 orow += p.n_pairs;
@@ -686,7 +692,26 @@ __global__ __launch_bounds__(256) void stitch_kernel(K2Params p) {
         an += p.tail[o]; ad += p.tail[plane + o]; ak += p.tail[2 * plane + o];
     }
     const size_t o = (size_t)me.z * p.n_pairs + q;
-    p.seg_num[o] = an + p.seg_num[o]; p.seg_den[o] = ad + p.seg_den[o]; p.seg_k[o] = ak + p.seg_k[o];
+    SegRow &row = p.seg_rows[o];
+    row.num = an + row.num; row.den = ad + row.den; row.k = ak + row.k;
+}
+
+// the segment table as the four arrays the host getter hands out
+__global__ __launch_bounds__(256) void unpack_segments_kernel(const SegRow *__restrict__ rows, size_t n, double *__restrict__ num,
+                                                              double *__restrict__ den, double *__restrict__ k, int32_t *__restrict__ end) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SegRow r = rows[i];
+    if (num) num[i] = r.num;
+    if (den) den[i] = r.den;
+    if (k) k[i] = r.k;
+    if (end) end[i] = r.end;
+}
+
+hipError_t launch_unpack_segments(const SegRow *rows, size_t n, double *num, double *den, double *k, int32_t *end, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_segments_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rows, n, num, den, k, end);
+    return hipGetLastError();
 }
 
 hipError_t launch_stitch(const K2Params &p, hipStream_t st) {
@@ -709,7 +734,8 @@ __global__ void totals_kernel(K2Params p, const int64_t *__restrict__ base, cons
     if (totals)
         for (int64_t r = 0; r < rows; ++r) {
             const size_t o = (size_t)r * p.n_pairs + q;
-            an += p.seg_num[o]; ad += p.seg_den[o]; ak += p.seg_k[o];
+            const SegRow row = p.seg_rows[o];
+            an += row.num; ad += row.den; ak += row.k;
         }
     int cl = p.n_chunks - 1;
     while (cl >= 0 && p.tail_n[(size_t)cl * p.n_pairs + q].y == 0) --cl;
