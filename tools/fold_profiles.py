@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Folds the output of tools/gpu_profile.sh (gpurun_out/prof_<cfg>/) into profiles/: the rocprofv3 kernel_stats.csv of
+the configuration and its entry in r01_traffic.json (FETCH_SIZE / WRITE_SIZE are KB per launch; on gfx950 FETCH_SIZE
+counts 128-byte requests of wide reads as 64, hence x 2 -- MI355X_MICROARCH.md, HBM section).
+python3 tools/fold_profiles.py cfg2 cfg4s ..."""
+import glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+traffic = json.load(open(tp)) if os.path.exists(tp) else {}
+for cfg in sys.argv[1:]:
+    d = os.path.join(ROOT, "gpurun_out", "prof_" + cfg)
+    summ = json.load(open(os.path.join(d, "summary.json")))
+    out = {}
+    for name, v in summ.items():
+        short = name.replace("void ", "").replace("evofst::", "").split("<")[0]
+        if short.startswith("__amd") or short == "synth_kernel" or "avg_ns" not in v:
+            continue
+        e = {"avg_ns": v["avg_ns"], "calls": v["calls"]}
+        if "fetch_size_raw_per_launch" in v and "write_size_raw_per_launch" in v:
+            e["FETCH_SIZE_KB_raw"] = v["fetch_size_raw_per_launch"]
+            e["WRITE_SIZE_KB_raw"] = v["write_size_raw_per_launch"]
+            e["hbm_read_bytes"] = v["fetch_size_raw_per_launch"] * 1024 * 2
+            e["hbm_write_bytes"] = v["write_size_raw_per_launch"] * 1024
+        out[short] = e
+    traffic[cfg] = out
+    stats = glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(ROOT, "profiles", "r01_%s_kernel_stats.csv" % cfg))
+    print(cfg, {k: (round(v["avg_ns"] / 1e3, 1), round((v.get("hbm_read_bytes", 0) + v.get("hbm_write_bytes", 0)) / 1e6, 1)) for k, v in out.items()})
+json.dump(traffic, open(tp, "w"), indent=1)
