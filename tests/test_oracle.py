@@ -271,6 +271,31 @@ def test_stats_variant_counts_rules():
     assert multi == 1 and list(ms) == [1, 0] and list(hp) == [0, 0, 0, 2]
 
 
+def test_golden_vectors_of_the_reference_functions():
+    """The oracle against tests/golden/ref_consumer_vectors.json: outputs of the reference's own calculatePBSfromAFs,
+    calculateABSfromAFs and diffs_between_individuals*, recorded by tools/make_golden_ref.py where /root/reference
+    exists.  Bit for bit, NaN signs included; runs everywhere (the fixture travels, the reference does not)."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_consumer_vectors.json")))
+
+    def from_bits(rows):
+        return np.array([[int(x, 16) for x in r] for r in rows], np.uint64).view(np.float64)
+
+    want = from_bits(g["pbs"]["pbs"])
+    got = np.array([O.pbs_from_afs(*[c / n for c, n in t], *[float(n) for c, n in t]) for t in g["pbs"]["counts_c_n"]])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) and np.isnan(want).any()
+    want = from_bits(g["abs"]["abs_absalt"])
+    got = np.array([O.abs_from_afs(*[c / n for c, n in t], *[float(n) for c, n in t]) for t in g["abs"]["counts_c_n"]])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) and np.isnan(want).any()
+    d = g["indiv_diffs"]
+    n = d["n"]
+    r = O.indiv_diffs(d["ind_with_variant"], d["haps"], np.array(d["missing"], np.uint8), np.array(d["multi"], np.uint8))
+    for k in ("diffs", "diffs_me", "hets_vs_homs"):
+        w = np.array([int(x, 16) for x in d[k]], np.uint64).reshape(n, n)
+        assert np.array_equal(r[k].view(np.uint64), w), k
+    assert np.array_equal(r["miss"].ravel(), d["miss"])
+
+
 def test_rcp_division_identity():
     """The kernels' reciprocal-table quotient is bit-identical to IEEE division on the whole domain."""
     assert O.lib().orc_check_rcp_division(2047) == 0
