@@ -287,6 +287,17 @@ def test_golden_vectors_of_the_reference_functions():
     want = from_bits(g["abs"]["abs_absalt"])
     got = np.array([O.abs_from_afs(*[c / n for c, n in t], *[float(n) for c, n in t]) for t in g["abs"]["counts_c_n"]])
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) and np.isnan(want).any()
+    L = O.lib()
+    want = from_bits(g["fst_math"]["p1_p2_num_den_het_hetNei78"])
+    rows = []
+    with np.errstate(all="ignore"):
+        for c1, n1, c2, n2 in g["fst_math"]["c1_n1_c2_n2"]:
+            p1 = float(np.float64(c1) / np.float64(n1)); p2 = float(np.float64(c2) / np.float64(n2))
+            rows.append([p1, p2, L.orc_fst_numerator(p1, p2, n1, n2), L.orc_fst_denominator(p1, p2), L.orc_het_simple(p1),
+                         L.orc_het_nei78(p1, n1)])
+    got = np.array(rows)
+    same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))   # 0/0: numpy's NaN sign is its own
+    assert same.all() and np.isnan(want).any() and len(rows) > 400
     d = g["indiv_diffs"]
     n = d["n"]
     r = O.indiv_diffs(d["ind_with_variant"], d["haps"], np.array(d["missing"], np.uint8), np.array(d["multi"], np.uint8))

@@ -4,6 +4,8 @@ the shims of oracle/_ref (compiled from /root/reference where it lies; see oracl
     calculatePBSfromAFs                             evo_PBS.cpp:69-98
     calculateABSfromAFs                             evo_ABS.cpp:58-106
     diffs_between_individuals[_with_multialleleics] process_vcf_stats_functions.cpp:180-281
+    calculateAlleleFrequencies, calculateFstNumerator / Denominator, calculateExpectedHeterozygositySimple / Nei78
+                                                    process_vcf_utils.h:272-275, process_vcf_fst.h:19-45
 Doubles are stored as the hex of their 64 bits, so the fixture pins NaN signs too.  Needs /root/reference (run in the
 build container); the fixture travels, the reference does not.
 python3 tools/make_golden_ref.py"""
@@ -49,6 +51,18 @@ r = O.indiv_diffs(iv, haps, missing, multi, use_reference=True)
 out["indiv_diffs"] = {"n": n, "ind_with_variant": iv.tolist(), "haps": haps.tolist(), "missing": missing.tolist(), "multi": multi.tolist(),
                       "diffs": bits(r["diffs"]), "diffs_me": bits(r["diffs_me"]), "hets_vs_homs": bits(r["hets_vs_homs"]),
                       "miss": r["miss"].ravel().tolist()}
+R = O.ref()
+assert R is not None
+rows_in, rows_out = [], []
+quads = [(c1, n1, c2, n2) for n1 in range(0, 4) for c1 in range(n1 + 1) for n2 in range(0, 4) for c2 in range(n2 + 1)]
+quads += [(int(rng.integers(0, a + 1)), int(a), int(rng.integers(0, b + 1)), int(b)) for a, b in rng.integers(1, 500, (400, 2))]
+for c1, n1, c2, n2 in quads:
+    p1 = C.c_double(); p2 = C.c_double()
+    R.ref_calculateAlleleFrequencies(c1, n1, c2, n2, C.byref(p1), C.byref(p2))
+    vals = [p1.value, p2.value, R.ref_calculateFstNumerator(p1.value, p2.value, n1, n2), R.ref_calculateFstDenominator(p1.value, p2.value),
+            R.ref_calculateExpectedHeterozygositySimple(p1.value), R.ref_calculateExpectedHeterozygosityNei78(p1.value, n1)]
+    rows_in.append([c1, n1, c2, n2]); rows_out.append(bits(vals))
+out["fst_math"] = {"c1_n1_c2_n2": rows_in, "p1_p2_num_den_het_hetNei78": rows_out}
 p = os.path.join(ROOT, "tests", "golden", "ref_consumer_vectors.json")
 json.dump(out, open(p, "w"), separators=(",", ":"))
 print(p, os.path.getsize(p), "bytes;", len(pbs_in), "PBS,", len(abs_in), "ABS cases")
