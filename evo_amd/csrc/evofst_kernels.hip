@@ -427,6 +427,16 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
         uint32_t cv[EPT];
         double rh = 0.0, rt = 0.0;           // sums over this vector's sites
         uint32_t rc = 0;
+        // the table entries of all sites first: the compiler cannot move an LDS read of rcp[] above an LDS write of
+        // pt[] / xt[] (same shared array), so reads inside the loop below would wait for each other site by site
+        RcpEntry ent[use_rcp ? EPT : 1];
+        if (use_rcp) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const uint32_t v = (w[(j * EB) / 32] >> ((j * EB) % 32)) & (uint32_t)((1ull << EB) - 1ull);
+                ent[j] = rcp[v >> CountTraits<CT>::shift];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const uint32_t v = (w[(j * EB) / 32] >> ((j * EB) % 32)) & (uint32_t)((1ull << EB) - 1ull);
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
             double pp, tt, hh;
             uint32_t x = c;
             if (use_rcp) {
-                const RcpEntry e = rcp[nm];
+                const RcpEntry e = ent[j];
                 pp = dc * e.r0;                                       // c / nm to 1 ulp (0 when nm == 0)
                 tt = (double)(c * (nm - c)) * e.rr0;                  // p(1-p), exactly 0 when c is 0 or nm
                 hh = tt * e.r1;                                       // t / (nm - 1)     (0 when nm < 2)
