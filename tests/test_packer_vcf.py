@@ -60,3 +60,42 @@ def test_bulk_packer_rejects_malformed_lines(tmp_path):
         with pytest.raises(Exception):
             e.pack_vcf_lines(bad, MODE_FST, 10, None, n_threads=2)
     e.close()
+
+
+def test_packer_survives_malformed_lines():
+    """Truncated and corrupted lines: every entry point that reads VCF text answers EVOFST_OK or an error code, never
+    reads past the terminator (the tests run this a few thousand times on seeded mutations of valid lines)."""
+    import ctypes as C
+    from evo_amd import api
+    rng = np.random.default_rng(99)
+    n = 11
+    good = ["chr1\t%d\t.\tA\t%s\t9\t.\tDP=1\tGT:DP\t" % (100 + i, alt) + "\t".join(
+        "%s%s%s:%d" % (rng.choice(list("01.2")), rng.choice(list("/|")), rng.choice(list("01.2")), rng.integers(0, 99)) for _ in range(n))
+        for i, alt in enumerate(["G", "G,*", "*,G", "G,T,*", "GT", "*", ""])]
+    e = api.EvoFst(-1)
+    e.set_layout(np.arange(n) % 3, 3)
+    L = api.load_library()
+    seen = set()
+    for trial in range(3000):
+        b = bytearray(good[trial % len(good)].encode())
+        kind = trial % 4
+        if kind == 0:
+            b = b[:int(rng.integers(0, len(b) + 1))]
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(1, 256))
+        elif kind == 2:
+            k = int(rng.integers(0, len(b)))
+            del b[k:k + int(rng.integers(1, 8))]
+        line = bytes(b).replace(b"\x00", b"x")
+        for mode in (0, 1, 2):
+            tiles = np.zeros(e.tiles_bytes(1), np.uint8); flags = np.zeros(1, np.uint8)
+            arr = (C.c_char_p * 1)(line)
+            rc = L.evofst_pack_vcf_lines(e.h, mode, 1, arr, n, None, 1, tiles.ctypes.data_as(C.c_void_p), flags.ctypes.data_as(api._u8p))
+            seen.add(rc)
+        al = np.zeros(2 * n, np.uint8)
+        seen.add(L.evofst_alleles_from_vcf_line(line, n, al.ctypes.data_as(api._u8p)))
+        d = C.c_int64(0)
+        arr = (C.c_char_p * 1)(line)
+        seen.add(L.evofst_stats_phase_draws(1, arr, n, 1, C.byref(d)))
+    assert seen <= {0, -1} and seen == {0, -1}, seen          # EVOFST_OK and EVOFST_ERR_ARG both occur
