@@ -603,8 +603,10 @@ int parse_vcf_line(const char *line, int mode, int n_samples, uint8_t *codes, ui
             }
             codes[2 * i + h] = code;
         }
-        const char *t = std::strchr(p + 3, '\t');
-        if (!t) {
+        // to the next column: genotype fields are a dozen characters, so a plain scan beats a library call
+        const char *t = p + 3;
+        while (*t != '\t' && *t != '\0') ++t;
+        if (*t == '\0') {
             if (i != n_samples - 1) return EVOFST_ERR_ARG;
             break;
         }
