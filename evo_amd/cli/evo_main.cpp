@@ -20,6 +20,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -121,6 +122,20 @@ void x86_nan_sign(std::vector<double> &v) {
         if (x != x) x = -__builtin_fabs(x);
 }
 
+// EVO_TIMING=1: where the wall time of a run goes (stderr, at exit).  Reading = everything outside the batches.
+struct Timing {
+    bool on = getenv("EVO_TIMING") != nullptr;
+    double pack = 0, device = 0, batches = 0;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    static double since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
+    ~Timing() {
+        if (!on) return;
+        const double total = since(t0);
+        std::cerr << "[timing] total " << total << " s: reading + start-up " << total - batches << ", packing " << pack << ", upload + counts " << device
+                  << ", per-site results + window replay " << batches - pack - device << std::endl;
+    }
+} g_timing;
+
 // One batch of parsed sites waiting for the device.
 struct Batch {
     std::vector<string> lines;    // the VCF data lines as read
@@ -153,12 +168,17 @@ struct Device {
         std::vector<const char *> ptr(b.n);
         for (size_t i = 0; i < b.n; ++i) ptr[i] = b.lines[i].c_str();
         const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        auto t = std::chrono::steady_clock::now();
         if (evofst_pack_vcf_lines(ctx, mode, (int64_t)b.n, ptr.data(), nVcfSamples, layoutToVcf.empty() ? nullptr : layoutToVcf.data(),
                                   threads, tiles.data(), b.flags.data()) != EVOFST_OK)
             die("malformed VCF line among lines " + numToString(firstLineNo) + ".." + numToString(firstLineNo + (long long)b.n - 1) +
                 " (diploid GT fields with single-digit alleles are required)");
+        g_timing.pack += Timing::since(t);
+        t = std::chrono::steady_clock::now();
         check(ctx, evofst_upload(ctx, (int64_t)b.n, tiles.data(), b.flags.data(), nullptr), "upload");
         check(ctx, evofst_run_counts(ctx), "run_counts");
+        check(ctx, evofst_sync(ctx), "sync");
+        g_timing.device += Timing::since(t);
     }
 };
 
@@ -268,6 +288,8 @@ int fstMain(int argc, char **argv) {
     auto flush = [&]() {
         if (batch.n == 0) return;
         const size_t n = batch.n;
+        const auto tFlush = std::chrono::steady_clock::now();
+        struct Acc { std::chrono::steady_clock::time_point t; ~Acc() { g_timing.batches += Timing::since(t); } } acc{tFlush};
         dev.load(batch, EVOFST_MODE_FST, nSamples, virt32, totalVariantNumber - (long long)n + 1);
         num.resize(n); den.resize(n); dxy.resize(n); inc.resize(n);
         het.resize(2 * n); hetNei.resize(2 * n); pi.resize(2 * n);

@@ -27,7 +27,9 @@ open(sets, "w").write(",".join(names[: N // 2]) + "\n" + ",".join(names[N // 2:]
 print("VCF: %d sites x %d samples, %.0f MB" % (S, N, os.path.getsize(vcf) / 1e6))
 cli = os.path.join(ROOT, "evo_amd", "cli", "evo")
 t0 = time.perf_counter()
-subprocess.check_call([cli, "fst", "--vcf=" + vcf, "--sets=" + sets, "-w", "100,100", "-n", "gpu"], cwd=d, stderr=subprocess.DEVNULL)
+r = subprocess.run([cli, "fst", "--vcf=" + vcf, "--sets=" + sets, "-w", "100,100", "-n", "gpu"], cwd=d, stderr=subprocess.PIPE, text=True,
+                   env=dict(os.environ, EVO_TIMING="1"), check=True)
+print([l for l in r.stderr.splitlines() if l.startswith("[timing]")])
 t_gpu = time.perf_counter() - t0
 from oracle import oracle as O
 od = os.path.join(d, "ora"); os.makedirs(od)
