@@ -259,7 +259,9 @@ GlobalParams make_global(evofst_ctx *c) {
     p.chunk_used_kept_off = (const int64_t *)c->d_uk_off.p;
     p.size = c->snp_size; p.step = c->snp_step;
     p.tn_max = 0;
-    for (int32_t k : c->use_idx) p.tn_max += c->n_full[k];
+    int max_n_use = 0;
+    for (int32_t k : c->use_idx) { p.tn_max += c->n_full[k]; max_n_use = std::max(max_n_use, c->n_full[k]); }
+    { int lo, hi; global_rcp_split(p.tn_max, max_n_use, &lo, &hi); p.rcp_lo = lo; p.rcp_hi = hi; }
     p.base = (const int64_t *)c->d_base.p;
     p.halo_n = c->halo_n;
     p.halo_num = (const double *)c->d_halo_num.p; p.halo_den = (const double *)c->d_halo_den.p;
@@ -1072,9 +1074,10 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
     } else {
         if (c->snp_size <= 0) return fail(c, EVOFST_ERR_ARG, "run_stats: against-all mode needs set_windows(size, step)");
         const int nu = (int)c->use_idx.size();
-        int tn_max = 0;
-        for (int32_t k : c->use_idx) tn_max += c->n_full[k];
-        const size_t lds = global_lds_bytes(tn_max, nu, c->snp_size);
+        int tn_max = 0, max_n_use = 0;
+        for (int32_t k : c->use_idx) { tn_max += c->n_full[k]; max_n_use = std::max(max_n_use, c->n_full[k]); }
+        size_t lds = global_lds_bytes(tn_max, max_n_use, nu, c->snp_size);
+        if (const char *e = getenv("EVOFST_DEBUG_GLOBAL_LDS")) lds += (size_t)atoi(e);   // occupancy experiments
         if (lds > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: SIZE * populations too large for the LDS deque");
         if ((rc = ensure(c, c->d_chunk_rows, (size_t)c->n_chunks * 4))) return rc;
         if ((rc = ensure(c, c->d_row_off, (size_t)c->n_chunks * 8))) return rc;

@@ -153,7 +153,8 @@ struct GlobalParams {
     int32_t chunk_tiles, n_chunks;
     const int64_t *chunk_used_kept_off;  // [2][n_chunks] used / kept sites before the chunk
     int32_t size, step;
-    int32_t tn_max;       // total chromosomes of populationsToUse (reciprocal-table size)
+    int32_t tn_max;       // total chromosomes of populationsToUse
+    int32_t rcp_lo, rcp_hi; // reciprocal table: 1/n for n <= rcp_lo, 1/(tn_max - d) for d <= rcp_hi (global_rcp_split)
     const int64_t *base;  // {used, kept} sites that precede this shard (device)
     int32_t halo_n;       // the last halo_n (<= size) of them, oldest first: what the deques hold when the shard starts
     const double *halo_num, *halo_den;   // [halo_n][n_use]
@@ -224,6 +225,7 @@ hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st);
 size_t k2_lds_bytes(int P, int max_n);
-size_t global_lds_bytes(int tn_max, int n_use, int size);
+size_t global_lds_bytes(int tn_max, int max_n, int n_use, int size);
+void global_rcp_split(int tn_max, int max_n, int *lo, int *hi);
 
 }  // namespace evofst

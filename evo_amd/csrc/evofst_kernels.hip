@@ -1562,10 +1562,22 @@ hipError_t launch_global_rows(const uint64_t *kept_mask, const uint64_t *skip_ma
     return hipGetLastError();
 }
 
-constexpr int kRcpMaxGlobal = 4095;   // reciprocal table up to the total chromosome count of populationsToUse
-size_t global_lds_bytes(int tn_max, int n_use, int size) {
+// Reciprocal table of the against-all kernel.  The divisors are a population's called alleles n1 (and n1 - 1): at most
+// max_n; and the complement's n2 = Tn - n1 (and n2 - 1): close below the total chromosome count tn_max unless a site
+// has lost most of its genotypes.  So the table holds 1/n for n <= lo and 1/(tn_max - d) for d <= hi, and the rare
+// divisor in between is divided for real -- the same correctly rounded value.  (A full table of tn_max + 1 doubles
+// was 16 KB of LDS per block on the cfg3 shard, a quarter of what limits this latency-bound kernel's occupancy.)
+constexpr int kRcpHiGlobal = 255;
+void global_rcp_split(int tn_max, int max_n, int *lo, int *hi) {
+    *lo = std::min(tn_max, max_n + 1);
+    *hi = std::min(kRcpHiGlobal, tn_max - *lo - 1);      // < 0: the low part already covers everything
+    if (*hi < 0) *hi = -1;
+}
+size_t global_lds_bytes(int tn_max, int max_n, int n_use, int size) {
     // ring [size][n_use] x {num, den} + ring of site ids + reciprocal table
-    return (size_t)size * n_use * 16 + (size_t)size * 4 + (tn_max <= kRcpMaxGlobal ? (size_t)(tn_max + 1) * 8 : 0) + 64;
+    int lo, hi;
+    global_rcp_split(tn_max, max_n, &lo, &hi);
+    return (size_t)size * n_use * 16 + (size_t)size * 4 + (size_t)(lo + 1 + hi + 1) * 8 + 64;
 }
 
 // a / b through the reciprocal table (bit-identical to IEEE a/b on this path's domain, see K2)
@@ -1574,9 +1586,26 @@ __device__ __forceinline__ double rcp_div(double a, double b, double r) {
     return fma(fma(-q0, b, a), r, q0);
 }
 
+struct GlobalRcp {
+    const double *tab;    // [lo + 1] then [hi + 1]
+    int lo, hi, tn_max;
+    // divisor known to be a population's own allele count (or one less): always in the low part
+    __device__ __forceinline__ double small(int n) const { return tab[n]; }
+    // divisor from the complement: in the high part unless the site lost most of its genotypes -- then, for the whole
+    // wave at once (the branch is wave-uniform and all but never taken), the low part or a real division
+    __device__ __forceinline__ double large(int n) const {
+        const int d = tn_max - n;
+        double r = tab[lo + 1 + (d <= hi ? d : 0)];
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(d > hi) != 0, 0)) {
+            if (d > hi) r = n <= lo ? tab[n] : 1.0 / (double)n;
+        }
+        return r;
+    }
+};
+
 template <bool RCP>
 __device__ __forceinline__ void global_eval(uint32_t c, uint32_t nm, uint32_t Tc, uint32_t Tn, double thr,
-                                            const double *__restrict__ rcp, double &num, double &den) {
+                                            const GlobalRcp &rcp, double &num, double &den) {
     // evo_FstAgainstAll.cpp:245-261 with p1 = setAAFs (-1.0 when the pop has no alleles,
     // utils.h:75 + utils.cpp:56-58), p2 = complement AAF (utils.cpp:95)
     const int n1 = (int)nm, n2 = (int)(Tn - nm);
@@ -1584,10 +1613,10 @@ __device__ __forceinline__ void global_eval(uint32_t c, uint32_t nm, uint32_t Tc
         double p1, p2, f1, f2;
         const double dc2 = (double)(int)(Tc - c), dn1 = (double)n1, dn2 = (double)n2;
         if (RCP) {
-            p1 = nm > 0 ? rcp_div((double)c, dn1, rcp[n1]) : -1.0;
-            p2 = rcp_div(dc2, dn2, rcp[n2]);
-            f1 = rcp_div(p1 * (1.0 - p1), (double)(n1 - 1), rcp[n1 > 0 ? n1 - 1 : 0]);
-            f2 = rcp_div(p2 * (1.0 - p2), (double)(n2 - 1), rcp[n2 > 0 ? n2 - 1 : 0]);
+            p1 = nm > 0 ? rcp_div((double)c, dn1, rcp.small(n1)) : -1.0;
+            p2 = rcp_div(dc2, dn2, rcp.large(n2));
+            f1 = rcp_div(p1 * (1.0 - p1), (double)(n1 - 1), rcp.small(n1 > 0 ? n1 - 1 : 0));
+            f2 = rcp_div(p2 * (1.0 - p2), (double)(n2 - 1), rcp.large(n2 > 0 ? n2 - 1 : 0));
         } else {
             p1 = nm > 0 ? (double)c / dn1 : -1.0;
             p2 = dc2 / dn2;
@@ -1611,8 +1640,9 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     double *ring_n = reinterpret_cast<double *>(smem);                       // [size][n_use]
     double *ring_d = ring_n + (size_t)p.size * p.n_use;
-    double *rcp = ring_d + (size_t)p.size * p.n_use;                         // [tn_max+1] when RCP
-    int32_t *ring_s = reinterpret_cast<int32_t *>(rcp + (RCP ? p.tn_max + 1 : 0));  // [size]
+    double *rcp_tab = ring_d + (size_t)p.size * p.n_use;                     // [rcp_lo + 1] + [rcp_hi + 1]
+    int32_t *ring_s = reinterpret_cast<int32_t *>(rcp_tab + (p.rcp_lo + 1 + p.rcp_hi + 1));  // [size]
+    const GlobalRcp rcp{rcp_tab, p.rcp_lo, p.rcp_hi, p.tn_max};
 
     const int c = blockIdx.x;
     const int u = threadIdx.x;
@@ -1621,8 +1651,8 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     const double thr = active ? p.thresholds[u] : 0.0;
     for (int i = threadIdx.x; i < p.size * p.n_use; i += blockDim.x) { ring_n[i] = 0.0; ring_d[i] = 0.0; }
     for (int i = threadIdx.x; i < p.size; i += blockDim.x) ring_s[i] = -1;
-    if (RCP)
-        for (int i = threadIdx.x; i <= p.tn_max; i += blockDim.x) rcp[i] = 1.0 / (double)i;
+    for (int i = threadIdx.x; i <= p.rcp_lo; i += blockDim.x) rcp_tab[i] = 1.0 / (double)i;
+    for (int i = threadIdx.x; i <= p.rcp_hi; i += blockDim.x) rcp_tab[p.rcp_lo + 1 + i] = 1.0 / (double)(p.tn_max - i);
 
     const int t0 = c * p.chunk_tiles, t1 = min(t0 + p.chunk_tiles, p.n_tiles);
     // ---- where the replay starts: walk back until SIZE kept sites of this shard are found
@@ -1757,7 +1787,7 @@ hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_byte
     if (p.n_chunks <= 0 || p.n_use <= 0) return hipSuccess;
     int threads = ((p.n_use + 63) / 64) * 64;
     dim3 grid(p.n_chunks), block(threads);
-    const bool rcp = p.tn_max <= kRcpMaxGlobal;
+    const bool rcp = true;   // the table is small whatever tn_max is
     if (count_bytes == 2) return rcp ? launch_global_t<uint16_t, true>(p, lds_bytes, grid, block, st)
                                      : launch_global_t<uint16_t, false>(p, lds_bytes, grid, block, st);
     return rcp ? launch_global_t<uint32_t, true>(p, lds_bytes, grid, block, st)
@@ -1778,7 +1808,7 @@ __global__ __launch_bounds__(256) void global_site_kernel(GlobalParams p) {
     for (int u = blockIdx.y; u < p.n_use; u += gridDim.y) {
         const uint32_t v = cp[(size_t)p.use_idx[u] * kTileSites];
         double num, den;
-        global_eval<false>(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, T.x, T.y, p.thresholds[u], nullptr, num, den);
+        global_eval<false>(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, T.x, T.y, p.thresholds[u], GlobalRcp{nullptr, 0, 0, 0}, num, den);
         if (p.site_num) p.site_num[(size_t)u * p.n_out_sites + ls] = num;
         if (p.site_den) p.site_den[(size_t)u * p.n_out_sites + ls] = den;
     }

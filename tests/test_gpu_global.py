@@ -50,7 +50,10 @@ def _run(engine, rng, S, N, P, miss, size, step, use=None, set_sizes=None, flags
 
 @pytest.mark.parametrize("S,N,P,miss,size,step", [(3000, 60, 6, 0.05, 20, 10), (2000, 40, 4, 0.3, 10, 10),
                                                   (5000, 200, 20, 0.1, 20, 10), (1500, 30, 3, 0.6, 7, 3),
-                                                  (4000, 300, 100, 0.05, 20, 10), (1500, 900, 3, 0.2, 20, 10)])
+                                                  (4000, 300, 100, 0.05, 20, 10), (1500, 900, 3, 0.2, 20, 10),
+                                                  # 800 chromosomes, half of them missing: complement counts far from the total take the
+                                                  # real-division path of the kernel's reciprocal table
+                                                  (1200, 400, 4, 0.5, 20, 10), (1200, 400, 8, 0.35, 10, 5)])
 def test_global_windows(engine, S, N, P, miss, size, step):
     rows = _run(engine, np.random.default_rng(S + P), S, N, P, miss, size, step, flags=True)
     assert rows > 0
