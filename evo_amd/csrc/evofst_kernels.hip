@@ -1250,65 +1250,64 @@ hipError_t launch_pbs_sites(const PbsParams &p, int count_bytes, hipStream_t st)
 }
 
 // Outgroup-to-ingroup dxy per caller-cut window (DistOutMain, evo_distanceToOutgroups.cpp:274-294, DxyPerSNPfromAFs :62-65).
-// One wave per (window, outgroup); lane = ingroup, so every (outgroup, ingroup) sum is accumulated by one lane in site
-// order, exactly the order of the reference's vector_average_withRegion -- the sums are bit-identical, not just close.
-// The site loop reads the outgroup's count (wave-uniform address) and each lane its ingroup's count of the same site;
-// four sites are in flight at a time.  carry_first: window 0 continues the running values already in the arrays.
+// One lane per (window, outgroup, ingroup): the lane walks its window's sites in order, so its sum is accumulated
+// exactly in the order of the reference's vector_average_withRegion -- bit-identical, not just close.  Four sites are
+// in flight per lane.  The lane of ingroup 0 also writes the outgroup's own counters.  carry_first: window 0
+// continues the running values already in the arrays.  (The first version gave a whole wave to one window and
+// outgroup, with as many lanes busy as there were ingroups.)
 template <typename CT>
 __global__ __launch_bounds__(256) void dist_window_kernel(DistParams p) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave >= (int64_t)p.n_windows * p.n_out) return;
-    const int w = (int)(wave / p.n_out), i = (int)(wave % p.n_out);
+    const int nin = p.n_in > 0 ? p.n_in : 1;              // without ingroups one lane per (window, outgroup) still counts
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= (int64_t)p.n_windows * p.n_out * nin) return;
+    const int w = (int)(item / ((int64_t)p.n_out * nin));
+    const int rem = (int)(item - (int64_t)w * p.n_out * nin);
+    const int i = rem / nin, j = rem - i * nin;
+    const bool act = j < p.n_in;
     const int64_t s0 = p.win_off[w], s1 = p.win_off[w + 1];
     const CT *counts = reinterpret_cast<const CT *>(p.counts);
     const int ko = p.out_idx[i];
+    const int kj = act ? p.in_idx[j] : ko;
     const bool carry = p.carry_first && w == 0;
     const size_t wi = (size_t)w * p.n_out + i;
-    // at least one pass even without ingroups: the outgroup's own counters are written by lane 0 of pass 0
-    for (int j0 = 0; j0 == 0 || j0 < p.n_in; j0 += 64) {
-        const int j = j0 + lane;
-        const bool act = j < p.n_in;
-        const int kj = act ? p.in_idx[j] : ko;
-        const size_t o = wi * p.n_in + (act ? j : 0);
-        double sum = (carry && act) ? p.sum[o] : 0.0;
-        int nsnp = (carry && act) ? p.nsnp[o] : 0, miss = (carry && act) ? p.miss[o] : 0;
-        int used = carry ? p.used[wi] : 0, missing = carry ? p.missing[wi] : 0;
-        for (int64_t s = s0; s < s1; s += 4) {
-            uint32_t vo[4], vj[4];
-            bool ok[4];
+    const size_t o = wi * p.n_in + (act ? j : 0);
+    double sum = (carry && act) ? p.sum[o] : 0.0;
+    int nsnp = (carry && act) ? p.nsnp[o] : 0, miss = (carry && act) ? p.miss[o] : 0;
+    int used = carry ? p.used[wi] : 0, missing = carry ? p.missing[wi] : 0;
+    for (int64_t s = s0; s < s1; s += 4) {
+        uint32_t vo[4], vj[4];
+        bool ok[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t su = s + u;
-                ok[u] = su < s1 && !(p.site_flags && (p.site_flags[su] & 1u));
-                const int64_t sc = su < s1 ? su : s1 - 1;
-                const CT *cp = counts + (size_t)(sc >> 6) * p.P * kTileSites + (int)(sc & 63);
-                vo[u] = cp[(size_t)ko * kTileSites];
-                vj[u] = cp[(size_t)kj * kTileSites];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!ok[u]) continue;
-                const int co = (int)(vo[u] & CountTraits<CT>::mask), mo = (int)(vo[u] >> CountTraits<CT>::shift);
-                if (mo == 0) { ++missing; continue; }                       // AFout == -1 (:278-282)
-                ++used;
-                const int cj = (int)(vj[u] & CountTraits<CT>::mask), mj = (int)(vj[u] >> CountTraits<CT>::shift);
-                if (mj != 0) {
-                    const double AFout = (double)co / (double)mo, AFin = (double)cj / (double)mj;
-                    sum += AFout * (1 - AFin) + AFin * (1 - AFout);
-                    ++nsnp;
-                } else ++miss;
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int64_t su = s + u;
+            const int64_t sc = su < s1 ? su : s1 - 1;
+            ok[u] = su < s1 && !(p.site_flags && (p.site_flags[sc] & 1u));
+            const CT *cp = counts + (size_t)(sc >> 6) * p.P * kTileSites + (int)(sc & 63);
+            vo[u] = cp[(size_t)ko * kTileSites];
+            vj[u] = cp[(size_t)kj * kTileSites];
         }
-        if (act) { p.sum[o] = sum; p.nsnp[o] = nsnp; p.miss[o] = miss; }
-        if (j0 == 0 && lane == 0) { p.used[wi] = used; p.missing[wi] = missing; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const int co = (int)(vo[u] & CountTraits<CT>::mask), mo = (int)(vo[u] >> CountTraits<CT>::shift);
+            if (mo == 0) { ++missing; continue; }                       // AFout == -1 (:278-282)
+            ++used;
+            const int cj = (int)(vj[u] & CountTraits<CT>::mask), mj = (int)(vj[u] >> CountTraits<CT>::shift);
+            if (mj != 0) {
+                const double AFout = (double)co / (double)mo, AFin = (double)cj / (double)mj;
+                sum += AFout * (1 - AFin) + AFin * (1 - AFout);
+                ++nsnp;
+            } else ++miss;
+        }
     }
+    if (act) { p.sum[o] = sum; p.nsnp[o] = nsnp; p.miss[o] = miss; }
+    if (j == 0) { p.used[wi] = used; p.missing[wi] = missing; }
 }
 
 hipError_t launch_dist_windows(const DistParams &p, int count_bytes, hipStream_t st) {
     if (p.n_windows <= 0 || p.n_out <= 0) return hipSuccess;
-    const int64_t waves = (int64_t)p.n_windows * p.n_out;
-    dim3 block(256), grid((unsigned)((waves + 3) / 4));
+    const int64_t items = (int64_t)p.n_windows * p.n_out * (p.n_in > 0 ? p.n_in : 1);
+    dim3 block(256), grid((unsigned)((items + 255) / 256));
     if (count_bytes == 2) hipLaunchKernelGGL((dist_window_kernel<uint16_t>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((dist_window_kernel<uint32_t>), grid, block, 0, st, p);
     return hipGetLastError();
