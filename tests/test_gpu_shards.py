@@ -109,3 +109,18 @@ def test_global_shards_agree_with_oracle(engine, n_shards, size, step, miss):
         gf = mn / md
         gf[(gf < 0) | (md == 0)] = 0
     assert_same_bits(gf, ow["fst"], "window Fst across shards")
+
+
+def test_device_side_exchange_equals_host_forms():
+    """The entry points bench.py's multi-rank step uses -- evofst_copy_included_totals, evofst_set_base_offsets_device,
+    evofst_copy_boundary, all on a caller's stream with device buffers -- against the host forms (included_totals,
+    set_base_offsets, boundary, segments) on three shards with non-zero base offsets.  The "all-gather" is a plain
+    device tensor that collects what each shard copied out.  Runs in a process of its own
+    (tests/_device_exchange_check.py): torch must initialise the GPU before the library does, as in bench.py."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_device_exchange_check.py")], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "device-side exchange: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
