@@ -310,8 +310,10 @@ int fstMain(int argc, char **argv) {
             het1S.push_back(het[s]); het2S.push_back(het[n + s]);
             het1N.push_back(hetNei[s]); het2N.push_back(hetNei[n + s]);
             // physical windows, fst.cpp:589-629
-            std::vector<string> sse = split(windowStartEnd, '\t');
-            if (sse[0] == scaffold) {
+            // (the reference splits windowStartEnd at every site to compare its first field; the comparison alone is enough)
+            const size_t tab0 = windowStartEnd.find('\t');
+            const size_t len0 = tab0 == string::npos ? windowStartEnd.size() : tab0;
+            if (len0 == scaffold.size() && windowStartEnd.compare(0, len0, scaffold) == 0) {
                 if (atoi(loc.c_str()) > (fixedWindowStart + physicalWindowSize)) {
                     int acc = physicalWindowSize;
                     double fDxy = vector_tail_with_region(fwDxy, fwDxy.size(), acc);
