@@ -126,7 +126,10 @@ def main():
     e.reserve(S)
     e.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=rank * S)
     e.sync()
-    e.set_profiling(False)          # no event records inside the timed region
+    # No event records inside the timed region: eight hipEventRecord per step cost 0.030 ms of a 0.107 ms step on
+    # cfg2 (measured with EVOFST_BENCH_EVENTS=1).  The per-kernel durations come from the same launches repeated
+    # right after the timed region (below), on the library's stream; profiles/ holds the rocprofv3 view of them.
+    e.set_profiling(os.environ.get("EVOFST_BENCH_EVENTS") is not None)
     from evo_amd import shard
     ag = shard.torch_all_gather(device="cuda") if multi else None
     if multi and cfg["mode"] == "pairs":
