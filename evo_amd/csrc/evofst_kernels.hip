@@ -306,6 +306,9 @@ constexpr int kSubPad = kSub + 1;   // row stride in entries: pop-indexed reads 
 #ifndef EVOFST_K2_GRP
 #define EVOFST_K2_GRP 4
 #endif
+#ifndef EVOFST_K2_UNROLL
+#define EVOFST_K2_UNROLL 8
+#endif
 #ifndef EVOFST_K2_WPS
 #define EVOFST_K2_WPS 3
 #endif
@@ -314,7 +317,7 @@ constexpr int kK2WavesPerSimd = EVOFST_K2_WPS;  // register budget: 512 / waves 
 constexpr uint32_t kXBadNum = 1u << 30;         // nm < 2  (h undefined)
 constexpr uint32_t kXBadDen = 1u << 31;         // nm == 0 (p undefined)
 
-struct __align__(16) RcpEntry { double r0, rr0, r1; uint32_t flags, pad; };
+struct __align__(16) RcpEntry { double r0, rr0, r1; uint32_t flags, pad; };   // read as two 16-byte halves
 
 size_t k2_lds_bytes(int P, int max_n) {
     return (size_t)P * kSubPad * (3 * 8 + 2 * 4) + (size_t)P * (2 * 8 + 4 + 8) +
@@ -422,7 +425,12 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
         const int k = vi / VPR, r = vi - k * VPR;
         const int o = k * kSubPad + r * EPT;
         const uint32_t skipbits = skiphalf >> (r * EPT);
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+        uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+        if (skiphalf != 0u) {                 // uniform and rare: a skipped site contributes 0 everywhere (c = 0)
+#pragma unroll
+            for (int j = 0; j < EPT; ++j)
+                if ((skipbits >> j) & 1u) w[(j * EB) / 32] &= ~(CountTraits<CT>::mask << ((j * EB) % 32));
+        }
         double tv[EPT], hv[EPT];
         uint32_t cv[EPT];
         double rh = 0.0, rt = 0.0;           // sums over this vector's sites
@@ -434,15 +442,17 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
                 const uint32_t v = (w[(j * EB) / 32] >> ((j * EB) % 32)) & (uint32_t)((1ull << EB) - 1ull);
-                ent[j] = rcp[v >> CountTraits<CT>::shift];
+                const uint4 *ep = reinterpret_cast<const uint4 *>(rcp + (v >> CountTraits<CT>::shift));
+                const uint4 lo = ep[0], hi = ep[1];
+                ent[j].r0 = __hiloint2double((int)lo.y, (int)lo.x); ent[j].rr0 = __hiloint2double((int)lo.w, (int)lo.z);
+                ent[j].r1 = __hiloint2double((int)hi.y, (int)hi.x); ent[j].flags = hi.z;
             }
         }
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const uint32_t v = (w[(j * EB) / 32] >> ((j * EB) % 32)) & (uint32_t)((1ull << EB) - 1ull);
-            uint32_t c = v & CountTraits<CT>::mask;
+            const uint32_t c = v & CountTraits<CT>::mask;
             const uint32_t nm = v >> CountTraits<CT>::shift;
-            if (skiphalf != 0u && ((skipbits >> j) & 1u)) c = 0;    // a skipped site contributes 0 everywhere
             const double dc = (double)c;
             double pp, tt, hh;
             uint32_t x = c;
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
             uint32_t sexi = exi, sexj = exj, sbn = bn, sbd = bd;   // (the regular loop leaves these four alone)
             if (p.debug & 8) {
             } else if (!general) {
-#pragma unroll 1
+#pragma unroll EVOFST_K2_UNROLL
                 for (int sb = 0; sb < kSub; sb += kGrp) {
                     double a[kGrp], bb[kGrp];
                     uint32_t xi[kGrp], xj[kGrp];

@@ -1,7 +1,7 @@
-# chunk size sweep on the bench configuration (run through gpurun)
+# chunk size sweep: per-kernel times on cfg2 (EVOFST_CHUNK_TILES overrides the default)
 cd $GRAFT_REPO_ROOT
-for CT in 1 2 3 4 5 6 8; do
-  EVOFST_CHUNK_TILES=$CT timeout -k 10 120 python3 bench.py --config ${CFG:-cfg2} --steps 50 --warmup 5 --cpu-sites 0 > gpurun_out/ct.json 2> gpurun_out/ct.err || { tail -3 gpurun_out/ct.err; exit 1; }
+for X in ${CTS:-2 3 4 6 8}; do
+  EVOFST_CHUNK_TILES=$X timeout -k 10 200 python3 bench.py --config ${CFG:-cfg2} --steps 50 --warmup 5 --cpu-sites 0 > gpurun_out/ct.json 2> gpurun_out/ct.err || { tail -3 gpurun_out/ct.err; exit 1; }
   python3 -c "
-import json; d=json.load(open('gpurun_out/ct.json')); k=d['roofline']['kernels_ms']; print('chunk_tiles=$CT ms/step %.4f  K1 %.1f scan %.1f K2 %.1f stitch %.1f us' % (d['ms_per_step'], k['k1_count_kernel']*1e3, k['scan_kernel']*1e3, k['k2_window_kernel']*1e3, k['stitch_kernel']*1e3))"
+import json; d=json.load(open('gpurun_out/ct.json')); k=d['roofline']['kernels_ms']; print('chunk_tiles $X: step %.4f ms  ' % d['ms_per_step'] + '  '.join('%s %.1f' % (n[:6], v*1e3) for n, v in k.items()))"
 done
