@@ -171,3 +171,29 @@ def test_base_offsets_shift_windows(engine):
         b = whole["sum_num"][f:f + n, q]
         assert np.allclose(a, b, rtol=0, atol=1e-12 * 50)
         assert np.array_equal(part["end_site"][:n, q] + cut, whole["end_site"][f:f + n, q])
+
+
+@pytest.mark.parametrize("S", [1, 2, 63, 64, 65, 129])
+def test_tiny_and_ragged_inputs(engine, S):
+    """Fewer sites than a tile, exactly a tile, one more: the ragged last tile never leaks into counts or windows."""
+    rng = np.random.default_rng(1000 + S)
+    sp, codes, fl = _setup(engine, rng, S, 24, 3, 0.1, flags=False)
+    engine.set_pairs()
+    engine.run_counts()
+    alt, nm = engine.counts()
+    oalt, onm = O.counts_from_codes(codes, sp, 3)
+    assert alt.shape[0] == S and np.array_equal(alt, oalt) and np.array_equal(nm, onm)
+    _check_windows(engine, sp, codes, fl, 3, 5, 5)
+    _check_windows(engine, sp, codes, fl, 3, 1000, 1000)     # no window completes: zero segments, totals still exact
+
+
+def test_empty_shard_is_refused(engine):
+    """Zero sites: the library refuses the upload with an error (no launch over an empty grid); callers skip empty
+    batches, as the CLI and evo_amd.shard do."""
+    from evo_amd.api import EvoFstError
+    sp = round_robin_pops(24, 3)
+    engine.set_layout(sp, 3)
+    engine.set_pairs()
+    engine.set_windows(10, 10)
+    with pytest.raises(EvoFstError, match="n_sites must be positive"):
+        engine.upload(np.zeros(0, np.uint8), 0)
