@@ -137,8 +137,12 @@ def main():
         stream = torch.cuda.Stream()
         e.set_stream(stream.cuda_stream)
         nq = e.n_pairs
-        t_tot = torch.zeros(nq, dtype=torch.int64, device="cuda"); t_all = torch.zeros(world * nq, dtype=torch.int64, device="cuda")
-        t_carry = torch.zeros(nq * 4, dtype=torch.float64, device="cuda"); t_allc = torch.zeros(world * nq * 4, dtype=torch.float64, device="cuda")
+        # one message per rank and pass: [included-site totals of this pass (nq x i64) | carries of the pass before
+        # (nq x 4 f64, bit patterns)].  The totals are needed before K2; the carries only by the host after the
+        # pass, so they ride with the next pass's totals and one more gather after the last pass delivers the rest.
+        t_send = torch.zeros(nq * 5, dtype=torch.int64, device="cuda")
+        t_recv = torch.zeros(world * nq * 5, dtype=torch.int64, device="cuda")
+        p_tot, p_carry = t_send.data_ptr(), t_send[nq:].data_ptr()
         keep = {}
 
     e_prof = [False]
@@ -159,19 +163,25 @@ def main():
             # {used, kept} totals and the last SIZE kept sites of every shard (all-gathers over RCCL)
             shard.compute_sharded_global(e, ag, rank, cfg["size"], cfg["step"])
         else:
-            # two window-boundary exchanges per pass (evo_amd/shard.py): included-site totals after K1
-            # (all-gather over RCCL) -> base offsets; carries behind the last complete segment after K2.
+            # the two window-boundary exchanges of a pass (evo_amd/shard.py): included-site totals after K1
+            # (all-gather over RCCL) -> base offsets; carries behind the last complete segment after K2, which
+            # travel in the next pass's message (one collective per pass instead of two).
             # Nothing in this step waits on the host; what the gathered carries are used for (completing the
             # windows that straddle the left edge, evo_amd.shard.carry_in) is host bookkeeping after the pass.
             with torch.cuda.stream(stream):
                 e.run_counts()
-                e.copy_included_totals(t_tot.data_ptr())
-                dist.all_gather_into_tensor(t_all, t_tot)
-                keep["base"] = t_all.view(world, nq)[:rank].sum(0) if rank > 0 else torch.zeros_like(t_tot)
+                e.copy_included_totals(p_tot)
+                dist.all_gather_into_tensor(t_recv, t_send)
+                keep["base"] = t_recv.view(world, 5 * nq)[:rank, :nq].sum(0) if rank > 0 else torch.zeros(nq, dtype=torch.int64, device="cuda")
                 e.set_base_offsets_device(keep["base"].data_ptr())
                 e.run_stats()
-                e.copy_boundary(t_carry.data_ptr())
-                dist.all_gather_into_tensor(t_allc, t_carry)
+                e.copy_boundary(p_carry)
+
+    def flush():
+        # the carries of the last pass (multi-rank pairs mode): one more gather, inside the timed region
+        if multi and cfg["mode"] == "pairs":
+            with torch.cuda.stream(stream):
+                dist.all_gather_into_tensor(t_recv, t_send)
 
     def fence():
         e.sync()
@@ -187,6 +197,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
+    flush()
     fence()
     dt = time.perf_counter() - t0
     # per-kernel durations from HIP events on the library's stream (last step; then a few more
@@ -203,6 +214,8 @@ def main():
             except Exception:
                 kms[i, k] = 0.0
     kavg = kms[:reps].mean(axis=0)
+    flush()          # every rank: the carries of the last profiled pass, for the exchange check below
+    fence()
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -277,7 +290,7 @@ def main():
         # sanity of the device-side exchange: the gathered carries equal what the host getter returns (reported, and
         # said loudly on stderr, rather than raised: the timing above is valid either way)
         try:
-            own = t_allc.view(world, nq, 4)[rank].cpu().numpy()
+            own = t_recv.view(world, 5 * nq)[rank, nq:].contiguous().view(torch.float64).view(nq, 4).cpu().numpy()
             ok = bool(np.array_equal(own, e.boundary(), equal_nan=True))
         except Exception as ex:  # noqa: BLE001
             ok = False
