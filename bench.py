@@ -144,6 +144,7 @@ def main():
         t_recv = torch.zeros(world * nq * 5, dtype=torch.int64, device="cuda")
         p_tot, p_carry = t_send.data_ptr(), t_send[nq:].data_ptr()
         keep = {}
+        base_zero = torch.zeros(nq, dtype=torch.int64, device="cuda")
 
     e_prof = [False]
 
@@ -172,7 +173,7 @@ def main():
                 e.run_counts()
                 e.copy_included_totals(p_tot)
                 dist.all_gather_into_tensor(t_recv, t_send)
-                keep["base"] = t_recv.view(world, 5 * nq)[:rank, :nq].sum(0) if rank > 0 else torch.zeros(nq, dtype=torch.int64, device="cuda")
+                keep["base"] = t_recv.view(world, 5 * nq)[:rank, :nq].sum(0) if rank > 0 else base_zero
                 e.set_base_offsets_device(keep["base"].data_ptr())
                 e.run_stats()
                 e.copy_boundary(p_carry)
