@@ -63,21 +63,34 @@ template <typename T> string numToString(T i) { std::stringstream out; out << i;
 // createReader (process_vcf_utils.cpp:872-886): gz by suffix; zlib reads plain files transparently
 struct LineReader {
     gzFile f = nullptr;
-    std::vector<char> buf;
-    explicit LineReader(const string &path) : buf(1 << 16) {
+    std::vector<char> buf;          // decompressed text is taken in 4 MiB blocks and cut at '\n' with memchr
+    size_t pos = 0, len = 0;
+    bool eof = false;
+    explicit LineReader(const string &path) : buf(4u << 20) {
         f = gzopen(path.c_str(), "rb");
         if (!f) die("could not open " + path);
         gzbuffer(f, 1 << 20);
     }
     ~LineReader() { if (f) gzclose(f); }
+    bool fill() {
+        if (eof) return false;
+        const int n = gzread(f, buf.data(), (unsigned)buf.size());
+        if (n <= 0) { eof = true; return false; }
+        pos = 0; len = (size_t)n;
+        return true;
+    }
+    // std::getline's contract: false only when nothing is left; a last line without '\n' is returned
     bool getline(string &line) {
         line.clear();
+        bool any = false;
         for (;;) {
-            if (!gzgets(f, buf.data(), (int)buf.size())) return !line.empty();
-            size_t n = strlen(buf.data());
-            if (n && buf[n - 1] == '\n') { line.append(buf.data(), n - 1); return true; }
-            line.append(buf.data(), n);
-            if (gzeof(f)) return true;
+            if (pos == len && !fill()) return any;
+            any = true;
+            const char *p = buf.data() + pos;
+            const char *nl = static_cast<const char *>(memchr(p, '\n', len - pos));
+            if (nl) { line.append(p, (size_t)(nl - p)); pos = (size_t)(nl - buf.data()) + 1; return true; }
+            line.append(p, len - pos);
+            pos = len;
         }
     }
 };
