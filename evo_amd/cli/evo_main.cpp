@@ -28,7 +28,9 @@
 #include <deque>
 #include <fstream>
 #include <iostream>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -61,37 +63,81 @@ std::vector<string> split(const string &s, char delim) {
 template <typename T> string numToString(T i) { std::stringstream out; out << i; return out.str(); }
 
 // createReader (process_vcf_utils.cpp:872-886): gz by suffix; zlib reads plain files transparently
+// A reader thread takes the decompressed text in 4 MiB blocks, cuts it at '\n' with memchr and hands the lines over in
+// blocks of 2048, so reading overlaps the packing and the device work of the batch before.
 struct LineReader {
     gzFile f = nullptr;
-    std::vector<char> buf;          // decompressed text is taken in 4 MiB blocks and cut at '\n' with memchr
-    size_t pos = 0, len = 0;
-    bool eof = false;
-    explicit LineReader(const string &path) : buf(4u << 20) {
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cvData, cvRoom;
+    std::deque<std::vector<string>> queue;
+    bool done = false, stop = false;
+    std::vector<string> cur;
+    size_t curPos = 0;
+    static constexpr size_t kBlockLines = 2048, kMaxQueued = 16;
+
+    explicit LineReader(const string &path) {
         f = gzopen(path.c_str(), "rb");
         if (!f) die("could not open " + path);
         gzbuffer(f, 1 << 20);
+        worker = std::thread([this] { produce(); });
     }
-    ~LineReader() { if (f) gzclose(f); }
-    bool fill() {
-        if (eof) return false;
-        const int n = gzread(f, buf.data(), (unsigned)buf.size());
-        if (n <= 0) { eof = true; return false; }
-        pos = 0; len = (size_t)n;
+    ~LineReader() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cvRoom.notify_all();
+        if (worker.joinable()) worker.join();
+        if (f) gzclose(f);
+    }
+    // false when the consumer has gone away
+    bool push(std::vector<string> &block) {
+        std::unique_lock<std::mutex> lk(mu);
+        cvRoom.wait(lk, [this] { return stop || queue.size() < kMaxQueued; });
+        if (stop) return false;
+        queue.emplace_back(std::move(block));
+        block.clear();
+        block.reserve(kBlockLines);
+        lk.unlock();
+        cvData.notify_one();
         return true;
+    }
+    void produce() {
+        std::vector<char> buf(4u << 20);
+        std::vector<string> block;
+        block.reserve(kBlockLines);
+        string partial;
+        bool havePartial = false;        // text behind the last '\n' seen so far (std::getline returns it as the last line)
+        for (;;) {
+            const int n = gzread(f, buf.data(), (unsigned)buf.size());
+            if (n <= 0) break;
+            const char *p = buf.data(), *end = p + n;
+            while (p < end) {
+                const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+                if (!nl) { partial.append(p, (size_t)(end - p)); havePartial = true; break; }
+                if (havePartial) { partial.append(p, (size_t)(nl - p)); block.emplace_back(std::move(partial)); partial.clear(); havePartial = false; }
+                else block.emplace_back(p, (size_t)(nl - p));
+                p = nl + 1;
+                if (block.size() == kBlockLines && !push(block)) return;
+            }
+        }
+        if (havePartial) block.emplace_back(std::move(partial));
+        if (!block.empty() && !push(block)) return;
+        { std::lock_guard<std::mutex> lk(mu); done = true; }
+        cvData.notify_all();
     }
     // std::getline's contract: false only when nothing is left; a last line without '\n' is returned
     bool getline(string &line) {
-        line.clear();
-        bool any = false;
-        for (;;) {
-            if (pos == len && !fill()) return any;
-            any = true;
-            const char *p = buf.data() + pos;
-            const char *nl = static_cast<const char *>(memchr(p, '\n', len - pos));
-            if (nl) { line.append(p, (size_t)(nl - p)); pos = (size_t)(nl - buf.data()) + 1; return true; }
-            line.append(p, len - pos);
-            pos = len;
+        if (curPos == cur.size()) {
+            std::unique_lock<std::mutex> lk(mu);
+            cvData.wait(lk, [this] { return done || !queue.empty(); });
+            if (queue.empty()) { line.clear(); return false; }
+            cur = std::move(queue.front());
+            queue.pop_front();
+            curPos = 0;
+            lk.unlock();
+            cvRoom.notify_one();
         }
+        line = std::move(cur[curPos++]);
+        return true;
     }
 };
 
