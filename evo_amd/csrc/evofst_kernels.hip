@@ -703,18 +703,29 @@ __global__ __launch_bounds__(256) void stitch_kernel(K2Params p) {
     const size_t plane = (size_t)p.n_pairs * p.n_chunks;
     if (cq >= plane) return;
     const int c = (int)(cq / p.n_pairs), q = (int)(cq - (size_t)c * p.n_pairs);
+    // The usual case is that the chunk before completed a segment too, so its tail is all there is to add: ask for
+    // it together with this chunk's own entry instead of after it (the kernel is a chain of dependent loads).
+    const bool has_prev = c > 0;
+    const size_t op = has_prev ? cq - (size_t)p.n_pairs : cq;
     const int4 me = p.tail_n[cq];
+    const int4 pv = p.tail_n[op];
+    const double pn = p.tail[op], pd = p.tail[plane + op], pk = p.tail[2 * plane + op];
     if (me.y == 0) return;                                  // this chunk completed no segment
-    int cp = c - 1;
-    while (cp >= 0 && p.tail_n[(size_t)cp * p.n_pairs + q].y == 0) --cp;
-    double an = 0.0, ad = 0.0, ak = 0.0;
-    for (int cc_ = (cp < 0 ? 0 : cp); cc_ < c; ++cc_) {
-        const size_t o = (size_t)cc_ * p.n_pairs + q;
-        an += p.tail[o]; ad += p.tail[plane + o]; ak += p.tail[2 * plane + o];
-    }
     const size_t o = (size_t)me.z * p.n_pairs + q;
     SegRow &row = p.seg_rows[o];
-    row.num = an + row.num; row.den = ad + row.den; row.k = ak + row.k;
+    const double rn = row.num, rd = row.den, rk = row.k;
+    double an = 0.0, ad = 0.0, ak = 0.0;
+    if (has_prev && pv.y != 0) {
+        an += pn; ad += pd; ak += pk;
+    } else if (has_prev) {
+        int cp = c - 2;
+        while (cp >= 0 && p.tail_n[(size_t)cp * p.n_pairs + q].y == 0) --cp;
+        for (int cc_ = (cp < 0 ? 0 : cp); cc_ < c; ++cc_) {
+            const size_t oc = (size_t)cc_ * p.n_pairs + q;
+            an += p.tail[oc]; ad += p.tail[plane + oc]; ak += p.tail[2 * plane + oc];
+        }
+    }
+    row.num = an + rn; row.den = ad + rd; row.k = ak + rk;
 }
 
 // the segment table as the four arrays the host getter hands out
