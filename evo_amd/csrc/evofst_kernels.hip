@@ -306,6 +306,9 @@ constexpr int kSubPad = kSub + 1;   // row stride in entries: pop-indexed reads 
 #ifndef EVOFST_K2_GRP
 #define EVOFST_K2_GRP 4
 #endif
+#ifndef EVOFST_K2_ENT_BATCH
+#define EVOFST_K2_ENT_BATCH 4
+#endif
 #ifndef EVOFST_K2_UNROLL
 #define EVOFST_K2_UNROLL 8
 #endif
@@ -435,21 +438,24 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
         uint32_t cv[EPT];
         double rh = 0.0, rt = 0.0;           // sums over this vector's sites
         uint32_t rc = 0;
-        // the table entries of all sites first: the compiler cannot move an LDS read of rcp[] above an LDS write of
-        // pt[] / xt[] (same shared array), so reads inside the loop below would wait for each other site by site
+        // the table entries of 4 sites at a time: the compiler cannot move an LDS read of rcp[] above an LDS write of
+        // pt[] / xt[] (same shared array), so reads issued site by site would wait for each other; all 8 at once cost
+        // 56 registers at the kernel's pressure peak (spills: 10 MB of scratch traffic on cfg2)
         RcpEntry ent[use_rcp ? EPT : 1];
-        if (use_rcp) {
+        constexpr int HB = EVOFST_K2_ENT_BATCH;      // entries requested at a time
+        auto read_ent = [&](int j0) {
 #pragma unroll
-            for (int j = 0; j < EPT; ++j) {
+            for (int j = j0; j < j0 + HB && j < EPT; ++j) {
                 const uint32_t v = (w[(j * EB) / 32] >> ((j * EB) % 32)) & (uint32_t)((1ull << EB) - 1ull);
                 const uint4 *ep = reinterpret_cast<const uint4 *>(rcp + (v >> CountTraits<CT>::shift));
                 const uint4 lo = ep[0], hi = ep[1];
                 ent[j].r0 = __hiloint2double((int)lo.y, (int)lo.x); ent[j].rr0 = __hiloint2double((int)lo.w, (int)lo.z);
                 ent[j].r1 = __hiloint2double((int)hi.y, (int)hi.x); ent[j].flags = hi.z;
             }
-        }
+        };
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
+            if (use_rcp && j % HB == 0) read_ent(j);
             const uint32_t v = (w[(j * EB) / 32] >> ((j * EB) % 32)) & (uint32_t)((1ull << EB) - 1ull);
             const uint32_t c = v & CountTraits<CT>::mask;
             const uint32_t nm = v >> CountTraits<CT>::shift;
