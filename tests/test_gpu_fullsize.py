@@ -86,3 +86,114 @@ def test_cfg2_properties(engine):
                     fin = np.isfinite(b)
                     assert (np.isfinite(a) == fin).all()
                     assert np.all(np.abs(a[fin] - b[fin]) <= 1e-12 * SIZE)
+
+
+def _with_chunk_tiles(ct, fn):
+    old = os.environ.get("EVOFST_CHUNK_TILES")
+    os.environ["EVOFST_CHUNK_TILES"] = str(ct)
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop("EVOFST_CHUNK_TILES", None)
+        else:
+            os.environ["EVOFST_CHUNK_TILES"] = old
+
+
+def test_cfg3_shard_properties(engine):
+    """One GPU's share of BASELINE configs[2] (10 M sites x 1000 samples, 100 populations against all, -w 20,10 over
+    8 GPUs = 1.25 M sites): the window rows must not depend on the chunking at all (every lane sums its deque column
+    oldest -> newest, so they are bit-identical), and the first sites agree with the oracle bit for bit."""
+    S3, N3, P3, size, step = 1_250_000, 1000, 100, 20, 10
+    sp = round_robin_pops(N3, P3)
+    engine.set_layout(sp, P3)
+    use = np.arange(P3, dtype=np.int32)
+    set_sizes = np.full(P3, N3 // P3, np.int64)
+    engine.set_against_all(use, set_sizes)
+    engine.set_windows(size, step)
+    engine.reserve(S3)
+    engine.synth(S3, seed=20261110, missing_rate=0.02)
+
+    def run():
+        engine.run()
+        return engine.global_windows(), engine.included_totals().copy()
+    ga, ta = _with_chunk_tiles(4, run)
+    gb, tb = _with_chunk_tiles(9, run)
+    assert np.array_equal(ta, tb)
+    assert len(ga["end_site"]) == len(gb["end_site"]) > 100_000
+    for k in ("start_site", "end_site"):
+        assert np.array_equal(ga[k], gb[k])
+    for k in ("mean_num", "mean_den"):
+        assert_same_bits(ga[k], gb[k], k)
+
+    n = 6000
+    tiles = engine.download_tiles()
+    codes = engine.unpack_codes(tiles, n)
+    oalt, onm = O.counts_from_codes(codes, sp, P3)
+    alt, nm = engine.counts(0, n)
+    assert np.array_equal(alt, oalt) and np.array_equal(nm, onm)
+    okept, onum, oden = O.global_site_stats(oalt, onm, use, set_sizes, None)
+    gnum, gden, gkept = engine.global_site_stats(0, n)
+    assert np.array_equal(gkept, okept)
+    k = okept == 1
+    with np.errstate(all="ignore"):
+        assert_same_bits(gnum.T[k], onum[k], "global num")
+        assert_same_bits(gden.T[k], oden[k], "global den")
+    ow = O.global_windows(okept, onum, oden, size, step, None)
+    r = len(ow["end_site"])
+    assert r > 400
+    assert np.array_equal(ga["end_site"][:r], ow["end_site"]) and np.array_equal(ga["start_site"][:r], ow["start_site"])
+    with np.errstate(all="ignore"):
+        gf = ga["mean_num"][:r] / ga["mean_den"][:r]
+        gf[(gf < 0) | (ga["mean_den"][:r] == 0)] = 0
+    assert_same_bits(gf, ow["fst"], "window Fst")
+
+
+def test_cfg5_geometry_properties(engine):
+    """The geometry of BASELINE configs[4] (5000 samples, 500 populations = 124 750 pairs, 15 % missing genotypes) on
+    100 k sites: windows of 200 sites equal the sums of their two 100-site halves (integers exactly, doubles to 1e-12 of
+    the terms), and the first windows agree with the oracle."""
+    S5, N5, P5 = 100_000, 5000, 500
+    sp = round_robin_pops(N5, P5)
+    engine.set_layout(sp, P5)
+    engine.set_gram()
+    engine.reserve(S5)
+    engine.synth(S5, seed=20261110, missing_rate=0.15)
+    engine.run_counts()
+    engine.set_site_windows(np.arange(0, S5 + 1, 100, dtype=np.int64))
+    engine.run_gram(500, 20)
+    fine = engine.gram()
+    engine.run_gram(0, 3)
+    head = engine.gram()
+    engine.set_site_windows(np.arange(0, S5 + 1, 200, dtype=np.int64))
+    engine.run_gram(250, 10)
+    coarse = engine.gram()
+    for k in ("sum_dxy_k", "n_included"):
+        assert np.array_equal(coarse[k], fine[k][0::2] + fine[k][1::2])
+    for k in ("sum_num", "sum_den"):
+        a, b = coarse[k], fine[k][0::2] + fine[k][1::2]
+        assert (np.isnan(a) == np.isnan(b)).all()
+        fin = ~np.isnan(b)
+        assert np.all(np.abs(a[fin] - b[fin]) <= 1e-12 * 400)       # |term| <= 1; num is formed from den's terms too
+
+    n = 300
+    codes = engine.unpack_codes(engine.download_tiles(), n)
+    oalt, onm = O.counts_from_codes(codes, sp, P5)
+    alt, nm = engine.counts(0, n)
+    assert np.array_equal(alt, oalt) and np.array_equal(nm, onm)
+    nf = n_full_of(sp, P5)
+    pi, pj = np.triu_indices(P5, 1)
+    pi = pi.astype(np.int32); pj = pj.astype(np.int32)
+    onum, oden, odxy, oinc = O.pair_site_stats(oalt, onm, nf, pi, pj, None)
+    odxy_k = np.rint(odxy * (nf[pi] * nf[pj])[None, :].astype(np.float64))
+    for w in range(3):
+        m = oinc[100 * w:100 * w + 100] == 1
+        assert np.array_equal(head["n_included"][w], m.sum(axis=0))
+        assert np.array_equal(head["sum_dxy_k"][w], np.where(m, odxy_k[100 * w:100 * w + 100], 0.0).sum(axis=0))
+        with np.errstate(all="ignore"):
+            rn = np.where(m, onum[100 * w:100 * w + 100], 0.0).sum(axis=0)
+            rd = np.where(m, oden[100 * w:100 * w + 100], 0.0).sum(axis=0)
+        for a, b in ((head["sum_num"][w], rn), (head["sum_den"][w], rd)):
+            assert (np.isnan(a) == np.isnan(b)).all()
+            fin = ~np.isnan(b)
+            assert np.all(np.abs(a[fin] - b[fin]) <= 1e-12 * 200)
