@@ -85,8 +85,12 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-sites", type=int, default=-1, help="sites of the CPU baseline sample (0 = skip)")
     ap.add_argument("--dist-path", action="store_true", help="rehearsal: take the multi-rank step even with one rank")
+    ap.add_argument("--sites", type=int, default=0, help="experiments only: another number of sites per GPU (the label says so)")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.sites > 0:
+        cfg["sites"] = args.sites
+        cfg["label"] += " [EXPERIMENT: %d sites per GPU]" % args.sites
 
     import torch
     import torch.distributed as dist
