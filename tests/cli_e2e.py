@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end CLI timing: evo fst on a synthetic VCF, GPU front-end vs the CPU oracle driver.
-python tools/cli_e2e.py [n_sites] [n_samples]   (needs a GPU for the first leg)"""
+python tests/cli_e2e.py [n_sites] [n_samples]   (needs a GPU for the first leg)"""
 import os, subprocess, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

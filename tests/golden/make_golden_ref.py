@@ -8,10 +8,10 @@ the shims of oracle/_ref (compiled from /root/reference where it lies; see oracl
                                                     process_vcf_utils.h:272-275, process_vcf_fst.h:19-45
 Doubles are stored as the hex of their 64 bits, so the fixture pins NaN signs too.  Needs /root/reference (run in the
 build container); the fixture travels, the reference does not.
-python3 tools/make_golden_ref.py"""
+python3 tests/golden/make_golden_ref.py"""
 import ctypes as C, json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O
 

@@ -273,7 +273,7 @@ def test_stats_variant_counts_rules():
 
 def test_golden_vectors_of_the_reference_functions():
     """The oracle against tests/golden/ref_consumer_vectors.json: outputs of the reference's own calculatePBSfromAFs,
-    calculateABSfromAFs and diffs_between_individuals*, recorded by tools/make_golden_ref.py where /root/reference
+    calculateABSfromAFs and diffs_between_individuals*, recorded by tests/golden/make_golden_ref.py where /root/reference
     exists.  Bit for bit, NaN signs included; runs everywhere (the fixture travels, the reference does not)."""
     import json
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_consumer_vectors.json")))
