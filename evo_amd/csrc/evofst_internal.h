@@ -6,7 +6,7 @@
 namespace evofst {
 
 constexpr int kTileSites = 64;
-constexpr int kK1Threads = 256;    // 4 waves: wave w of a block walks tiles w, w+4, ... of its chunk
+constexpr int kK1Threads = 256;    // 4 waves = 4 consecutive chunks (one wave per chunk) sharing the layout tables in LDS
 constexpr int kK2Threads = 256;    // pairs per K2 block
 constexpr int kPadSites = 65;      // LDS row stride (sites + 1) -> conflict-free pop-indexed reads
 constexpr int kScanParts = 16;
