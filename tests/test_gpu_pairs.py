@@ -81,8 +81,8 @@ def test_site_stats_bit_exact(engine, S, N, P, miss, flags):
     assert np.array_equal(engine.included_totals(), oinc.sum(axis=0))
 
 
-def _check_windows(engine, sp, codes, fl, P, size, step):
-    pi, pj = engine.all_pairs()
+def _check_windows(engine, sp, codes, fl, P, size, step, pairs=None):
+    pi, pj = engine.all_pairs() if pairs is None else pairs
     nf = n_full_of(sp, P)
     oalt, onm = O.counts_from_codes(codes, sp, P)
     onum, oden, odxy, oinc = O.pair_site_stats(oalt, onm, nf, pi, pj, fl)
@@ -127,6 +127,38 @@ def test_snp_windows(engine, S, N, P, miss, size, step):
     sp, codes, fl = _setup(engine, rng, S, N, P, miss, flags=True)
     engine.set_pairs()
     _check_windows(engine, sp, codes, fl, P, size, step)
+
+
+def test_snp_windows_many_pairs(engine):
+    """435 pairs: more than one K2 block per chunk (blockIdx.y > 0), each deriving the same tables."""
+    rng = np.random.default_rng(435)
+    sp, codes, fl = _setup(engine, rng, 2000, 90, 30, 0.1, flags=True)
+    engine.set_pairs()
+    assert engine.n_pairs == 435
+    _check_windows(engine, sp, codes, fl, 30, 25, 25)
+
+
+def test_snp_windows_few_pairs_of_many_populations(engine):
+    """A short pair list over 40 populations: one 64-thread K2 block has to stage 80 mask words and 160 count
+    vectors per half tile (the loops that run past the block's thread count)."""
+    rng = np.random.default_rng(40)
+    P = 40
+    sp, codes, fl = _setup(engine, rng, 1800, 120, P, 0.15, flags=True)
+    pi = np.array([0, 3, 39, 17, 5, 38, 20], np.int32)
+    pj = np.array([39, 4, 1, 18, 31, 37, 21], np.int32)
+    engine.set_pairs(pi, pj)
+    _check_windows(engine, sp, codes, fl, P, 30, 15, pairs=(pi, pj))
+
+
+def test_snp_windows_lds_near_the_limit(engine):
+    """130 populations: K2's per-population tables take 140 KB of the 160 KB of LDS (dynamic size above 48 KB)."""
+    rng = np.random.default_rng(130)
+    P = 130
+    sp, codes, fl = _setup(engine, rng, 700, 260, P, 0.1, flags=False)
+    pi = np.array([0, 129, 64, 7], np.int32)
+    pj = np.array([129, 1, 65, 100], np.int32)
+    engine.set_pairs(pi, pj)
+    _check_windows(engine, sp, codes, fl, P, 20, 20, pairs=(pi, pj))
 
 
 def test_snp_windows_small_chunks(engine, monkeypatch):
