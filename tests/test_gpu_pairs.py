@@ -229,3 +229,30 @@ def test_empty_shard_is_refused(engine):
     engine.set_windows(10, 10)
     with pytest.raises(EvoFstError, match="n_sites must be positive"):
         engine.upload(np.zeros(0, np.uint8), 0)
+
+
+def test_limits_are_refused_not_launched(engine):
+    """shapes the kernels' LDS tables cannot hold come back as errors before any launch."""
+    from evo_amd.api import EvoFstError
+    rng = np.random.default_rng(8)
+    # 200 populations in pairs mode: K2's tables would need 211 KB of LDS
+    P = 200
+    sp = round_robin_pops(400, P)
+    codes = random_codes(rng, 300, sp, P, miss=0.05)
+    engine.set_layout(sp, P)
+    engine.upload(engine.pack_codes(codes), 300)
+    engine.set_pairs(np.array([0, 5], np.int32), np.array([199, 6], np.int32))
+    engine.set_windows(10, 10)
+    with pytest.raises(EvoFstError):
+        engine.run()
+    # the same data goes through the Gram path
+    engine.set_gram()
+    engine.set_site_windows(np.array([0, 100, 300], np.int64))
+    engine.run_counts()
+    engine.run_gram()
+    assert engine.gram()["n_included"].shape == (2, P * (P - 1) // 2)
+    # against all with a deque of 400 sites x 200 populations x 16 B = 1.28 MB
+    engine.set_against_all(np.arange(P, dtype=np.int32), np.full(P, 2, np.int64))
+    engine.set_windows(400, 400)
+    with pytest.raises(EvoFstError):
+        engine.run()
