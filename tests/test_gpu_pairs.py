@@ -120,6 +120,7 @@ def _check_windows(engine, sp, codes, fl, P, size, step, pairs=None):
 @pytest.mark.parametrize("S,N,P,miss,size,step", [(6000, 40, 4, 0.05, 100, 100), (5000, 60, 5, 0.1, 20, 10),
                                                   (3000, 30, 3, 0.0, 7, 7), (4000, 40, 4, 0.2, 30, 12),
                                                   (700, 40, 4, 0.05, 1000, 1000),
+                                                  (500, 20, 2, 0.1, 1, 1), (800, 40, 4, 0.1, 3, 1), (900, 40, 4, 0.05, 64, 32),
                                                   (2500, 900, 3, 0.1, 50, 25),       # 600 chromosomes per population: 32-bit packed counts
                                                   (1200, 2100, 2, 0.02, 40, 40)])    # 2100 per population: beyond the reciprocal table
 def test_snp_windows(engine, S, N, P, miss, size, step):
