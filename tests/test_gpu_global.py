@@ -53,7 +53,8 @@ def _run(engine, rng, S, N, P, miss, size, step, use=None, set_sizes=None, flags
                                                   (4000, 300, 100, 0.05, 20, 10), (1500, 900, 3, 0.2, 20, 10),
                                                   # 800 chromosomes, half of them missing: complement counts far from the total take the
                                                   # real-division path of the kernel's reciprocal table
-                                                  (1200, 400, 4, 0.5, 20, 10), (1200, 400, 8, 0.35, 10, 5)])
+                                                  (1200, 400, 4, 0.5, 20, 10), (1200, 400, 8, 0.35, 10, 5),
+                                                  (600, 20, 2, 0.1, 1, 1), (1500, 40, 4, 0.1, 50, 7), (900, 40, 4, 0.1, 5, 20)])
 def test_global_windows(engine, S, N, P, miss, size, step):
     rows = _run(engine, np.random.default_rng(S + P), S, N, P, miss, size, step, flags=True)
     assert rows > 0
