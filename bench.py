@@ -159,8 +159,7 @@ def main():
         t_send = torch.zeros(nq * 5, dtype=torch.int64, device="cuda")
         t_recv = torch.zeros(world * nq * 5, dtype=torch.int64, device="cuda")
         p_tot, p_carry = t_send.data_ptr(), t_send[nq:].data_ptr()
-        keep = {}
-        base_zero = torch.zeros(nq, dtype=torch.int64, device="cuda")
+        p_recv = t_recv.data_ptr()
 
     e_prof = [False]
 
@@ -189,8 +188,7 @@ def main():
                 e.run_counts()
                 e.copy_included_totals(p_tot)
                 dist.all_gather_into_tensor(t_recv, t_send)
-                keep["base"] = t_recv.view(world, 5 * nq)[:rank, :nq].sum(0) if rank > 0 else base_zero
-                e.set_base_offsets_device(keep["base"].data_ptr())
+                e.set_base_offsets_gathered(p_recv, 5 * nq, rank)     # sum of the earlier ranks' totals
                 e.run_stats()
                 e.copy_boundary(p_carry)
 

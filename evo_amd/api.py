@@ -58,6 +58,7 @@ SIGNATURES = {
     "evofst_set_pairs": (C.c_int, [_vp, _i32p, _i32p, C.c_int]),
     "evofst_set_against_all": (C.c_int, [_vp, _i32p, C.c_int, _i64p]),
     "evofst_set_base_offsets_device": (C.c_int, [_vp, _vp]),
+    "evofst_set_base_offsets_gathered": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
     "evofst_copy_included_totals": (C.c_int, [_vp, _vp]),
     "evofst_copy_boundary": (C.c_int, [_vp, _vp]),
     "evofst_set_global_halo": (C.c_int, [_vp, C.c_int, _i32p, _dp, _dp]),
@@ -274,6 +275,11 @@ class EvoFst:
 
     def set_base_offsets_device(self, d_ptr):
         self._chk(self.L.evofst_set_base_offsets_device(self.h, C.c_void_p(d_ptr)))
+
+    def set_base_offsets_gathered(self, d_gathered, row_stride, n_rows):
+        """Base offsets = sum of the first n_rows rows (row_stride int64 values each, totals first) of an all-gather
+        buffer in device memory."""
+        self._chk(self.L.evofst_set_base_offsets_gathered(self.h, d_gathered, row_stride, n_rows))
 
     def copy_included_totals(self, d_ptr):
         self._chk(self.L.evofst_copy_included_totals(self.h, C.c_void_p(d_ptr)))

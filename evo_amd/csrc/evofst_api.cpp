@@ -965,6 +965,25 @@ extern "C" int evofst_set_base_offsets_device(evofst_ctx *c, const void *d_offse
     return abi_exception(c);
 }
 
+extern "C" int evofst_set_base_offsets_gathered(evofst_ctx *c, const void *d_gathered, int64_t row_stride, int n_rows) try {
+    if (!c || !d_gathered || n_rows < 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->mode != MODE_PAIRS && c->mode != MODE_GLOBAL) return fail(c, EVOFST_ERR_STATE, "set_base_offsets_gathered: choose a mode first");
+    const size_t n = c->mode == MODE_PAIRS ? c->pairs.size() : 2;
+    if (row_stride < (int64_t)n) return fail(c, EVOFST_ERR_ARG, "set_base_offsets_gathered: row_stride is smaller than a row of totals");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->base.assign(n, 0);
+    int rc = ensure(c, c->d_base, n * 8);
+    if (rc) return rc;
+    HIPCHK(c, launch_sum_rows((const int64_t *)d_gathered, row_stride, n_rows, (int)n, (int64_t *)c->d_base.p, c->stream));
+    c->base_host_valid = false;
+    c->offsets_dirty = true;
+    c->stats_done = false;
+    return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
+}
+
 extern "C" int evofst_copy_included_totals(evofst_ctx *c, void *d_dst) try {
     if (!c || !d_dst) return EVOFST_ERR_ARG;
     NEED_GPU(c);

@@ -734,6 +734,22 @@ __global__ __launch_bounds__(256) void stitch_kernel(K2Params p) {
     row.num = an + rn; row.den = ad + rd; row.k = ak + rk;
 }
 
+// base[q] = sum over the first n_rows rows of an all-gather buffer (rows of row_stride int64 values, the totals first)
+__global__ __launch_bounds__(256) void sum_rows_kernel(const int64_t *__restrict__ gathered, int64_t row_stride, int n_rows, int n,
+                                                       int64_t *__restrict__ base) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    int64_t a = 0;
+    for (int r = 0; r < n_rows; ++r) a += gathered[(size_t)r * row_stride + q];
+    base[q] = a;
+}
+
+hipError_t launch_sum_rows(const int64_t *gathered, int64_t row_stride, int n_rows, int n, int64_t *base, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gathered, row_stride, n_rows, n, base);
+    return hipGetLastError();
+}
+
 // the segment table as the four arrays the host getter hands out
 __global__ __launch_bounds__(256) void unpack_segments_kernel(const SegRow *__restrict__ rows, size_t n, double *__restrict__ num,
                                                               double *__restrict__ den, double *__restrict__ k, int32_t *__restrict__ end) {

@@ -67,6 +67,24 @@ def main():
             for q in range(nq):
                 n = int(seg["n_segments"][q])
                 assert np.array_equal(np.asarray(got[k])[:n, q], np.asarray(seg[k])[:n, q], equal_nan=True), (r, k, q)
+    # the same offsets formed by the library from the gathered buffer itself: rows padded to 5 * nq values (totals
+    # first, as bench.py's message is laid out), shard r sums rows 0 .. r-1
+    t_msg = torch.full((n_shards, 5 * nq), 7_777, dtype=torch.int64, device="cuda")
+    t_msg[:, :nq] = t_all.view(n_shards, nq)
+    for r in range(n_shards):
+        with torch.cuda.stream(stream):
+            load(r)
+            engine.set_base_offsets_gathered(t_msg.data_ptr(), 5 * nq, r)
+            engine.run_stats()
+            engine.copy_boundary(t_carry.data_ptr())
+        stream.synchronize()
+        seg, carry = host[r]
+        assert np.array_equal(t_carry.cpu().numpy().reshape(nq, 4), carry, equal_nan=True), r
+        got = engine.segments()
+        assert np.array_equal(got["first_segment"], seg["first_segment"]) and np.array_equal(got["n_segments"], seg["n_segments"])
+        for q in range(nq):
+            n = int(seg["n_segments"][q])
+            assert np.array_equal(np.asarray(got["sum_num"])[:n, q], np.asarray(seg["sum_num"])[:n, q], equal_nan=True), (r, q)
     engine.close()
     print("device-side exchange: ok")
 
