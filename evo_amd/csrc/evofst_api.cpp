@@ -943,7 +943,7 @@ extern "C" int evofst_set_base_offsets(evofst_ctx *c, const int64_t *offsets) tr
     return abi_exception(c);
 }
 
-static int launch_totals_and_carry(evofst_ctx *c, bool want_totals);
+static int launch_totals_and_carry(evofst_ctx *c, bool want_totals, double *d_carry_out = nullptr);
 
 // Device-side forms of the multi-GPU exchange: nothing here waits for the GPU, so a pass over a shard stays one
 // stream of kernels, copies and collectives (bench.py, N > 1).
@@ -1004,10 +1004,7 @@ extern "C" int evofst_copy_boundary(evofst_ctx *c, void *d_dst) try {
     NEED_GPU(c);
     if (!c->stats_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "copy_boundary: pairs mode + run_stats first");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = launch_totals_and_carry(c, false);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(d_dst, c->d_carry.p, c->pairs.size() * 4 * 8, hipMemcpyDeviceToDevice, c->stream));
-    return EVOFST_OK;
+    return launch_totals_and_carry(c, false, (double *)d_dst);   // the kernel writes the caller's buffer: no copy behind it
 } catch (...) {
     return abi_exception(c);
 }
@@ -1655,14 +1652,14 @@ extern "C" int evofst_get_segments(evofst_ctx *c, int64_t *first_segment, int64_
     return abi_exception(c);
 }
 
-static int launch_totals_and_carry(evofst_ctx *c, bool want_totals) {
+static int launch_totals_and_carry(evofst_ctx *c, bool want_totals, double *d_carry_out) {
     const size_t np = c->pairs.size();
     int rc;
     if ((rc = ensure(c, c->d_totals, np * 4 * 8))) return rc;
     if ((rc = ensure(c, c->d_carry, np * 4 * 8))) return rc;
     K2Params p = make_k2(c);
     HIPCHK(c, launch_totals(p, (const int64_t *)c->d_base.p, (const int64_t *)c->d_incl_totals.p,
-                            want_totals ? (double *)c->d_totals.p : nullptr, (double *)c->d_carry.p, c->stream));
+                            want_totals ? (double *)c->d_totals.p : nullptr, d_carry_out ? d_carry_out : (double *)c->d_carry.p, c->stream));
     return EVOFST_OK;
 }
 
