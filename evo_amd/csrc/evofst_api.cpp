@@ -77,6 +77,9 @@ struct evofst_ctx {
     int64_t seg_cap = 0;
     std::vector<int64_t> win_start;   // Gram mode: site windows
     bool base_host_valid = true;      // c->base mirrors d_base (false after a device-to-device set_base_offsets)
+    const int64_t *gathered = nullptr; // pending evofst_set_base_offsets_gathered: the next scan sums these rows into d_base
+    int64_t gathered_stride = 0;
+    int gathered_rows = 0;
     int halo_n = 0;                   // against-all mode: kept sites handed over by the shards before this one
     int64_t gram_windows = 0;         // windows of the last run_gram
     int gram_missing = -1;            // -1 unknown, else whether any site needs the missing-allele correction
@@ -198,7 +201,7 @@ int run_scan(evofst_ctx *c) {
         record(c, 1, 0);
         HIPCHK(c, launch_scan((const uint32_t *)c->d_census.p, (const int64_t *)c->d_base.p, (int64_t *)c->d_offsets.p,
                               (int64_t *)c->d_incl_totals.p, c->n_chunks, np, std::max(1, c->g), (int64_t *)c->d_first_seg.p,
-                              c->stream));
+                              c->stream, c->gathered, c->gathered_stride, c->gathered_rows, (int64_t *)c->d_base.p));
         record(c, 1, 1);
     } else if (c->mode == MODE_GLOBAL) {
         int rc;
@@ -206,10 +209,12 @@ int run_scan(evofst_ctx *c) {
         if ((rc = ensure(c, c->d_uk_tot, 2 * 8))) return rc;
         record(c, 1, 0);
         HIPCHK(c, launch_scan((const uint32_t *)c->d_used_kept.p, (const int64_t *)c->d_base.p, (int64_t *)c->d_uk_off.p,
-                              (int64_t *)c->d_uk_tot.p, c->n_chunks, 2, 1, nullptr, c->stream));
+                              (int64_t *)c->d_uk_tot.p, c->n_chunks, 2, 1, nullptr, c->stream, c->gathered, c->gathered_stride,
+                              c->gathered_rows, (int64_t *)c->d_base.p));
         record(c, 1, 1);
     }
     c->offsets_dirty = false;
+    c->gathered = nullptr;            // d_base holds the sums from here on
     return EVOFST_OK;
 }
 
@@ -219,6 +224,7 @@ int set_base_internal(evofst_ctx *c, const int64_t *offsets) {
     if (offsets) std::copy(offsets, offsets + n, c->base.begin());
     int rc = upload_vec(c, c->d_base, c->base);
     if (rc) return rc;
+    c->gathered = nullptr;
     c->base_host_valid = true;
     c->offsets_dirty = true;
     c->stats_done = false;
@@ -957,6 +963,7 @@ extern "C" int evofst_set_base_offsets_device(evofst_ctx *c, const void *d_offse
     int rc = ensure(c, c->d_base, n * 8);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_base.p, d_offsets, n * 8, hipMemcpyDeviceToDevice, c->stream));
+    c->gathered = nullptr;
     c->base_host_valid = false;
     c->offsets_dirty = true;
     c->stats_done = false;
@@ -975,7 +982,9 @@ extern "C" int evofst_set_base_offsets_gathered(evofst_ctx *c, const void *d_gat
     c->base.assign(n, 0);
     int rc = ensure(c, c->d_base, n * 8);
     if (rc) return rc;
-    HIPCHK(c, launch_sum_rows((const int64_t *)d_gathered, row_stride, n_rows, (int)n, (int64_t *)c->d_base.p, c->stream));
+    // the next scan (run_stats) forms the sums itself, in stream order behind the caller's collective: the buffer
+    // must keep its contents until then
+    c->gathered = (const int64_t *)d_gathered; c->gathered_stride = row_stride; c->gathered_rows = n_rows;
     c->base_host_valid = false;
     c->offsets_dirty = true;
     c->stats_done = false;

@@ -224,13 +224,20 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const uint32_t *__re
                                                             const int64_t *__restrict__ base,
                                                             int64_t *__restrict__ offsets,
                                                             int64_t *__restrict__ totals, int n_chunks, int n_cols,
-                                                            int64_t g, int64_t *__restrict__ first_seg) {
+                                                            int64_t g, int64_t *__restrict__ first_seg,
+                                                            const int64_t *__restrict__ gathered, int64_t row_stride, int n_rows,
+                                                            int64_t *__restrict__ base_out) {
     __shared__ uint32_t wsum[kScanThreads / 64];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int q = blockIdx.x;
     const uint32_t *in = census + (size_t)q * n_chunks;
     int64_t *out = offsets + (size_t)q * n_chunks;
-    const int64_t b0 = base ? base[q] : 0;
+    int64_t b0 = base ? base[q] : 0;
+    if (gathered) {   // the base offset is the sum of the earlier ranks' totals, straight from the all-gather buffer
+        b0 = 0;
+        for (int r = 0; r < n_rows; ++r) b0 += gathered[(size_t)r * row_stride + q];
+        if (threadIdx.x == 0) base_out[q] = b0;
+    }
     int64_t carry = b0;
     for (int c0 = 0; c0 < n_chunks; c0 += kScanThreads * kScanPer) {
         const int first = c0 + threadIdx.x * kScanPer;
@@ -265,10 +272,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const uint32_t *__re
 }
 
 hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *offsets, int64_t *totals,
-                       int n_chunks, int n_cols, int64_t g, int64_t *first_seg, hipStream_t st) {
+                       int n_chunks, int n_cols, int64_t g, int64_t *first_seg, hipStream_t st,
+                       const int64_t *gathered, int64_t row_stride, int n_rows, int64_t *base_out) {
     if (n_cols <= 0 || n_chunks <= 0) return hipSuccess;
     hipLaunchKernelGGL(scan_kernel, dim3(n_cols), dim3(kScanThreads), 0, st, census, base, offsets, totals, n_chunks, n_cols,
-                       g, first_seg);
+                       g, first_seg, gathered, row_stride, n_rows, base_out);
     return hipGetLastError();
 }
 
@@ -732,22 +740,6 @@ __global__ __launch_bounds__(256) void stitch_kernel(K2Params p) {
         }
     }
     row.num = an + rn; row.den = ad + rd; row.k = ak + rk;
-}
-
-// base[q] = sum over the first n_rows rows of an all-gather buffer (rows of row_stride int64 values, the totals first)
-__global__ __launch_bounds__(256) void sum_rows_kernel(const int64_t *__restrict__ gathered, int64_t row_stride, int n_rows, int n,
-                                                       int64_t *__restrict__ base) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    int64_t a = 0;
-    for (int r = 0; r < n_rows; ++r) a += gathered[(size_t)r * row_stride + q];
-    base[q] = a;
-}
-
-hipError_t launch_sum_rows(const int64_t *gathered, int64_t row_stride, int n_rows, int n, int64_t *base, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gathered, row_stride, n_rows, n, base);
-    return hipGetLastError();
 }
 
 // the segment table as the four arrays the host getter hands out

@@ -179,7 +179,8 @@ int evofst_set_base_offsets_device(evofst_ctx *ctx, const void *d_offsets);
 /* The same from the result of the all-gather itself: d_gathered holds one row of row_stride int64 values per rank,
  * each starting with that rank's included totals; the base offsets of rank r are the sums of rows 0 .. n_rows-1 with
  * n_rows = r (the exclusive prefix the reference's running countedVariantNumber amounts to, process_vcf_fst.cpp:544-545;
- * evo_FstAgainstAll.cpp:188,204), formed by one small kernel on the context's stream. */
+ * evo_FstAgainstAll.cpp:188,204).  The sums are formed by the offset scan of the next evofst_run_stats, on the
+ * context's stream: the buffer has to keep its contents until that call's kernels have run (stream order is enough). */
 int evofst_set_base_offsets_gathered(evofst_ctx *ctx, const void *d_gathered, int64_t row_stride, int n_rows);
 int evofst_copy_included_totals(evofst_ctx *ctx, void *d_dst);
 int evofst_copy_boundary(evofst_ctx *ctx, void *d_dst);
