@@ -191,7 +191,7 @@ int plan_chunks(evofst_ctx *c) {
     return EVOFST_OK;
 }
 
-int run_scan(evofst_ctx *c) {
+int run_scan(evofst_ctx *c, int64_t *totals_copy = nullptr) {
     if (c->mode == MODE_PAIRS) {
         const int np = (int)c->pairs.size();
         int rc;
@@ -201,7 +201,7 @@ int run_scan(evofst_ctx *c) {
         record(c, 1, 0);
         HIPCHK(c, launch_scan((const uint32_t *)c->d_census.p, (const int64_t *)c->d_base.p, (int64_t *)c->d_offsets.p,
                               (int64_t *)c->d_incl_totals.p, c->n_chunks, np, std::max(1, c->g), (int64_t *)c->d_first_seg.p,
-                              c->stream, c->gathered, c->gathered_stride, c->gathered_rows, (int64_t *)c->d_base.p));
+                              c->stream, c->gathered, c->gathered_stride, c->gathered_rows, (int64_t *)c->d_base.p, totals_copy));
         record(c, 1, 1);
     } else if (c->mode == MODE_GLOBAL) {
         int rc;
@@ -210,7 +210,7 @@ int run_scan(evofst_ctx *c) {
         record(c, 1, 0);
         HIPCHK(c, launch_scan((const uint32_t *)c->d_used_kept.p, (const int64_t *)c->d_base.p, (int64_t *)c->d_uk_off.p,
                               (int64_t *)c->d_uk_tot.p, c->n_chunks, 2, 1, nullptr, c->stream, c->gathered, c->gathered_stride,
-                              c->gathered_rows, (int64_t *)c->d_base.p));
+                              c->gathered_rows, (int64_t *)c->d_base.p, totals_copy));
         record(c, 1, 1);
     }
     c->offsets_dirty = false;
@@ -998,8 +998,8 @@ extern "C" int evofst_copy_included_totals(evofst_ctx *c, void *d_dst) try {
     NEED_GPU(c);
     if (!c->counts_done || (c->mode != MODE_PAIRS && c->mode != MODE_GLOBAL)) return fail(c, EVOFST_ERR_STATE, "copy_included_totals: run_counts in a mode first");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc;
-    if (c->offsets_dirty && (rc = run_scan(c))) return rc;
+    // right after run_counts the scan is still to do: it writes the totals into the caller's buffer as well (no copy)
+    if (c->offsets_dirty) return run_scan(c, (int64_t *)d_dst);
     const void *src = c->mode == MODE_PAIRS ? c->d_incl_totals.p : c->d_uk_tot.p;
     const size_t n = c->mode == MODE_PAIRS ? c->pairs.size() : 2;
     HIPCHK(c, hipMemcpyAsync(d_dst, src, n * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -1064,7 +1064,7 @@ extern "C" int evofst_run_counts(evofst_ctx *c) try {
     HIPCHK(c, launch_k1(p, c->count_bytes, c->mode, c->stream));
     record(c, 0, 1);
     c->counts_done = true; c->stats_done = false;
-    if (c->mode != MODE_COUNTS && c->mode != MODE_GRAM && (rc = run_scan(c))) return rc;
+    c->offsets_dirty = true;     // the offset scan runs with the first call that needs it (run_stats, the totals getters)
     return EVOFST_OK;
 } catch (...) {
     return abi_exception(c);

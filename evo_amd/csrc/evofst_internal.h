@@ -202,7 +202,8 @@ struct SynthParams {
 hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t st);
 hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *offsets, int64_t *totals,
                        int n_chunks, int n_cols, int64_t g, int64_t *first_seg, hipStream_t st,
-                       const int64_t *gathered = nullptr, int64_t row_stride = 0, int n_rows = 0, int64_t *base_out = nullptr);
+                       const int64_t *gathered = nullptr, int64_t row_stride = 0, int n_rows = 0, int64_t *base_out = nullptr,
+                       int64_t *totals_copy = nullptr);
 hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st);
 hipError_t launch_stitch(const K2Params &p, hipStream_t st);
 hipError_t launch_totals(const K2Params &p, const int64_t *base, const int64_t *incl_totals, double *totals, double *carry,

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const uint32_t *__re
                                                             int64_t *__restrict__ totals, int n_chunks, int n_cols,
                                                             int64_t g, int64_t *__restrict__ first_seg,
                                                             const int64_t *__restrict__ gathered, int64_t row_stride, int n_rows,
-                                                            int64_t *__restrict__ base_out) {
+                                                            int64_t *__restrict__ base_out, int64_t *__restrict__ totals_copy) {
     __shared__ uint32_t wsum[kScanThreads / 64];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int q = blockIdx.x;
@@ -268,15 +268,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const uint32_t *__re
         __syncthreads();
     }
     if (threadIdx.x == 0 && totals) totals[q] = carry - b0;
+    if (threadIdx.x == 0 && totals_copy) totals_copy[q] = carry - b0;   // the caller's buffer (evofst_copy_included_totals)
     if (threadIdx.x == 0 && first_seg) first_seg[q] = b0 / g;    // segment-table row 0 of the pair in this shard
 }
 
 hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *offsets, int64_t *totals,
                        int n_chunks, int n_cols, int64_t g, int64_t *first_seg, hipStream_t st,
-                       const int64_t *gathered, int64_t row_stride, int n_rows, int64_t *base_out) {
+                       const int64_t *gathered, int64_t row_stride, int n_rows, int64_t *base_out, int64_t *totals_copy) {
     if (n_cols <= 0 || n_chunks <= 0) return hipSuccess;
     hipLaunchKernelGGL(scan_kernel, dim3(n_cols), dim3(kScanThreads), 0, st, census, base, offsets, totals, n_chunks, n_cols,
-                       g, first_seg, gathered, row_stride, n_rows, base_out);
+                       g, first_seg, gathered, row_stride, n_rows, base_out, totals_copy);
     return hipGetLastError();
 }
 
