@@ -156,10 +156,8 @@ def main():
         # one message per rank and pass: [included-site totals of this pass (nq x i64) | carries of the pass before
         # (nq x 4 f64, bit patterns)].  The totals are needed before K2; the carries only by the host after the
         # pass, so they ride with the next pass's totals and one more gather after the last pass delivers the rest.
-        t_send = torch.zeros(nq * 5, dtype=torch.int64, device="cuda")
-        t_recv = torch.zeros(world * nq * 5, dtype=torch.int64, device="cuda")
-        p_tot, p_carry = t_send.data_ptr(), t_send[nq:].data_ptr()
-        p_recv = t_recv.data_ptr()
+        msg = shard.PairsPassMessage(nq, world, rank, "cuda")
+        p_tot, p_carry, p_recv = msg.totals_ptr(), msg.carry_ptr(), msg.recv_ptr()
 
     e_prof = [False]
 
@@ -187,8 +185,8 @@ def main():
             with torch.cuda.stream(stream):
                 e.run_counts()
                 e.copy_included_totals(p_tot)
-                dist.all_gather_into_tensor(t_recv, t_send)
-                e.set_base_offsets_gathered(p_recv, 5 * nq, rank)     # sum of the earlier ranks' totals
+                msg.gather(dist)
+                e.set_base_offsets_gathered(p_recv, msg.row, rank)     # sum of the earlier ranks' totals
                 e.run_stats()
                 e.copy_boundary(p_carry)
 
@@ -196,7 +194,7 @@ def main():
         # the carries of the last pass (multi-rank pairs mode): one more gather, inside the timed region
         if multi and cfg["mode"] == "pairs":
             with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(t_recv, t_send)
+                msg.gather(dist)
 
     def fence():
         e.sync()
@@ -305,7 +303,7 @@ def main():
         # sanity of the device-side exchange: the gathered carries equal what the host getter returns (reported, and
         # said loudly on stderr, rather than raised: the timing above is valid either way)
         try:
-            own = t_recv.view(world, 5 * nq)[rank, nq:].contiguous().view(torch.float64).view(nq, 4).cpu().numpy()
+            own = msg.gathered_carries()[rank].cpu().numpy()
             ok = bool(np.array_equal(own, e.boundary(), equal_nan=True))
         except Exception as ex:  # noqa: BLE001
             ok = False

@@ -33,6 +33,44 @@ def torch_all_gather(group=None, device=None):
     return ag
 
 
+class PairsPassMessage:
+    """The one message a rank sends per pass in pairs mode when the pass stays on the device (bench.py):
+    row = [included-site totals of this pass (n_pairs x int64) | carries of the pass before (n_pairs x 4 float64, bit
+    patterns)].  The totals are needed on the device before K2 (evofst_set_base_offsets_gathered sums the rows of the
+    earlier ranks); the carries are host bookkeeping after the pass, so they ride with the next pass's totals and one
+    more gather after the last pass delivers the rest.  Tensors are torch tensors on `device`."""
+
+    def __init__(self, n_pairs, world, rank, device):
+        import torch
+        self.nq, self.world, self.rank = n_pairs, world, rank
+        self.row = 5 * n_pairs                                   # int64 values per rank
+        self.send = torch.zeros(self.row, dtype=torch.int64, device=device)
+        self.recv = torch.zeros(world * self.row, dtype=torch.int64, device=device)
+
+    # where the library writes / reads (device pointers for evofst_copy_included_totals, evofst_copy_boundary,
+    # evofst_set_base_offsets_gathered)
+    def totals_ptr(self):
+        return self.send.data_ptr()
+
+    def carry_ptr(self):
+        return self.send[self.nq:].data_ptr()
+
+    def recv_ptr(self):
+        return self.recv.data_ptr()
+
+    def gather(self, dist):
+        dist.all_gather_into_tensor(self.recv, self.send)
+
+    def gathered_totals(self):
+        """[world][n_pairs] int64: every rank's included-site totals of the pass just gathered"""
+        return self.recv.view(self.world, self.row)[:, :self.nq]
+
+    def gathered_carries(self):
+        """[world][n_pairs][4] float64: every rank's carries of the pass before the one just gathered"""
+        import torch
+        return self.recv.view(self.world, self.row)[:, self.nq:].contiguous().view(torch.float64).view(self.world, self.nq, 4)
+
+
 def base_offsets(all_totals, rank):
     """Exchange 1: included sites (per pair) that precede shard `rank`."""
     tot = np.asarray(all_totals[0]) * 0

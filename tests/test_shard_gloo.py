@@ -137,3 +137,39 @@ def test_against_all_exchange_matches_single_shard(world, size, step, cuts):
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+def _message_worker(rank, world, port, n_pass, ret):
+    """bench.py's multi-rank pairs pass with the kernels replaced by known numbers: per pass every rank learns the
+    totals of all ranks (base offsets = sum of the earlier rows) and, one gather later, the carries of that pass."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nq = 6
+        msg = shard.PairsPassMessage(nq, world, rank, "cpu")
+        tot_of = lambda r, k: torch.arange(nq, dtype=torch.int64) * 7 + 100 * r + k             # noqa: E731
+        car_of = lambda r, k: (torch.arange(nq * 4, dtype=torch.float64) + r + 0.25 * k).view(nq, 4)  # noqa: E731
+        ok = True
+        for k in range(n_pass):
+            msg.send[:nq] = tot_of(rank, k)                   # evofst_copy_included_totals
+            msg.gather(dist)
+            base = msg.gathered_totals()[:rank].sum(0)        # what evofst_set_base_offsets_gathered forms
+            ok &= bool(torch.equal(base, sum((tot_of(r, k) for r in range(rank)), torch.zeros(nq, dtype=torch.int64))))
+            if k > 0:
+                for r in range(world):
+                    ok &= bool(torch.equal(msg.gathered_carries()[r], car_of(r, k - 1)))
+            msg.send[nq:] = car_of(rank, k).view(-1).view(torch.int64)   # evofst_copy_boundary (bit patterns)
+        msg.gather(dist)                                      # the flush after the last pass
+        for r in range(world):
+            ok &= bool(torch.equal(msg.gathered_carries()[r], car_of(r, n_pass - 1)))
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_message_per_pass_protocol(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_message_worker, args=(world, _free_port(), 4, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)) and len(ret) == world
