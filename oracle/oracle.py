@@ -15,6 +15,7 @@ _REF = os.path.join(_HERE, "_ref", "libevo_refmath.so")
 _REF_PBS = os.path.join(_HERE, "_ref", "libevo_refpbs.so")
 _REF_ABS = os.path.join(_HERE, "_ref", "libevo_refabs.so")
 _REF_DIFFS = os.path.join(_HERE, "_ref", "libevo_refdiffs.so")
+_REF_DIST = os.path.join(_HERE, "_ref", "libevo_refdist.so")
 
 _dp = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -29,7 +30,8 @@ def build(force=False):
             os.path.join(_HERE, "evo_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "libevo_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF) or not os.path.exists(_REF_PBS)
-                                             or not os.path.exists(_REF_ABS) or not os.path.exists(_REF_DIFFS)):
+                                             or not os.path.exists(_REF_ABS) or not os.path.exists(_REF_DIFFS)
+                                             or not os.path.exists(_REF_DIST)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -165,6 +167,23 @@ def ref_pbs():
         R.ref_calculatePBSfromAFs.argtypes = [C.c_double] * 6 + [_dp]
         _ref_pbs = R
     return _ref_pbs
+
+
+_ref_dist = None
+
+
+def ref_dist():
+    """The reference's own DxyPerSNPfromAFs (evo_distanceToOutgroups.cpp:62-65), or None when oracle/_ref was never built."""
+    global _ref_dist
+    if _ref_dist is None:
+        build()
+        if not os.path.exists(_REF_DIST):
+            return None
+        R = C.CDLL(_REF_DIST)
+        R.ref_DxyPerSNPfromAFs.restype = C.c_double
+        R.ref_DxyPerSNPfromAFs.argtypes = [C.c_double, C.c_double]
+        _ref_dist = R
+    return _ref_dist
 
 
 _ref_abs = None

@@ -185,6 +185,26 @@ def test_abs_bit_equal_to_reference():
         assert_same_bits(b[:], a[:], "ABS %r" % (args,))
 
 
+@pytest.mark.skipif(O.ref_dist() is None, reason="oracle/_ref not built (no /root/reference here)")
+def test_dxy_from_afs_bit_equal_to_reference():
+    """orc_dxy_from_afs vs the reference's own DxyPerSNPfromAFs (evo_distanceToOutgroups.cpp:62-65) compiled from
+    /root/reference: every pair of allele frequencies c/n with n <= 24, the -1 sentinel of a population without a called
+    allele (process_vcf_utils.h:75), NaN, and random frequencies of larger populations."""
+    R = O.ref_dist()
+    L = O.lib()
+    L.orc_dxy_from_afs.restype = C.c_double
+    L.orc_dxy_from_afs.argtypes = [C.c_double, C.c_double]
+    afs = sorted({c / n for n in range(1, 25) for c in range(n + 1)}) + [-1.0, float("nan")]
+    got = np.array([[L.orc_dxy_from_afs(a, b) for b in afs] for a in afs])
+    want = np.array([[R.ref_DxyPerSNPfromAFs(a, b) for b in afs] for a in afs])
+    assert_same_bits(got, want, "DxyPerSNPfromAFs")
+    rng = np.random.default_rng(7)
+    n = rng.integers(1, 4000, (20000, 2)); c = (rng.random((20000, 2)) * (n + 1)).astype(np.int64)
+    a = c / n
+    got = np.array([L.orc_dxy_from_afs(x, y) for x, y in a]); want = np.array([R.ref_DxyPerSNPfromAFs(x, y) for x, y in a])
+    assert_same_bits(got, want, "DxyPerSNPfromAFs (random)")
+
+
 def test_dist_windows_against_numpy():
     """orc_dist_windows (evo_distanceToOutgroups.cpp:274-294) against a direct numpy evaluation, incl. carry."""
     rng = np.random.default_rng(9)
