@@ -42,39 +42,88 @@ HBM_PEAK_GBS = 8000.0
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(e, cfg, sample_sites):
-    """The CPU oracle (closed-form restatement, 1 thread) on the first sample_sites sites of the
-    same workload: counts from allele codes, per-site pair statistics, SNP windows."""
-    from oracle import oracle as O
-    S = sample_sites
-    tiles = e.download_tiles()
-    codes = e.unpack_codes(tiles, S)
-    sp = (np.arange(cfg["samples"]) % cfg["pops"]).astype(np.int32)
-    nf = e.pop_chroms()
-    t0 = time.perf_counter()
+def host_cores():
+    """Host cores this process may use: its affinity mask, capped by the pool's share (OMP_NUM_THREADS is 16 per GPU on
+    the GPU box, where os.cpu_count() reports the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        n = min(n, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    except ValueError:
+        n = min(n, 16)
+    return max(1, n)
+
+
+def _cpu_pass(O, cfg, codes, sp, nf, pairs):
+    """One pass of the CPU oracle over a range of sites: counts from allele codes, per-site statistics, windows."""
     alt, nm = O.counts_from_codes(codes, sp, cfg["pops"])
     if cfg["mode"] == "gram":
-        pi, pj = np.triu_indices(cfg["pops"], 1)
-        num, den, dxy, inc = O.pair_site_stats(alt, nm, nf, pi.astype(np.int32), pj.astype(np.int32))
-        starts = np.arange(0, S, cfg["size"])
+        pi, pj = pairs
+        num, den, dxy, inc = O.pair_site_stats(alt, nm, nf, pi, pj)
+        starts = np.arange(0, len(codes), cfg["size"])
         m = inc == 1
         for a in (num, den, dxy):
             np.add.reduceat(np.where(m, a, 0.0), starts, axis=0)
-        evals = S * len(pi)
     elif cfg["mode"] == "pairs":
-        pi, pj = e.all_pairs()
+        pi, pj = pairs
         num, den, dxy, inc = O.pair_site_stats(alt, nm, nf, pi, pj)
         for q in range(len(pi)):
             O.snp_windows(num, den, dxy, inc, q, cfg["size"], cfg["step"])
-        evals = S * len(pi)
     else:
         use = np.arange(cfg["pops"], dtype=np.int32)
         sizes = np.full(cfg["pops"], cfg["samples"] // cfg["pops"], np.int64)
         kept, num, den = O.global_site_stats(alt, nm, use, sizes)
         O.global_windows(kept, num, den, cfg["size"], cfg["step"])
-        evals = S * cfg["pops"]
-    dt = time.perf_counter() - t0
-    return evals / dt, dt
+
+
+def cpu_baseline(e, cfg, sample_sites):
+    """The CPU oracle (closed-form restatement in C, oracle/evo_oracle.c) on the first sample_sites sites of the same
+    workload, on one host core and then on every host core this process may use (site ranges in threads: the oracle's
+    C functions run without the GIL).  Returns (evaluations/s on all cores, cores, seconds, evaluations/s on one core,
+    seconds)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    S = sample_sites
+    codes = e.unpack_codes(e.download_tiles(0, S), S)
+    sp = (np.arange(cfg["samples"]) % cfg["pops"]).astype(np.int32)
+    nf = e.pop_chroms()
+    if cfg["mode"] == "global":
+        pairs, units = None, cfg["pops"]
+    else:
+        pi, pj = np.triu_indices(cfg["pops"], 1)
+        pairs, units = (pi.astype(np.int32), pj.astype(np.int32)), len(pi)
+    evals = float(S) * units
+    t0 = time.perf_counter()
+    _cpu_pass(O, cfg, codes, sp, nf, pairs)
+    dt1 = time.perf_counter() - t0
+    cores = host_cores()
+    # site ranges cut on multiples of the window step so every thread runs whole windows
+    per = max(cfg["size"] or 1, -(-S // cores))
+    per = -(-per // max(1, cfg["size"] or 1)) * max(1, cfg["size"] or 1)
+    ranges = [(a, min(S, a + per)) for a in range(0, S, per)]
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(lambda r: _cpu_pass(O, cfg, codes[r[0]:r[1]], sp, nf, pairs), ranges))
+        dtn = time.perf_counter() - t0
+    return evals / dtn, cores, dtn, evals / dt1, dt1
+
+
+def spawn_ranks(n):
+    """python bench.py --gpus N without torch.distributed.run: N children, one per GPU, rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    return rc
 
 
 def main():
@@ -85,6 +134,8 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-sites", type=int, default=-1, help="sites of the CPU baseline sample (0 = skip)")
     ap.add_argument("--dist-path", action="store_true", help="rehearsal: take the multi-rank step even with one rank")
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="no GPU work: the ranks only meet (gloo, CPU) and rank 0 prints how many there are -- tests the launch path")
     ap.add_argument("--sites", type=int, default=0, help="experiments only: another number of sites per GPU (the label says so)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -92,11 +143,29 @@ def main():
         cfg["sites"] = args.sites
         cfg["label"] += " [EXPERIMENT: %d sites per GPU]" % args.sites
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start one child per GPU before this process touches torch.cuda or HIP, wait for all of them and
+        # pass rank 0's JSON line through (rank 0 is the only child that writes to stdout)
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run --nproc-per-node %d, "
+                         "or without a launcher: bench.py starts the ranks itself)" % (args.gpus, world, args.gpus))
+    if args.rendezvous_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous_check": True, "n_gpus": args.gpus, "ranks": dist.get_world_size(), "rank_sum": int(t.item())}))
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
     torch.cuda.set_device(local_rank)
@@ -111,6 +180,8 @@ def main():
         os.dup2(2, 1)
         try:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if dist.get_world_size() != args.gpus:
+                raise SystemExit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -289,16 +360,20 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["label"], "sites_per_gpu": S, "samples": N, "pops": P,
-                   "units_per_site": units_per_site, "sharding": "contiguous site shards, one per GPU"},
+                   "units_per_site": units_per_site, "sharding": "contiguous site shards, one per GPU",
+                   "rccl_ranks": dist.get_world_size() if multi else 1},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and args.cpu_sites != 0:
         # the oracle does ~3e7 evaluations/s on one core: 6e8 evaluations are ~20 s; the whole cfg2 workload is less
         cs = args.cpu_sites if args.cpu_sites > 0 else min(S, max(2_000, int(6e8 / units_per_site)))
-        v, secs = cpu_baseline(e, cfg, cs)
-        out["cpu_baseline"] = {"value": v, "unit": "site*pair/s", "cores": 1, "kind": "port",
-                               "sample": "first %d sites of the same workload, oracle/evo_oracle.c closed-form "
-                                         "restatement on allele codes (counts + per-site stats + windows), %.1f s" % (cs, secs)}
+        v, cores, secs, v1, secs1 = cpu_baseline(e, cfg, cs)
+        out["cpu_baseline"] = {"value": v, "unit": "site*pair/s", "cores": cores, "kind": "port",
+                               "one_core": {"value": v1, "cores": 1, "seconds": secs1},
+                               "sample": "first %d sites of the same workload, oracle/evo_oracle.c closed-form restatement on "
+                                         "allele codes (counts + per-site stats + windows): %.1f s on 1 core, %.1f s with the "
+                                         "sites cut into %d ranges on %d threads (all host cores of this process's share)"
+                                         % (cs, secs1, secs, cores, cores)}
     if multi and cfg["mode"] == "pairs" and rank == 0:
         # sanity of the device-side exchange: the gathered carries equal what the host getter returns (reported, and
         # said loudly on stderr, rather than raised: the timing above is valid either way)

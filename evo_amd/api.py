@@ -55,6 +55,7 @@ SIGNATURES = {
     "evofst_attach_device": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     "evofst_synth": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_uint64, C.c_double]),
     "evofst_download_tiles": (C.c_int, [_vp, _vp]),
+    "evofst_download_tile_range": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
     "evofst_set_pairs": (C.c_int, [_vp, _i32p, _i32p, C.c_int]),
     "evofst_set_against_all": (C.c_int, [_vp, _i32p, C.c_int, _i64p]),
     "evofst_set_base_offsets_device": (C.c_int, [_vp, _vp]),
@@ -242,9 +243,17 @@ class EvoFst:
         self._chk(self.L.evofst_synth(self.h, n_sites, first_site_global, seed, missing_rate))
         self.n_sites = n_sites
 
-    def download_tiles(self):
-        tiles = np.empty(self.tiles_bytes(self.n_sites) // 8, np.uint64)
-        self._chk(self.L.evofst_download_tiles(self.h, tiles.ctypes.data_as(_vp)))
+    def download_tiles(self, first_site=0, n_sites=None):
+        """Tiles of the shard (or of the 64-site-aligned range [first_site, first_site + n_sites)) as uint64 words."""
+        if first_site == 0 and n_sites is None:
+            tiles = np.empty(self.tiles_bytes(self.n_sites) // 8, np.uint64)
+            self._chk(self.L.evofst_download_tiles(self.h, tiles.ctypes.data_as(_vp)))
+            return tiles
+        assert first_site % 64 == 0
+        n_sites = self.n_sites - first_site if n_sites is None else n_sites
+        nt = (n_sites + 63) // 64
+        tiles = np.empty(self.tiles_bytes(nt * 64) // 8, np.uint64)
+        self._chk(self.L.evofst_download_tile_range(self.h, first_site // 64, nt, tiles.ctypes.data_as(_vp)))
         return tiles
 
     # ---- modes

@@ -825,6 +825,20 @@ extern "C" int evofst_download_tiles(evofst_ctx *c, void *tiles) try {
     return abi_exception(c);
 }
 
+extern "C" int evofst_download_tile_range(evofst_ctx *c, int64_t first_tile, int64_t n_tiles, void *tiles) try {
+    if (!c || !tiles || first_tile < 0 || n_tiles <= 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_sites == 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "no data on the device");
+    if (first_tile + n_tiles > (int64_t)n_tiles_of(c->n_sites)) return fail(c, EVOFST_ERR_ARG, "download_tile_range: tile range out of bounds");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t tb = (size_t)c->W * kTileSites * 16;
+    HIPCHK(c, hipMemcpyAsync(tiles, (const char *)c->tiles + (size_t)first_tile * tb, (size_t)n_tiles * tb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
+}
+
 // ================================================================== modes
 
 extern "C" int evofst_set_pairs(evofst_ctx *c, const int32_t *pair_i, const int32_t *pair_j, int n_pairs) try {

@@ -142,6 +142,8 @@ int evofst_synth(evofst_ctx *ctx, int64_t n_sites, int64_t first_site_global, ui
                  double missing_rate);
 /* D2H copy of the tile buffer (tests). */
 int evofst_download_tiles(evofst_ctx *ctx, void *tiles);
+/* The same for tiles [first_tile, first_tile + n_tiles) only (n_tiles * tile_bytes bytes). */
+int evofst_download_tile_range(evofst_ctx *ctx, int64_t first_tile, int64_t n_tiles, void *tiles);
 
 /* ------------------------------------------------------------------ modes */
 

@@ -43,6 +43,8 @@ def test_cfg4_shard_properties(engine):
 
 
 def _pairs_properties(engine, S, N, P, slices, miss):
+    from tests import parity_log
+    from tests.test_gpu_pairs import _window_abs_sums
     sp = round_robin_pops(N, P)
     engine.set_layout(sp, P)
     engine.set_pairs()
@@ -61,7 +63,12 @@ def _pairs_properties(engine, S, N, P, slices, miss):
         assert np.array_equal(seg_a["sum_dxy_k"][:n, q], seg_b["sum_dxy_k"][:n, q])          # integers: exact
         for name in ("sum_num", "sum_den"):
             a, b = seg_a[name][:n, q], seg_b[name][:n, q]
-            assert np.all(np.abs(a - b) <= 1e-12 * SIZE)                                       # |term| <= 1
+            # two GPU runs against each other: every |num term| and den term of a window is <= its den term, so the
+            # window's denominator sum bounds the sum of |terms| of either (each run is within 1e-12 of that of the truth)
+            scale = np.maximum(seg_a["sum_den"][:n, q], seg_b["sum_den"][:n, q])
+            err = np.abs(a - b)
+            parity_log.record("fullsize_%dx%d/chunking_invariance/%s" % (S, N, name), err, 2e-12 * scale)
+            assert np.all(err <= 2e-12 * scale)
         # additivity: segments + carry = totals
         for col, name in ((0, "sum_num"), (1, "sum_den"), (2, "sum_dxy_k")):
             s = seg_a[name][:n, q].sum() + car_a[q, col]
@@ -69,14 +76,12 @@ def _pairs_properties(engine, S, N, P, slices, miss):
         assert n * SIZE + car_a[q, 3] == tot_a[q, 3]
 
     # oracle parity on slices: the first 20k sites (windows from the start) and two interior slices (per-site values)
-    tiles = engine.download_tiles()
-    last = max(f + n for f, n in slices)
-    codes = engine.unpack_codes(tiles, last)   # the tiles are in site order: a prefix is enough
-    del tiles
     nf = n_full_of(sp, P)
     pi, pj = engine.all_pairs()
     for first, n in slices:
-        oalt, onm = O.counts_from_codes(codes[first:first + n], sp, P)
+        a0 = first - first % 64
+        codes = engine.unpack_codes(engine.download_tiles(a0, first + n - a0), first + n - a0)[first - a0:]
+        oalt, onm = O.counts_from_codes(codes, sp, P)
         alt, nm = engine.counts(first, n)
         assert np.array_equal(alt, oalt) and np.array_equal(nm, onm)
         onum, oden, odxy, oinc = O.pair_site_stats(oalt, onm, nf, pi, pj)
@@ -92,11 +97,18 @@ def _pairs_properties(engine, S, N, P, slices, miss):
                 k = len(ow["end_site"])
                 assert k > 50
                 assert np.array_equal(gw["end_site"][:k], ow["end_site"])
-                for name in ("sum_num", "sum_den", "sum_dxy"):
+                m = oinc[:, q] == 1
+                with np.errstate(all="ignore"):     # the three terms of calculateFstNumerator per site (test_gpu_pairs.py)
+                    power = (oalt[m, pi[q]] / onm[m, pi[q]] - oalt[m, pj[q]] / onm[m, pj[q]]) ** 2
+                    num_terms = power + np.abs(power - onum[m, q])
+                for name, terms in (("sum_num", num_terms), ("sum_den", oden[m, q]), ("sum_dxy", odxy[m, q])):
                     a, b = gw[name][:k], ow[name]
                     fin = np.isfinite(b)
                     assert (np.isfinite(a) == fin).all()
-                    assert np.all(np.abs(a[fin] - b[fin]) <= 1e-12 * SIZE)
+                    bar = 1e-12 * _window_abs_sums(terms, ow["first_var"], SIZE)[fin]
+                    err = np.abs(a[fin] - b[fin])
+                    parity_log.record("fullsize_%dx%d/first_windows/%s" % (S, N, name), err, bar)
+                    assert np.all(err <= bar)
 
 
 def _with_chunk_tiles(ct, fn):
@@ -111,11 +123,11 @@ def _with_chunk_tiles(ct, fn):
             os.environ["EVOFST_CHUNK_TILES"] = old
 
 
-def test_cfg3_shard_properties(engine):
-    """One GPU's share of BASELINE configs[2] (10 M sites x 1000 samples, 100 populations against all, -w 20,10 over
-    8 GPUs = 1.25 M sites): the window rows must not depend on the chunking at all (every lane sums its deque column
-    oldest -> newest, so they are bit-identical), and the first sites agree with the oracle bit for bit."""
-    S3, N3, P3, size, step = 1_250_000, 1000, 100, 20, 10
+def test_cfg3_full_size_properties(engine):
+    """BASELINE configs[2] whole on one GPU (10 M sites x 1000 samples = 5 GB of tiles, 100 populations against all,
+    -w 20,10): the window rows must not depend on the chunking at all (every lane sums its deque column oldest ->
+    newest, so they are bit-identical), and the first sites agree with the oracle bit for bit."""
+    S3, N3, P3, size, step = 10_000_000, 1000, 100, 20, 10
     sp = round_robin_pops(N3, P3)
     engine.set_layout(sp, P3)
     use = np.arange(P3, dtype=np.int32)
@@ -128,18 +140,18 @@ def test_cfg3_shard_properties(engine):
     def run():
         engine.run()
         return engine.global_windows(), engine.included_totals().copy()
-    ga, ta = _with_chunk_tiles(4, run)
+    ga, ta = _with_chunk_tiles(0, run)      # the library's own choice
     gb, tb = _with_chunk_tiles(9, run)
     assert np.array_equal(ta, tb)
-    assert len(ga["end_site"]) == len(gb["end_site"]) > 100_000
+    assert len(ga["end_site"]) == len(gb["end_site"]) > 800_000
     for k in ("start_site", "end_site"):
         assert np.array_equal(ga[k], gb[k])
     for k in ("mean_num", "mean_den"):
         assert_same_bits(ga[k], gb[k], k)
 
+    del gb
     n = 6000
-    tiles = engine.download_tiles()
-    codes = engine.unpack_codes(tiles, n)
+    codes = engine.unpack_codes(engine.download_tiles(0, n), n)
     oalt, onm = O.counts_from_codes(codes, sp, P3)
     alt, nm = engine.counts(0, n)
     assert np.array_equal(alt, oalt) and np.array_equal(nm, onm)
@@ -160,11 +172,12 @@ def test_cfg3_shard_properties(engine):
     assert_same_bits(gf, ow["fst"], "window Fst")
 
 
-def test_cfg5_geometry_properties(engine):
-    """The geometry of BASELINE configs[4] (5000 samples, 500 populations = 124 750 pairs, 15 % missing genotypes) on
-    100 k sites: windows of 200 sites equal the sums of their two 100-site halves (integers exactly, doubles to 1e-12 of
-    the terms), and the first windows agree with the oracle."""
-    S5, N5, P5 = 100_000, 5000, 500
+def test_cfg5_shard_properties(engine):
+    """One GPU's share of BASELINE configs[4] (20 M sites x 5000 samples over 8 GPUs = 2.5 M sites, 6.25 GB of tiles;
+    500 populations = 124 750 pairs, 15 % missing genotypes): windows of 200 sites equal the sums of their two 100-site
+    halves (integers exactly, doubles to 1e-12 of the terms) in the middle and at the end of the shard, and the first
+    windows agree with the oracle."""
+    S5, N5, P5 = 2_500_000, 5000, 500
     sp = round_robin_pops(N5, P5)
     engine.set_layout(sp, P5)
     engine.set_gram()
@@ -172,23 +185,34 @@ def test_cfg5_geometry_properties(engine):
     engine.synth(S5, seed=20261110, missing_rate=0.15)
     engine.run_counts()
     engine.set_site_windows(np.arange(0, S5 + 1, 100, dtype=np.int64))
-    engine.run_gram(500, 20)
-    fine = engine.gram()
+    from tests import parity_log
+    n100 = S5 // 100
+    fines = []
+    for w0 in (12_000, n100 - 20):
+        engine.run_gram(w0, 20)
+        fines.append(engine.gram())
     engine.run_gram(0, 3)
     head = engine.gram()
     engine.set_site_windows(np.arange(0, S5 + 1, 200, dtype=np.int64))
-    engine.run_gram(250, 10)
-    coarse = engine.gram()
-    for k in ("sum_dxy_k", "n_included"):
-        assert np.array_equal(coarse[k], fine[k][0::2] + fine[k][1::2])
-    for k in ("sum_num", "sum_den"):
-        a, b = coarse[k], fine[k][0::2] + fine[k][1::2]
-        assert (np.isnan(a) == np.isnan(b)).all()
-        fin = ~np.isnan(b)
-        assert np.all(np.abs(a[fin] - b[fin]) <= 1e-12 * 400)       # |term| <= 1; num is formed from den's terms too
+    for w0, fine in zip((6_000, n100 // 2 - 10), fines):
+        engine.run_gram(w0, 10)
+        coarse = engine.gram()
+        for k in ("sum_dxy_k", "n_included"):
+            assert np.array_equal(coarse[k], fine[k][0::2] + fine[k][1::2])
+        for k in ("sum_num", "sum_den"):
+            a, b = coarse[k], fine[k][0::2] + fine[k][1::2]
+            assert (np.isnan(a) == np.isnan(b)).all()
+            fin = ~np.isnan(b)
+            # num is formed from den's terms too, and every |term| of either is <= the den term: the window's den sum
+            # bounds the sum of |terms| (two GPU results against each other: 2e-12)
+            with np.errstate(all="ignore"):
+                scale = np.abs(fine["sum_den"][0::2]) + np.abs(fine["sum_den"][1::2])
+            err = np.abs(a[fin] - b[fin])
+            parity_log.record("cfg5_shard/halves_add_up/" + k, err, 2e-12 * scale[fin] + 1e-300)
+            assert np.all(err <= 2e-12 * scale[fin] + 1e-300)
 
     n = 300
-    codes = engine.unpack_codes(engine.download_tiles(), n)
+    codes = engine.unpack_codes(engine.download_tiles(0, n), n)
     oalt, onm = O.counts_from_codes(codes, sp, P5)
     alt, nm = engine.counts(0, n)
     assert np.array_equal(alt, oalt) and np.array_equal(nm, onm)
@@ -204,7 +228,12 @@ def test_cfg5_geometry_properties(engine):
         with np.errstate(all="ignore"):
             rn = np.where(m, onum[100 * w:100 * w + 100], 0.0).sum(axis=0)
             rd = np.where(m, oden[100 * w:100 * w + 100], 0.0).sum(axis=0)
-        for a, b in ((head["sum_num"][w], rn), (head["sum_den"][w], rd)):
+        with np.errstate(all="ignore"):
+            an = np.where(m, np.abs(onum[100 * w:100 * w + 100]), 0.0).sum(axis=0)
+        for name, a, b, scale in (("sum_num", head["sum_num"][w], rn, an + rd), ("sum_den", head["sum_den"][w], rd, rd)):
             assert (np.isnan(a) == np.isnan(b)).all()
             fin = ~np.isnan(b)
-            assert np.all(np.abs(a[fin] - b[fin]) <= 1e-12 * 200)
+            # the Gram path forms num = den - sum t - sum h: its bar is 1e-12 of the |terms| of both sums
+            err = np.abs(a[fin] - b[fin])
+            parity_log.record("cfg5_shard/first_windows/" + name, err, 1e-12 * scale[fin] + 1e-300)
+            assert np.all(err <= 1e-12 * scale[fin] + 1e-300)

@@ -81,7 +81,16 @@ def test_site_stats_bit_exact(engine, S, N, P, miss, flags):
     assert np.array_equal(engine.included_totals(), oinc.sum(axis=0))
 
 
-def _check_windows(engine, sp, codes, fl, P, size, step, pairs=None):
+def _window_abs_sums(terms, first_var, size):
+    """Sum of |terms| over each window: terms = the pair's included sites in order, a window covers the `size` of them
+    that start at 1-based rank first_var."""
+    ca = np.concatenate(([0.0], np.cumsum(np.abs(np.nan_to_num(terms, nan=0.0, posinf=0.0, neginf=0.0)))))
+    lo = np.asarray(first_var, np.int64) - 1
+    return ca[lo + size] - ca[lo]
+
+
+def _check_windows(engine, sp, codes, fl, P, size, step, pairs=None, tag="snp_windows"):
+    from tests import parity_log
     pi, pj = engine.all_pairs() if pairs is None else pairs
     nf = n_full_of(sp, P)
     oalt, onm = O.counts_from_codes(codes, sp, P)
@@ -97,24 +106,41 @@ def _check_windows(engine, sp, codes, fl, P, size, step, pairs=None):
         assert np.array_equal(gw["first_var"], ow["first_var"]), q
         assert np.array_equal(gw["end_site"], ow["end_site"]), q
         m = oinc[:, q] == 1
-        for name, terms in (("sum_num", onum[m, q]), ("sum_den", oden[m, q]), ("sum_dxy", odxy[m, q])):
+        absn = absd = None
+        # The terms of a window's numerator sum are the three terms of calculateFstNumerator (process_vcf_fst.h:19-25) at
+        # every site: power = (p1 - p2)^2, fraction1, fraction2 (num = power - fraction1 - fraction2); those of the
+        # denominator and of dxy are the per-site values themselves (all >= 0).
+        with np.errstate(all="ignore"):
+            power = (oalt[m, pi[q]] / onm[m, pi[q]] - oalt[m, pj[q]] / onm[m, pj[q]]) ** 2
+            num_terms = power + np.abs(power - onum[m, q])
+        for name, terms in (("sum_num", num_terms), ("sum_den", oden[m, q]), ("sum_dxy", odxy[m, q])):
             a, b = gw[name], ow[name]
             ok_nan = np.isnan(a) == np.isnan(b)
             assert ok_nan.all(), (q, name)
             fin = ~np.isnan(b)
-            # scale: sum of |terms| of a window is bounded by size * max|term|
-            scale = size * np.nanmax(np.abs(terms)) if terms.size and np.isfinite(np.nanmax(np.abs(terms))) else 1.0
-            assert np.all(np.abs(a[fin] - b[fin]) <= REL_TOL * max(scale, 1e-300)), (q, name)
-        # Fst of a window: same clamp and NaN behaviour, 1e-12 where the denominator is not degenerate
+            # the bar of the north star: 1e-12 of the sum of |terms| of that very window
+            scale = _window_abs_sums(terms, ow["first_var"], size)
+            if name == "sum_num": absn = scale
+            if name == "sum_den": absd = scale
+            err = np.abs(a[fin] - b[fin])
+            parity_log.record("%s/%s" % (tag, name), err, REL_TOL * scale[fin])
+            assert np.all(err <= REL_TOL * scale[fin]), (q, name, float(np.max(err / np.maximum(scale[fin], 1e-300))))
+        # Fst of a window = sum num / sum den: same clamp and NaN behaviour, and 1e-12 * sum|num terms| / sum den
         fa, fb = gw["fst"], ow["fst"]
         assert (np.isnan(fa) == np.isnan(fb)).all()
-        fin = np.isfinite(fb) & (fb > 1e-6)
-        assert np.all(np.abs(fa[fin] - fb[fin]) <= 1e-9 * np.abs(fb[fin]))
+        fin = np.isfinite(fb) & np.isfinite(ow["sum_num"]) & (ow["sum_den"] > 0)
+        with np.errstate(all="ignore"):
+            fbar = REL_TOL * (absn + absd * np.abs(fb)) / ow["sum_den"]       # d(n/d) <= (dn + |f| dd) / d
+        err = np.abs(fa[fin] - fb[fin])
+        parity_log.record("%s/fst" % tag, err, fbar[fin])
+        assert np.all(err <= fbar[fin]), (q, "fst")
         # whole-shard sums
         assert tot[q, 3] == m.sum()
         if m.any() and np.isfinite(onum[m, q]).all():
-            assert abs(tot[q, 0] - onum[m, q].sum()) <= REL_TOL * np.abs(onum[m, q]).sum() + 1e-300
-            assert abs(tot[q, 1] - oden[m, q].sum()) <= REL_TOL * np.abs(oden[m, q]).sum() + 1e-300
+            for col, vals, terms in ((0, onum[m, q], num_terms), (1, oden[m, q], oden[m, q])):
+                err = abs(tot[q, col] - vals.sum()); bar = REL_TOL * np.abs(terms).sum() + 1e-300
+                parity_log.record("%s/totals" % tag, err, bar)
+                assert err <= bar
 
 
 @pytest.mark.parametrize("S,N,P,miss,size,step", [(6000, 40, 4, 0.05, 100, 100), (5000, 60, 5, 0.1, 20, 10),
@@ -170,6 +196,17 @@ def test_snp_windows_small_chunks(engine, monkeypatch):
     engine.set_pairs()
     _check_windows(engine, sp, codes, fl, 4, 150, 150)
     _check_windows(engine, sp, codes, fl, 4, 64, 32)
+
+
+def test_snp_windows_longest_chunks(engine, monkeypatch):
+    """Chunks of 256 tiles (16 k sites, the library's maximum) with short overlapping windows: the error of a window's
+    sums must not grow with the position of the window in its chunk."""
+    monkeypatch.setenv("EVOFST_CHUNK_TILES", "256")
+    rng = np.random.default_rng(256)
+    sp, codes, fl = _setup(engine, rng, 40000, 40, 4, 0.05, flags=True)
+    engine.set_pairs()
+    _check_windows(engine, sp, codes, fl, 4, 20, 10, tag="snp_windows_256_tile_chunks")
+    _check_windows(engine, sp, codes, fl, 4, 100, 100, tag="snp_windows_256_tile_chunks")
 
 
 def test_base_offsets_shift_windows(engine):
