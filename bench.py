@@ -277,7 +277,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kms = np.zeros((args.steps, 4))
+    kms = np.zeros((args.steps, 5))
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
@@ -292,7 +292,7 @@ def main():
     for i in range(reps):
         step()
         e.sync()
-        for k in range(4):
+        for k in range(5):
             try:
                 kms[i, k] = e.kernel_ms(k)
             except Exception:
@@ -320,17 +320,25 @@ def main():
     else:
         k2_bytes = S * P * cb + S * 8.0 + (S / cfg["step"]) * P * 16.0
     names = ["k1_count_kernel", "scan_kernel",
-             {"pairs": "k2_window_kernel", "gram": "gram_kernel"}.get(cfg["mode"], "global_window_kernel"), "stitch_kernel"]
+             {"pairs": "k2_window_kernel", "gram": "gram_kernel"}.get(cfg["mode"], "global_window_kernel"), "stitch_kernel",
+             "fused_pairs_kernel"]
     if cfg["mode"] == "gram":
         kavg[2] = float(np.sum(gram_ms))          # popsums + gram launches of every batch of one step
-    dom = 0 if kavg[0] >= kavg[2] else 2
-    dom_bytes = k1_bytes if dom == 0 else k2_bytes
+    fused = cfg["mode"] == "pairs" and not multi and kavg[4] > 0
+    if fused:
+        # one kernel from the tiles to the segment rows: 2 bits per haplotype read, one 28-byte row per segment and pair written
+        dom = 4
+        kavg[0] = kavg[1] = kavg[2] = 0.0         # stale events of a K1 launch behind a getter, if any
+        dom_bytes = S * (N / 2.0) + (S / g) * e.n_pairs * 28.0
+    else:
+        dom = 0 if kavg[0] >= kavg[2] else 2
+        dom_bytes = k1_bytes if dom == 0 else k2_bytes
     achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9 if kavg[dom] > 0 else 0.0
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 +
     # WRITE_SIZE; profiles/README.md says how they were collected) -- null for a configuration not profiled
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
             tr = json.load(f).get(args.config, {}).get(names[dom])
         if tr:
             traffic = tr["hbm_read_bytes"] + tr["hbm_write_bytes"]
@@ -340,7 +348,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "pipeline_GBps": pipeline_bytes * world / (dt / args.steps) / 1e9,
-                "kernels_ms": {names[k]: float(kavg[k]) for k in range(4)},
+                "kernels_ms": {names[k]: float(kavg[k]) for k in range(5) if kavg[k] > 0},
                 "k1_GBps": k1_bytes / (kavg[0] * 1e-3) / 1e9 if kavg[0] > 0 else 0.0,
                 "algorithmic_bytes": dom_bytes}
 

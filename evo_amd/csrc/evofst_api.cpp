@@ -29,7 +29,7 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
-constexpr int kNumKernels = 4;
+constexpr int kNumKernels = 5;   // 0 counts, 1 offsets scan, 2 pair / against-all / Gram statistics, 3 stitch, 4 fused pairs pass
 
 }  // namespace
 
@@ -88,6 +88,11 @@ struct evofst_ctx {
         d_row_end, d_row_num, d_row_den;
     int64_t row_cap = 0;
 
+    // fused pairs pass (evofst_fused.hip): look-back granules, ticket + error words, launch epoch
+    DevBuf d_agg0, d_agg1, d_agg2, d_fsync;
+    uint32_t epoch = 0;
+    bool fused_check = false;         // a fused launch has not had its error word looked at yet
+    bool plain_counts = false;        // d_counts holds the counts of the loaded data (from any K1 launch)
     bool counts_done = false, stats_done = false;
     bool profiling = false;
     hipEvent_t ev[kNumKernels][2] = {};
@@ -286,6 +291,112 @@ int d2h(evofst_ctx *c, T *dst, const void *src, size_t n) {
     return EVOFST_OK;
 }
 
+
+// (Re)allocates a buffer whose words a kernel polls: new memory is zeroed (a tag of a past epoch is as good as zero).
+int ensure_zeroed(evofst_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return EVOFST_OK;
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(b.p, 0, b.bytes, c->stream));
+    return EVOFST_OK;
+}
+
+constexpr int kFusedFan = 32, kFusedMaxChunks = 32 * 32 * 64;
+
+// Tiles per chunk of the fused pairs pass, or 0 when this shape goes through K1 + scan + K2 instead.
+int fused_chunk_tiles(evofst_ctx *c) {
+    if (c->mode != MODE_PAIRS || c->pairs.size() > (size_t)kK2Threads || c->gathered) return 0;
+    if (getenv("EVOFST_NO_FUSE")) return 0;
+    const int n_tiles = n_tiles_of(c->n_sites);
+    const int max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
+    auto lds = [&](int ct) { return fused_lds_bytes(c->n_pops, c->W, (int)c->segs.size(), max_n, ct, c->count_bytes); };
+    int ct = 0;
+    if (const char *e = getenv("EVOFST_CHUNK_TILES")) ct = atoi(e);
+    if (ct <= 0) ct = 4;
+    ct = std::max(ct, (n_tiles + kFusedMaxChunks - 1) / kFusedMaxChunks);
+    const size_t budget = 64 * 1024;                       // two workgroups per CU at the very least
+    while (ct > 1 && lds(ct) > budget && (n_tiles + (ct - 1) - 1) / (ct - 1) <= kFusedMaxChunks) --ct;
+    if (lds(ct) > 150 * 1024) return 0;
+    return ct;
+}
+
+int run_fused(evofst_ctx *c, int ct) {
+    const size_t np = c->pairs.size();
+    c->n_tiles = n_tiles_of(c->n_sites);
+    c->chunk_tiles = ct;
+    c->n_chunks = (c->n_tiles + ct - 1) / ct;
+    const int64_t g = c->g;
+    c->seg_cap = c->n_sites / g + 2;
+    int rc;
+    if ((rc = ensure(c, c->d_incl_totals, np * 8)) || (rc = ensure(c, c->d_first_seg, np * 8))) return rc;
+    if ((rc = ensure(c, c->d_seg_rows, (size_t)c->seg_cap * np * sizeof(SegRow)))) return rc;
+    const size_t cq = (size_t)c->n_chunks * np;
+    if ((rc = ensure(c, c->d_tail, cq * 3 * 8)) || (rc = ensure(c, c->d_tail_n, cq * 16))) return rc;
+    const size_t n1 = (c->n_chunks + kFusedFan - 1) / kFusedFan, n2 = (n1 + kFusedFan - 1) / kFusedFan;
+    if (c->epoch == 0xffffffffu) {     // the epoch counter wraps: forget every tag
+        release(c->d_agg0); release(c->d_agg1); release(c->d_agg2);
+        c->epoch = 0;
+    }
+    if ((rc = ensure_zeroed(c, c->d_agg0, cq * 8)) || (rc = ensure_zeroed(c, c->d_agg1, n1 * np * 8)) ||
+        (rc = ensure_zeroed(c, c->d_agg2, n2 * np * 8)) || (rc = ensure_zeroed(c, c->d_fsync, 256))) return rc;
+    FusedParams p{};
+    p.tiles = (const ulonglong2 *)c->tiles;
+    p.site_flags = c->have_flags ? c->flags : nullptr;
+    p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.W = c->W; p.P = c->n_pops;
+    p.segs = (const SegDesc *)c->d_segs.p; p.word_seg_start = (const int32_t *)c->d_wss.p; p.n_segs = (int)c->segs.size();
+    p.n_full = (const int32_t *)c->d_nfull.p;
+    p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
+    p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)np;
+    p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
+    p.g = c->g;
+    p.base = (const int64_t *)c->d_base.p;
+    p.first_segment = (int64_t *)c->d_first_seg.p; p.incl_totals = (int64_t *)c->d_incl_totals.p;
+    p.seg_cap = c->seg_cap; p.seg_rows = (SegRow *)c->d_seg_rows.p;
+    p.tail = (double *)c->d_tail.p; p.tail_n = (int4 *)c->d_tail_n.p;
+    p.agg0 = (uint64_t *)c->d_agg0.p; p.agg1 = (uint64_t *)c->d_agg1.p; p.agg2 = (uint64_t *)c->d_agg2.p;
+    p.ticket = (uint32_t *)c->d_fsync.p; p.err = (uint32_t *)c->d_fsync.p + 32;
+    p.epoch = ++c->epoch;
+    int max_blocks = 0;
+    if (const char *e = getenv("EVOFST_FUSED_BLOCKS")) max_blocks = atoi(e);
+    record(c, 4, 0);
+    HIPCHK(c, launch_fused(p, c->count_bytes, max_blocks, c->stream, nullptr));
+    record(c, 4, 1);
+    K2Params k2 = make_k2(c);
+    record(c, 3, 0);
+    HIPCHK(c, launch_stitch(k2, c->stream));
+    record(c, 3, 1);
+    c->fused_check = true;
+    c->offsets_dirty = false;
+    c->counts_done = false;          // K1's census / masks are not there (plain_counts says whether its counts are)
+    c->stats_done = true;
+    return EVOFST_OK;
+}
+
+// After the stream has been waited for: did a wait inside the last fused launch give up?
+int fused_verdict(evofst_ctx *c) {
+    if (!c->fused_check) return EVOFST_OK;
+    uint32_t err = 0;
+    HIPCHK(c, hipMemcpyAsync(&err, (const uint32_t *)c->d_fsync.p + 32, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->fused_check = false;
+    if (err) {
+        HIPCHK(c, hipMemsetAsync(c->d_fsync.p, 0, 256, c->stream));
+        c->stats_done = false;
+        return fail(c, EVOFST_ERR_HIP, "fused pairs pass: a look-back wait gave up (results discarded)");
+    }
+    return EVOFST_OK;
+}
+
+int launch_k1_counts(evofst_ctx *c, int mode);
+
+// Getters that need the per-site counts: K1 runs on demand (the fused pairs pass keeps no counts in HBM).
+int need_counts(evofst_ctx *c, const char *who) {
+    if (c->plain_counts) return EVOFST_OK;
+    if (c->n_sites == 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, std::string(who) + ": no data");
+    return launch_k1_counts(c, MODE_COUNTS);
+}
+
 }  // namespace
 
 // ================================================================== lifecycle
@@ -330,7 +441,8 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
                       &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_halo_num, &c->d_halo_den, &c->d_halo_tag, &c->d_gU, &c->d_gC, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_carry,
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
-                      &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles};
+                      &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles, &c->d_agg0, &c->d_agg1,
+                      &c->d_agg2, &c->d_fsync};
     for (DevBuf *b : bufs) release(*b);
     for (auto &pair : c->ev)
         for (auto &e : pair)
@@ -412,6 +524,7 @@ extern "C" int evofst_set_layout(evofst_ctx *c, int n_samples, int n_pops, const
     c->mode = MODE_COUNTS;
     c->pairs.clear(); c->use_idx.clear(); c->thresholds.clear();
     c->counts_done = c->stats_done = false;
+    c->plain_counts = false;
     c->cap_sites = 0; c->n_sites = 0;
     if (c->host_only) return EVOFST_OK;
     return upload_layout(c);
@@ -746,6 +859,7 @@ static int begin_data(evofst_ctx *c, int64_t n_sites) {
     if ((int64_t)n_tiles_of(n_sites) * kTileSites > (int64_t)INT_MAX) return fail(c, EVOFST_ERR_UNSUPPORTED, "too many sites for one shard");
     HIPCHK(c, hipSetDevice(c->device));
     c->counts_done = c->stats_done = false;
+    c->plain_counts = false;
     c->offsets_dirty = true;
     c->n_multi = 0;
     return EVOFST_OK;
@@ -1034,11 +1148,11 @@ extern "C" int evofst_copy_boundary(evofst_ctx *c, void *d_dst) try {
 
 // ================================================================== compute
 
-extern "C" int evofst_run_counts(evofst_ctx *c) try {
-    if (!c) return EVOFST_ERR_ARG;
-    NEED_GPU(c);
-    if (c->n_sites == 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "run_counts: no data");
-    HIPCHK(c, hipSetDevice(c->device));
+namespace {
+// K1 in the given mode.  MODE_COUNTS (the on-demand form behind the getters) leaves the chunk plan of a finished
+// statistics pass alone: its tails are indexed by it.
+int launch_k1_counts(evofst_ctx *c, int mode) {
+    const int keep_ct = c->chunk_tiles, keep_nc = c->n_chunks;
     plan_chunks(c);
     K1Params p{};
     p.tiles = (const ulonglong2 *)c->tiles;
@@ -1046,11 +1160,11 @@ extern "C" int evofst_run_counts(evofst_ctx *c) try {
     p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.W = c->W; p.P = c->n_pops;
     p.segs = (const SegDesc *)c->d_segs.p; p.word_seg_start = (const int32_t *)c->d_wss.p; p.n_segs = (int)c->segs.size();
     p.n_full = (const int32_t *)c->d_nfull.p;
+    int rc;
+    if ((rc = ensure(c, c->d_counts, (size_t)c->n_tiles * c->n_pops * kTileSites * c->count_bytes))) return rc;
     p.counts = c->d_counts.p;
     p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
-    if (const char *e = getenv("EVOFST_DEBUG_K1")) p.debug = atoi(e);
-    int rc;
-    if (c->mode == MODE_PAIRS) {
+    if (mode == MODE_PAIRS) {
         p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)c->pairs.size();
         if ((size_t)p.n_pairs * 20 + (size_t)c->n_pops * 128 + (size_t)c->segs.size() * 16 > 140 * 1024)
             return fail(c, EVOFST_ERR_UNSUPPORTED, "run_counts: too many pairs for the per-chunk census in LDS (use the Gram path: evofst_set_gram)");
@@ -1060,13 +1174,13 @@ extern "C" int evofst_run_counts(evofst_ctx *c) try {
         if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
         if ((rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8))) return rc;
         p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
-    } else if (c->mode == MODE_GRAM) {
+    } else if (mode == MODE_GRAM) {
         if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 32))) return rc;
         if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
         if ((rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8))) return rc;
         p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
         c->gram_missing = -1;
-    } else if (c->mode == MODE_GLOBAL) {
+    } else if (mode == MODE_GLOBAL) {
         if ((rc = ensure(c, c->d_gtotals, (size_t)c->n_tiles * kTileSites * 8))) return rc;
         if ((rc = ensure(c, c->d_kept, (size_t)c->n_tiles * 8))) return rc;
         if ((rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8))) return rc;
@@ -1075,9 +1189,23 @@ extern "C" int evofst_run_counts(evofst_ctx *c) try {
         p.chunk_used_kept = (uint32_t *)c->d_used_kept.p;
     }
     record(c, 0, 0);
-    HIPCHK(c, launch_k1(p, c->count_bytes, c->mode, c->stream));
+    HIPCHK(c, launch_k1(p, c->count_bytes, mode, c->stream));
     record(c, 0, 1);
-    c->counts_done = true; c->stats_done = false;
+    c->plain_counts = true;
+    if (mode == MODE_COUNTS && c->stats_done) { c->chunk_tiles = keep_ct; c->n_chunks = keep_nc; }
+    return EVOFST_OK;
+}
+}  // namespace
+
+extern "C" int evofst_run_counts(evofst_ctx *c) try {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_sites == 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "run_counts: no data");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->stats_done = false;
+    int rc = launch_k1_counts(c, c->mode);
+    if (rc) return rc;
+    c->counts_done = true;
     c->offsets_dirty = true;     // the offset scan runs with the first call that needs it (run_stats, the totals getters)
     return EVOFST_OK;
 } catch (...) {
@@ -1205,6 +1333,15 @@ extern "C" int evofst_get_gram(evofst_ctx *c, double *sum_num, double *sum_den, 
 }
 
 extern "C" int evofst_run(evofst_ctx *c) try {
+    if (!c) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->mode == MODE_PAIRS && c->n_sites > 0 && c->tiles) {
+        // pairs mode: one streaming kernel from the tiles to the segment rows (no counts kept in HBM; the getters
+        // that want them run K1 on demand)
+        HIPCHK(c, hipSetDevice(c->device));
+        const int ct = fused_chunk_tiles(c);
+        if (ct > 0) return run_fused(c, ct);
+    }
     int rc = evofst_run_counts(c);
     if (rc) return rc;
     return evofst_run_stats(c);
@@ -1217,7 +1354,7 @@ extern "C" int evofst_sync(evofst_ctx *c) try {
     NEED_GPU(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return EVOFST_OK;
+    return fused_verdict(c);
 } catch (...) {
     return abi_exception(c);
 }
@@ -1252,10 +1389,10 @@ static int check_range(evofst_ctx *c, int64_t first, int64_t n) {
 extern "C" int evofst_get_counts(evofst_ctx *c, int64_t first_site, int64_t n_sites, int32_t *alt, int32_t *nm) try {
     if (!c || !alt || !nm) return EVOFST_ERR_ARG;
     NEED_GPU(c);
-    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "get_counts: run_counts first");
     int rc = check_range(c, first_site, n_sites);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = need_counts(c, "get_counts"))) return rc;
     const size_t n = (size_t)n_sites * c->n_pops;
     DevBuf da, dn;
     if ((rc = ensure(c, da, n * 4)) || (rc = ensure(c, dn, n * 4))) { release(da); release(dn); return rc; }
@@ -1274,10 +1411,11 @@ extern "C" int evofst_get_counts(evofst_ctx *c, int64_t first_site, int64_t n_si
 extern "C" int evofst_get_included_totals(evofst_ctx *c, int64_t *totals) try {
     if (!c || !totals) return EVOFST_ERR_ARG;
     NEED_GPU(c);
-    if (!c->counts_done || c->mode == MODE_COUNTS) return fail(c, EVOFST_ERR_STATE, "get_included_totals: run_counts in a mode first");
+    const bool fused = c->stats_done && !c->counts_done && c->mode == MODE_PAIRS;   // the fused pass wrote the totals itself
+    if ((!c->counts_done && !fused) || c->mode == MODE_COUNTS) return fail(c, EVOFST_ERR_STATE, "get_included_totals: run_counts in a mode first");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if (c->offsets_dirty && (rc = run_scan(c))) return rc;
+    if (!fused && c->offsets_dirty && (rc = run_scan(c))) return rc;
     if (c->mode == MODE_PAIRS) { if ((rc = d2h(c, totals, c->d_incl_totals.p, c->pairs.size()))) return rc; }
     else { if ((rc = d2h(c, totals, c->d_uk_tot.p, 2))) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1290,10 +1428,11 @@ extern "C" int evofst_get_site_stats(evofst_ctx *c, int64_t first_site, int64_t 
                                      double *dxy, uint8_t *include) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
-    if (!c->counts_done || c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_site_stats: pairs mode + run_counts first");
+    if (c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_site_stats: pairs mode first");
     int rc = check_range(c, first_site, n_sites);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = need_counts(c, "get_site_stats"))) return rc;
     const size_t n = (size_t)n_sites * c->pairs.size();
     DevBuf b[4];
     SiteStatParams p{};
@@ -1329,9 +1468,10 @@ int branch_site_stats(evofst_ctx *c, const char *what, int arity, int n_out, int
                       const int32_t *sets, double *out, uint8_t *used) {
     if (!c || !sets || !out || !used || n_sets <= 0) return EVOFST_ERR_ARG;
     NEED_GPU(c);
-    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, std::string(what) + ": run_counts first");
     int rc = check_range(c, first_site, n_sites);
     if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = need_counts(c, what))) return rc;
     for (int i = 0; i < arity * n_sets; ++i)
         if (sets[i] < 0 || sets[i] >= c->n_pops) return fail(c, EVOFST_ERR_ARG, std::string(what) + ": population index out of range");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1379,7 +1519,7 @@ extern "C" int evofst_get_dist_windows(evofst_ctx *c, int n_windows, const int64
     if (!c || !win_off || !out_idx || !used || !missing || n_windows <= 0 || n_out <= 0 || n_in < 0) return EVOFST_ERR_ARG;
     if (n_in > 0 && (!in_idx || !sum || !nsnp || !miss)) return EVOFST_ERR_ARG;
     NEED_GPU(c);
-    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "get_dist_windows: run_counts first");
+    if (!c->host_only) { (void)hipSetDevice(c->device); int rc0 = need_counts(c, "get_dist_windows"); if (rc0) return rc0; }
     if (win_off[0] < 0 || win_off[n_windows] > c->n_sites) return fail(c, EVOFST_ERR_ARG, "get_dist_windows: window offsets out of bounds");
     for (int w = 0; w < n_windows; ++w)
         if (win_off[w] > win_off[w + 1]) return fail(c, EVOFST_ERR_ARG, "get_dist_windows: window offsets must not decrease");
@@ -1592,10 +1732,10 @@ extern "C" int evofst_get_pop_site_div(evofst_ctx *c, int64_t first_site, int64_
                                        double *pi) try {
     if (!c) return EVOFST_ERR_ARG;
     NEED_GPU(c);
-    if (!c->counts_done) return fail(c, EVOFST_ERR_STATE, "get_pop_site_div: run_counts first");
     int rc = check_range(c, first_site, n_sites);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = need_counts(c, "get_pop_site_div"))) return rc;
     const size_t n = (size_t)n_sites * c->n_pops;
     DevBuf b[3];
     PopDivParams p{};
@@ -1628,6 +1768,7 @@ extern "C" int64_t evofst_max_segments(evofst_ctx *c) {
 
 static int segment_rows(evofst_ctx *c, std::vector<int64_t> &first, std::vector<int64_t> &rows) {
     const size_t np = c->pairs.size();
+    { int rc0 = fused_verdict(c); if (rc0) return rc0; }
     std::vector<int64_t> tot(np);
     int rc = d2h(c, tot.data(), c->d_incl_totals.p, np);
     if (rc) return rc;
@@ -1688,7 +1829,9 @@ static int launch_totals_and_carry(evofst_ctx *c, bool want_totals, double *d_ca
 
 static int totals_and_carry(evofst_ctx *c, double *totals, double *carry) {
     const size_t np = c->pairs.size();
-    int rc = launch_totals_and_carry(c, totals != nullptr);
+    int rc = fused_verdict(c);
+    if (rc) return rc;
+    rc = launch_totals_and_carry(c, totals != nullptr);
     if (rc) return rc;
     if ((rc = d2h(c, totals, c->d_totals.p, np * 4))) return rc;
     if ((rc = d2h(c, carry, c->d_carry.p, np * 4))) return rc;

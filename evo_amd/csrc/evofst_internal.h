@@ -30,6 +30,47 @@ constexpr uint32_t kXFixed = 1u << 29;  // c == nm       (or site skipped)
 
 enum { MODE_COUNTS = 0, MODE_PAIRS = 1, MODE_GLOBAL = 2, MODE_GRAM = 3 };
 
+// ---- device helpers shared by evofst_kernels.hip and evofst_fused.hip
+template <typename CT> struct CountTraits;
+template <> struct CountTraits<uint16_t> { static constexpr int shift = 8; static constexpr uint32_t mask = 0xffu; };
+template <> struct CountTraits<uint32_t> { static constexpr int shift = 16; static constexpr uint32_t mask = 0xffffu; };
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+constexpr int kRcpMax = 1023;
+constexpr int kSub = 32;            // sites per LDS table fill (half a tile)
+constexpr int kSubPad = kSub + 1;   // row stride in entries: pop-indexed reads stay conflict-free
+#ifndef EVOFST_K2_GRP
+#define EVOFST_K2_GRP 4
+#endif
+#ifndef EVOFST_K2_ENT_BATCH
+#define EVOFST_K2_ENT_BATCH 4
+#endif
+#ifndef EVOFST_K2_UNROLL
+#define EVOFST_K2_UNROLL 8
+#endif
+#ifndef EVOFST_K2_WPS
+#define EVOFST_K2_WPS 3
+#endif
+constexpr int kGrp = EVOFST_K2_GRP;             // sites per snapshot group
+constexpr int kK2WavesPerSimd = EVOFST_K2_WPS;  // register budget: 512 / waves per SIMD
+constexpr uint32_t kXBadNum = 1u << 30;         // nm < 2  (h undefined)
+constexpr uint32_t kXBadDen = 1u << 31;         // nm == 0 (p undefined)
+
+struct __align__(16) RcpEntry { double r0, rr0, r1; uint32_t flags, pad; };   // read as two 16-byte halves
+
+// position of the n-th (1-based) set bit of m; needs 1 <= n <= popc(m)
+__device__ __forceinline__ int nth_set_bit(uint32_t m, int n) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        const int c = __popc(m & ((1u << w) - 1u));
+        if (n > c) { n -= c; pos += w; m >>= w; }
+    }
+    return pos;
+}
+
+
 struct K1Params {
     const ulonglong2 *tiles;
     const uint8_t *site_flags;  // may be null
@@ -80,6 +121,37 @@ struct K2Params {
     // chunk-boundary partials, planes [chunk][pair] (a wave writes contiguous rows)
     double *tail;                  // [3][n_chunks][n_pairs] {num, den, k} after the last completed segment
     int4 *tail_n;                  // {sites summed in the tail, segments the chunk completed, row of its first segment, -}
+};
+
+// pairs mode in one streaming kernel (evofst_fused.hip): tiles -> segment rows, nothing else read from or kept in HBM
+struct FusedParams {
+    const ulonglong2 *tiles;
+    const uint8_t *site_flags;  // may be null
+    int64_t n_sites;
+    int32_t n_tiles, W, P;
+    const SegDesc *segs;
+    const int32_t *word_seg_start;  // [W+1]
+    int32_t n_segs;
+    const int32_t *n_full;          // [P]
+    int32_t max_n;
+    const uint32_t *pairs;          // i | j << 16
+    int32_t n_pairs;
+    int32_t chunk_tiles, n_chunks;
+    int32_t g;
+    const int64_t *base;            // [n_pairs] included sites of the pair before this shard
+    int64_t *first_segment;         // [n_pairs] out: base / g
+    int64_t *incl_totals;           // [n_pairs] out: included sites of the shard
+    int64_t seg_cap;
+    SegRow *seg_rows;               // [seg_cap][n_pairs]
+    double *tail;                   // [3][n_chunks][n_pairs], as K2 writes it
+    int4 *tail_n;                   // [n_chunks][n_pairs]
+    // look-back state: 8-byte {epoch, count} granules, valid when the tag is this launch's epoch
+    uint64_t *agg0;                 // [n_chunks][n_pairs] included sites of a chunk
+    uint64_t *agg1;                 // [ceil(n_chunks / 32)][n_pairs] ... of a group of 32 chunks
+    uint64_t *agg2;                 // [ceil(n_chunks / 1024)][n_pairs] ... of a group of 32 groups
+    uint32_t *ticket;               // chunk tickets; back to 0 when the launch ends
+    uint32_t *err;                  // set when a wait gave up
+    uint32_t epoch;
 };
 
 struct SiteStatParams {
@@ -227,6 +299,9 @@ hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st);
 size_t k2_lds_bytes(int P, int max_n);
+size_t fused_lds_bytes(int P, int W, int n_segs, int max_n, int chunk_tiles, int count_bytes);
+// max_blocks <= 0: as many workgroups as the device holds at once (occupancy query)
+hipError_t launch_fused(const FusedParams &p, int count_bytes, int max_blocks, hipStream_t st, int *grid_out);
 size_t global_lds_bytes(int tn_max, int max_n, int n_use, int size);
 void global_rcp_split(int tn_max, int max_n, int *lo, int *hi);
 

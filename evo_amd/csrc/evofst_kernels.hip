@@ -19,11 +19,6 @@
 
 namespace evofst {
 
-template <typename CT> struct CountTraits;
-template <> struct CountTraits<uint16_t> { static constexpr int shift = 8; static constexpr uint32_t mask = 0xffu; };
-template <> struct CountTraits<uint32_t> { static constexpr int shift = 16; static constexpr uint32_t mask = 0xffffu; };
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // =====================================================================================
 // K1: allele counting.  Replaces the per-sample loops of getVariantCountsForFst
@@ -309,43 +304,11 @@ hipError_t launch_scan(const uint32_t *census, const int64_t *base, int64_t *off
 //
 // Reciprocals come from a per-block LDS table {1/nm, 1/nm^2, 1/(nm-1), flags} (0 where undefined).
 // =====================================================================================
-constexpr int kRcpMax = 1023;
-constexpr int kSub = 32;            // sites per LDS table fill (half a tile)
-constexpr int kSubPad = kSub + 1;   // row stride in entries: pop-indexed reads stay conflict-free
-#ifndef EVOFST_K2_GRP
-#define EVOFST_K2_GRP 4
-#endif
-#ifndef EVOFST_K2_ENT_BATCH
-#define EVOFST_K2_ENT_BATCH 4
-#endif
-#ifndef EVOFST_K2_UNROLL
-#define EVOFST_K2_UNROLL 8
-#endif
-#ifndef EVOFST_K2_WPS
-#define EVOFST_K2_WPS 3
-#endif
-constexpr int kGrp = EVOFST_K2_GRP;             // sites per snapshot group
-constexpr int kK2WavesPerSimd = EVOFST_K2_WPS;  // register budget: 512 / waves per SIMD
-constexpr uint32_t kXBadNum = 1u << 30;         // nm < 2  (h undefined)
-constexpr uint32_t kXBadDen = 1u << 31;         // nm == 0 (p undefined)
-
-struct __align__(16) RcpEntry { double r0, rr0, r1; uint32_t flags, pad; };   // read as two 16-byte halves
-
 size_t k2_lds_bytes(int P, int max_n) {
     return (size_t)P * kSubPad * (3 * 8 + 2 * 4) + (size_t)P * (2 * 8 + 4 + 8) +
            (max_n <= kRcpMax ? (size_t)(max_n + 1) * sizeof(RcpEntry) : 0) + 64;
 }
 
-// position of the n-th (1-based) set bit of m; needs 1 <= n <= popc(m)
-__device__ __forceinline__ int nth_set_bit(uint32_t m, int n) {
-    int pos = 0;
-#pragma unroll
-    for (int w = 16; w >= 1; w >>= 1) {
-        const int c = __popc(m & ((1u << w) - 1u));
-        if (n > c) { n -= c; pos += w; m >>= w; }
-    }
-    return pos;
-}
 
 template <typename CT, bool use_rcp>
 __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(K2Params p) {
