@@ -106,7 +106,7 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("evo_amd: %s is missing -- build it with `make -C evo_amd/csrc` "
                                "(there is no CPU fallback)" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get("EVOFST_LIB", LIB_PATH))   # tools/ point this at the -DEVOFST_EXPERIMENTS build
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if the library does not export the symbol
             f.restype = res

@@ -243,7 +243,9 @@ K2Params make_k2(evofst_ctx *c) {
     p.n_sites = c->n_sites;
     p.n_tiles = c->n_tiles; p.P = c->n_pops;
     p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
+#ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_DEBUG_K2")) p.debug = atoi(e);
+#endif
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.pairs = (const uint32_t *)c->d_pairs.p;
     p.n_pairs = (int)c->pairs.size();
@@ -304,28 +306,37 @@ int ensure_zeroed(evofst_ctx *c, DevBuf &b, size_t bytes) {
 
 constexpr int kFusedFan = 32, kFusedMaxChunks = 32 * 32 * 64;
 
-// Tiles per chunk of the fused pairs pass, or 0 when this shape goes through K1 + scan + K2 instead.
-int fused_chunk_tiles(evofst_ctx *c) {
+// Tiles per chunk of the fused pairs pass and sites per table fill, or 0 when this shape goes through K1 + scan + K2.
+int fused_plan(evofst_ctx *c, int *sub_out) {
     if (c->mode != MODE_PAIRS || c->pairs.size() > (size_t)kK2Threads || c->gathered) return 0;
     if (getenv("EVOFST_NO_FUSE")) return 0;
     const int n_tiles = n_tiles_of(c->n_sites);
+    const int np = (int)c->pairs.size();
     const int max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
-    auto lds = [&](int ct) { return fused_lds_bytes(c->n_pops, c->W, (int)c->segs.size(), max_n, ct, c->count_bytes); };
+    const int unit = np <= 64 ? 4 : 1;                    // up to 64 pairs: every wave of the workgroup owns a quarter of a chunk
+    int sub = 32;
+#ifdef EVOFST_EXPERIMENTS
+    if (const char *e = getenv("EVOFST_FUSED_SUB")) sub = atoi(e) == 16 ? 16 : 32;
+#endif
+    auto lds = [&](int ct) { return fused_lds_bytes(c->n_pops, max_n, np, ct, c->count_bytes, sub); };
     int ct = 0;
     if (const char *e = getenv("EVOFST_CHUNK_TILES")) ct = atoi(e);
-    if (ct <= 0) ct = 4;
+    if (ct <= 0) ct = 4 * unit;
     ct = std::max(ct, (n_tiles + kFusedMaxChunks - 1) / kFusedMaxChunks);
-    const size_t budget = 64 * 1024;                       // two workgroups per CU at the very least
-    while (ct > 1 && lds(ct) > budget && (n_tiles + (ct - 1) - 1) / (ct - 1) <= kFusedMaxChunks) --ct;
+    ct = (ct + unit - 1) / unit * unit;
+    const size_t budget = 72 * 1024;                      // two workgroups per CU at the very least
+    while (ct > unit && lds(ct) > budget && (n_tiles + (ct - unit) - 1) / (ct - unit) <= kFusedMaxChunks) ct -= unit;
     if (lds(ct) > 150 * 1024) return 0;
+    *sub_out = sub;
     return ct;
 }
 
-int run_fused(evofst_ctx *c, int ct) {
+int run_fused(evofst_ctx *c, int ct, int sub) {
     const size_t np = c->pairs.size();
     c->n_tiles = n_tiles_of(c->n_sites);
     c->chunk_tiles = ct;
-    c->n_chunks = (c->n_tiles + ct - 1) / ct;
+    const int n_chunks = (c->n_tiles + ct - 1) / ct;
+    c->n_chunks = fused_tail_chunks((int)np, n_chunks);   // entries of the tail table, which stitch_kernel / totals_kernel walk
     const int64_t g = c->g;
     c->seg_cap = c->n_sites / g + 2;
     int rc;
@@ -333,22 +344,21 @@ int run_fused(evofst_ctx *c, int ct) {
     if ((rc = ensure(c, c->d_seg_rows, (size_t)c->seg_cap * np * sizeof(SegRow)))) return rc;
     const size_t cq = (size_t)c->n_chunks * np;
     if ((rc = ensure(c, c->d_tail, cq * 3 * 8)) || (rc = ensure(c, c->d_tail_n, cq * 16))) return rc;
-    const size_t n1 = (c->n_chunks + kFusedFan - 1) / kFusedFan, n2 = (n1 + kFusedFan - 1) / kFusedFan;
+    const size_t n1 = (n_chunks + kFusedFan - 1) / kFusedFan, n2 = (n1 + kFusedFan - 1) / kFusedFan;
     if (c->epoch == 0xffffffffu) {     // the epoch counter wraps: forget every tag
         release(c->d_agg0); release(c->d_agg1); release(c->d_agg2);
         c->epoch = 0;
     }
-    if ((rc = ensure_zeroed(c, c->d_agg0, cq * 8)) || (rc = ensure_zeroed(c, c->d_agg1, n1 * np * 8)) ||
+    if ((rc = ensure_zeroed(c, c->d_agg0, (size_t)n_chunks * np * 8)) || (rc = ensure_zeroed(c, c->d_agg1, n1 * np * 8)) ||
         (rc = ensure_zeroed(c, c->d_agg2, n2 * np * 8)) || (rc = ensure_zeroed(c, c->d_fsync, 256))) return rc;
     FusedParams p{};
     p.tiles = (const ulonglong2 *)c->tiles;
     p.site_flags = c->have_flags ? c->flags : nullptr;
     p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.W = c->W; p.P = c->n_pops;
-    p.segs = (const SegDesc *)c->d_segs.p; p.word_seg_start = (const int32_t *)c->d_wss.p; p.n_segs = (int)c->segs.size();
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
     p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)np;
-    p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
+    p.chunk_tiles = ct; p.n_chunks = n_chunks;
     p.g = c->g;
     p.base = (const int64_t *)c->d_base.p;
     p.first_segment = (int64_t *)c->d_first_seg.p; p.incl_totals = (int64_t *)c->d_incl_totals.p;
@@ -358,9 +368,12 @@ int run_fused(evofst_ctx *c, int ct) {
     p.ticket = (uint32_t *)c->d_fsync.p; p.err = (uint32_t *)c->d_fsync.p + 32;
     p.epoch = ++c->epoch;
     int max_blocks = 0;
+#ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_FUSED_BLOCKS")) max_blocks = atoi(e);
+    if (const char *e = getenv("EVOFST_DEBUG_FUSED")) p.debug = atoi(e);
+#endif
     record(c, 4, 0);
-    HIPCHK(c, launch_fused(p, c->count_bytes, max_blocks, c->stream, nullptr));
+    HIPCHK(c, launch_fused(p, c->count_bytes, sub, max_blocks, c->stream));
     record(c, 4, 1);
     K2Params k2 = make_k2(c);
     record(c, 3, 0);
@@ -1244,7 +1257,9 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
         int tn_max = 0, max_n_use = 0;
         for (int32_t k : c->use_idx) { tn_max += c->n_full[k]; max_n_use = std::max(max_n_use, c->n_full[k]); }
         size_t lds = global_lds_bytes(tn_max, max_n_use, nu, c->snp_size);
+#ifdef EVOFST_EXPERIMENTS
         if (const char *e = getenv("EVOFST_DEBUG_GLOBAL_LDS")) lds += (size_t)atoi(e);   // occupancy experiments
+#endif
         if (lds > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: SIZE * populations too large for the LDS deque");
         if ((rc = ensure(c, c->d_chunk_rows, (size_t)c->n_chunks * 4))) return rc;
         if ((rc = ensure(c, c->d_row_off, (size_t)c->n_chunks * 8))) return rc;
@@ -1307,7 +1322,9 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p;
     p.n_pairs = np;
     p.out_num = (double *)c->d_gnum.p; p.out_den = (double *)c->d_gden.p; p.out_k = (double *)c->d_gk.p; p.out_cnt = (double *)c->d_gcnt.p;
+#ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_DEBUG_GRAM")) p.debug = atoi(e);
+#endif
     record(c, 2, 0);
     HIPCHK(c, launch_gram(p, c->count_bytes, c->gram_missing != 0, c->stream));
     record(c, 2, 1);
@@ -1339,8 +1356,9 @@ extern "C" int evofst_run(evofst_ctx *c) try {
         // pairs mode: one streaming kernel from the tiles to the segment rows (no counts kept in HBM; the getters
         // that want them run K1 on demand)
         HIPCHK(c, hipSetDevice(c->device));
-        const int ct = fused_chunk_tiles(c);
-        if (ct > 0) return run_fused(c, ct);
+        int sub = 32;
+        const int ct = fused_plan(c, &sub);
+        if (ct > 0) return run_fused(c, ct, sub);
     }
     int rc = evofst_run_counts(c);
     if (rc) return rc;

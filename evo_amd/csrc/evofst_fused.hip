@@ -4,22 +4,27 @@
 // (process_vcf_fst.cpp:243-280), the site filter (:543-544), calculateFstNumerator / Denominator
 // (process_vcf_fst.h:19-30), calculateDxy (process_vcf_fst.cpp:297-323) and the SNP windows (:638-650).
 //
-// A workgroup takes chunks of a few tiles in ticket order (one atomic per chunk) and does, per chunk:
-//   phase A  lane = site: 16-byte coalesced loads of the tile rows, popcounts under wave-uniform masks, packed
-//            {alt, non-missing} counts and the zero / fixed ballots of every population INTO LDS (nothing
-//            but the tiles is read from HBM and no counts are written to it);
-//   census   thread = pair: included sites of the chunk from the ballots (filter :543-544);
-//   look-back the chunk publishes its census as 8-byte {epoch, count} granules and sums those of the
-//            chunks before it (three levels of fan-out 32: chunks of its group, groups of its super-group,
+// A workgroup works through chunks of a few tiles: its first chunk is its own index, the later ones come in ticket
+// order (one atomic per chunk).  Per chunk:
+//   phase A  lane = site: 16-byte coalesced loads of the tile rows, popcounts under wave-uniform masks that the
+//            scalar unit forms from the population sizes while the vector unit counts, packed {alt, non-missing}
+//            counts and the zero / fixed ballots of every population INTO LDS (nothing but the tiles is read
+//            from HBM and no counts are written to it);
+//   census   lane = pair: included sites of the chunk from the ballots (filter :543-544);
+//   look-back the chunk publishes its census as 8-byte {epoch, count} granules and sums those of the chunks
+//            before it (three levels of fan-out 32: chunks of its group, groups of its super-group,
 //            super-groups; the owner of a group's last chunk has read all the others of the group for its
-//            own prefix, so it publishes the group's aggregate for free).  Tickets are taken by running
-//            workgroups only, so everything a chunk waits for belongs to a workgroup that is running
-//            or done, and phase A waits for nothing: the waits always end.  Spins are bounded anyway and
-//            give up through an error word that every workgroup polls;
-//   phase B  the counts in LDS -> per-population tables (p, prefix sums of h, t, c) per half tile, thread =
-//            pair walks the sites, segment sums at the window boundaries (K2's scheme, see evofst_kernels.hip),
-//            with accumulators that restart with every chunk of at most a few hundred sites.
-// The segment a chunk starts in the middle of is completed by stitch_kernel from the chunks' tails, as before.
+//            own prefix, so it publishes the group's aggregate for free).  A chunk only ever waits for chunks
+//            with smaller indices and phase A waits for nothing, so the waits end as long as workgroups start
+//            in index order or all fit on the device (the grid is sized by the occupancy query); spins are
+//            bounded and give up through an error word that every workgroup polls;
+//   phase B  the counts in LDS -> per-population tables (p, prefix sums of h, t, c) per group of SUB sites,
+//            lane = pair walks the sites, segment sums at the window boundaries (K2's scheme, see
+//            evofst_kernels.hip), with accumulators that restart with every (sub-)chunk of a few hundred sites.
+// Two shapes: up to 64 pairs -- every wave of the workgroup owns a quarter of the chunk's tiles through phases A
+// and B with tables of its own (no workgroup barrier inside them); more pairs -- the waves share one set of tables
+// and split the pairs.  The segment a (sub-)chunk starts in the middle of is completed by stitch_kernel from the
+// tails, as before.
 #include "evofst_internal.h"
 
 #include <algorithm>
@@ -28,22 +33,34 @@ namespace evofst {
 
 constexpr int kFan = 32;                  // look-back fan-out per level
 constexpr int kFuseNB = 8;                // tile rows per load batch (8 KiB per wave)
+constexpr int kFuseWaves = 4;             // waves per workgroup in the wave-private shape
 constexpr uint32_t kSpinLimit = 1u << 22; // polls before a wait gives up (seconds; a healthy wait takes microseconds)
 
-size_t fused_lds_bytes(int P, int W, int n_segs, int max_n, int chunk_tiles, int count_bytes) {
-    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+static size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// LDS of one region: the tables of phase B and the counts / ballots of `tiles` tiles.
+static size_t fused_region_bytes(int P, int tiles, int count_bytes, int sub) {
+    const size_t subp = (size_t)sub + 1;
     size_t b = 0;
-    b += a16(max_n <= kRcpMax ? (size_t)(max_n + 1) * sizeof(RcpEntry) : 0);
-    b += 3 * a16((size_t)P * kSubPad * 8);      // pt, PH, PT
+    b += 3 * a16((size_t)P * subp * 8);         // pt, PH, PT
     b += 2 * a16((size_t)P * 8);                // carH, carT
-    b += 2 * a16((size_t)P * kSubPad * 4);      // xt, PC
+    b += 2 * a16((size_t)P * subp * 4);         // xt, PC
     b += a16((size_t)P * 4);                    // carC
-    b += a16((size_t)n_segs * sizeof(SegDesc));
-    b += a16((size_t)(W + 1) * 4);
-    b += a16((size_t)chunk_tiles * P * kTileSites * count_bytes);
-    b += a16((size_t)chunk_tiles * 2 * P * 8);  // zero / fixed ballots
-    b += 2 * a16((size_t)chunk_tiles * 8);      // irregular, skip
-    b += 16;                                    // ticket broadcast
+    b += a16((size_t)tiles * P * kTileSites * count_bytes);
+    b += a16((size_t)tiles * 2 * P * 8);        // zero / fixed ballots
+    b += 2 * a16((size_t)tiles * 8);            // irregular, skip
+    return b;
+}
+
+size_t fused_lds_bytes(int P, int max_n, int n_pairs, int chunk_tiles, int count_bytes, int sub) {
+    const bool wp = n_pairs <= 64;
+    size_t b = a16(max_n <= kRcpMax ? (size_t)(max_n + 1) * sizeof(RcpEntry) : 0) + 64 + a16((size_t)(P + 2) * 4);
+    if (wp) {
+        b += a16((size_t)kFuseWaves * 64 * 4) + a16((size_t)kFuseWaves * 3 * 64 * 4);   // census and look-back partials of the waves
+        b += kFuseWaves * fused_region_bytes(P, chunk_tiles / kFuseWaves, count_bytes, sub);
+    } else {
+        b += fused_region_bytes(P, chunk_tiles, count_bytes, sub);
+    }
     return b;
 }
 
@@ -57,60 +74,198 @@ __device__ __forceinline__ uint64_t load_granule(const uint64_t *g) {
     return __hip_atomic_load((gu64 *)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Sum of the values of granule rows [lo, hi) of one column (stride = granules per row); waits for rows that are
-// not yet published.  Returns false when the wait gave up (error word set, by this or by another thread).
-__device__ __forceinline__ bool sum_granules(const uint64_t *col, size_t stride, int lo, int hi, uint32_t epoch,
-                                             uint32_t *err, uint64_t &sum) {
+// The granule rows a chunk adds up for its prefix, as one list: chunks [grp0 * 32, chunk) of level 0, groups
+// [grp1 * 32, grp0) of level 1, super-groups [0, grp1) of level 2.  This thread takes rows part, part + nparts, ...
+// of the list and column q; s[level] get the sums.  Waits for rows that are not yet published; false when the wait
+// gave up (error word set, by this or by another thread).
+__device__ __forceinline__ bool sum_granule_rows(const FusedParams &p, int chunk, int q, int part, int nparts, uint32_t (&s)[3]) {
     constexpr int B = 8;
+    const int grp0 = chunk / kFan, grp1 = grp0 / kFan;
+    const int n0 = chunk - grp0 * kFan, n1 = grp0 - grp1 * kFan, n2 = grp1;
+    const int total = n0 + n1 + n2;
+    const size_t np = (size_t)p.n_pairs;
     uint32_t spins = 0;
-    for (int r0 = lo; r0 < hi; r0 += B) {
+    for (int r0 = part; r0 < total; r0 += B * nparts) {
+        const uint64_t *ptr[B];
+        int lev[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int r = min(r0 + u * nparts, total - 1);
+            lev[u] = r < n0 ? 0 : (r < n0 + n1 ? 1 : 2);
+            ptr[u] = lev[u] == 0 ? p.agg0 + (size_t)(grp0 * kFan + r) * np + q
+                   : lev[u] == 1 ? p.agg1 + (size_t)(grp1 * kFan + r - n0) * np + q
+                                 : p.agg2 + (size_t)(r - n0 - n1) * np + q;
+        }
         uint64_t x[B];
         for (;;) {
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < B; ++u) x[u] = load_granule(col + (size_t)min(r0 + u, hi - 1) * stride);
+            for (int u = 0; u < B; ++u) x[u] = load_granule(ptr[u]);
 #pragma unroll
-            for (int u = 0; u < B; ++u) ok = ok && (uint32_t)(x[u] >> 32) == epoch;
+            for (int u = 0; u < B; ++u) ok = ok && (uint32_t)(x[u] >> 32) == p.epoch;
             if (ok) break;
-            if (++spins > kSpinLimit) { __hip_atomic_store((gu32 *)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
-            if ((spins & 255u) == 0u && __hip_atomic_load((gu32 *)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (++spins > kSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+            if ((spins & 255u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int u = 0; u < B; ++u) sum += r0 + u < hi ? (uint64_t)(uint32_t)x[u] : 0ull;
+        for (int u = 0; u < B; ++u) {
+            const uint32_t v = r0 + u * nparts < total ? (uint32_t)x[u] : 0u;
+            s[0] += lev[u] == 0 ? v : 0u; s[1] += lev[u] == 1 ? v : 0u; s[2] += lev[u] == 2 ? v : 0u;
+        }
     }
     return true;
 }
 
-template <typename CT, bool use_rcp>
-__global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kernel(FusedParams p) {
+// Phase A for the tiles of one wave: tile_first, tile_first + tile_stride, ... (n_my of them) go to slots slot_first,
+// slot_first + slot_stride, ... of a region.  All arguments but `lane` are wave-uniform.
+//
+// A tile is W rows of 64 x 16 bytes {ALT word, MISSING word}; the wave reads them in batches of 8 rows (8 KiB) and
+// requests the next batch -- of this tile or of the next -- before it counts the current one.  Populations are
+// contiguous bit ranges of the haplotype axis, so the mask of a (word, population) overlap is a bit field the scalar
+// unit forms from the population sizes (no descriptor table, nothing to wait for but the tile rows).
+template <typename CT>
+__device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane, int n_my, int tile_first, int tile_stride,
+                                                 int slot_first, int slot_stride, CT *lcnt, uint64_t *lzf, uint64_t *lirr,
+                                                 uint64_t *lskip, const int32_t *lnfull) {
+    const int P = p.P;
+    const int nb = (p.W + kFuseNB - 1) / kFuseNB;      // load batches per tile
+    const int n_items = n_my * nb;
+    ulonglong2 cur[kFuseNB], nxt[kFuseNB];
+    auto load_item = [&](ulonglong2 (&r)[kFuseNB], int item) {
+        const int tj = item / nb, wb = (item - tj * nb) * kFuseNB;
+        const ulonglong2 *tp = p.tiles + (size_t)(tile_first + tj * tile_stride) * p.W * kTileSites + lane;
+#pragma unroll
+        for (int u = 0; u < kFuseNB; ++u)   // unconditional (clamped): all loads of a batch are in flight together
+            r[u] = tp[(size_t)min(wb + u, p.W - 1) * kTileSites];
+    };
+#ifdef EVOFST_EXPERIMENTS
+    if (p.debug & 4) {
+#pragma unroll
+        for (int u = 0; u < kFuseNB; ++u) cur[u] = nxt[u] = make_ulonglong2(0x5555555555555555ull * (lane & 1), 0);
+    }
+#define EVOFST_FUSED_LOAD(r, item) do { if (!(p.debug & 4)) load_item(r, item); } while (0)
+#else
+#define EVOFST_FUSED_LOAD(r, item) load_item(r, item)
+#endif
+    if (n_items > 0) EVOFST_FUSED_LOAD(cur, 0);
+    uint32_t c = 0, mc = 0;
+    bool irregular = false, skip = false;
+    uint64_t skipmask = 0;
+    int k = 0, rem = 0;                    // population being counted, bits of it still to come (uniform)
+    uint32_t nfull = 0, nnext = 0;         // chromosomes of population k and k + 1 (the table has two zeros behind its end)
+    int zl = 0, zh = 0, fl = 0, fh = 0;    // ballots of populations 64 j + lane, handed to their lanes as they complete
+    for (int item = 0; item < n_items; ++item) {
+        const int tj = item / nb, bi = item - tj * nb;
+        const int slot = slot_first + tj * slot_stride, wb = bi * kFuseNB;
+        if (item + 1 < n_items) EVOFST_FUSED_LOAD(nxt, item + 1);
+        if (bi == 0) {
+            const int64_t site = (int64_t)(tile_first + tj * tile_stride) * kTileSites + lane;
+            skip = site >= p.n_sites;
+            if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
+            skipmask = __ballot(skip);
+            c = 0; mc = 0; irregular = false;
+            k = 0; nfull = (uint32_t)__builtin_amdgcn_readfirstlane(lnfull[0]); rem = (int)nfull;
+            nnext = (uint32_t)__builtin_amdgcn_readfirstlane(lnfull[1]);
+        }
+        CT *cp = lcnt + (size_t)slot * P * kTileSites + lane;
+        uint64_t *zp = lzf + (size_t)slot * 2 * P;
+#ifdef EVOFST_EXPERIMENTS
+        if (!(p.debug & 32))
+#endif
+#pragma unroll
+        for (int u = 0; u < kFuseNB; ++u) {
+            if (wb + u < p.W) {
+                int bitpos = 0;
+                while (bitpos < 64 && k < P) {
+                    const int len = min(rem, 64 - bitpos);
+                    const uint64_t mask = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << bitpos;
+                    c += __popcll(cur[u].x & mask);
+                    mc += __popcll(cur[u].y & mask);
+                    rem -= len; bitpos += len;
+                    if (rem == 0) {                 // population k is complete
+                        const uint32_t nm = nfull - mc;
+                        cp[(size_t)k * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
+                        const uint64_t z = __ballot(c == 0) | skipmask;
+                        const uint64_t f = __ballot(c == nm) | skipmask;
+                        const int kl = k & 63;
+                        const bool mine = lane == kl;
+                        zl = mine ? (int)(uint32_t)z : zl; zh = mine ? (int)(uint32_t)(z >> 32) : zh;
+                        fl = mine ? (int)(uint32_t)f : fl; fh = mine ? (int)(uint32_t)(f >> 32) : fh;
+                        // sites phase B must take through its general loop: a NaN in the reference (nm < 2) or an
+                        // excluded site with a dxy term (fixed with missing alleles)
+                        irregular = irregular || nm < 2 || (c == nm && nm < nfull);
+                        if (kl == 63 || k == P - 1) {
+                            if (lane <= kl) {
+                                zp[(k & ~63) + lane] = ((uint64_t)(uint32_t)zh << 32) | (uint32_t)zl;
+                                zp[P + (k & ~63) + lane] = ((uint64_t)(uint32_t)fh << 32) | (uint32_t)fl;
+                            }
+                        }
+                        ++k;
+                        nfull = nnext; rem = (int)nfull;
+                        nnext = (uint32_t)__builtin_amdgcn_readfirstlane(lnfull[k + 1]);   // asked for a population ahead of its use
+                        c = 0; mc = 0;
+                    }
+                }
+            }
+        }
+        if (bi == nb - 1) {
+            const uint64_t im = __ballot(irregular && !skip);
+            if (lane == 0) { lirr[slot] = im; lskip[slot] = skipmask; }
+        }
+        if (item + 1 < n_items) {
+#pragma unroll
+            for (int u = 0; u < kFuseNB; ++u) cur[u] = nxt[u];
+        }
+    }
+}
+
+// WP: wave-private shape (n_pairs <= 64).  SUB: sites per table fill (16 or 32).
+template <typename CT, bool use_rcp, bool WP, int SUB>
+__global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int SUBP = SUB + 1;                 // row stride in entries: pop-indexed reads stay conflict-free
+    constexpr int SPT = kTileSites / SUB;         // table fills per tile
+    constexpr uint32_t FULL = SUB == 32 ? 0xffffffffu : ((1u << (SUB & 31)) - 1u);
     constexpr int EPT = 16 / (int)sizeof(CT);     // sites per 16-byte count vector
-    constexpr int VPR = kSub / EPT;               // vectors per population row of a half tile
+    constexpr int VPR = SUB / EPT;                // vectors per population row of a fill
     constexpr int EB = 8 * (int)sizeof(CT);
     const int P = p.P;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = blockDim.x, NWV = nthreads >> 6;
+    const int TR = WP ? p.chunk_tiles / NWV : p.chunk_tiles;     // tiles of a region
     size_t off = 0;
     auto carve = [&](size_t bytes) { unsigned char *r = smem + off; off += (bytes + 15) & ~(size_t)15; return r; };
     RcpEntry *rcp = reinterpret_cast<RcpEntry *>(carve(use_rcp ? (size_t)(p.max_n + 1) * sizeof(RcpEntry) : 0));
-    double *pt = reinterpret_cast<double *>(carve((size_t)P * kSubPad * 8));   // [P][33] p = c / nm
-    double *PH = reinterpret_cast<double *>(carve((size_t)P * kSubPad * 8));   // [P][33] sum of h from the start of the chunk
-    double *PT = reinterpret_cast<double *>(carve((size_t)P * kSubPad * 8));   // [P][33] sum of t
-    double *carH = reinterpret_cast<double *>(carve((size_t)P * 8));           // [P] the same sums after the last derived half tile
+    int32_t *lmisc = reinterpret_cast<int32_t *>(carve(64));
+    int32_t *lnfull = reinterpret_cast<int32_t *>(carve((size_t)(P + 2) * 4));   // [P] chromosomes per population, then two zeros
+    uint32_t *wcen = nullptr, *lb = nullptr;
+    if (WP) {
+        wcen = reinterpret_cast<uint32_t *>(carve((size_t)kFuseWaves * 64 * 4));        // [wave][pair] census of the wave's tiles
+        lb = reinterpret_cast<uint32_t *>(carve((size_t)kFuseWaves * 3 * 64 * 4));      // [wave][level][pair] look-back partial sums
+        const size_t rb = ((size_t)3 * (((size_t)P * SUBP * 8 + 15) & ~(size_t)15)) + 2 * (((size_t)P * 8 + 15) & ~(size_t)15) +
+                          2 * (((size_t)P * SUBP * 4 + 15) & ~(size_t)15) + (((size_t)P * 4 + 15) & ~(size_t)15) +
+                          (((size_t)TR * P * kTileSites * sizeof(CT) + 15) & ~(size_t)15) + (((size_t)TR * 2 * P * 8 + 15) & ~(size_t)15) +
+                          2 * (((size_t)TR * 8 + 15) & ~(size_t)15);
+        off += (size_t)wave * rb;
+    }
+    double *pt = reinterpret_cast<double *>(carve((size_t)P * SUBP * 8));   // [P][SUB + 1] p = c / nm
+    double *PH = reinterpret_cast<double *>(carve((size_t)P * SUBP * 8));   // sum of h from the start of the (sub-)chunk
+    double *PT = reinterpret_cast<double *>(carve((size_t)P * SUBP * 8));   // sum of t
+    double *carH = reinterpret_cast<double *>(carve((size_t)P * 8));        // [P] the same sums after the last derived fill
     double *carT = reinterpret_cast<double *>(carve((size_t)P * 8));
-    uint32_t *xt = reinterpret_cast<uint32_t *>(carve((size_t)P * kSubPad * 4));   // [P][33] c | flags
-    uint32_t *PC = reinterpret_cast<uint32_t *>(carve((size_t)P * kSubPad * 4));   // [P][33] sum of c
+    uint32_t *xt = reinterpret_cast<uint32_t *>(carve((size_t)P * SUBP * 4));   // c | flags
+    uint32_t *PC = reinterpret_cast<uint32_t *>(carve((size_t)P * SUBP * 4));   // sum of c
     uint32_t *carC = reinterpret_cast<uint32_t *>(carve((size_t)P * 4));
-    SegDesc *lsegs = reinterpret_cast<SegDesc *>(carve((size_t)p.n_segs * sizeof(SegDesc)));
-    int32_t *lwss = reinterpret_cast<int32_t *>(carve((size_t)(p.W + 1) * 4));
-    CT *lcnt = reinterpret_cast<CT *>(carve((size_t)p.chunk_tiles * P * kTileSites * sizeof(CT)));   // [tile][P][64]
-    uint64_t *lzf = reinterpret_cast<uint64_t *>(carve((size_t)p.chunk_tiles * 2 * P * 8));          // [tile][z|f][P]
-    uint64_t *lirr = reinterpret_cast<uint64_t *>(carve((size_t)p.chunk_tiles * 8));
-    uint64_t *lskip = reinterpret_cast<uint64_t *>(carve((size_t)p.chunk_tiles * 8));
-    int32_t *lmisc = reinterpret_cast<int32_t *>(carve(16));
+    CT *lcnt = reinterpret_cast<CT *>(carve((size_t)TR * P * kTileSites * sizeof(CT)));   // [tile][P][64]
+    uint64_t *lzf = reinterpret_cast<uint64_t *>(carve((size_t)TR * 2 * P * 8));          // [tile][z|f][P]
+    uint64_t *lirr = reinterpret_cast<uint64_t *>(carve((size_t)TR * 8));
+    uint64_t *lskip = reinterpret_cast<uint64_t *>(carve((size_t)TR * 8));
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nthreads = blockDim.x, NWV = nthreads >> 6;
-    const int q = tid;
+    const int dtid = WP ? lane : tid;          // thread index and count of the group that shares one region
+    const int dn = WP ? 64 : nthreads;
+    const int q = dtid;
     const bool active = q < p.n_pairs;
     uint32_t pi = 0, pj = 0, ni = 0, nj = 0;
     int64_t b0 = 0;
@@ -121,9 +276,8 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
         b0 = p.base[q];
     }
     const int64_t first_seg = b0 / p.g;
-    const uint32_t io = pi * kSubPad, jo = pj * kSubPad;
-    for (int i = tid; i <= p.W; i += nthreads) lwss[i] = p.word_seg_start[i];
-    for (int i = tid; i < p.n_segs; i += nthreads) lsegs[i] = p.segs[i];
+    const uint32_t io = pi * SUBP, jo = pj * SUBP;
+    for (int i = tid; i < P + 2; i += nthreads) lnfull[i] = i < P ? p.n_full[i] : 0;
     if (use_rcp)
         for (int i = tid; i <= p.max_n; i += nthreads) {
             RcpEntry e;
@@ -135,17 +289,24 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
             rcp[i] = e;
         }
     const double kNaN = __longlong_as_double(0x7ff8000000000000ll);
-    const int nb = (p.W + kFuseNB - 1) / kFuseNB;      // load batches per tile
-    const uint32_t n_tickets = (uint32_t)p.n_chunks + gridDim.x;   // every workgroup draws exactly one ticket past the end
     bool dead = false;                                 // a wait gave up somewhere: draw the remaining tickets, do nothing
+    auto region_sync = [&]() {                         // orders the LDS traffic of the threads that share a region
+        if (WP) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+        else __syncthreads();
+    };
 
-    for (;;) {
+    for (int iter = 0;; ++iter) {
         __syncthreads();                               // the tables above; the previous chunk's readers of lmisc / LDS
         if (tid == 0) {
-            const uint32_t t = __hip_atomic_fetch_add((gu32 *)p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // the last ticket of the launch: nobody adds after it, so the counter can go back to zero for the next launch
-            if (t == n_tickets - 1u) __hip_atomic_store((gu32 *)p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lmisc[0] = (int32_t)min(t, (uint32_t)p.n_chunks);
+            int32_t chunk = (int32_t)blockIdx.x;       // first chunk: the workgroup's own index (the grid is not larger than n_chunks)
+            if (iter > 0) {
+                // n_chunks draws in all: every workgroup draws until its chunk is past the end
+                const uint32_t t = __hip_atomic_fetch_add((gu32 *)p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the last draw of the launch: nobody adds after it, so the counter can go back to zero for the next launch
+                if (t == (uint32_t)p.n_chunks - 1u) __hip_atomic_store((gu32 *)p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                chunk = (int32_t)min((uint32_t)gridDim.x + t, (uint32_t)p.n_chunks);
+            }
+            lmisc[0] = chunk;
             lmisc[1] = (int32_t)__hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
@@ -154,108 +315,83 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
         if (chunk >= p.n_chunks) break;
         if (dead) continue;
         const int t0 = chunk * p.chunk_tiles;
-        const int nt = min(p.chunk_tiles, p.n_tiles - t0);
+        const int nt = min(p.chunk_tiles, p.n_tiles - t0);           // tiles of the chunk
+        // tiles of this region: WP -- tiles [wave * TR, wave * TR + TR) of the chunk; shared -- all of them
+        const int rt0 = WP ? min(wave * TR, nt) : 0;
+        const int rnt = WP ? min(TR, nt - rt0) : nt;
 
         // ------------------------------------------------------------------ phase A: tiles -> counts and ballots in LDS
+#ifdef EVOFST_EXPERIMENTS
+        if (!(p.debug & 8))
+#endif
         {
-            const int my_nt = wave < nt ? (nt - wave + NWV - 1) / NWV : 0;   // tiles wave, wave + NWV, ...
-            const int n_items = my_nt * nb;
-            ulonglong2 cur[kFuseNB], nxt[kFuseNB];
-            auto load_item = [&](ulonglong2 (&r)[kFuseNB], int item) {
-                const int tj = item / nb, wb = (item - tj * nb) * kFuseNB;
-                const ulonglong2 *tp = p.tiles + (size_t)(t0 + wave + tj * NWV) * p.W * kTileSites + lane;
-#pragma unroll
-                for (int u = 0; u < kFuseNB; ++u)   // unconditional (clamped): all loads of a batch are in flight together
-                    r[u] = tp[(size_t)min(wb + u, p.W - 1) * kTileSites];
-            };
-            if (n_items > 0) load_item(cur, 0);
-            uint32_t c = 0, mc = 0;
-            bool irregular = false, skip = false;
-            uint64_t skipmask = 0;
-            for (int item = 0; item < n_items; ++item) {
-                const int tj = item / nb, bi = item - tj * nb;
-                const int ti = wave + tj * NWV, wb = bi * kFuseNB;
-                if (item + 1 < n_items) load_item(nxt, item + 1);
-                if (bi == 0) {
-                    const int64_t site = (int64_t)(t0 + ti) * kTileSites + lane;
-                    skip = site >= p.n_sites;
-                    if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
-                    skipmask = __ballot(skip);
-                    c = 0; mc = 0; irregular = false;
-                }
-                CT *cp = lcnt + (size_t)ti * P * kTileSites + lane;
-                uint64_t *zp = lzf + (size_t)ti * 2 * P;
-#pragma unroll
-                for (int u = 0; u < kFuseNB; ++u) {
-                    if (wb + u < p.W) {
-                        const int s0 = lwss[wb + u], s1 = lwss[wb + u + 1];
-                        for (int s = s0; s < s1; ++s) {
-                            const SegDesc d = lsegs[s];
-                            c += __popcll(cur[u].x & d.mask);
-                            mc += __popcll(cur[u].y & d.mask);
-                            if (d.flags & kSegLast) {
-                                const uint32_t nfull = d.flags >> kSegNFullShift;
-                                const uint32_t nm = nfull - mc;
-                                cp[(size_t)d.pop * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
-                                const uint64_t z = __ballot(c == 0) | skipmask;
-                                const uint64_t f = __ballot(c == nm) | skipmask;
-                                if (lane == 0) { zp[d.pop] = z; zp[P + d.pop] = f; }
-                                // sites phase B must take through its general loop: a NaN in the reference (nm < 2) or an
-                                // excluded site with a dxy term (fixed with missing alleles)
-                                irregular = irregular || nm < 2 || (c == nm && nm < nfull);
-                                c = 0; mc = 0;
-                            }
-                        }
-                    }
-                }
-                if (bi == nb - 1) {
-                    const uint64_t im = __ballot(irregular && !skip);
-                    if (lane == 0) { lirr[ti] = im; lskip[ti] = skipmask; }
-                }
-                if (item + 1 < n_items) {
-#pragma unroll
-                    for (int u = 0; u < kFuseNB; ++u) cur[u] = nxt[u];
-                }
-            }
+            if (WP) count_wave_tiles<CT>(p, lane, rnt, t0 + rt0, 1, 0, 1, lcnt, lzf, lirr, lskip, lnfull);
+            else count_wave_tiles<CT>(p, lane, wave < nt ? (nt - wave + NWV - 1) / NWV : 0, t0 + wave, NWV, wave, NWV, lcnt, lzf, lirr, lskip, lnfull);
         }
-        for (int i = tid; i < P; i += nthreads) { carH[i] = 0.0; carT[i] = 0.0; carC[i] = 0u; }
-        __syncthreads();
+        for (int i = dtid; i < P; i += dn) { carH[i] = 0.0; carT[i] = 0.0; carC[i] = 0u; }
+        region_sync();
 
         // ------------------------------------------------------------------ census, publish, look back
-        uint32_t cen = 0;
-        int64_t g0 = b0;
-        bool ok = true;
-        if (active) {
-            for (int ti = 0; ti < nt; ++ti) {
+        uint32_t cen = 0;                      // included sites of the region's tiles
+#ifdef EVOFST_EXPERIMENTS
+        if (p.debug & 64) continue;
+#endif
+        if (active)
+            for (int ti = 0; ti < rnt; ++ti) {
                 const uint64_t *zp = lzf + (size_t)ti * 2 * P;
                 const uint64_t ex = (zp[pi] & zp[pj]) | (zp[P + pi] & zp[P + pj]);     // fst.cpp:543-544
                 cen += 64u - (uint32_t)__popcll(ex);
             }
-            const size_t np = (size_t)p.n_pairs;
-            store_granule(p.agg0 + (size_t)chunk * np + q, p.epoch, cen);
-            const int grp0 = chunk / kFan, grp1 = grp0 / kFan;
-            uint64_t sum0 = 0, sum1 = 0, sum2 = 0;
-            ok = sum_granules(p.agg0 + q, np, grp0 * kFan, chunk, p.epoch, p.err, sum0);
-            if (ok && chunk % kFan == kFan - 1) store_granule(p.agg1 + (size_t)grp0 * np + q, p.epoch, (uint32_t)(sum0 + cen));
-            ok = ok && sum_granules(p.agg1 + q, np, grp1 * kFan, grp0, p.epoch, p.err, sum1);
-            if (ok && chunk % kFan == kFan - 1 && grp0 % kFan == kFan - 1)
-                store_granule(p.agg2 + (size_t)grp1 * np + q, p.epoch, (uint32_t)(sum1 + sum0 + cen));
-            ok = ok && sum_granules(p.agg2 + q, np, 0, grp1, p.epoch, p.err, sum2);
-            g0 += (int64_t)(sum2 + sum1 + sum0);
-            if (chunk == p.n_chunks - 1) p.incl_totals[q] = g0 - b0 + (int64_t)cen;
-            if (chunk == 0) p.first_segment[q] = first_seg;
+        uint32_t cen_chunk = cen, cen_before = 0;      // of the whole chunk; of the chunk's regions before this one
+        if (WP) {
+            wcen[wave * 64 + lane] = cen;
+            __syncthreads();
+            cen_chunk = 0;
+            for (int w = 0; w < NWV; ++w) {
+                const uint32_t v = wcen[w * 64 + lane];
+                cen_chunk += v;
+                cen_before += w < wave ? v : 0u;
+            }
+        }
+        const bool publisher = active && (!WP || wave == 0);
+        if (publisher) store_granule(p.agg0 + (size_t)chunk * p.n_pairs + q, p.epoch, cen_chunk);
+        uint32_t s[3] = {0u, 0u, 0u};
+        bool ok = true;
+#ifdef EVOFST_EXPERIMENTS
+        if (p.debug & 1) s[0] = (uint32_t)chunk * 100u / (WP ? NWV : 1); else
+#endif
+        if (active) ok = sum_granule_rows(p, chunk, q, WP ? wave : 0, WP ? NWV : 1, s);
+        if (WP) {
+            lb[(wave * 3 + 0) * 64 + lane] = s[0]; lb[(wave * 3 + 1) * 64 + lane] = s[1]; lb[(wave * 3 + 2) * 64 + lane] = s[2];
         }
         if (__syncthreads_or(!ok)) { dead = true; continue; }
+        if (WP) {
+            s[0] = s[1] = s[2] = 0u;
+            for (int w = 0; w < NWV; ++w) { s[0] += lb[(w * 3 + 0) * 64 + lane]; s[1] += lb[(w * 3 + 1) * 64 + lane]; s[2] += lb[(w * 3 + 2) * 64 + lane]; }
+        }
+        if (publisher) {
+            const int grp0 = chunk / kFan, grp1 = grp0 / kFan;
+            if (chunk % kFan == kFan - 1) {
+                store_granule(p.agg1 + (size_t)grp0 * p.n_pairs + q, p.epoch, s[0] + cen_chunk);
+                if (grp0 % kFan == kFan - 1) store_granule(p.agg2 + (size_t)grp1 * p.n_pairs + q, p.epoch, s[1] + s[0] + cen_chunk);
+            }
+            if (chunk == p.n_chunks - 1) p.incl_totals[q] = (int64_t)s[2] + (int64_t)s[1] + (int64_t)s[0] + (int64_t)cen_chunk;
+            if (chunk == 0) p.first_segment[q] = first_seg;
+        }
+        const int64_t g0 = b0 + (int64_t)s[2] + (int64_t)s[1] + (int64_t)s[0] + (int64_t)cen_before;
+#ifdef EVOFST_EXPERIMENTS
+        if (p.debug & 2) continue;
+#endif
 
-        // ------------------------------------------------------------------ phase B: K2's walk over the chunk's half tiles
+        // ------------------------------------------------------------------ phase B: K2's walk over the region's tiles
         int64_t m = g0 / p.g;
         int32_t left = p.g - (int32_t)(g0 - m * p.g);
         const int32_t left0 = left;
         const int32_t row0 = (int32_t)(m - first_seg);
         size_t orow = (size_t)row0 * p.n_pairs + q;
-        double D = 0.0;                       // sum d^2 (masked by the site filter in general half tiles)
+        double D = 0.0;                       // sum d^2 (masked by the site filter in general fills)
         uint64_t cc = 0;                      // sum c_i c_j
-        uint32_t exi = 0, exj = 0;            // sum of c_i / c_j over excluded sites (general half tiles only)
+        uint32_t exi = 0, exj = 0;            // sum of c_i / c_j over excluded sites (general fills only)
         uint32_t bn = 0, bd = 0;              // included sites whose numerator / denominator is NaN in the reference
         double prevN = 0.0, prevD = 0.0;      // their values at the last boundary
         uint32_t prevCi = 0, prevCj = 0, prevBn = 0, prevBd = 0;
@@ -264,12 +400,12 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
         const int nvec = P * VPR;
 
         // One vector = EPT consecutive sites of population k.
-        auto derive_vec = [&](int vi, const uint4 &vv, uint32_t skiphalf) {
+        auto derive_vec = [&](int vi, const uint4 &vv, uint32_t skipfill) {
             const int k = vi / VPR, r = vi - k * VPR;
-            const int o = k * kSubPad + r * EPT;
-            const uint32_t skipbits = skiphalf >> (r * EPT);
+            const int o = k * SUBP + r * EPT;
+            const uint32_t skipbits = skipfill >> (r * EPT);
             uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-            if (skiphalf != 0u) {                 // uniform and rare: a skipped site contributes 0 everywhere (c = 0)
+            if (skipfill != 0u) {                 // uniform and rare: a skipped site contributes 0 everywhere (c = 0)
 #pragma unroll
                 for (int j = 0; j < EPT; ++j)
                     if ((skipbits >> j) & 1u) w[(j * EB) / 32] &= ~(CountTraits<CT>::mask << ((j * EB) % 32));
@@ -306,10 +442,10 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
                     hh = tt * e.r1;                                       // t / (nm - 1)     (0 when nm < 2)
                     x |= e.flags;
                 } else {
-                    const double dn = (double)nm;
-                    pp = nm ? dc / dn : 0.0;                              // utils.h:272-275
+                    const double dn_ = (double)nm;
+                    pp = nm ? dc / dn_ : 0.0;                             // utils.h:272-275
                     tt = pp * (1.0 - pp);
-                    hh = nm > 1 ? tt / (dn - 1.0) : 0.0;                  // fst.h:21-22
+                    hh = nm > 1 ? tt / (dn_ - 1.0) : 0.0;                 // fst.h:21-22
                     if (nm < 2) x |= kXBadNum;
                     if (nm == 0) x |= kXBadDen;
                 }
@@ -317,6 +453,7 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
                 tv[j] = tt; hv[j] = hh; cv[j] = c;
                 rh += hh; rt += tt; rc += c;
             }
+            // exclusive scan of the vector totals over the VPR lanes of the row (consecutive lanes of one wave)
             double eh = rh, et = rt;
             uint32_t ec = rc;
 #pragma unroll
@@ -328,7 +465,7 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
             const double ch = carH[k], ct = carT[k];
             const uint32_t ccar = carC[k];
             if (r == VPR - 1) { carH[k] = ch + eh; carT[k] = ct + et; carC[k] = ccar + ec; }
-            double ah = ch + (eh - rh), at = ct + (et - rt);
+            double ah = ch + (eh - rh), at = ct + (et - rt);       // sums before this vector
             uint32_t ac = ccar + (ec - rc);
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
@@ -337,34 +474,34 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
             }
         };
 
-        for (int st = 0; st < 2 * nt; ++st) {
-            const int ti = st >> 1, sh = (st & 1) * kSub;
-            const uint32_t skiphalf = (uint32_t)(lskip[ti] >> sh);
-            const bool general = (uint32_t)(lirr[ti] >> sh) != 0u;   // uniform
+        for (int st = 0; st < SPT * rnt; ++st) {
+            const int ti = st / SPT, sh = (st - ti * SPT) * SUB;
+            const uint32_t skipfill = (uint32_t)(lskip[ti] >> sh) & FULL;
+            const bool general = ((uint32_t)(lirr[ti] >> sh) & FULL) != 0u;   // uniform
             {
                 const uint4 *vp = reinterpret_cast<const uint4 *>(lcnt + (size_t)ti * P * kTileSites);
-                for (int vi = tid; vi < nvec; vi += nthreads) {
+                for (int vi = dtid; vi < nvec; vi += dn) {
                     const int k = vi / VPR, r = vi - k * VPR;
-                    derive_vec(vi, vp[k * (kTileSites / EPT) + (st & 1) * VPR + r], skiphalf);
+                    derive_vec(vi, vp[k * (kTileSites / EPT) + sh / EPT + r], skipfill);
                 }
             }
-            __syncthreads();
+            region_sync();
             if (active) {
                 const uint64_t *zp = lzf + (size_t)ti * 2 * P;
-                const uint32_t incl = ~(uint32_t)(((zp[pi] & zp[pj]) | (zp[P + pi] & zp[P + pj])) >> sh);   // fst.cpp:543-544
-                int b = kSub;                                  // site of this lane's next boundary in the half tile (kSub: none)
+                const uint32_t incl = ~(uint32_t)(((zp[pi] & zp[pj]) | (zp[P + pi] & zp[P + pj])) >> sh) & FULL;   // fst.cpp:543-544
+                int b = SUB;                                   // site of this lane's next boundary in the fill (SUB: none)
                 {
                     const int cnt = __popc(incl);
                     if (left <= cnt) b = nth_set_bit(incl, left);
                     else left -= cnt;
                 }
                 const int bgrp = b & ~(kGrp - 1);
-                double sD = D;
+                double sD = D;                                 // snapshots at the end of the boundary's group
                 uint64_t scc = cc;
-                uint32_t sexi = exi, sexj = exj, sbn = bn, sbd = bd;
+                uint32_t sexi = exi, sexj = exj, sbn = bn, sbd = bd;   // (the regular loop leaves these four alone)
                 if (!general) {
-#pragma unroll EVOFST_K2_UNROLL
-                    for (int sb = 0; sb < kSub; sb += kGrp) {
+#pragma unroll
+                    for (int sb = 0; sb < SUB; sb += kGrp) {
                         double a[kGrp], bb[kGrp];
                         uint32_t xi[kGrp], xj[kGrp];
 #pragma unroll
@@ -372,19 +509,19 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
                             a[u] = pt[io + sb + u]; bb[u] = pt[jo + sb + u];
                             xi[u] = xt[io + sb + u]; xj[u] = xt[jo + sb + u];
                         }
-                        uint32_t cch = 0;
+                        uint32_t cch = 0;                      // c_i c_j of kGrp sites (< 2^30)
 #pragma unroll
                         for (int u = 0; u < kGrp; ++u) {
                             const double d = a[u] - bb[u];
                             D = fma(d, d, D);
-                            cch += __umul24(xi[u], xj[u]);
+                            cch += __umul24(xi[u], xj[u]);     // low 24 bits: c (the flags sit above)
                         }
                         cc += cch;
                         if (sb == bgrp) { sD = D; scc = cc; }
                     }
                 } else {
 #pragma unroll 1
-                    for (int sb = 0; sb < kSub; sb += kGrp) {
+                    for (int sb = 0; sb < SUB; sb += kGrp) {
                         double a[kGrp], bb[kGrp];
                         uint32_t xi[kGrp], xj[kGrp];
 #pragma unroll
@@ -413,13 +550,14 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
                     const double H = PH[io + b] + PH[jo + b], T = PT[io + b] + PT[jo + b];
                     const uint32_t Ci = PC[io + b] - cexi, Cj = PC[jo + b] - cexj;
                     const double cumN = cD - H, cumD = cD + T;
+                    // sumKij (fst.cpp:299-321) of the segment, exact: differences are taken modulo 2^32 / 2^64
                     const uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC);
                     SegRow row;
                     row.num = cbn != prevBn ? kNaN : cumN - prevN;
                     row.den = cbd != prevBd ? kNaN : cumD - prevD;
                     row.k = (double)kk;
-                    row.end = (t0 * 2 + st) * kSub + b; row.pad = 0;
-                    {
+                    row.end = (t0 + rt0 + ti) * kTileSites + sh + b; row.pad = 0;
+                    {   // two 16-byte stores into one 32-byte sector
                         uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
                         const uint4 *src = reinterpret_cast<const uint4 *>(&row);
                         dst[0] = src[0]; dst[1] = src[1];
@@ -427,12 +565,13 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
                     prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevBn = cbn; prevBd = cbd;
                     ++nflush;
                     orow += p.n_pairs;
-                    const uint32_t rem = b >= kSub - 1 ? 0u : incl & ~((2u << b) - 1u);
+                    const uint32_t rem = b >= SUB - 1 ? 0u : incl & ~((2u << b) - 1u);
                     const int c2 = __popc(rem);
                     if (p.g <= c2) b = nth_set_bit(rem, p.g);
-                    else { left = p.g - c2; b = kSub; }
+                    else { left = p.g - c2; b = SUB; }
                 };
-                if (b < kSub) {
+                if (b < SUB) {
+                    // first boundary: the group snapshot minus the (at most kGrp - 1) sites of the group behind b
                     {
                         double cD = sD;
                         uint64_t ccc = scc;
@@ -442,8 +581,8 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
                         const int room = (kGrp - 1) - (b & (kGrp - 1));   // sites of the group behind b
 #pragma unroll
                         for (int u = 1; u < kGrp; ++u) {
-                            const int s = u <= room ? b + u : b;
-                            pa[u - 1] = pt[io + s]; pb[u - 1] = pt[jo + s]; xa[u - 1] = xt[io + s]; xb[u - 1] = xt[jo + s];
+                            const int s_ = u <= room ? b + u : b;
+                            pa[u - 1] = pt[io + s_]; pb[u - 1] = pt[jo + s_]; xa[u - 1] = xt[io + s_]; xb[u - 1] = xt[jo + s_];
                         }
 #pragma unroll
                         for (int u = 1; u < kGrp; ++u) {
@@ -461,15 +600,16 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
                         }
                         emit(cD, ccc, cexi, cexj, cbn, cbd);
                     }
-                    while (b < kSub) {
+                    // further boundaries of the same fill (windows shorter than it): from the end of the fill
+                    while (b < SUB) {
                         double cD = D;
                         uint64_t ccc = cc;
                         uint32_t cexi = exi, cexj = exj, cbn = bn, cbd = bd;
-                        for (int s = b + 1; s < kSub; ++s) {
-                            const uint32_t xi = xt[io + s], xj = xt[jo + s];
-                            const double d = pt[io + s] - pt[jo + s];
+                        for (int s_ = b + 1; s_ < SUB; ++s_) {
+                            const uint32_t xi = xt[io + s_], xj = xt[jo + s_];
+                            const double d = pt[io + s_] - pt[jo + s_];
                             const uint32_t ci = xi & kXMask, cj = xj & kXMask;
-                            const bool inc = !general || ((incl >> s) & 1u) != 0u;
+                            const bool inc = !general || ((incl >> s_) & 1u) != 0u;
                             if (inc) {
                                 cD = fma(-d, d, cD);
                                 ccc -= (uint64_t)(ci * cj);
@@ -482,56 +622,73 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void fused_pairs_kerne
                     }
                 }
             }
-            __syncthreads();
+            region_sync();
         }
         if (active) {
-            // what the chunk holds behind its last boundary
-            const size_t cq = (size_t)chunk * p.n_pairs + q;
-            const size_t plane = (size_t)p.n_pairs * p.n_chunks;
+            // what the (sub-)chunk holds behind its last boundary
+            const int n_sub = WP ? p.n_chunks * NWV : p.n_chunks;
+            const int sub = WP ? chunk * NWV + wave : chunk;
+            const size_t cq = (size_t)sub * p.n_pairs + q;
+            const size_t plane = (size_t)p.n_pairs * n_sub;
             const double H = carH[pi] + carH[pj], T = carT[pi] + carT[pj];
             const uint32_t Ci = carC[pi] - exi, Cj = carC[pj] - exj;
             const uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (cc - prevCC);
             p.tail[cq] = bn != prevBn ? kNaN : (D - H) - prevN;
             p.tail[plane + cq] = bd != prevBd ? kNaN : (D + T) - prevD;
             p.tail[2 * plane + cq] = (double)kk;
-            p.tail_n[cq] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);
+            p.tail_n[cq] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);   // {sites summed in the tail, segments completed, row of the first}
         }
     }
 }
 
-template <typename CT, bool RCP>
-static hipError_t launch_fused_t(const FusedParams &p, size_t lds, int threads, int max_blocks, hipStream_t st, int *grid_out) {
-    const void *fn = reinterpret_cast<const void *>(&fused_pairs_kernel<CT, RCP>);
+template <typename CT, bool RCP, bool WP, int SUB>
+static hipError_t launch_fused_t(const FusedParams &p, size_t lds, int threads, int max_blocks, hipStream_t st) {
+    const void *fn = reinterpret_cast<const void *>(&fused_pairs_kernel<CT, RCP, WP, SUB>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     int grid = max_blocks;
     if (grid <= 0) {
-        int per_cu = 0, dev = 0, cus = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds);
+        // workgroups the device holds at once; asked once per shape (the query costs more than a launch)
+        static thread_local struct { const void *fn; int threads; size_t lds; int dev; int grid; } memo = {nullptr, 0, 0, -1, 0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        grid = std::max(1, per_cu) * std::max(1, cus);
+        if (memo.fn != fn || memo.threads != threads || memo.lds != lds || memo.dev != dev) {
+            int per_cu = 0, cus = 0;
+            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds)) != hipSuccess) return e;
+            if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+            memo = {fn, threads, lds, dev, std::max(1, per_cu) * std::max(1, cus)};
+        }
+        grid = memo.grid;
     }
     grid = std::max(1, std::min(grid, p.n_chunks));
-    if (grid_out) *grid_out = grid;
-    hipLaunchKernelGGL((fused_pairs_kernel<CT, RCP>), dim3(grid), dim3(threads), lds, st, p);
+    hipLaunchKernelGGL((fused_pairs_kernel<CT, RCP, WP, SUB>), dim3(grid), dim3(threads), lds, st, p);
     return hipGetLastError();
 }
 
-hipError_t launch_fused(const FusedParams &p, int count_bytes, int max_blocks, hipStream_t st, int *grid_out) {
+int fused_threads(int n_pairs) { return n_pairs <= 64 ? 64 * kFuseWaves : 64 * ((n_pairs + 63) / 64); }
+int fused_tail_chunks(int n_pairs, int n_chunks) { return n_pairs <= 64 ? n_chunks * kFuseWaves : n_chunks; }
+
+hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_blocks, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
-    if (p.n_pairs > kK2Threads) return hipErrorInvalidValue;
-    const int threads = 64 * ((p.n_pairs + 63) / 64);
-    const size_t lds = fused_lds_bytes(p.P, p.W, p.n_segs, p.max_n, p.chunk_tiles, count_bytes);
+    if (p.n_pairs > kK2Threads || (sub != 16 && sub != 32)) return hipErrorInvalidValue;
+    const bool wp = p.n_pairs <= 64;
+    if (wp && p.chunk_tiles % kFuseWaves != 0) return hipErrorInvalidValue;
+    const int threads = fused_threads(p.n_pairs);
+    const size_t lds = fused_lds_bytes(p.P, p.max_n, p.n_pairs, p.chunk_tiles, count_bytes, sub);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool rcp = p.max_n <= kRcpMax;
-    if (count_bytes == 2) return rcp ? launch_fused_t<uint16_t, true>(p, lds, threads, max_blocks, st, grid_out)
-                                     : launch_fused_t<uint16_t, false>(p, lds, threads, max_blocks, st, grid_out);
-    return rcp ? launch_fused_t<uint32_t, true>(p, lds, threads, max_blocks, st, grid_out)
-               : launch_fused_t<uint32_t, false>(p, lds, threads, max_blocks, st, grid_out);
+#define EVOFST_FUSED_GO(CT, R, W_, S_) return launch_fused_t<CT, R, W_, S_>(p, lds, threads, max_blocks, st)
+#define EVOFST_FUSED_SUB(CT, R, W_) do { if (sub == 16) EVOFST_FUSED_GO(CT, R, W_, 16); else EVOFST_FUSED_GO(CT, R, W_, 32); } while (0)
+#define EVOFST_FUSED_WP(CT, R) do { if (wp) EVOFST_FUSED_SUB(CT, R, true); else EVOFST_FUSED_SUB(CT, R, false); } while (0)
+    if (count_bytes == 2) { if (rcp) EVOFST_FUSED_WP(uint16_t, true); else EVOFST_FUSED_WP(uint16_t, false); }
+    else { if (rcp) EVOFST_FUSED_WP(uint32_t, true); else EVOFST_FUSED_WP(uint32_t, false); }
+#undef EVOFST_FUSED_GO
+#undef EVOFST_FUSED_SUB
+#undef EVOFST_FUSED_WP
+    return hipErrorInvalidValue;
 }
 
 }  // namespace evofst

@@ -129,10 +129,7 @@ struct FusedParams {
     const uint8_t *site_flags;  // may be null
     int64_t n_sites;
     int32_t n_tiles, W, P;
-    const SegDesc *segs;
-    const int32_t *word_seg_start;  // [W+1]
-    int32_t n_segs;
-    const int32_t *n_full;          // [P]
+    const int32_t *n_full;          // [P] chromosomes per population = its bits on the haplotype axis, in order
     int32_t max_n;
     const uint32_t *pairs;          // i | j << 16
     int32_t n_pairs;
@@ -143,8 +140,8 @@ struct FusedParams {
     int64_t *incl_totals;           // [n_pairs] out: included sites of the shard
     int64_t seg_cap;
     SegRow *seg_rows;               // [seg_cap][n_pairs]
-    double *tail;                   // [3][n_chunks][n_pairs], as K2 writes it
-    int4 *tail_n;                   // [n_chunks][n_pairs]
+    double *tail;                   // [3][fused_tail_chunks()][n_pairs], as K2 writes it
+    int4 *tail_n;                   // [fused_tail_chunks()][n_pairs]
     // look-back state: 8-byte {epoch, count} granules, valid when the tag is this launch's epoch
     uint64_t *agg0;                 // [n_chunks][n_pairs] included sites of a chunk
     uint64_t *agg1;                 // [ceil(n_chunks / 32)][n_pairs] ... of a group of 32 chunks
@@ -152,6 +149,7 @@ struct FusedParams {
     uint32_t *ticket;               // chunk tickets; back to 0 when the launch ends
     uint32_t *err;                  // set when a wait gave up
     uint32_t epoch;
+    int32_t debug;                  // -DEVOFST_EXPERIMENTS builds only (tools/): 1 no look-back waits, 2 no phase B, 4 no tile loads
 };
 
 struct SiteStatParams {
@@ -299,9 +297,11 @@ hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st);
 size_t k2_lds_bytes(int P, int max_n);
-size_t fused_lds_bytes(int P, int W, int n_segs, int max_n, int chunk_tiles, int count_bytes);
-// max_blocks <= 0: as many workgroups as the device holds at once (occupancy query)
-hipError_t launch_fused(const FusedParams &p, int count_bytes, int max_blocks, hipStream_t st, int *grid_out);
+size_t fused_lds_bytes(int P, int max_n, int n_pairs, int chunk_tiles, int count_bytes, int sub);
+int fused_threads(int n_pairs);
+int fused_tail_chunks(int n_pairs, int n_chunks);   // entries per pair of the tail table (sub-chunks when every wave owns a part of a chunk)
+// sub: sites per table fill (16 or 32); max_blocks <= 0: as many workgroups as the device holds at once (occupancy query)
+hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_blocks, hipStream_t st);
 size_t global_lds_bytes(int tn_max, int max_n, int n_use, int size);
 void global_rcp_split(int tn_max, int max_n, int *lo, int *hi);
 

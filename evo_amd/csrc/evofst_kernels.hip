@@ -667,7 +667,9 @@ hipError_t launch_k2(const K2Params &p, int count_bytes, hipStream_t st) {
     const int threads = 64 * ((std::min(p.n_pairs, kK2Threads) + 63) / 64);
     dim3 grid(p.n_chunks, (p.n_pairs + threads - 1) / threads), block(threads);
     size_t lds = k2_lds_bytes(p.P, p.max_n);
+#ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_DEBUG_K2_LDS")) lds += (size_t)atoi(e);   // occupancy experiments
+#endif
     const bool rcp = p.max_n <= kRcpMax;
     if (count_bytes == 2) return rcp ? launch_k2_t<uint16_t, true>(p, lds, grid, block, st) : launch_k2_t<uint16_t, false>(p, lds, grid, block, st);
     return rcp ? launch_k2_t<uint32_t, true>(p, lds, grid, block, st) : launch_k2_t<uint32_t, false>(p, lds, grid, block, st);
