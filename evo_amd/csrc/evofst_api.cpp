@@ -165,7 +165,7 @@ int upload_layout(evofst_ctx *c) {
         if (!c->use_idx.empty()) first_use = c->use_idx[0];
     }
     for (auto &d : c->segs) {
-        d.flags &= kSegLast;
+        d.flags &= kSegLast | kSegWordEnd;
         if (use[d.pop]) d.flags |= kSegUse;
         if ((int)d.pop == first_use) d.flags |= kSegFirstUse;
         d.flags |= (uint32_t)c->n_full[d.pop] << kSegNFullShift;
@@ -318,7 +318,7 @@ int fused_plan(evofst_ctx *c, int *sub_out) {
 #ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_FUSED_SUB")) sub = atoi(e) == 16 ? 16 : 32;
 #endif
-    auto lds = [&](int ct) { return fused_lds_bytes(c->n_pops, max_n, np, ct, c->count_bytes, sub); };
+    auto lds = [&](int ct) { return fused_lds_bytes(c->n_pops, (int)c->segs.size(), max_n, np, ct, c->count_bytes, sub); };
     int ct = 0;
     if (const char *e = getenv("EVOFST_CHUNK_TILES")) ct = atoi(e);
     if (ct <= 0) ct = 4 * unit;
@@ -355,6 +355,7 @@ int run_fused(evofst_ctx *c, int ct, int sub) {
     p.tiles = (const ulonglong2 *)c->tiles;
     p.site_flags = c->have_flags ? c->flags : nullptr;
     p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.W = c->W; p.P = c->n_pops;
+    p.segs = (const SegDesc *)c->d_segs.p; p.n_segs = (int)c->segs.size();
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
     p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)np;
@@ -532,6 +533,7 @@ extern "C" int evofst_set_layout(evofst_ctx *c, int n_samples, int n_pops, const
             d.flags = (hi == c->pop_off[k + 1]) ? kSegLast : 0u;
             c->segs.push_back(d);
         }
+        if ((int)c->segs.size() > c->word_seg_start[w]) c->segs.back().flags |= kSegWordEnd;
     }
     c->word_seg_start[c->W] = (int)c->segs.size();
     c->mode = MODE_COUNTS;

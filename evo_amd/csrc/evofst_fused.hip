@@ -48,13 +48,13 @@ static size_t fused_region_bytes(int P, int tiles, int count_bytes, int sub) {
     b += a16((size_t)P * 4);                    // carC
     b += a16((size_t)tiles * P * kTileSites * count_bytes);
     b += a16((size_t)tiles * 2 * P * 8);        // zero / fixed ballots
-    b += 2 * a16((size_t)tiles * 8);            // irregular, skip
+    b += 3 * a16((size_t)tiles * 8);            // irregular, skip, any-missing
     return b;
 }
 
-size_t fused_lds_bytes(int P, int max_n, int n_pairs, int chunk_tiles, int count_bytes, int sub) {
+size_t fused_lds_bytes(int P, int n_segs, int max_n, int n_pairs, int chunk_tiles, int count_bytes, int sub) {
     const bool wp = n_pairs <= 64;
-    size_t b = a16(max_n <= kRcpMax ? (size_t)(max_n + 1) * sizeof(RcpEntry) : 0) + 64 + a16((size_t)(P + 2) * 4);
+    size_t b = a16(max_n <= kRcpMax ? (size_t)(max_n + 1) * sizeof(RcpEntry) : 0) + 64 + a16((size_t)(n_segs + 1) * sizeof(SegDesc));
     if (wp) {
         b += a16((size_t)kFuseWaves * 64 * 4) + a16((size_t)kFuseWaves * 3 * 64 * 4);   // census and look-back partials of the waves
         b += kFuseWaves * fused_region_bytes(P, chunk_tiles / kFuseWaves, count_bytes, sub);
@@ -121,13 +121,13 @@ __device__ __forceinline__ bool sum_granule_rows(const FusedParams &p, int chunk
 // slot_first + slot_stride, ... of a region.  All arguments but `lane` are wave-uniform.
 //
 // A tile is W rows of 64 x 16 bytes {ALT word, MISSING word}; the wave reads them in batches of 8 rows (8 KiB) and
-// requests the next batch -- of this tile or of the next -- before it counts the current one.  Populations are
-// contiguous bit ranges of the haplotype axis, so the mask of a (word, population) overlap is a bit field the scalar
-// unit forms from the population sizes (no descriptor table, nothing to wait for but the tile rows).
+// requests the next batch -- of this tile or of the next -- before it counts the current one.  Counting walks the
+// (word, population) overlaps of the layout, a stream of 16-byte descriptors in LDS that is read one descriptor ahead
+// of its use, so the loop waits for nothing but the tile rows.
 template <typename CT>
 __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane, int n_my, int tile_first, int tile_stride,
                                                  int slot_first, int slot_stride, CT *lcnt, uint64_t *lzf, uint64_t *lirr,
-                                                 uint64_t *lskip, const int32_t *lnfull) {
+                                                 uint64_t *lskip, uint64_t *lmiss, const uint4 *lsegs) {
     const int P = p.P;
     const int nb = (p.W + kFuseNB - 1) / kFuseNB;      // load batches per tile
     const int n_items = n_my * nb;
@@ -150,11 +150,10 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 #endif
     if (n_items > 0) EVOFST_FUSED_LOAD(cur, 0);
     uint32_t c = 0, mc = 0;
-    bool irregular = false, skip = false;
+    bool irregular = false, skip = false, anymiss = false;
     uint64_t skipmask = 0;
-    int k = 0, rem = 0;                    // population being counted, bits of it still to come (uniform)
-    uint32_t nfull = 0, nnext = 0;         // chromosomes of population k and k + 1 (the table has two zeros behind its end)
-    int zl = 0, zh = 0, fl = 0, fh = 0;    // ballots of populations 64 j + lane, handed to their lanes as they complete
+    int sidx = 0;                          // next descriptor of the stream
+    uint4 d = lsegs[0];                    // {mask lo, mask hi, pop, flags | n_full << 8}
     for (int item = 0; item < n_items; ++item) {
         const int tj = item / nb, bi = item - tj * nb;
         const int slot = slot_first + tj * slot_stride, wb = bi * kFuseNB;
@@ -164,9 +163,8 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
             skip = site >= p.n_sites;
             if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
             skipmask = __ballot(skip);
-            c = 0; mc = 0; irregular = false;
-            k = 0; nfull = (uint32_t)__builtin_amdgcn_readfirstlane(lnfull[0]); rem = (int)nfull;
-            nnext = (uint32_t)__builtin_amdgcn_readfirstlane(lnfull[1]);
+            c = 0; mc = 0; irregular = false; anymiss = false;
+            sidx = 0; d = lsegs[0];
         }
         CT *cp = lcnt + (size_t)slot * P * kTileSites + lane;
         uint64_t *zp = lzf + (size_t)slot * 2 * P;
@@ -176,42 +174,35 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 #pragma unroll
         for (int u = 0; u < kFuseNB; ++u) {
             if (wb + u < p.W) {
-                int bitpos = 0;
-                while (bitpos < 64 && k < P) {
-                    const int len = min(rem, 64 - bitpos);
-                    const uint64_t mask = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << bitpos;
-                    c += __popcll(cur[u].x & mask);
-                    mc += __popcll(cur[u].y & mask);
-                    rem -= len; bitpos += len;
-                    if (rem == 0) {                 // population k is complete
+                const uint32_t xlo = (uint32_t)cur[u].x, xhi = (uint32_t)(cur[u].x >> 32);
+                const uint32_t ylo = (uint32_t)cur[u].y, yhi = (uint32_t)(cur[u].y >> 32);
+                bool more = true;
+                while (more) {
+                    const uint4 dn = lsegs[sidx + 1];      // the table ends with one spare entry
+                    c = __popc(xlo & d.x) + c; c = __popc(xhi & d.y) + c;
+                    mc = __popc(ylo & d.x) + mc; mc = __popc(yhi & d.y) + mc;
+                    const uint32_t fl = d.w;
+                    if (fl & kSegLast) {                   // population d.z is complete
+                        const uint32_t nfull = fl >> kSegNFullShift;
                         const uint32_t nm = nfull - mc;
-                        cp[(size_t)k * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
+                        cp[(size_t)d.z * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
                         const uint64_t z = __ballot(c == 0) | skipmask;
                         const uint64_t f = __ballot(c == nm) | skipmask;
-                        const int kl = k & 63;
-                        const bool mine = lane == kl;
-                        zl = mine ? (int)(uint32_t)z : zl; zh = mine ? (int)(uint32_t)(z >> 32) : zh;
-                        fl = mine ? (int)(uint32_t)f : fl; fh = mine ? (int)(uint32_t)(f >> 32) : fh;
+                        if (lane == 0) { zp[d.z] = z; zp[P + d.z] = f; }
                         // sites phase B must take through its general loop: a NaN in the reference (nm < 2) or an
                         // excluded site with a dxy term (fixed with missing alleles)
                         irregular = irregular || nm < 2 || (c == nm && nm < nfull);
-                        if (kl == 63 || k == P - 1) {
-                            if (lane <= kl) {
-                                zp[(k & ~63) + lane] = ((uint64_t)(uint32_t)zh << 32) | (uint32_t)zl;
-                                zp[P + (k & ~63) + lane] = ((uint64_t)(uint32_t)fh << 32) | (uint32_t)fl;
-                            }
-                        }
-                        ++k;
-                        nfull = nnext; rem = (int)nfull;
-                        nnext = (uint32_t)__builtin_amdgcn_readfirstlane(lnfull[k + 1]);   // asked for a population ahead of its use
+                        anymiss = anymiss || mc != 0;
                         c = 0; mc = 0;
                     }
+                    more = (fl & kSegWordEnd) == 0u;
+                    d = dn; ++sidx;
                 }
             }
         }
         if (bi == nb - 1) {
-            const uint64_t im = __ballot(irregular && !skip);
-            if (lane == 0) { lirr[slot] = im; lskip[slot] = skipmask; }
+            const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss);
+            if (lane == 0) { lirr[slot] = im; lskip[slot] = skipmask; lmiss[slot] = mm; }
         }
         if (item + 1 < n_items) {
 #pragma unroll
@@ -239,7 +230,7 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
     auto carve = [&](size_t bytes) { unsigned char *r = smem + off; off += (bytes + 15) & ~(size_t)15; return r; };
     RcpEntry *rcp = reinterpret_cast<RcpEntry *>(carve(use_rcp ? (size_t)(p.max_n + 1) * sizeof(RcpEntry) : 0));
     int32_t *lmisc = reinterpret_cast<int32_t *>(carve(64));
-    int32_t *lnfull = reinterpret_cast<int32_t *>(carve((size_t)(P + 2) * 4));   // [P] chromosomes per population, then two zeros
+    uint4 *lsegs = reinterpret_cast<uint4 *>(carve((size_t)(p.n_segs + 1) * sizeof(SegDesc)));   // descriptor stream + one spare entry
     uint32_t *wcen = nullptr, *lb = nullptr;
     if (WP) {
         wcen = reinterpret_cast<uint32_t *>(carve((size_t)kFuseWaves * 64 * 4));        // [wave][pair] census of the wave's tiles
@@ -247,7 +238,7 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
         const size_t rb = ((size_t)3 * (((size_t)P * SUBP * 8 + 15) & ~(size_t)15)) + 2 * (((size_t)P * 8 + 15) & ~(size_t)15) +
                           2 * (((size_t)P * SUBP * 4 + 15) & ~(size_t)15) + (((size_t)P * 4 + 15) & ~(size_t)15) +
                           (((size_t)TR * P * kTileSites * sizeof(CT) + 15) & ~(size_t)15) + (((size_t)TR * 2 * P * 8 + 15) & ~(size_t)15) +
-                          2 * (((size_t)TR * 8 + 15) & ~(size_t)15);
+                          3 * (((size_t)TR * 8 + 15) & ~(size_t)15);
         off += (size_t)wave * rb;
     }
     double *pt = reinterpret_cast<double *>(carve((size_t)P * SUBP * 8));   // [P][SUB + 1] p = c / nm
@@ -262,6 +253,7 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
     uint64_t *lzf = reinterpret_cast<uint64_t *>(carve((size_t)TR * 2 * P * 8));          // [tile][z|f][P]
     uint64_t *lirr = reinterpret_cast<uint64_t *>(carve((size_t)TR * 8));
     uint64_t *lskip = reinterpret_cast<uint64_t *>(carve((size_t)TR * 8));
+    uint64_t *lmiss = reinterpret_cast<uint64_t *>(carve((size_t)TR * 8));    // sites where some population has a missing allele
 
     const int dtid = WP ? lane : tid;          // thread index and count of the group that shares one region
     const int dn = WP ? 64 : nthreads;
@@ -277,7 +269,14 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
     }
     const int64_t first_seg = b0 / p.g;
     const uint32_t io = pi * SUBP, jo = pj * SUBP;
-    for (int i = tid; i < P + 2; i += nthreads) lnfull[i] = i < P ? p.n_full[i] : 0;
+    // clean fills (no missing allele, no skipped site; 8-bit counts): exact integer sums, scaled once per segment
+    constexpr bool kInt = sizeof(CT) == 2;
+    const uint64_t ni2 = (uint64_t)ni * ni, nj2 = (uint64_t)nj * nj, ninj = (uint64_t)ni * nj;
+    const double rE = active ? 1.0 / ((double)ninj * (double)ninj) : 0.0;          // d^2 = (c_i n_j - c_j n_i)^2 / (n_i n_j)^2
+    const double rTi = active ? 1.0 / (double)ni2 : 0.0, rTj = active ? 1.0 / (double)nj2 : 0.0;   // t = c (n - c) / n^2
+    const double rHi = ni > 1 ? rTi / (double)(ni - 1) : 0.0, rHj = nj > 1 ? rTj / (double)(nj - 1) : 0.0;   // h = t / (n - 1)
+    for (int i = tid; i <= p.n_segs; i += nthreads)
+        lsegs[i] = i < p.n_segs ? reinterpret_cast<const uint4 *>(p.segs)[i] : make_uint4(0u, 0u, 0u, kSegWordEnd);
     if (use_rcp)
         for (int i = tid; i <= p.max_n; i += nthreads) {
             RcpEntry e;
@@ -325,8 +324,8 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
         if (!(p.debug & 8))
 #endif
         {
-            if (WP) count_wave_tiles<CT>(p, lane, rnt, t0 + rt0, 1, 0, 1, lcnt, lzf, lirr, lskip, lnfull);
-            else count_wave_tiles<CT>(p, lane, wave < nt ? (nt - wave + NWV - 1) / NWV : 0, t0 + wave, NWV, wave, NWV, lcnt, lzf, lirr, lskip, lnfull);
+            if (WP) count_wave_tiles<CT>(p, lane, rnt, t0 + rt0, 1, 0, 1, lcnt, lzf, lirr, lskip, lmiss, lsegs);
+            else count_wave_tiles<CT>(p, lane, wave < nt ? (nt - wave + NWV - 1) / NWV : 0, t0 + wave, NWV, wave, NWV, lcnt, lzf, lirr, lskip, lmiss, lsegs);
         }
         for (int i = dtid; i < P; i += dn) { carH[i] = 0.0; carT[i] = 0.0; carC[i] = 0u; }
         region_sync();
@@ -397,7 +396,18 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
         uint32_t prevCi = 0, prevCj = 0, prevBn = 0, prevBd = 0;
         uint64_t prevCC = 0;
         int32_t nflush = 0;
+        uint64_t aCC = 0, aCi = 0, aCj = 0, aQi = 0, aQj = 0;   // clean fills since the last boundary: sums of c_i c_j, c, c^2
         const int nvec = P * VPR;
+
+        // integer sums of clean fills -> their share of the numerator / denominator sums (added to numI / denI) and of sumKij
+        auto int_parts = [&](uint64_t iCC, uint64_t iCi, uint64_t iCj, uint64_t iQi, uint64_t iQj, double &numI, double &denI, uint64_t &kI) {
+            const uint64_t E = nj2 * iQi + ni2 * iQj - 2ull * ninj * iCC;       // sum (c_i n_j - c_j n_i)^2, exact
+            const double dTi = (double)((uint64_t)ni * iCi - iQi), dTj = (double)((uint64_t)nj * iCj - iQj);   // sum c (n - c)
+            const double dE = (double)E * rE;
+            numI = dE - dTi * rHi - dTj * rHj;
+            denI = dE + dTi * rTi + dTj * rTj;
+            kI += (uint64_t)nj * iCi + (uint64_t)ni * iCj - 2ull * iCC;
+        };
 
         // One vector = EPT consecutive sites of population k.
         auto derive_vec = [&](int vi, const uint4 &vv, uint32_t skipfill) {
@@ -478,7 +488,8 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
             const int ti = st / SPT, sh = (st - ti * SPT) * SUB;
             const uint32_t skipfill = (uint32_t)(lskip[ti] >> sh) & FULL;
             const bool general = ((uint32_t)(lirr[ti] >> sh) & FULL) != 0u;   // uniform
-            {
+            const bool clean = kInt && ((uint32_t)((lmiss[ti] | lskip[ti] | lirr[ti]) >> sh) & FULL) == 0u;   // uniform
+            if (!clean) {
                 const uint4 *vp = reinterpret_cast<const uint4 *>(lcnt + (size_t)ti * P * kTileSites);
                 for (int vi = dtid; vi < nvec; vi += dn) {
                     const int k = vi / VPR, r = vi - k * VPR;
@@ -495,6 +506,77 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
                     if (left <= cnt) b = nth_set_bit(incl, left);
                     else left -= cnt;
                 }
+                // emit: the accumulators right after boundary site b -> one row of the segment table, then the next boundary.
+                // H, T, PCi, PCj: the per-population prefix sums at b; i*: the integer sums of the segment's clean fills.
+                auto emit = [&](double cD, uint64_t ccc, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd, double H, double T,
+                                uint32_t PCi, uint32_t PCj, uint64_t iCC, uint64_t iCi, uint64_t iCj, uint64_t iQi, uint64_t iQj) {
+                    const uint32_t Ci = PCi - cexi, Cj = PCj - cexj;
+                    const double cumN = cD - H, cumD = cD + T;
+                    // sumKij (fst.cpp:299-321) of the segment, exact: differences are taken modulo 2^32 / 2^64
+                    uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC);
+                    double numI = 0.0, denI = 0.0;
+                    if (kInt) int_parts(iCC, iCi, iCj, iQi, iQj, numI, denI, kk);
+                    SegRow row;
+                    row.num = cbn != prevBn ? kNaN : (cumN - prevN) + numI;
+                    row.den = cbd != prevBd ? kNaN : (cumD - prevD) + denI;
+                    row.k = (double)kk;
+                    row.end = (t0 + rt0 + ti) * kTileSites + sh + b; row.pad = 0;
+                    {   // two 16-byte stores into one 32-byte sector
+                        uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
+                        const uint4 *src = reinterpret_cast<const uint4 *>(&row);
+                        dst[0] = src[0]; dst[1] = src[1];
+                    }
+                    prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevBn = cbn; prevBd = cbd;
+                    ++nflush;
+                    orow += p.n_pairs;
+                    const uint32_t rem = b >= SUB - 1 ? 0u : incl & ~((2u << b) - 1u);
+                    const int c2 = __popc(rem);
+                    if (p.g <= c2) b = nth_set_bit(rem, p.g);
+                    else { left = p.g - c2; b = SUB; }
+                };
+                if (clean) {
+                    // ---- no missing allele and no skipped site in this fill: p = c / n with constant n, so the sums of d^2, t
+                    // and h over a range of sites follow exactly from the integer sums of c_i c_j, c and c^2 (4 sites per
+                    // v_dot4_u32_u8); no tables are derived
+                    constexpr int NW4 = SUB / 4;
+                    constexpr uint32_t kOnes = 0x01010101u;
+                    uint32_t wi[NW4], wj[NW4];
+                    {
+                        const uint4 *ri = reinterpret_cast<const uint4 *>(lcnt + ((size_t)ti * P + pi) * kTileSites + sh);
+                        const uint4 *rj = reinterpret_cast<const uint4 *>(lcnt + ((size_t)ti * P + pj) * kTileSites + sh);
+#pragma unroll
+                        for (int v = 0; v < SUB / 8; ++v) {       // 8 packed {c, nm} pairs -> two words of 4 c bytes
+                            const uint4 x = ri[v], y = rj[v];
+                            wi[2 * v] = __builtin_amdgcn_perm(x.y, x.x, 0x06040200u); wi[2 * v + 1] = __builtin_amdgcn_perm(x.w, x.z, 0x06040200u);
+                            wj[2 * v] = __builtin_amdgcn_perm(y.y, y.x, 0x06040200u); wj[2 * v + 1] = __builtin_amdgcn_perm(y.w, y.z, 0x06040200u);
+                        }
+                    }
+                    uint32_t tCC = 0, tCi = 0, tCj = 0, tQi = 0, tQj = 0;     // over the whole fill (< 2^22)
+#pragma unroll
+                    for (int m_ = 0; m_ < NW4; ++m_) {
+                        tCC = __builtin_amdgcn_udot4(wi[m_], wj[m_], tCC, false);
+                        tCi = __builtin_amdgcn_udot4(wi[m_], kOnes, tCi, false); tCj = __builtin_amdgcn_udot4(wj[m_], kOnes, tCj, false);
+                        tQi = __builtin_amdgcn_udot4(wi[m_], wi[m_], tQi, false); tQj = __builtin_amdgcn_udot4(wj[m_], wj[m_], tQj, false);
+                    }
+                    uint32_t dCC = 0, dCi = 0, dCj = 0, dQi = 0, dQj = 0;     // of them, up to the last boundary
+                    while (b < SUB) {
+                        uint32_t pCC = 0, pCi = 0, pCj = 0, pQi = 0, pQj = 0;  // sites 0 .. b
+#pragma unroll
+                        for (int m_ = 0; m_ < NW4; ++m_) {
+                            const int nbv = b + 1 - 4 * m_;
+                            const uint32_t mk = nbv >= 4 ? 0xffffffffu : (nbv <= 0 ? 0u : ((1u << (8 * nbv)) - 1u));
+                            const uint32_t x = wi[m_] & mk, y = wj[m_] & mk;
+                            pCC = __builtin_amdgcn_udot4(x, y, pCC, false);
+                            pCi = __builtin_amdgcn_udot4(x, kOnes, pCi, false); pCj = __builtin_amdgcn_udot4(y, kOnes, pCj, false);
+                            pQi = __builtin_amdgcn_udot4(x, x, pQi, false); pQj = __builtin_amdgcn_udot4(y, y, pQj, false);
+                        }
+                        emit(D, cc, exi, exj, bn, bd, carH[pi] + carH[pj], carT[pi] + carT[pj], carC[pi], carC[pj],
+                             aCC + (pCC - dCC), aCi + (pCi - dCi), aCj + (pCj - dCj), aQi + (pQi - dQi), aQj + (pQj - dQj));
+                        aCC = aCi = aCj = aQi = aQj = 0;
+                        dCC = pCC; dCi = pCi; dCj = pCj; dQi = pQi; dQj = pQj;
+                    }
+                    aCC += tCC - dCC; aCi += tCi - dCi; aCj += tCj - dCj; aQi += tQi - dQi; aQj += tQj - dQj;
+                } else {
                 const int bgrp = b & ~(kGrp - 1);
                 double sD = D;                                 // snapshots at the end of the boundary's group
                 uint64_t scc = cc;
@@ -545,30 +627,10 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
                         if (sb == bgrp) { sD = D; scc = cc; sexi = exi; sexj = exj; sbn = bn; sbd = bd; }
                     }
                 }
-                // emit: the accumulators right after boundary site b -> one row of the segment table, then the next boundary
-                auto emit = [&](double cD, uint64_t ccc, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd) {
-                    const double H = PH[io + b] + PH[jo + b], T = PT[io + b] + PT[jo + b];
-                    const uint32_t Ci = PC[io + b] - cexi, Cj = PC[jo + b] - cexj;
-                    const double cumN = cD - H, cumD = cD + T;
-                    // sumKij (fst.cpp:299-321) of the segment, exact: differences are taken modulo 2^32 / 2^64
-                    const uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC);
-                    SegRow row;
-                    row.num = cbn != prevBn ? kNaN : cumN - prevN;
-                    row.den = cbd != prevBd ? kNaN : cumD - prevD;
-                    row.k = (double)kk;
-                    row.end = (t0 + rt0 + ti) * kTileSites + sh + b; row.pad = 0;
-                    {   // two 16-byte stores into one 32-byte sector
-                        uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
-                        const uint4 *src = reinterpret_cast<const uint4 *>(&row);
-                        dst[0] = src[0]; dst[1] = src[1];
-                    }
-                    prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevBn = cbn; prevBd = cbd;
-                    ++nflush;
-                    orow += p.n_pairs;
-                    const uint32_t rem = b >= SUB - 1 ? 0u : incl & ~((2u << b) - 1u);
-                    const int c2 = __popc(rem);
-                    if (p.g <= c2) b = nth_set_bit(rem, p.g);
-                    else { left = p.g - c2; b = SUB; }
+                auto emit_general = [&](double cD, uint64_t ccc, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd) {
+                    emit(cD, ccc, cexi, cexj, cbn, cbd, PH[io + b] + PH[jo + b], PT[io + b] + PT[jo + b], PC[io + b], PC[jo + b],
+                         aCC, aCi, aCj, aQi, aQj);
+                    aCC = aCi = aCj = aQi = aQj = 0;
                 };
                 if (b < SUB) {
                     // first boundary: the group snapshot minus the (at most kGrp - 1) sites of the group behind b
@@ -598,7 +660,7 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
                                 cbn -= bad & 1u; cbd -= bad >> 1;
                             }
                         }
-                        emit(cD, ccc, cexi, cexj, cbn, cbd);
+                        emit_general(cD, ccc, cexi, cexj, cbn, cbd);
                     }
                     // further boundaries of the same fill (windows shorter than it): from the end of the fill
                     while (b < SUB) {
@@ -618,9 +680,10 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
                                 cexi -= ci; cexj -= cj;
                             }
                         }
-                        emit(cD, ccc, cexi, cexj, cbn, cbd);
+                        emit_general(cD, ccc, cexi, cexj, cbn, cbd);
                     }
                 }
+                }   // general fill
             }
             region_sync();
         }
@@ -632,9 +695,11 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
             const size_t plane = (size_t)p.n_pairs * n_sub;
             const double H = carH[pi] + carH[pj], T = carT[pi] + carT[pj];
             const uint32_t Ci = carC[pi] - exi, Cj = carC[pj] - exj;
-            const uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (cc - prevCC);
-            p.tail[cq] = bn != prevBn ? kNaN : (D - H) - prevN;
-            p.tail[plane + cq] = bd != prevBd ? kNaN : (D + T) - prevD;
+            uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (cc - prevCC);
+            double numI = 0.0, denI = 0.0;
+            if (kInt) int_parts(aCC, aCi, aCj, aQi, aQj, numI, denI, kk);
+            p.tail[cq] = bn != prevBn ? kNaN : ((D - H) - prevN) + numI;
+            p.tail[plane + cq] = bd != prevBd ? kNaN : ((D + T) - prevD) + denI;
             p.tail[2 * plane + cq] = (double)kk;
             p.tail_n[cq] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);   // {sites summed in the tail, segments completed, row of the first}
         }
@@ -677,7 +742,7 @@ hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_
     const bool wp = p.n_pairs <= 64;
     if (wp && p.chunk_tiles % kFuseWaves != 0) return hipErrorInvalidValue;
     const int threads = fused_threads(p.n_pairs);
-    const size_t lds = fused_lds_bytes(p.P, p.max_n, p.n_pairs, p.chunk_tiles, count_bytes, sub);
+    const size_t lds = fused_lds_bytes(p.P, p.n_segs, p.max_n, p.n_pairs, p.chunk_tiles, count_bytes, sub);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool rcp = p.max_n <= kRcpMax;
 #define EVOFST_FUSED_GO(CT, R, W_, S_) return launch_fused_t<CT, R, W_, S_>(p, lds, threads, max_blocks, st)

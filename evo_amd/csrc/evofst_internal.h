@@ -18,7 +18,7 @@ struct SegDesc {
     uint32_t flags;  // bit0: last segment of the population, bit1: pop is in populationsToUse,
                      // bit2: pop is populationsToUse[0]
 };
-constexpr uint32_t kSegLast = 1u, kSegUse = 2u, kSegFirstUse = 4u;
+constexpr uint32_t kSegLast = 1u, kSegUse = 2u, kSegFirstUse = 4u, kSegWordEnd = 8u;   // bit3: last segment of its word
 constexpr int kSegNFullShift = 8;   // flags >> 8: n_full of the population
 
 
@@ -129,7 +129,9 @@ struct FusedParams {
     const uint8_t *site_flags;  // may be null
     int64_t n_sites;
     int32_t n_tiles, W, P;
-    const int32_t *n_full;          // [P] chromosomes per population = its bits on the haplotype axis, in order
+    const SegDesc *segs;            // [n_segs] (word, population) overlaps in bit order, flags incl. kSegWordEnd
+    int32_t n_segs;
+    const int32_t *n_full;          // [P]
     int32_t max_n;
     const uint32_t *pairs;          // i | j << 16
     int32_t n_pairs;
@@ -297,7 +299,7 @@ hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st);
 size_t k2_lds_bytes(int P, int max_n);
-size_t fused_lds_bytes(int P, int max_n, int n_pairs, int chunk_tiles, int count_bytes, int sub);
+size_t fused_lds_bytes(int P, int n_segs, int max_n, int n_pairs, int chunk_tiles, int count_bytes, int sub);
 int fused_threads(int n_pairs);
 int fused_tail_chunks(int n_pairs, int n_chunks);   // entries per pair of the tail table (sub-chunks when every wave owns a part of a chunk)
 // sub: sites per table fill (16 or 32); max_blocks <= 0: as many workgroups as the device holds at once (occupancy query)

@@ -56,12 +56,9 @@ def timed(env, steps=20):
 
 
 print("%s: %d sites x %d samples, %d pops" % (name, S, N, P))
-for sub in (32,):
-    for ct in (16,):
-        for dbg, what in ((0, "all"), (7, "no loads, no waits, no B"), (7 + 64, "... and no census/publish"), (7 + 32, "... no count loop"),
-                          (7 + 32 + 64, "... neither"), (15, "no phase A"), (15 + 64, "no phase A no census"), (7 + 16, "7 + static chunks")):
+for sub in (32, 16):
+    for ct in (8, 16, 32):
+        for dbg, what in ((0, "all"), (1, "no waits"), (2, "no phase B"), (3, "A + census only"), (7, "no loads, no waits, no B")):
             print("sub %2d chunk_tiles %2d  %-26s %s" % (sub, ct, what, timed({"EVOFST_FUSED_SUB": sub, "EVOFST_CHUNK_TILES": ct, "EVOFST_DEBUG_FUSED": dbg})), flush=True)
-for blocks in (256, 512, 768, 1024):
-    print("blocks %d %s" % (blocks, timed({"EVOFST_CHUNK_TILES": 16, "EVOFST_FUSED_BLOCKS": blocks, "EVOFST_DEBUG_FUSED": 7})), flush=True)
 print("unfused %s" % timed({"EVOFST_NO_FUSE": 1}))
 e.close()
