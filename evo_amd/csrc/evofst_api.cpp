@@ -89,7 +89,7 @@ struct evofst_ctx {
     int64_t row_cap = 0;
 
     // fused pairs pass (evofst_fused.hip): look-back granules, ticket + error words, launch epoch
-    DevBuf d_agg0, d_agg1, d_agg2, d_fsync;
+    DevBuf d_agg0, d_agg1, d_agg2, d_fsync, d_miss;
     uint32_t epoch = 0;
     bool fused_check = false;         // a fused launch has not had its error word looked at yet
     bool plain_counts = false;        // d_counts holds the counts of the loaded data (from any K1 launch)
@@ -255,6 +255,7 @@ K2Params make_k2(evofst_ctx *c) {
     p.g = c->g; p.seg_cap = c->seg_cap;
     p.seg_rows = (SegRow *)c->d_seg_rows.p;
     p.zf_masks = (const uint64_t *)c->d_zf.p; p.irr_mask = (const uint64_t *)c->d_irr.p; p.skip_mask = (const uint64_t *)c->d_skip.p;
+    p.miss_mask = (const uint64_t *)c->d_miss.p;
     p.tail = (double *)c->d_tail.p;
     p.tail_n = (int4 *)c->d_tail_n.p;
     return p;
@@ -309,7 +310,9 @@ constexpr int kFusedFan = 32, kFusedMaxChunks = 32 * 32 * 64;
 // Tiles per chunk of the fused pairs pass and sites per table fill, or 0 when this shape goes through K1 + scan + K2.
 int fused_plan(evofst_ctx *c, int *sub_out) {
     if (c->mode != MODE_PAIRS || c->pairs.size() > (size_t)kK2Threads || c->gathered) return 0;
-    if (getenv("EVOFST_NO_FUSE")) return 0;
+    // Opt-in for now: on cfg2 the one-kernel pass equals K1 + scan + K2 in time and on many-pair shapes it is slower (its
+    // workgroups move through their phases in lockstep), so the default stays the three-kernel pass.
+    if (!getenv("EVOFST_FUSE")) return 0;
     const int n_tiles = n_tiles_of(c->n_sites);
     const int np = (int)c->pairs.size();
     const int max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
@@ -456,7 +459,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles, &c->d_agg0, &c->d_agg1,
-                      &c->d_agg2, &c->d_fsync};
+                      &c->d_agg2, &c->d_fsync, &c->d_miss};
     for (DevBuf *b : bufs) release(*b);
     for (auto &pair : c->ev)
         for (auto &e : pair)
@@ -1188,7 +1191,9 @@ int launch_k1_counts(evofst_ctx *c, int mode) {
         if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 16))) return rc;
         if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
         if ((rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8))) return rc;
+        if ((rc = ensure(c, c->d_miss, (size_t)c->n_tiles * 8))) return rc;
         p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
+        p.miss_mask = (uint64_t *)c->d_miss.p;
     } else if (mode == MODE_GRAM) {
         if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 32))) return rc;
         if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
@@ -1248,7 +1253,29 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
         if (k2_lds_bytes(c->n_pops, *std::max_element(c->n_full.begin(), c->n_full.end())) > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: too many populations for the LDS table");
         K2Params p = make_k2(c);
         record(c, 2, 0);
-        HIPCHK(c, launch_k2(p, c->count_bytes, c->stream));
+        // up to 256 pairs: the walk of evofst_fused.hip over K1's counts (regions in LDS, exact integer sums where no allele
+        // is missing); more pairs, or layouts its LDS regions cannot hold: k2_window_kernel
+        bool lds_walk = false;
+        if (np <= (size_t)kK2Threads && !getenv("EVOFST_OLD_K2")) {
+            FusedParams f{};
+            f.site_flags = p.site_flags; f.n_sites = c->n_sites; f.n_tiles = c->n_tiles; f.W = c->W; f.P = c->n_pops;
+            f.n_segs = 0; f.n_full = p.n_full; f.max_n = p.max_n; f.pairs = p.pairs; f.n_pairs = p.n_pairs;
+            f.chunk_tiles = c->chunk_tiles; f.n_chunks = c->n_chunks; f.g = c->g;
+            f.base = (const int64_t *)c->d_base.p;
+            f.first_segment = (int64_t *)c->d_first_seg.p; f.incl_totals = (int64_t *)c->d_incl_totals.p;
+            f.seg_cap = c->seg_cap; f.seg_rows = p.seg_rows; f.tail = p.tail; f.tail_n = p.tail_n;
+            f.counts = p.counts; f.zf_masks = p.zf_masks; f.irr_mask = p.irr_mask; f.skip_mask = p.skip_mask; f.miss_mask = p.miss_mask;
+            f.chunk_offsets = p.chunk_offsets;
+            const int dn = np <= 64 ? 64 : fused_threads((int)np);
+            const int per_tile = c->n_pops * kTileSites * c->count_bytes / 16;            // 16-byte vectors of one tile's counts
+            f.piece_tiles = std::max(1, std::min(std::min(4, c->chunk_tiles), 8 * dn / std::max(1, per_tile)));
+            const size_t lds = fused_lds_bytes(c->n_pops, 0, p.max_n, (int)np, f.piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, 32);
+            if (lds <= 100 * 1024) {
+                HIPCHK(c, launch_fused(f, c->count_bytes, 32, 0, c->stream));
+                lds_walk = true;
+            }
+        }
+        if (!lds_walk) HIPCHK(c, launch_k2(p, c->count_bytes, c->stream));
         record(c, 2, 1);
         record(c, 3, 0);
         HIPCHK(c, launch_stitch(p, c->stream));

@@ -34,6 +34,9 @@ namespace evofst {
 constexpr int kFan = 32;                  // look-back fan-out per level
 constexpr int kFuseNB = 8;                // tile rows per load batch (8 KiB per wave)
 constexpr int kFuseWaves = 4;             // waves per workgroup in the wave-private shape
+#ifndef EVOFST_FUSED_WPS
+#define EVOFST_FUSED_WPS 2             // waves per SIMD the register allocation aims at
+#endif
 constexpr uint32_t kSpinLimit = 1u << 22; // polls before a wait gives up (seconds; a healthy wait takes microseconds)
 
 static size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -212,8 +215,11 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 }
 
 // WP: wave-private shape (n_pairs <= 64).  SUB: sites per table fill (16 or 32).
-template <typename CT, bool use_rcp, bool WP, int SUB>
-__global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams p) {
+// HBM: the statistics half on its own (evofst_run_stats after evofst_run_counts, the multi-GPU pass): a region is one of
+// K1's chunks, its counts and ballots come from HBM in pieces of a few tiles (the next piece is requested before the
+// current one is walked) and its offsets from the scan kernel; no phase A, no look-back, no tickets.
+template <typename CT, bool use_rcp, bool WP, int SUB, bool HBM>
+__global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kernel(FusedParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int SUBP = SUB + 1;                 // row stride in entries: pop-indexed reads stay conflict-free
     constexpr int SPT = kTileSites / SUB;         // table fills per tile
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = blockDim.x, NWV = nthreads >> 6;
-    const int TR = WP ? p.chunk_tiles / NWV : p.chunk_tiles;     // tiles of a region
+    const int TR = HBM ? p.piece_tiles : (WP ? p.chunk_tiles / NWV : p.chunk_tiles);     // tiles a region holds in LDS
     size_t off = 0;
     auto carve = [&](size_t bytes) { unsigned char *r = smem + off; off += (bytes + 15) & ~(size_t)15; return r; };
     RcpEntry *rcp = reinterpret_cast<RcpEntry *>(carve(use_rcp ? (size_t)(p.max_n + 1) * sizeof(RcpEntry) : 0));
@@ -275,8 +281,9 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
     const double rE = active ? 1.0 / ((double)ninj * (double)ninj) : 0.0;          // d^2 = (c_i n_j - c_j n_i)^2 / (n_i n_j)^2
     const double rTi = active ? 1.0 / (double)ni2 : 0.0, rTj = active ? 1.0 / (double)nj2 : 0.0;   // t = c (n - c) / n^2
     const double rHi = ni > 1 ? rTi / (double)(ni - 1) : 0.0, rHj = nj > 1 ? rTj / (double)(nj - 1) : 0.0;   // h = t / (n - 1)
-    for (int i = tid; i <= p.n_segs; i += nthreads)
-        lsegs[i] = i < p.n_segs ? reinterpret_cast<const uint4 *>(p.segs)[i] : make_uint4(0u, 0u, 0u, kSegWordEnd);
+    if (!HBM)
+        for (int i = tid; i <= p.n_segs; i += nthreads)
+            lsegs[i] = i < p.n_segs ? reinterpret_cast<const uint4 *>(p.segs)[i] : make_uint4(0u, 0u, 0u, kSegWordEnd);
     if (use_rcp)
         for (int i = tid; i <= p.max_n; i += nthreads) {
             RcpEntry e;
@@ -296,9 +303,10 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
 
     for (int iter = 0;; ++iter) {
         __syncthreads();                               // the tables above; the previous chunk's readers of lmisc / LDS
+        if (HBM && iter > 0) break;                    // one chunk (or four of K1's) per workgroup
         if (tid == 0) {
             int32_t chunk = (int32_t)blockIdx.x;       // first chunk: the workgroup's own index (the grid is not larger than n_chunks)
-            if (iter > 0) {
+            if (!HBM && iter > 0) {
                 // n_chunks draws in all: every workgroup draws until its chunk is past the end
                 const uint32_t t = __hip_atomic_fetch_add((gu32 *)p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // the last draw of the launch: nobody adds after it, so the counter can go back to zero for the next launch
@@ -306,24 +314,28 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
                 chunk = (int32_t)min((uint32_t)gridDim.x + t, (uint32_t)p.n_chunks);
             }
             lmisc[0] = chunk;
-            lmisc[1] = (int32_t)__hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lmisc[1] = HBM ? 0 : (int32_t)__hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         const int chunk = lmisc[0];
         dead = dead || lmisc[1] != 0;
-        if (chunk >= p.n_chunks) break;
+        if (!HBM && chunk >= p.n_chunks) break;
         if (dead) continue;
         const int t0 = chunk * p.chunk_tiles;
         const int nt = min(p.chunk_tiles, p.n_tiles - t0);           // tiles of the chunk
         // tiles of this region: WP -- tiles [wave * TR, wave * TR + TR) of the chunk; shared -- all of them
         const int rt0 = WP ? min(wave * TR, nt) : 0;
-        const int rnt = WP ? min(TR, nt - rt0) : nt;
+        // HBM: the region is K1's chunk kc
+        const int kc = WP ? chunk * NWV + wave : chunk;
+        const bool kvalid = kc < p.n_chunks;
+        const int rg0 = HBM ? (kvalid ? kc * p.chunk_tiles : 0) : t0 + rt0;     // first tile of the region
+        const int rnt = HBM ? (kvalid ? min(p.chunk_tiles, p.n_tiles - rg0) : 0) : (WP ? min(TR, nt - rt0) : nt);
 
         // ------------------------------------------------------------------ phase A: tiles -> counts and ballots in LDS
 #ifdef EVOFST_EXPERIMENTS
         if (!(p.debug & 8))
 #endif
-        {
+        if (!HBM) {
             if (WP) count_wave_tiles<CT>(p, lane, rnt, t0 + rt0, 1, 0, 1, lcnt, lzf, lirr, lskip, lmiss, lsegs);
             else count_wave_tiles<CT>(p, lane, wave < nt ? (nt - wave + NWV - 1) / NWV : 0, t0 + wave, NWV, wave, NWV, lcnt, lzf, lirr, lskip, lmiss, lsegs);
         }
@@ -335,6 +347,10 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
 #ifdef EVOFST_EXPERIMENTS
         if (p.debug & 64) continue;
 #endif
+        int64_t g0 = b0;
+        if (HBM) {
+            if (active && kvalid) g0 = p.chunk_offsets[(size_t)q * p.n_chunks + kc];
+        } else {
         if (active)
             for (int ti = 0; ti < rnt; ++ti) {
                 const uint64_t *zp = lzf + (size_t)ti * 2 * P;
@@ -377,7 +393,8 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
             if (chunk == p.n_chunks - 1) p.incl_totals[q] = (int64_t)s[2] + (int64_t)s[1] + (int64_t)s[0] + (int64_t)cen_chunk;
             if (chunk == 0) p.first_segment[q] = first_seg;
         }
-        const int64_t g0 = b0 + (int64_t)s[2] + (int64_t)s[1] + (int64_t)s[0] + (int64_t)cen_before;
+        g0 = b0 + (int64_t)s[2] + (int64_t)s[1] + (int64_t)s[0] + (int64_t)cen_before;
+        }
 #ifdef EVOFST_EXPERIMENTS
         if (p.debug & 2) continue;
 #endif
@@ -484,7 +501,50 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
             }
         };
 
-        for (int st = 0; st < SPT * rnt; ++st) {
+        // HBM: the region's counts and ballots come in pieces of TR tiles, held in registers from the request to the
+        // moment the piece before has been walked
+        constexpr int NVP = 8, NVZ = 4;
+        uint4 pre[NVP];
+        uint64_t prez[NVZ], prem[3] = {0, 0, 0};
+        auto piece_tiles_of = [&](int piece) { return min(TR, rnt - piece * TR); };
+        auto prefetch_piece = [&](int piece) {
+            const int g = rg0 + piece * TR, pnt = piece_tiles_of(piece);
+            const int nvp = pnt * P * kTileSites * (int)sizeof(CT) / 16, nz = pnt * 2 * P;
+            const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)g * P * kTileSites);
+#pragma unroll
+            for (int j = 0; j < NVP; ++j) pre[j] = src[min(dtid + j * dn, nvp - 1)];
+            const uint64_t *zsrc = p.zf_masks + (size_t)g * 2 * P;
+#pragma unroll
+            for (int j = 0; j < NVZ; ++j) prez[j] = zsrc[min(dtid + j * dn, nz - 1)];
+            const int tt = g + min(dtid, pnt - 1);
+            prem[0] = p.irr_mask[tt]; prem[1] = p.skip_mask[tt]; prem[2] = p.miss_mask[tt];
+        };
+        auto store_piece = [&](int piece) {
+            const int g = rg0 + piece * TR, pnt = piece_tiles_of(piece);
+            const int nvp = pnt * P * kTileSites * (int)sizeof(CT) / 16, nz = pnt * 2 * P;
+            uint4 *dst = reinterpret_cast<uint4 *>(lcnt);
+#pragma unroll
+            for (int j = 0; j < NVP; ++j) { const int v = dtid + j * dn; if (v < nvp) dst[v] = pre[j]; }
+            const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)g * P * kTileSites);
+            for (int v = dtid + NVP * dn; v < nvp; v += dn) dst[v] = src[v];          // layouts too large for the registers
+#pragma unroll
+            for (int j = 0; j < NVZ; ++j) { const int v = dtid + j * dn; if (v < nz) lzf[v] = prez[j]; }
+            const uint64_t *zsrc = p.zf_masks + (size_t)g * 2 * P;
+            for (int v = dtid + NVZ * dn; v < nz; v += dn) lzf[v] = zsrc[v];
+            if (dtid < pnt) { lirr[dtid] = prem[0]; lskip[dtid] = prem[1]; lmiss[dtid] = prem[2]; }
+            for (int v = dtid + dn; v < pnt; v += dn) { lirr[v] = p.irr_mask[g + v]; lskip[v] = p.skip_mask[g + v]; lmiss[v] = p.miss_mask[g + v]; }
+        };
+        const int n_pieces = HBM ? (rnt + TR - 1) / TR : 1;
+        if (HBM && rnt > 0) prefetch_piece(0);
+        for (int piece = 0; piece < n_pieces; ++piece) {
+        const int pnt = HBM ? piece_tiles_of(piece) : rnt;     // tiles in LDS
+        const int gtile0 = HBM ? rg0 + piece * TR : rg0;       // and the first of them
+        if (HBM) {
+            store_piece(piece);
+            if (piece + 1 < n_pieces) prefetch_piece(piece + 1);
+            region_sync();
+        }
+        for (int st = 0; st < SPT * pnt; ++st) {
             const int ti = st / SPT, sh = (st - ti * SPT) * SUB;
             const uint32_t skipfill = (uint32_t)(lskip[ti] >> sh) & FULL;
             const bool general = ((uint32_t)(lirr[ti] >> sh) & FULL) != 0u;   // uniform
@@ -520,7 +580,7 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
                     row.num = cbn != prevBn ? kNaN : (cumN - prevN) + numI;
                     row.den = cbd != prevBd ? kNaN : (cumD - prevD) + denI;
                     row.k = (double)kk;
-                    row.end = (t0 + rt0 + ti) * kTileSites + sh + b; row.pad = 0;
+                    row.end = (gtile0 + ti) * kTileSites + sh + b; row.pad = 0;
                     {   // two 16-byte stores into one 32-byte sector
                         uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
                         const uint4 *src = reinterpret_cast<const uint4 *>(&row);
@@ -687,10 +747,11 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
             }
             region_sync();
         }
-        if (active) {
+        }   // pieces
+        if (active && (!HBM || kvalid)) {
             // what the (sub-)chunk holds behind its last boundary
-            const int n_sub = WP ? p.n_chunks * NWV : p.n_chunks;
-            const int sub = WP ? chunk * NWV + wave : chunk;
+            const int n_sub = HBM ? p.n_chunks : (WP ? p.n_chunks * NWV : p.n_chunks);
+            const int sub = HBM ? kc : (WP ? chunk * NWV + wave : chunk);
             const size_t cq = (size_t)sub * p.n_pairs + q;
             const size_t plane = (size_t)p.n_pairs * n_sub;
             const double H = carH[pi] + carH[pj], T = carT[pi] + carT[pj];
@@ -706,14 +767,15 @@ __global__ __launch_bounds__(kK2Threads, 2) void fused_pairs_kernel(FusedParams 
     }
 }
 
-template <typename CT, bool RCP, bool WP, int SUB>
+template <typename CT, bool RCP, bool WP, int SUB, bool HBM>
 static hipError_t launch_fused_t(const FusedParams &p, size_t lds, int threads, int max_blocks, hipStream_t st) {
-    const void *fn = reinterpret_cast<const void *>(&fused_pairs_kernel<CT, RCP, WP, SUB>);
+    const void *fn = reinterpret_cast<const void *>(&fused_pairs_kernel<CT, RCP, WP, SUB, HBM>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     int grid = max_blocks;
+    if (HBM) grid = WP ? (p.n_chunks + kFuseWaves - 1) / kFuseWaves : p.n_chunks;
     if (grid <= 0) {
         // workgroups the device holds at once; asked once per shape (the query costs more than a launch)
         static thread_local struct { const void *fn; int threads; size_t lds; int dev; int grid; } memo = {nullptr, 0, 0, -1, 0};
@@ -729,7 +791,7 @@ static hipError_t launch_fused_t(const FusedParams &p, size_t lds, int threads, 
         grid = memo.grid;
     }
     grid = std::max(1, std::min(grid, p.n_chunks));
-    hipLaunchKernelGGL((fused_pairs_kernel<CT, RCP, WP, SUB>), dim3(grid), dim3(threads), lds, st, p);
+    hipLaunchKernelGGL((fused_pairs_kernel<CT, RCP, WP, SUB, HBM>), dim3(grid), dim3(threads), lds, st, p);
     return hipGetLastError();
 }
 
@@ -740,12 +802,14 @@ hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
     if (p.n_pairs > kK2Threads || (sub != 16 && sub != 32)) return hipErrorInvalidValue;
     const bool wp = p.n_pairs <= 64;
-    if (wp && p.chunk_tiles % kFuseWaves != 0) return hipErrorInvalidValue;
+    const bool hbm = p.counts != nullptr;
+    if (!hbm && wp && p.chunk_tiles % kFuseWaves != 0) return hipErrorInvalidValue;
     const int threads = fused_threads(p.n_pairs);
-    const size_t lds = fused_lds_bytes(p.P, p.n_segs, p.max_n, p.n_pairs, p.chunk_tiles, count_bytes, sub);
+    const size_t lds = fused_lds_bytes(p.P, p.n_segs, p.max_n, p.n_pairs, hbm ? p.piece_tiles * (wp ? kFuseWaves : 1) : p.chunk_tiles, count_bytes, sub);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool rcp = p.max_n <= kRcpMax;
-#define EVOFST_FUSED_GO(CT, R, W_, S_) return launch_fused_t<CT, R, W_, S_>(p, lds, threads, max_blocks, st)
+#define EVOFST_FUSED_GO(CT, R, W_, S_) do { if (hbm) return launch_fused_t<CT, R, W_, S_, true>(p, lds, threads, max_blocks, st); \
+                                            return launch_fused_t<CT, R, W_, S_, false>(p, lds, threads, max_blocks, st); } while (0)
 #define EVOFST_FUSED_SUB(CT, R, W_) do { if (sub == 16) EVOFST_FUSED_GO(CT, R, W_, 16); else EVOFST_FUSED_GO(CT, R, W_, 32); } while (0)
 #define EVOFST_FUSED_WP(CT, R) do { if (wp) EVOFST_FUSED_SUB(CT, R, true); else EVOFST_FUSED_SUB(CT, R, false); } while (0)
     if (count_bytes == 2) { if (rcp) EVOFST_FUSED_WP(uint16_t, true); else EVOFST_FUSED_WP(uint16_t, false); }

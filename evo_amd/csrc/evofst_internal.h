@@ -89,6 +89,7 @@ struct K1Params {
     uint32_t *chunk_census;  // [n_pairs][n_chunks]
     uint64_t *zf_masks;      // [n_tiles][2][P] sites with c == 0 / c == nm (skipped sites set in both)
     uint64_t *irr_mask;      // [n_tiles] sites with nm < 2 or c == nm < n_full in some population
+    uint64_t *miss_mask;     // [n_tiles] sites where some population has a missing allele (pairs mode)
     // against-all mode
     uint2 *totals;            // [n_tiles*64] {sum alt, sum non-missing} over populationsToUse
     uint64_t *kept_mask;      // [n_tiles]
@@ -118,6 +119,7 @@ struct K2Params {
     SegRow *seg_rows;              // [seg_cap][n_pairs]: a lane writes the four values of a segment as one 32-byte
                                    // sector (four separate arrays made four partial-line writes of it)
     const uint64_t *zf_masks, *irr_mask, *skip_mask;   // from K1
+    const uint64_t *miss_mask;                         // from K1: sites where some population has a missing allele
     // chunk-boundary partials, planes [chunk][pair] (a wave writes contiguous rows)
     double *tail;                  // [3][n_chunks][n_pairs] {num, den, k} after the last completed segment
     int4 *tail_n;                  // {sites summed in the tail, segments the chunk completed, row of its first segment, -}
@@ -151,6 +153,11 @@ struct FusedParams {
     uint32_t *ticket;               // chunk tickets; back to 0 when the launch ends
     uint32_t *err;                  // set when a wait gave up
     uint32_t epoch;
+    // statistics half on its own (counts != null): a region is one of K1's n_chunks chunks of chunk_tiles tiles
+    const void *counts;             // K1's packed counts
+    const uint64_t *zf_masks, *irr_mask, *skip_mask, *miss_mask;   // K1's ballots
+    const int64_t *chunk_offsets;   // [n_pairs][n_chunks] from the scan
+    int32_t piece_tiles;            // tiles of a region held in LDS at a time
     int32_t debug;                  // -DEVOFST_EXPERIMENTS builds only (tools/): 1 no look-back waits, 2 no phase B, 4 no tile loads
 };
 

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     // per-tile state
     uint32_t c = 0, mc = 0;
     uint32_t Tc = 0, Tn = 0, c0 = 0, nm0 = 0;
-    bool irregular = false, skip = false;
+    bool irregular = false, skip = false, anymiss = false;
     uint64_t skipmask = 0;
     for (int item = 0; item < n_items; ++item) {
         const int ti = item / nb, bi = item - ti * nb;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             skip = site >= p.n_sites;
             if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
             skipmask = __ballot(skip);
-            c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false;
+            c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false; anymiss = false;
         }
         CT *cp = reinterpret_cast<CT *>(p.counts) + (size_t)t * p.P * kTileSites + lane;
         if (p.debug & 1) {   // profiling experiments only: loads without the counting loop
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                                 // sites K2 must take through its general loop: a NaN in the reference (nm < 2) or an
                                 // excluded site with a dxy term (fixed with missing alleles)
                                 irregular = irregular || nm < 2 || (c == nm && nm < nfull);
+                                anymiss = anymiss || mc != 0;
                             }
                             if (MODE == MODE_GLOBAL) {
                                 if (d.flags & kSegUse) { Tc += c; Tn += nm; }
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                 __builtin_amdgcn_wave_barrier();
             }
             if (MODE == MODE_PAIRS && !(p.debug & 4)) {
-                const uint64_t im = __ballot(irregular && !skip);
-                if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
+                const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss);
+                if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; p.miss_mask[t] = mm; }
                 // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
                 // (i,j) iff both counts are 0 or both pops are fixed for ALT (or the site is skipped).
                 __builtin_amdgcn_wave_barrier();
@@ -345,6 +346,22 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
         left = p.g - (int32_t)(g0 - m * p.g);
     }
     const int32_t left0 = left;
+    // clean half tiles (no missing allele, no skipped site; 8-bit counts): exact integer sums, scaled once per segment
+    constexpr bool kInt = sizeof(CT) == 2;
+    const uint64_t ni2 = (uint64_t)ni * ni, nj2 = (uint64_t)nj * nj, ninj = (uint64_t)ni * nj;
+    const double rE = active ? 1.0 / ((double)ninj * (double)ninj) : 0.0;          // d^2 = (c_i n_j - c_j n_i)^2 / (n_i n_j)^2
+    const double rTi = active ? 1.0 / (double)ni2 : 0.0, rTj = active ? 1.0 / (double)nj2 : 0.0;   // t = c (n - c) / n^2
+    const double rHi = ni > 1 ? rTi / (double)(ni - 1) : 0.0, rHj = nj > 1 ? rTj / (double)(nj - 1) : 0.0;   // h = t / (n - 1)
+    uint64_t aCC = 0, aCi = 0, aCj = 0, aQi = 0, aQj = 0;   // clean half tiles since the last boundary: sums of c_i c_j, c, c^2
+    // integer sums of clean half tiles -> their share of the numerator / denominator sums and of sumKij
+    auto int_parts = [&](uint64_t iCC, uint64_t iCi, uint64_t iCj, uint64_t iQi, uint64_t iQj, double &numI, double &denI, uint64_t &kI) {
+        const uint64_t E = nj2 * iQi + ni2 * iQj - 2ull * ninj * iCC;       // sum (c_i n_j - c_j n_i)^2, exact
+        const double dTi = (double)((uint64_t)ni * iCi - iQi), dTj = (double)((uint64_t)nj * iCj - iQj);   // sum c (n - c)
+        const double dE = (double)E * rE;
+        numI = dE - dTi * rHi - dTj * rHj;
+        denI = dE + dTi * rTi + dTj * rTj;
+        kI += (uint64_t)nj * iCi + (uint64_t)ni * iCj - 2ull * iCC;
+    };
     // Segment-table element of the next segment this lane completes.  The chunk's first one is only a part
     // (the stitch kernel adds what earlier chunks hold of it).
     const int32_t row0 = active ? (int32_t)(m - p.first_segment[q]) : 0;
@@ -380,12 +397,12 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
     constexpr int NV = 2;
     const int nvec = P * VPR;
     uint4 pre[NV];
-    uint64_t pre_zf = 0, pre_skip = 0, pre_irr = 0;   // K1's masks of the tile of the prefetched half tile
+    uint64_t pre_zf = 0, pre_skip = 0, pre_irr = 0, pre_miss = 0;   // K1's masks of the tile of the prefetched half tile
     auto fetch = [&](int st) {               // st = 2*tile + half
         if ((st & 1) == 0 || st == 2 * t0) {
             const int tile = st >> 1;
             pre_zf = p.zf_masks[(size_t)tile * 2 * P + min((int)threadIdx.x, 2 * P - 1)];   // (P > nthreads / 2: see below)
-            pre_skip = p.skip_mask[tile]; pre_irr = p.irr_mask[tile];
+            pre_skip = p.skip_mask[tile]; pre_irr = p.irr_mask[tile]; pre_miss = p.miss_mask[tile];
         }
         const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)(st >> 1) * P * kTileSites);
 #pragma unroll
@@ -480,7 +497,21 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
         // ---- derive the per-(pop, site) tables of this half tile
         const uint32_t skiphalf = (uint32_t)(pre_skip >> sh);
         const bool general = (uint32_t)(pre_irr >> sh) != 0u;   // uniform
-        if (!(p.debug & 2)) {
+        const bool clean = kInt && (uint32_t)((pre_miss | pre_skip | pre_irr) >> sh) == 0u;   // uniform
+        uint4 *stage = reinterpret_cast<uint4 *>(pt);           // clean half tiles: the raw count vectors [P][VPR] instead of tables
+        if (clean) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int vi = threadIdx.x + j * nthreads;
+                if (vi < nvec) stage[vi] = pre[j];
+            }
+            const uint4 *vp = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)tile * P * kTileSites);
+            for (int vi = threadIdx.x + NV * nthreads; vi < nvec; vi += nthreads) {
+                const int k = vi / VPR, r = vi - k * VPR;
+                stage[vi] = vp[k * (kTileSites / EPT) + (st & 1) * VPR + r];
+            }
+        }
+        if (!clean) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int vi = threadIdx.x + j * nthreads;
@@ -498,7 +529,7 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
         if (st + 1 < st1) fetch(st + 1);
         __syncthreads();
         // ---- pairs: lane = pair
-        if (active && !(p.debug & 1)) {
+        if (active) {
             const uint32_t incl = ~((zfm[pi] & zfm[pj]) | (zfm[P + pi] & zfm[P + pj]));   // fst.cpp:543-544
             int b = kSub;                                  // site of this lane's next boundary in the half tile (kSub: none)
             {
@@ -506,12 +537,78 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
                 if (left <= cnt) b = nth_set_bit(incl, left);
                 else left -= cnt;
             }
+            // emit: the accumulators right after boundary site b -> one row of the segment table, then the next boundary.
+            // H, T, PCi, PCj: the per-population prefix sums at b; i*: the integer sums of the segment's clean half tiles.
+            auto emit = [&](double cD, uint64_t ccc, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd, double H, double T,
+                            uint32_t PCi, uint32_t PCj, uint64_t iCC, uint64_t iCi, uint64_t iCj, uint64_t iQi, uint64_t iQj) {
+                const uint32_t Ci = PCi - cexi, Cj = PCj - cexj;
+                const double cumN = cD - H, cumD = cD + T;
+                // sumKij (fst.cpp:299-321) of the segment, exact: differences are taken modulo 2^32 / 2^64
+                uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC);
+                double numI = 0.0, denI = 0.0;
+                if (kInt) int_parts(iCC, iCi, iCj, iQi, iQj, numI, denI, kk);
+                SegRow row;
+                row.num = cbn != prevBn ? kNaN : (cumN - prevN) + numI;
+                row.den = cbd != prevBd ? kNaN : (cumD - prevD) + denI;
+                row.k = (double)kk;
+                row.end = st * kSub + b; row.pad = 0;
+                {   // two 16-byte stores into one 32-byte sector
+                    uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(&row);
+                    dst[0] = src[0]; dst[1] = src[1];
+                }
+                prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevBn = cbn; prevBd = cbd;
+                ++nflush;
+                orow += p.n_pairs;
+                const uint32_t rem = b >= kSub - 1 ? 0u : incl & ~((2u << b) - 1u);
+                const int c2 = __popc(rem);
+                if (p.g <= c2) b = nth_set_bit(rem, p.g);
+                else { left = p.g - c2; b = kSub; }
+            };
+            if (clean) {
+                // ---- no missing allele and no skipped site in this half tile: p = c / n with constant n, so the sums of d^2,
+                // t and h over a range of sites follow exactly from the integer sums of c_i c_j, c and c^2 (4 sites per
+                // v_dot4_u32_u8); no tables are derived
+                constexpr int NW4 = kSub / 4;
+                constexpr uint32_t kOnes = 0x01010101u;
+                uint32_t wi[NW4], wj[NW4];
+#pragma unroll
+                for (int v = 0; v < kSub / 8; ++v) {       // 8 packed {c, nm} pairs -> two words of 4 c bytes
+                    const uint4 x = stage[pi * VPR + v], y = stage[pj * VPR + v];
+                    wi[2 * v] = __builtin_amdgcn_perm(x.y, x.x, 0x06040200u); wi[2 * v + 1] = __builtin_amdgcn_perm(x.w, x.z, 0x06040200u);
+                    wj[2 * v] = __builtin_amdgcn_perm(y.y, y.x, 0x06040200u); wj[2 * v + 1] = __builtin_amdgcn_perm(y.w, y.z, 0x06040200u);
+                }
+                uint32_t tCC = 0, tCi = 0, tCj = 0, tQi = 0, tQj = 0;     // over the whole half tile (< 2^22)
+#pragma unroll
+                for (int m_ = 0; m_ < NW4; ++m_) {
+                    tCC = __builtin_amdgcn_udot4(wi[m_], wj[m_], tCC, false);
+                    tCi = __builtin_amdgcn_udot4(wi[m_], kOnes, tCi, false); tCj = __builtin_amdgcn_udot4(wj[m_], kOnes, tCj, false);
+                    tQi = __builtin_amdgcn_udot4(wi[m_], wi[m_], tQi, false); tQj = __builtin_amdgcn_udot4(wj[m_], wj[m_], tQj, false);
+                }
+                uint32_t dCC = 0, dCi = 0, dCj = 0, dQi = 0, dQj = 0;     // of them, up to the last boundary
+                while (b < kSub) {
+                    uint32_t pCC = 0, pCi = 0, pCj = 0, pQi = 0, pQj = 0;  // sites 0 .. b
+#pragma unroll
+                    for (int m_ = 0; m_ < NW4; ++m_) {
+                        const int nbv = b + 1 - 4 * m_;
+                        const uint32_t mk = nbv >= 4 ? 0xffffffffu : (nbv <= 0 ? 0u : ((1u << (8 * nbv)) - 1u));
+                        const uint32_t x = wi[m_] & mk, y = wj[m_] & mk;
+                        pCC = __builtin_amdgcn_udot4(x, y, pCC, false);
+                        pCi = __builtin_amdgcn_udot4(x, kOnes, pCi, false); pCj = __builtin_amdgcn_udot4(y, kOnes, pCj, false);
+                        pQi = __builtin_amdgcn_udot4(x, x, pQi, false); pQj = __builtin_amdgcn_udot4(y, y, pQj, false);
+                    }
+                    emit(D, cc, exi, exj, bn, bd, carH[pi] + carH[pj], carT[pi] + carT[pj], carC[pi], carC[pj],
+                         aCC + (pCC - dCC), aCi + (pCi - dCi), aCj + (pCj - dCj), aQi + (pQi - dQi), aQj + (pQj - dQj));
+                    aCC = aCi = aCj = aQi = aQj = 0;
+                    dCC = pCC; dCi = pCi; dCj = pCj; dQi = pQi; dQj = pQj;
+                }
+                aCC += tCC - dCC; aCi += tCi - dCi; aCj += tCj - dCj; aQi += tQi - dQi; aQj += tQj - dQj;
+            } else {
             const int bgrp = b & ~(kGrp - 1);
             double sD = D;                                 // snapshots at the end of the boundary's group
             uint64_t scc = cc;
             uint32_t sexi = exi, sexj = exj, sbn = bn, sbd = bd;   // (the regular loop leaves these four alone)
-            if (p.debug & 8) {
-            } else if (!general) {
+            if (!general) {
 #pragma unroll EVOFST_K2_UNROLL
                 for (int sb = 0; sb < kSub; sb += kGrp) {
                     double a[kGrp], bb[kGrp];
@@ -557,33 +654,12 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
                     if (sb == bgrp) { sD = D; scc = cc; sexi = exi; sexj = exj; sbn = bn; sbd = bd; }
                 }
             }
-            // ---- write the segments that end in this half tile (usually at most one per lane)
-            // emit: the accumulators right after boundary site b -> one row of the segment table, then the next boundary
-            auto emit = [&](double cD, uint64_t ccc, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd) {
-                const double H = PH[io + b] + PH[jo + b], T = PT[io + b] + PT[jo + b];
-                const uint32_t Ci = PC[io + b] - cexi, Cj = PC[jo + b] - cexj;
-                const double cumN = cD - H, cumD = cD + T;
-                // sumKij (fst.cpp:299-321) of the segment, exact: differences are taken modulo 2^32 / 2^64
-                const uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC);
-                SegRow row;
-                row.num = cbn != prevBn ? kNaN : cumN - prevN;
-                row.den = cbd != prevBd ? kNaN : cumD - prevD;
-                row.k = (double)kk;
-                row.end = st * kSub + b; row.pad = 0;
-                {   // two 16-byte stores into one 32-byte sector
-                    uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
-                    const uint4 *src = reinterpret_cast<const uint4 *>(&row);
-                    dst[0] = src[0]; dst[1] = src[1];
-                }
-                prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevBn = cbn; prevBd = cbd;
-                ++nflush;
-                orow += p.n_pairs;
-                const uint32_t rem = b >= kSub - 1 ? 0u : incl & ~((2u << b) - 1u);
-                const int c2 = __popc(rem);
-                if (p.g <= c2) b = nth_set_bit(rem, p.g);
-                else { left = p.g - c2; b = kSub; }
+            auto emit_general = [&](double cD, uint64_t ccc, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd) {
+                emit(cD, ccc, cexi, cexj, cbn, cbd, PH[io + b] + PH[jo + b], PT[io + b] + PT[jo + b], PC[io + b], PC[jo + b],
+                     aCC, aCi, aCj, aQi, aQj);
+                aCC = aCi = aCj = aQi = aQj = 0;
             };
-            if (b < kSub && !(p.debug & 4)) {
+            if (b < kSub) {
                 // first boundary: the group snapshot minus the (at most kGrp - 1) sites of the group behind b
                 {
                     double cD = sD;
@@ -611,7 +687,7 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
                             cbn -= bad & 1u; cbd -= bad >> 1;
                         }
                     }
-                    emit(cD, ccc, cexi, cexj, cbn, cbd);
+                    emit_general(cD, ccc, cexi, cexj, cbn, cbd);
                 }
                 // further boundaries of the same half tile (windows shorter than it): from the end of the half tile
                 while (b < kSub) {
@@ -631,9 +707,10 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
                             cexi -= ci; cexj -= cj;
                         }
                     }
-                    emit(cD, ccc, cexi, cexj, cbn, cbd);
+                    emit_general(cD, ccc, cexi, cexj, cbn, cbd);
                 }
             }
+                    }   // general half tile
         }
         __syncthreads();
     }
@@ -643,9 +720,11 @@ __global__ __launch_bounds__(kK2Threads, kK2WavesPerSimd) void k2_window_kernel(
         const size_t plane = (size_t)p.n_pairs * p.n_chunks;
         const double H = carH[pi] + carH[pj], T = carT[pi] + carT[pj];
         const uint32_t Ci = carC[pi] - exi, Cj = carC[pj] - exj;
-        const uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (cc - prevCC);
-        p.tail[cq] = bn != prevBn ? kNaN : (D - H) - prevN;
-        p.tail[plane + cq] = bd != prevBd ? kNaN : (D + T) - prevD;
+        uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (cc - prevCC);
+        double numI = 0.0, denI = 0.0;
+        if (kInt) int_parts(aCC, aCi, aCj, aQi, aQj, numI, denI, kk);
+        p.tail[cq] = bn != prevBn ? kNaN : ((D - H) - prevN) + numI;
+        p.tail[plane + cq] = bd != prevBd ? kNaN : ((D + T) - prevD) + denI;
         p.tail[2 * plane + cq] = (double)kk;
         p.tail_n[cq] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);   // {sites summed in the tail, segments completed, row of the first}
     }

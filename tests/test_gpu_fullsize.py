@@ -20,13 +20,16 @@ pytestmark = pytest.mark.gpu
 S, N, P, SIZE, STEP = 1_000_000, 200, 10, 100, 100
 
 
-def _run(engine, chunk_tiles):
+def _run(engine, chunk_tiles, fuse=False):
     old = os.environ.get("EVOFST_CHUNK_TILES")
     os.environ["EVOFST_CHUNK_TILES"] = str(chunk_tiles)
+    if fuse:
+        os.environ["EVOFST_FUSE"] = "1"
     try:
         engine.run()
         return engine.segments(), engine.totals(), engine.boundary()
     finally:
+        os.environ.pop("EVOFST_FUSE", None)
         if old is None:
             os.environ.pop("EVOFST_CHUNK_TILES", None)
         else:
@@ -52,7 +55,7 @@ def _pairs_properties(engine, S, N, P, slices, miss):
     engine.reserve(S)
     engine.synth(S, seed=20261110, missing_rate=miss)
     seg_a, tot_a, car_a = _run(engine, 0)      # the library's own choice
-    seg_b, tot_b, car_b = _run(engine, 7)      # chunk edges fall inside other windows
+    seg_b, tot_b, car_b = _run(engine, 7, fuse=True)      # the one-kernel pass, chunk edges inside other windows
     nq = engine.n_pairs
     assert np.array_equal(seg_a["n_segments"], seg_b["n_segments"])
     assert np.array_equal(tot_a[:, 3], tot_b[:, 3])

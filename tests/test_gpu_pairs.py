@@ -90,6 +90,19 @@ def _window_abs_sums(terms, first_var, size):
 
 
 def _check_windows(engine, sp, codes, fl, P, size, step, pairs=None, tag="snp_windows"):
+    """Both forms of the pairs pass against the oracle: K1 + scan + K2 + stitch (the default) and the one-kernel pass
+    (EVOFST_FUSE=1; it takes up to 256 pairs, more fall back to the default)."""
+    import os
+    for fuse in (False, True):
+        if fuse:
+            os.environ["EVOFST_FUSE"] = "1"
+        try:
+            _check_windows_once(engine, sp, codes, fl, P, size, step, pairs, tag + ("_fused" if fuse else ""))
+        finally:
+            os.environ.pop("EVOFST_FUSE", None)
+
+
+def _check_windows_once(engine, sp, codes, fl, P, size, step, pairs, tag):
     from tests import parity_log
     pi, pj = engine.all_pairs() if pairs is None else pairs
     nf = n_full_of(sp, P)
@@ -154,6 +167,23 @@ def test_snp_windows(engine, S, N, P, miss, size, step):
     sp, codes, fl = _setup(engine, rng, S, N, P, miss, flags=True)
     engine.set_pairs()
     _check_windows(engine, sp, codes, fl, P, size, step)
+
+
+@pytest.mark.parametrize("S,N,P,size,step,dirty", [(6000, 200, 10, 100, 100, 0), (5000, 40, 4, 20, 10, 0), (4096, 60, 5, 7, 7, 40),
+                                                     (3000, 250, 2, 50, 25, 3)])
+def test_snp_windows_without_missing_alleles(engine, S, N, P, size, step, dirty):
+    """No missing allele (but for `dirty` sites spread over the input): half tiles without one take the exact integer sums
+    (v_dot4_u32_u8) instead of the per-population tables, the others the tables, and segments mix both."""
+    rng = np.random.default_rng(S + size + dirty)
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=0.0, edge=False)
+    codes[0, :] = 0; codes[1, :] = 1                      # monomorphic / fixed sites
+    for s_ in rng.choice(S, dirty, replace=False):
+        codes[s_, rng.choice(2 * N, 3, replace=False)] = 2
+    engine.set_layout(sp, P)
+    engine.upload(engine.pack_codes(codes), S)
+    engine.set_pairs()
+    _check_windows(engine, sp, codes, None, P, size, step, tag="snp_windows_clean")
 
 
 def test_snp_windows_many_pairs(engine):

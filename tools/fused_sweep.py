@@ -57,8 +57,8 @@ def timed(env, steps=20):
 
 print("%s: %d sites x %d samples, %d pops" % (name, S, N, P))
 for sub in (32, 16):
-    for ct in (8, 16, 32):
-        for dbg, what in ((0, "all"), (1, "no waits"), (2, "no phase B"), (3, "A + census only"), (7, "no loads, no waits, no B")):
+    for ct in (8, 16):
+        for dbg, what in ((0, "all"), (1, "no waits"), (3, "A + census only")):
             print("sub %2d chunk_tiles %2d  %-26s %s" % (sub, ct, what, timed({"EVOFST_FUSED_SUB": sub, "EVOFST_CHUNK_TILES": ct, "EVOFST_DEBUG_FUSED": dbg})), flush=True)
 print("unfused %s" % timed({"EVOFST_NO_FUSE": 1}))
 e.close()
