@@ -81,7 +81,6 @@ struct K1Params {
     const int32_t *n_full;          // [P]
     void *counts;                   // CT [n_tiles][P][64], c | nm << (4*sizeof(CT))
     int32_t chunk_tiles, n_chunks;
-    int32_t debug;   // EVOFST_DEBUG_K1 (profiling experiments only)
     int32_t n_segs;  // entries of segs
     // pairs mode
     const uint32_t *pairs;  // i | j << 16

@@ -67,7 +67,10 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
 
     for (int i = threadIdx.x; i < npq; i += kK1Threads) lpairs[i] = p.pairs[i];
     for (int i = threadIdx.x; i <= p.W; i += kK1Threads) lwss[i] = p.word_seg_start[i];
-    for (int i = threadIdx.x; i < p.n_segs; i += kK1Threads) lsegs[i] = p.segs[i];
+    for (int i = threadIdx.x; i <= p.n_segs; i += kK1Threads) {
+        SegDesc e{}; e.flags = kSegWordEnd;            // the spare entry behind the stream
+        lsegs[i] = i < p.n_segs ? p.segs[i] : e;
+    }
     if (MODE == MODE_PAIRS)
         for (int q = lane; q < p.n_pairs; q += 64) cen[q] = 0;
     uint32_t used_cnt = 0, kept_cnt = 0;
@@ -78,6 +81,9 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     uint32_t Tc = 0, Tn = 0, c0 = 0, nm0 = 0;
     bool irregular = false, skip = false, anymiss = false;
     uint64_t skipmask = 0;
+    const uint4 *lsegs4 = reinterpret_cast<const uint4 *>(lsegs);
+    int sidx = 0;
+    uint4 d = lsegs4[0];
     for (int item = 0; item < n_items; ++item) {
         const int ti = item / nb, bi = item - ti * nb;
         const int t = t0 + ti, wb = bi * NB;
@@ -90,43 +96,45 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false; anymiss = false;
         }
         CT *cp = reinterpret_cast<CT *>(p.counts) + (size_t)t * p.P * kTileSites + lane;
-        if (p.debug & 1) {   // profiling experiments only: loads without the counting loop
+        if (bi == 0) { sidx = 0; d = lsegs4[0]; }
 #pragma unroll
-            for (int u = 0; u < NB; ++u) { c += (uint32_t)cur[u].x; mc += (uint32_t)cur[u].y; }
-            if (bi == nb - 1) cp[0] = (CT)(c + mc);
-        } else {
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                if (wb + u < p.W) {
-                    const int s0 = lwss[wb + u], s1 = lwss[wb + u + 1];
-                    for (int s = s0; s < s1; ++s) {
-                        const SegDesc d = lsegs[s];
-                        c += __popcll(cur[u].x & d.mask);
-                        mc += __popcll(cur[u].y & d.mask);
-                        if (d.flags & kSegLast) {
-                            const uint32_t nfull = d.flags >> kSegNFullShift;
-                            const uint32_t nm = nfull - mc;
-                            if (!(p.debug & 2)) cp[(size_t)d.pop * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
-                            if (MODE == MODE_GRAM) {
-                                const uint64_t b1 = __ballot(nm < 2) & ~skipmask, b0 = __ballot(nm == 0) & ~skipmask;
-                                if (lane == 0) { zm[2 * p.P + d.pop] = b1; zm[3 * p.P + d.pop] = b0; }
-                            }
-                            if (MODE == MODE_PAIRS || MODE == MODE_GRAM) {
-                                const uint64_t z = __ballot(c == 0) | skipmask;
-                                const uint64_t f = __ballot(c == nm) | skipmask;
-                                if (lane == 0) { zm[d.pop] = z; fm[d.pop] = f; }
-                                // sites K2 must take through its general loop: a NaN in the reference (nm < 2) or an
-                                // excluded site with a dxy term (fixed with missing alleles)
-                                irregular = irregular || nm < 2 || (c == nm && nm < nfull);
-                                anymiss = anymiss || mc != 0;
-                            }
-                            if (MODE == MODE_GLOBAL) {
-                                if (d.flags & kSegUse) { Tc += c; Tn += nm; }
-                                if (d.flags & kSegFirstUse) { c0 = c; nm0 = nm; }
-                            }
-                            c = 0; mc = 0;
+        for (int u = 0; u < NB; ++u) {
+            if (wb + u < p.W) {
+                const uint32_t xlo = (uint32_t)cur[u].x, xhi = (uint32_t)(cur[u].x >> 32);
+                const uint32_t ylo = (uint32_t)cur[u].y, yhi = (uint32_t)(cur[u].y >> 32);
+                bool more = true;
+                while (more) {
+                    // the descriptors {mask lo, mask hi, pop, flags | n_full << 8} are a stream in bit order, read one ahead of
+                    // its use (the table ends with a spare entry)
+                    const uint4 dn = lsegs4[sidx + 1];
+                    c = __popc(xlo & d.x) + c; c = __popc(xhi & d.y) + c;
+                    mc = __popc(ylo & d.x) + mc; mc = __popc(yhi & d.y) + mc;
+                    const uint32_t fl = d.w, pop = d.z;
+                    if (fl & kSegLast) {
+                        const uint32_t nfull = fl >> kSegNFullShift;
+                        const uint32_t nm = nfull - mc;
+                        cp[(size_t)pop * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
+                        if (MODE == MODE_GRAM) {
+                            const uint64_t b1 = __ballot(nm < 2) & ~skipmask, b0 = __ballot(nm == 0) & ~skipmask;
+                            if (lane == 0) { zm[2 * p.P + pop] = b1; zm[3 * p.P + pop] = b0; }
                         }
+                        if (MODE == MODE_PAIRS || MODE == MODE_GRAM) {
+                            const uint64_t z = __ballot(c == 0) | skipmask;
+                            const uint64_t f = __ballot(c == nm) | skipmask;
+                            if (lane == 0) { zm[pop] = z; fm[pop] = f; }
+                            // sites K2 must take through its general loop: a NaN in the reference (nm < 2) or an
+                            // excluded site with a dxy term (fixed with missing alleles)
+                            irregular = irregular || nm < 2 || (c == nm && nm < nfull);
+                            anymiss = anymiss || mc != 0;
+                        }
+                        if (MODE == MODE_GLOBAL) {
+                            if (fl & kSegUse) { Tc += c; Tn += nm; }
+                            if (fl & kSegFirstUse) { c0 = c; nm0 = nm; }
+                        }
+                        c = 0; mc = 0;
                     }
+                    more = (fl & kSegWordEnd) == 0u;
+                    d = dn; ++sidx;
                 }
             }
         }
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                 for (int i = lane; i < 4 * p.P; i += 64) p.zf_masks[(size_t)t * 4 * p.P + i] = zm[i];   // [tile][z|f|b1|b0][P]
                 __builtin_amdgcn_wave_barrier();
             }
-            if (MODE == MODE_PAIRS && !(p.debug & 4)) {
+            if (MODE == MODE_PAIRS) {
                 const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss);
                 if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; p.miss_mask[t] = mm; }
                 // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
@@ -186,7 +194,7 @@ hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t s
     if (p.n_chunks <= 0) return hipSuccess;
     constexpr int NW = kK1Threads / 64;
     const size_t npq = mode == MODE_PAIRS ? p.n_pairs : 0;
-    size_t lds = (size_t)NW * 4 * p.P * 8 + (NW + 1) * npq * 4 + (size_t)(p.W + 1) * 4 + 16 + (size_t)p.n_segs * sizeof(SegDesc) + 64;
+    size_t lds = (size_t)NW * 4 * p.P * 8 + (NW + 1) * npq * 4 + (size_t)(p.W + 1) * 4 + 16 + (size_t)(p.n_segs + 1) * sizeof(SegDesc) + 64;
     if (lds > 150 * 1024) return hipErrorInvalidValue;   // layouts with thousands of populations / words: not expected
     dim3 grid((p.n_chunks + NW - 1) / NW), block(kK1Threads);
 #define EVOFST_K1(CT, M) do { \
