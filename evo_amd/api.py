@@ -54,6 +54,8 @@ SIGNATURES = {
     "evofst_upload": (C.c_int, [_vp, C.c_int64, _vp, _u8p, _i32p]),
     "evofst_attach_device": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     "evofst_synth": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_uint64, C.c_double]),
+    "evofst_run_pairs_noalloc": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "evofst_noalloc_scratch_bytes": (C.c_int64, []),
     "evofst_download_tiles": (C.c_int, [_vp, _vp]),
     "evofst_download_tile_range": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
     "evofst_set_pairs": (C.c_int, [_vp, _i32p, _i32p, C.c_int]),

@@ -20,7 +20,17 @@
 
 using namespace evofst;
 
+// ---- scratch of evofst_run_pairs_noalloc: the look-back granules, ticket / error words and tail table of the one-kernel
+// pairs pass, for callers that cannot allocate.  One copy per GPU, held until the process ends; host code reaches it only
+// through the address hipGetSymbolAddress returned for that GPU (g_scratch_ptr), never through the array's name.
+constexpr size_t kNoAllocScratchBytes = (size_t)16 << 20;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+void *g_scratch_ptr[kMaxDevices] = {};        // per device, set by evofst_create
+uint32_t g_scratch_epoch[kMaxDevices] = {};   // per device: launch epochs of the granules in that GPU's scratch
 
 thread_local std::string g_create_error;
 
@@ -308,12 +318,12 @@ int ensure_zeroed(evofst_ctx *c, DevBuf &b, size_t bytes) {
 constexpr int kFusedFan = 32, kFusedMaxChunks = 32 * 32 * 64;
 
 // Tiles per chunk of the fused pairs pass and sites per table fill, or 0 when this shape goes through K1 + scan + K2.
-int fused_plan(evofst_ctx *c, int *sub_out) {
+int fused_plan(evofst_ctx *c, int64_t n_sites, bool always, int *sub_out) {
     if (c->mode != MODE_PAIRS || c->pairs.size() > (size_t)kK2Threads || c->gathered) return 0;
     // Opt-in for now: on cfg2 the one-kernel pass equals K1 + scan + K2 in time and on many-pair shapes it is slower (its
     // workgroups move through their phases in lockstep), so the default stays the three-kernel pass.
-    if (!getenv("EVOFST_FUSE")) return 0;
-    const int n_tiles = n_tiles_of(c->n_sites);
+    if (!always && !getenv("EVOFST_FUSE")) return 0;
+    const int n_tiles = n_tiles_of(n_sites);
     const int np = (int)c->pairs.size();
     const int max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
     const int unit = np <= 64 ? 4 : 1;                    // up to 64 pairs: every wave of the workgroup owns a quarter of a chunk
@@ -435,6 +445,15 @@ extern "C" evofst_ctx *evofst_create(int device_id) {
     if ((e = hipSetDevice(device_id)) != hipSuccess) {
         g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
         return nullptr;
+    }
+    if (device_id < kMaxDevices && !g_scratch_ptr[device_id]) {
+        // this GPU's copy of the no-allocation scratch array (evofst_run_pairs_noalloc)
+        void *sp = nullptr;
+        if ((e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch))) != hipSuccess) {
+            g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+            return nullptr;
+        }
+        g_scratch_ptr[device_id] = sp;
     }
     evofst_ctx *c = new (std::nothrow) evofst_ctx();
     if (!c) { g_create_error = "out of host memory"; return nullptr; }
@@ -1386,7 +1405,7 @@ extern "C" int evofst_run(evofst_ctx *c) try {
         // that want them run K1 on demand)
         HIPCHK(c, hipSetDevice(c->device));
         int sub = 32;
-        const int ct = fused_plan(c, &sub);
+        const int ct = fused_plan(c, c->n_sites, false, &sub);
         if (ct > 0) return run_fused(c, ct, sub);
     }
     int rc = evofst_run_counts(c);
@@ -1395,6 +1414,75 @@ extern "C" int evofst_run(evofst_ctx *c) try {
 } catch (...) {
     return abi_exception(c);
 }
+
+// One more form of evofst_run for callers that cannot allocate (no counterpart in the reference): the one-kernel pairs pass
+// on this GPU's static scratch array.  Calls no hipMalloc / hipFree.
+extern "C" int evofst_run_pairs_noalloc(evofst_ctx *c, int64_t n_sites, const void *d_tiles, const uint8_t *d_site_flags,
+                                        void *d_seg_rows, int64_t seg_rows_capacity, int64_t *d_first_segment,
+                                        int64_t *d_incl_totals, double *d_carry) try {
+    if (!c || !d_tiles || !d_seg_rows || !d_first_segment || !d_incl_totals || !d_carry || n_sites <= 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "run_pairs_noalloc: set_pairs first");
+    if (c->snp_size <= 0) return fail(c, EVOFST_ERR_STATE, "run_pairs_noalloc: set_windows first");
+    if (c->gathered) return fail(c, EVOFST_ERR_STATE, "run_pairs_noalloc: base offsets must be set with evofst_set_base_offsets[_device]");
+    if ((int64_t)n_tiles_of(n_sites) * kTileSites > (int64_t)INT_MAX) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_pairs_noalloc: too many sites for one shard");
+    const size_t np = c->pairs.size();
+    if (np > (size_t)kK2Threads) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_pairs_noalloc: more than 256 pairs");
+    if (c->device >= kMaxDevices || !g_scratch_ptr[c->device]) return fail(c, EVOFST_ERR_STATE, "run_pairs_noalloc: no scratch address for this device");
+    HIPCHK(c, hipSetDevice(c->device));
+    int sub = 32;
+    const int ct = fused_plan(c, n_sites, true, &sub);
+    if (ct <= 0) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_pairs_noalloc: this layout does not fit the one-kernel pass");
+    const int n_tiles = n_tiles_of(n_sites);
+    const int n_chunks = (n_tiles + ct - 1) / ct;
+    const int n_sub = fused_tail_chunks((int)np, n_chunks);
+    const int64_t seg_cap = n_sites / c->g + 2;
+    if (seg_rows_capacity < seg_cap) return fail(c, EVOFST_ERR_ARG, "run_pairs_noalloc: seg_rows_capacity is below n_sites / gcd(SIZE, STEP) + 2 rows");
+    // carve the scratch: [sync words 256 B][agg0][agg1][agg2][tail 3 planes][tail_n]
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t n1 = (n_chunks + kFusedFan - 1) / kFusedFan, n2 = (n1 + kFusedFan - 1) / kFusedFan;
+    const size_t o_agg0 = 256, o_agg1 = o_agg0 + a256((size_t)n_chunks * np * 8), o_agg2 = o_agg1 + a256(n1 * np * 8),
+                 o_tail = o_agg2 + a256(n2 * np * 8), o_tailn = o_tail + a256((size_t)n_sub * np * 24),
+                 need = o_tailn + a256((size_t)n_sub * np * 16);
+    if (need > kNoAllocScratchBytes)
+        return fail(c, EVOFST_ERR_UNSUPPORTED, "run_pairs_noalloc: " + std::to_string(need) + " bytes of scratch needed for this many sites x pairs, the static array holds " +
+                                                   std::to_string(kNoAllocScratchBytes) + " (use evofst_run)");
+    unsigned char *sp = (unsigned char *)g_scratch_ptr[c->device];     // the address, never the array's name
+    uint32_t &epoch = g_scratch_epoch[c->device];
+    if (epoch == 0xffffffffu) {            // the epoch counter wraps: forget every tag
+        HIPCHK(c, hipMemsetAsync(sp, 0, kNoAllocScratchBytes, c->stream));
+        epoch = 0;
+    }
+    HIPCHK(c, hipMemsetAsync(sp, 0, 256, c->stream));                  // ticket and error words start at zero
+    FusedParams p{};
+    p.tiles = (const ulonglong2 *)d_tiles;
+    p.site_flags = d_site_flags;
+    p.n_sites = n_sites; p.n_tiles = n_tiles; p.W = c->W; p.P = c->n_pops;
+    p.segs = (const SegDesc *)c->d_segs.p; p.n_segs = (int)c->segs.size();
+    p.n_full = (const int32_t *)c->d_nfull.p;
+    p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
+    p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)np;
+    p.chunk_tiles = ct; p.n_chunks = n_chunks;
+    p.g = c->g;
+    p.base = (const int64_t *)c->d_base.p;
+    p.first_segment = d_first_segment; p.incl_totals = d_incl_totals;
+    p.seg_cap = seg_cap; p.seg_rows = (SegRow *)d_seg_rows;
+    p.tail = (double *)(sp + o_tail); p.tail_n = (int4 *)(sp + o_tailn);
+    p.agg0 = (uint64_t *)(sp + o_agg0); p.agg1 = (uint64_t *)(sp + o_agg1); p.agg2 = (uint64_t *)(sp + o_agg2);
+    p.ticket = (uint32_t *)sp; p.err = (uint32_t *)sp + 32;
+    p.epoch = ++epoch;
+    HIPCHK(c, launch_fused(p, c->count_bytes, sub, 0, c->stream));
+    K2Params k2{};
+    k2.n_pairs = (int)np; k2.n_chunks = n_sub; k2.g = c->g; k2.seg_cap = seg_cap;
+    k2.seg_rows = (SegRow *)d_seg_rows; k2.tail = p.tail; k2.tail_n = p.tail_n;
+    HIPCHK(c, launch_stitch(k2, c->stream));
+    HIPCHK(c, launch_totals(k2, (const int64_t *)c->d_base.p, d_incl_totals, nullptr, d_carry, c->stream));
+    return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
+}
+
+extern "C" int64_t evofst_noalloc_scratch_bytes(void) { return (int64_t)kNoAllocScratchBytes; }
 
 extern "C" int evofst_sync(evofst_ctx *c) try {
     if (!c) return EVOFST_ERR_ARG;

@@ -217,6 +217,28 @@ int evofst_run_stats(evofst_ctx *ctx);
 int evofst_run(evofst_ctx *ctx);
 int evofst_sync(evofst_ctx *ctx);
 
+/* evofst_run for callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  It has NO counterpart in the reference (which has no device at all); it is a form of evofst_run in
+ * pairs mode that calls no hipMalloc / hipFree: the one-kernel pairs pass (evo_amd/csrc/evofst_fused.hip) keeps its look-back
+ * granules, ticket / error words and tail table in a static device array of evofst_noalloc_scratch_bytes() = 16 MiB that every
+ * GPU the library runs on holds until the process ends.  Shapes whose scratch would be larger (about n_sites / 16 x n_pairs
+ * x 42 bytes: 1 M sites x 45 pairs take 8 MiB) or with more than 256 pairs come back as EVOFST_ERR_UNSUPPORTED.
+ *
+ * Before: evofst_set_layout, evofst_set_pairs, evofst_set_windows (and evofst_set_base_offsets for a later shard); those
+ * allocate, this call does not.  The caller passes the input (device pointers to the packed tiles of n_sites sites and,
+ * or NULL, their site flags) and the outputs, all device memory of its own:
+ *   d_seg_rows       [seg_rows_capacity][n_pairs] rows of 32 bytes {double sum_num, sum_den, sum_dxy_k; int32 end_site, pad},
+ *                    seg_rows_capacity >= n_sites / gcd(SIZE, STEP) + 2; the rows evofst_get_segments hands out as four arrays,
+ *   d_first_segment  [n_pairs] index of the first segment that ends in this shard,
+ *   d_incl_totals    [n_pairs] included sites of the shard (n_segments = (base + total) / g - base / g),
+ *   d_carry          [n_pairs][4] {sum_num, sum_den, sum_dxy_k, n_sites} behind the last complete segment (evofst_get_boundary).
+ * Asynchronous on the context's stream.  All calls on one GPU share that GPU's scratch array: calls that overlap on one GPU
+ * (two contexts or streams at once) race; one at a time per GPU. */
+int evofst_run_pairs_noalloc(evofst_ctx *ctx, int64_t n_sites, const void *d_tiles, const uint8_t *d_site_flags,
+                             void *d_seg_rows, int64_t seg_rows_capacity, int64_t *d_first_segment, int64_t *d_incl_totals,
+                             double *d_carry);
+int64_t evofst_noalloc_scratch_bytes(void);
+
 /* When enabled, evofst_run_* bracket every kernel with HIP events on the context's stream. */
 int evofst_set_profiling(evofst_ctx *ctx, int enabled);
 /* Milliseconds of the last run of kernel `which` (0 = counts, 1 = offsets scan, 2 = pair/global
