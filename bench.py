@@ -107,6 +107,48 @@ def cpu_baseline(e, cfg, sample_sites):
     return evals / dtn, cores, dtn, evals / dt1, dt1
 
 
+def hbm_leg(device, steps=10):
+    """The pairs pass on one GPU's share of BASELINE configs[3] (6.25 M sites x 2000 samples, 190 pairs): 6.25 GB of tiles
+    per step, far beyond every cache.  Returns the roofline object of its dominant kernel (command: bench.py --config cfg4s)."""
+    from evo_amd import EvoFst
+    cfg = CONFIGS["cfg4s"]
+    S, N, P = cfg["sites"], cfg["samples"], cfg["pops"]
+    e = EvoFst(device)
+    e.set_layout((np.arange(N) % P).astype(np.int32), P)
+    e.set_pairs()
+    e.set_windows(cfg["size"], cfg["step"])
+    e.reserve(S)
+    e.synth(S, seed=20261110, missing_rate=cfg["miss"])
+    for _ in range(2):
+        e.run()
+    e.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e.run()
+    e.sync()
+    dt = (time.perf_counter() - t0) / steps
+    e.set_profiling(True)
+    km = np.zeros((3, 5))
+    for i in range(3):
+        e.run(); e.sync()
+        for k in range(5):
+            try:
+                km[i, k] = e.kernel_ms(k)
+            except Exception:
+                km[i, k] = 0.0
+    k = km.mean(axis=0)
+    cb = e.geometry().count_bytes
+    g = np.gcd(cfg["size"], cfg["step"])
+    k1_bytes = S * (N / 2.0) + S * P * cb + S / 64.0 * (2 * P + 3) * 8.0
+    e.close()
+    return {"workload": cfg["label"], "ms_per_step": dt * 1e3, "site_pairs_per_s": S * 190 / dt, "bound": "hbm",
+            "kernel": "k1_count_kernel", "algorithmic_bytes": k1_bytes, "achieved": k1_bytes / (k[0] * 1e-3) / 1e9 if k[0] > 0 else 0.0,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_bytes / (k[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if k[0] > 0 else 0.0,
+            "pipeline_GBps": S * (N / 2.0 + 4.0) / dt / 1e9, "pipeline_frac": S * (N / 2.0 + 4.0) / dt / 1e9 / HBM_PEAK_GBS,
+            "kernels_ms": {"k1_count_kernel": float(k[0]), "scan_kernel": float(k[1]), "fused_pairs_kernel(counts from HBM)": float(k[2]), "stitch_kernel": float(k[3])},
+            "command": "python bench.py --config cfg4s"}
+
+
 def spawn_ranks(n):
     """python bench.py --gpus N without torch.distributed.run: N children, one per GPU, rendezvous on 127.0.0.1."""
     import socket
@@ -136,6 +178,9 @@ def main():
     ap.add_argument("--dist-path", action="store_true", help="rehearsal: take the multi-rank step even with one rank")
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="no GPU work: the ranks only meet (gloo, CPU) and rank 0 prints how many there are -- tests the launch path")
+    ap.add_argument("--batches", type=int, default=0,
+                    help="resident synthetic batches the timed loop rotates over (0 = enough to exceed the 256 MiB Infinity Cache)")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the short cfg4-shard run behind roofline_hbm")
     ap.add_argument("--sites", type=int, default=0, help="experiments only: another number of sites per GPU (the label says so)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -213,6 +258,31 @@ def main():
     e.reserve(S)
     e.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=rank * S)
     e.sync()
+    # The timed loop rotates over several resident batches (contexts with different sites of the same genome) so that no
+    # step finds its input in the 256 MiB Infinity Cache: configs[1]'s 112 MB batch alone would stay there and its
+    # "HBM" rate would be a cache rate.  One stream for all of them: the steps run one after the other.
+    tiles_bytes = e.tiles_bytes(S)
+    n_batches = args.batches if args.batches > 0 else int(min(8, max(1, -(-640 * 2**20 // tiles_bytes))))
+    if multi or cfg["mode"] == "gram":
+        n_batches = 1
+    es = [e]
+    if n_batches > 1:
+        shared = torch.cuda.Stream()
+        e.set_stream(shared.cuda_stream)
+        for b in range(1, n_batches):
+            eb = EvoFst(local_rank)
+            eb.set_layout(sp, P)
+            if cfg["mode"] == "pairs":
+                eb.set_pairs()
+            else:
+                eb.set_against_all(np.arange(P, dtype=np.int32), np.full(P, N // P, np.int64))
+            eb.set_windows(cfg["size"], cfg["step"])
+            eb.set_stream(shared.cuda_stream)
+            eb.reserve(S)
+            eb.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=(rank * n_batches + b) * S)
+            eb.sync()
+            es.append(eb)
+    turn = [0]
     # No event records inside the timed region: eight hipEventRecord per step cost 0.030 ms of a 0.107 ms step on
     # cfg2 (measured with EVOFST_BENCH_EVENTS=1).  The per-kernel durations come from the same launches repeated
     # right after the timed region (below), on the library's stream; profiles/ holds the rocprofv3 view of them.
@@ -229,6 +299,7 @@ def main():
         # pass, so they ride with the next pass's totals and one more gather after the last pass delivers the rest.
         msg = shard.PairsPassMessage(nq, world, rank, "cuda")
         p_tot, p_carry, p_recv = msg.totals_ptr(), msg.carry_ptr(), msg.recv_ptr()
+        stream.wait_stream(torch.cuda.current_stream())      # the message tensors were filled on torch's current stream
 
     e_prof = [False]
 
@@ -243,7 +314,8 @@ def main():
                 if e_prof[0]:
                     e.sync(); gram_ms.append(e.kernel_ms(2))
         elif not multi:
-            e.run()
+            es[turn[0] % n_batches].run()
+            turn[0] += 1
         elif cfg["mode"] == "global":
             # {used, kept} totals and the last SIZE kept sites of every shard (all-gathers over RCCL)
             shard.compute_sharded_global(e, ag, rank, cfg["size"], cfg["step"])
@@ -268,7 +340,8 @@ def main():
                 msg.gather(dist)
 
     def fence():
-        e.sync()
+        for x in es:
+            x.sync()
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -289,12 +362,15 @@ def main():
     reps = min(args.steps, 20) if cfg["mode"] != "gram" else 1
     e.set_profiling(True)
     e_prof[0] = True
+    for x in es:
+        x.set_profiling(True)
     for i in range(reps):
+        cur = es[turn[0] % n_batches] if not multi and cfg["mode"] != "gram" else e
         step()
-        e.sync()
+        cur.sync()
         for k in range(5):
             try:
-                kms[i, k] = e.kernel_ms(k)
+                kms[i, k] = cur.kernel_ms(k)
             except Exception:
                 kms[i, k] = 0.0
     kavg = kms[:reps].mean(axis=0)
@@ -320,7 +396,7 @@ def main():
     else:
         k2_bytes = S * P * cb + S * 8.0 + (S / cfg["step"]) * P * 16.0
     names = ["k1_count_kernel", "scan_kernel",
-             {"pairs": "k2_window_kernel", "gram": "gram_kernel"}.get(cfg["mode"], "global_window_kernel"), "stitch_kernel",
+             {"pairs": "fused_pairs_kernel(counts from HBM)", "gram": "gram_kernel"}.get(cfg["mode"], "global_window_kernel"), "stitch_kernel",
              "fused_pairs_kernel"]
     if cfg["mode"] == "gram":
         kavg[2] = float(np.sum(gram_ms))          # popsums + gram launches of every batch of one step
@@ -369,6 +445,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["label"], "sites_per_gpu": S, "samples": N, "pops": P,
                    "units_per_site": units_per_site, "sharding": "contiguous site shards, one per GPU",
+                   "resident_batches": n_batches,
                    "rccl_ranks": dist.get_world_size() if multi else 1},
         "roofline": roofline,
     }
@@ -394,8 +471,16 @@ def main():
         out["config"]["exchange_check"] = ok
         if not ok:
             print("bench.py: device-side boundary copy differs from evofst_get_boundary", file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_hbm_leg and args.config == "cfg2" and args.sites == 0:
+        # cfg2 is small; the same pass on one GPU's share of configs[3] (6.25 GB of tiles per step) is the HBM measurement
+        for x in es[1:]:
+            x.close()
+        del es[1:]
+        out["roofline_hbm"] = hbm_leg(local_rank)
     if rank == 0:
         print(json.dumps(out))
+    for x in es[1:]:
+        x.close()
     e.close()
     if multi:
         dist.destroy_process_group()
