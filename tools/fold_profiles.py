@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Folds the output of tools/gpu_profile.sh (gpurun_out/prof_<cfg>/) into profiles/: the rocprofv3 kernel_stats.csv of
-the configuration and its entry in r01_traffic.json (FETCH_SIZE / WRITE_SIZE are KB per launch; on gfx950 FETCH_SIZE
+the configuration and its entry in <round>_traffic.json (ROUND, default r02) (FETCH_SIZE / WRITE_SIZE are KB per launch; on gfx950 FETCH_SIZE
 counts 128-byte requests of wide reads as 64, hence x 2 -- MI355X_MICROARCH.md, HBM section).
 python3 tools/fold_profiles.py cfg2 cfg4s ..."""
 import glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+RND = os.environ.get("ROUND", "r02")
+tp = os.path.join(ROOT, "profiles", RND + "_traffic.json")
 traffic = json.load(open(tp)) if os.path.exists(tp) else {}
 for cfg in sys.argv[1:]:
     d = os.path.join(ROOT, "gpurun_out", "prof_" + cfg)
@@ -25,6 +26,6 @@ for cfg in sys.argv[1:]:
     traffic[cfg] = out
     stats = glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
-        shutil.copy(stats[0], os.path.join(ROOT, "profiles", "r01_%s_kernel_stats.csv" % cfg))
+        shutil.copy(stats[0], os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (RND, cfg)))
     print(cfg, {k: (round(v["avg_ns"] / 1e3, 1), round((v.get("hbm_read_bytes", 0) + v.get("hbm_write_bytes", 0)) / 1e6, 1)) for k, v in out.items()})
 json.dump(traffic, open(tp, "w"), indent=1)
