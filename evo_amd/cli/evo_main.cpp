@@ -574,33 +574,68 @@ int FstGlobalMain(int argc, char **argv) {
     outFW << std::endl;
 
     const size_t nUse = populationsToUse.size();
-    std::deque<double> initFst(windowSize, 0.0);
-    std::vector<std::deque<double>> numDq(nUse, initFst), denDq(nUse, initFst);
-    std::deque<string> coordDeque(windowSize, "0");
     int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
-    int totalVariantNumber = 0, usedVariantNumber = 0;
+    int totalVariantNumber = 0;
+    int64_t usedBefore = 0, keptBefore = 0;          // used / kept sites of the batches before this one (:189, :204)
+    // the last SIZE kept sites seen so far, oldest first: what numDeque / denomDeque / coordDeque hold (:119-122, 237-240);
+    // they go to the device as the next batch's halo
+    struct HaloSite { string coord; std::vector<double> num, den; };
+    std::deque<HaloSite> halo;
 
     Device dev;
     Batch batch;
     int nSamples = 0;
-    std::vector<double> num, den;
+    std::vector<double> num, den, haloNum, haloDen, rowNum, rowDen;
+    std::vector<int32_t> haloTag, rowStart, rowEnd;
     std::vector<uint8_t> kept;
     bool haveHeader = false;
 
+    // The sliding windows are the device's: evofst_get_global_windows sums each deque oldest -> newest exactly as
+    // vector_average does (bit-identical rows); the host keeps the coordinates, the fixed-window table (which the reference
+    // fills with zeros, :222-235) and hands the deque contents from batch to batch.
     auto flush = [&]() {
         if (batch.n == 0) return;
         const size_t n = batch.n;
         dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
-        num.resize(nUse * n); den.resize(nUse * n); kept.resize(n);
-        check(dev.ctx, evofst_get_global_site_stats(dev.ctx, 0, (int64_t)n, num.data(), den.data(), kept.data()), "global_site_stats");
-        x86_nan_sign(num); x86_nan_sign(den);
+        int64_t tot[2] = {0, 0}, base[2] = {usedBefore, keptBefore};
+        check(dev.ctx, evofst_get_included_totals(dev.ctx, tot), "included_totals");
+        check(dev.ctx, evofst_set_base_offsets(dev.ctx, base), "set_base_offsets");
+        const int hn = (int)halo.size();
+        haloTag.resize(hn); haloNum.resize((size_t)hn * nUse); haloDen.resize((size_t)hn * nUse);
+        for (int e = 0; e < hn; ++e) {
+            haloTag[e] = -2 - e;
+            std::copy(halo[e].num.begin(), halo[e].num.end(), haloNum.begin() + (size_t)e * nUse);
+            std::copy(halo[e].den.begin(), halo[e].den.end(), haloDen.begin() + (size_t)e * nUse);
+        }
+        check(dev.ctx, evofst_set_global_halo(dev.ctx, hn, haloTag.data(), haloNum.data(), haloDen.data()), "set_global_halo");
+        check(dev.ctx, evofst_run_stats(dev.ctx), "run_stats");
+        const int64_t cap = evofst_max_global_rows(dev.ctx);
+        rowStart.resize(cap); rowEnd.resize(cap); rowNum.resize((size_t)cap * nUse); rowDen.resize((size_t)cap * nUse);
+        int64_t nRows = 0;
+        check(dev.ctx, evofst_get_global_windows(dev.ctx, &nRows, rowStart.data(), rowEnd.data(), rowNum.data(), rowDen.data()), "global_windows");
+        rowNum.resize((size_t)nRows * nUse); rowDen.resize((size_t)nRows * nUse);
+        x86_nan_sign(rowNum); x86_nan_sign(rowDen);
+        for (int64_t r = 0; r < nRows; ++r) {                        // :276-282, 298-300
+            const int32_t st = rowStart[r], en = rowEnd[r];
+            const string &first = st >= 0 ? batch.pos[st] : (st == -1 ? string("0") : halo[(size_t)(-2 - st)].coord);
+            outFile << batch.chrom[en] << "\t" << first << "\t" << batch.pos[en] << "\t" << "N";
+            for (size_t i = 0; i != nUse; i++) {
+                const double an = rowNum[(size_t)r * nUse + i], ad = rowDen[(size_t)r * nUse + i];
+                double Fst = an / ad; if (Fst < 0 || ad == 0) Fst = 0;
+                outFile << "\t" << Fst;
+            }
+            outFile << std::endl;
+        }
+        // kept sites in order: the fixed-window table, and the deque contents behind this batch
+        kept.resize(n);
+        check(dev.ctx, evofst_get_global_site_stats(dev.ctx, 0, (int64_t)n, nullptr, nullptr, kept.data()), "global_site_stats");
+        size_t tailFrom = n; int tailKept = 0;
+        for (size_t s = n; s-- > 0 && tailKept < windowSize;)
+            if (kept[s] && !(batch.flags[s] & EVOFST_SITE_SKIP)) { tailFrom = s; ++tailKept; }
         for (size_t s = 0; s < n; ++s) {
-            if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :185-188
-            usedVariantNumber++;                                     // :189
-            if (!kept[s]) continue;                                  // :198-203
+            if ((batch.flags[s] & EVOFST_SITE_SKIP) || !kept[s]) continue;
             const string &chr = batch.chrom[s];
-            const string &coord = batch.pos[s];
-            double coordDouble; { std::stringstream ss(coord); ss >> coordDouble; }
+            double coordDouble; { std::stringstream ss(batch.pos[s]); ss >> coordDouble; }
             if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {   // :222-235
                 outFW << chr << "\t" << currentWindowStart << "\t" << currentWindowEnd << "\t" << 0;
                 for (size_t i = 0; i != nUse; i++) { double FstFW = 0; outFW << "\t" << FstFW; }
@@ -608,23 +643,20 @@ int FstGlobalMain(int argc, char **argv) {
                 if (coordDouble > currentWindowEnd) { currentWindowStart = currentWindowStart + fixedWindowSize; currentWindowEnd = currentWindowEnd + fixedWindowSize; }
                 else if (coordDouble < currentWindowStart) { currentWindowStart = 0; currentWindowEnd = 0 + fixedWindowSize; }
             }
-            coordDeque.push_back(coord); coordDeque.pop_front();
-            const bool emit = (usedVariantNumber > windowSize || windowSize == windowStep) && (usedVariantNumber % windowStep == 0);
-            if (emit) outFile << chr << "\t" << coordDeque[0] << "\t" << coord << "\t" << "N";
-            for (size_t i = 0; i != nUse; i++) {                     // :244-282
-                numDq[i].push_back(num[i * n + s]); numDq[i].pop_front();
-                denDq[i].push_back(den[i * n + s]); denDq[i].pop_front();
-                if (emit) {
-                    double sn = 0, sd = 0;
-                    for (size_t t = 0; t < numDq[i].size(); t++) sn += numDq[i][t];
-                    for (size_t t = 0; t < denDq[i].size(); t++) sd += denDq[i][t];
-                    const double an = (double)sn / (double)numDq[i].size(), ad = (double)sd / (double)denDq[i].size();
-                    double Fst = an / ad; if (Fst < 0 || ad == 0) Fst = 0;
-                    outFile << "\t" << Fst;
-                }
-            }
-            if (emit) outFile << std::endl;
         }
+        if (tailKept > 0) {
+            const size_t m = n - tailFrom;
+            num.resize(nUse * m); den.resize(nUse * m);
+            check(dev.ctx, evofst_get_global_site_stats(dev.ctx, (int64_t)tailFrom, (int64_t)m, num.data(), den.data(), nullptr), "global_site_stats");
+            for (size_t s = tailFrom; s < n; ++s) {
+                if ((batch.flags[s] & EVOFST_SITE_SKIP) || !kept[s]) continue;
+                HaloSite h; h.coord = batch.pos[s]; h.num.resize(nUse); h.den.resize(nUse);
+                for (size_t i = 0; i < nUse; ++i) { h.num[i] = num[i * m + (s - tailFrom)]; h.den[i] = den[i * m + (s - tailFrom)]; }
+                halo.push_back(std::move(h));
+                if ((int)halo.size() > windowSize) halo.pop_front();
+            }
+        }
+        usedBefore += tot[0]; keptBefore += tot[1];
         batch.clear();
     };
 
@@ -656,6 +688,7 @@ int FstGlobalMain(int argc, char **argv) {
             dev.open();
             check(dev.ctx, evofst_set_layout(dev.ctx, nSamples, (int)populations.size(), sp.data()), "set_layout");
             check(dev.ctx, evofst_set_against_all(dev.ctx, use.data(), (int)nUse, setSizes.data()), "set_against_all");
+            check(dev.ctx, evofst_set_windows(dev.ctx, windowSize, windowStep), "set_windows");
             check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
             haveHeader = true;
             continue;
