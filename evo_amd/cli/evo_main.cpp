@@ -20,6 +20,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
+#include <numeric>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -244,7 +246,7 @@ struct Device {
 // ============================================================================================ fst
 
 namespace fstopt {
-string vcfFile, sampleSets, sampleNameFile, runName = "";
+string vcfFile, sampleSets, sampleNameFile, runName = "", popsFile, pairsArg;
 int windowSize = 0, windowStep = 0, physicalWindowSize = 10000;
 double regAbove = 0;
 }
@@ -259,9 +261,13 @@ const char *FST_USAGE =
     "       -s SAMPLES.txt, --samples=SAMPLES.txt   (optional) sample identifiers to be used for the VCF file\n"
     "       -w SIZE,STEP --window=SIZE,STEP         (optional) sliding window of SIZE SNPs moving by STEP\n"
     "       --regions-above=minFst                  (optional, requires -w)\n"
+    "       --pops=POPULATIONS.txt --pairs=all      (GPU build) instead of --sets: SAMPLE<TAB>POPULATION per line; every pair of\n"
+    "                                               populations in one pass over the VCF, one RUN_<POP1>_<POP2>_w_<SIZE>_fst.txt per\n"
+    "                                               pair = the _fst.txt file of `evo fst --sets` on those two populations (-w SIZE,STEP\n"
+    "                                               with SIZE > 1 required; no heterozygosity / fixed-window files in this mode)\n"
     "       --physicalWindowSize=SIZE               (optional; default 10000bp)\n\n";
 
-enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED };
+enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS };
 
 void parseFstOptions(int argc, char **argv) {
     static const struct option longopts[] = {
@@ -269,6 +275,7 @@ void parseFstOptions(int argc, char **argv) {
         {"window", required_argument, NULL, 'w'}, {"regions-above", required_argument, NULL, OPT_REG_ABOVE},
         {"physicalWindowSize", required_argument, NULL, OPT_PHYS}, {"samples", required_argument, NULL, 's'},
         {"run-name", required_argument, NULL, 'n'}, {"help", no_argument, NULL, 'h'},
+        {"pops", required_argument, NULL, OPT_POPS}, {"pairs", required_argument, NULL, OPT_PAIRS},
         {"ancSets", required_argument, NULL, OPT_UNSUPPORTED}, {"annot", required_argument, NULL, OPT_UNSUPPORTED},
         {"ms", required_argument, NULL, OPT_UNSUPPORTED}, {"eigen", required_argument, NULL, OPT_UNSUPPORTED},
         {"accessibleGenomeBED", required_argument, NULL, OPT_UNSUPPORTED}, {NULL, 0, NULL, 0}};
@@ -279,6 +286,8 @@ void parseFstOptions(int argc, char **argv) {
         switch (c) {
             case OPT_VCF: arg >> fstopt::vcfFile; break;
             case OPT_SETS: arg >> fstopt::sampleSets; break;
+            case OPT_POPS: arg >> fstopt::popsFile; break;
+            case OPT_PAIRS: arg >> fstopt::pairsArg; break;
             case 'w':
                 ws = split(arg.str(), ',');
                 if (ws.size() < 2) die("-w needs SIZE,STEP");
@@ -294,7 +303,15 @@ void parseFstOptions(int argc, char **argv) {
         }
     }
     if (argc - optind > 0) { std::cerr << "too many arguments\n"; dieFlag = true; }
-    if (fstopt::vcfFile.empty() || fstopt::sampleSets.empty()) {
+    if (!fstopt::pairsArg.empty() || !fstopt::popsFile.empty()) {
+        if (fstopt::pairsArg != "all" || fstopt::popsFile.empty() || fstopt::vcfFile.empty() || !fstopt::sampleSets.empty()) {
+            std::cerr << "The all-pairs mode needs --vcf, --pops=POPULATIONS.txt and --pairs=all (and no --sets)\n";
+            dieFlag = true;
+        } else if (fstopt::windowSize <= 1) {
+            std::cerr << "The all-pairs mode needs -w SIZE,STEP with SIZE > 1\n";
+            dieFlag = true;
+        }
+    } else if (fstopt::vcfFile.empty() || fstopt::sampleSets.empty()) {
         std::cerr << "To calculate Fst statistics from a vcf, you need to use both the --vcf and the --sets options\n";
         dieFlag = true;
     }
@@ -306,9 +323,163 @@ void parseFstOptions(int argc, char **argv) {
     if (dieFlag) { std::cout << "\n" << FST_USAGE; exit(EXIT_FAILURE); }
 }
 
+// evo fst --pops=POPULATIONS.txt --pairs=all (GPU build): the SNP windows of getFstFromVCF (process_vcf_fst.cpp:638-692) for
+// every pair of populations from ONE pass over the VCF.  The window sums are the device's segment sums (K1 + scan + pair walk,
+// evofst_get_segments); the host only replays, per pair, the coordinate bookkeeping of the reference's emitter -- the
+// "scaffold_0\t0" start string that swallows the first window elsewhere (:452, 682-686), the start / end strings -- and
+// carries the partial segment from one device batch to the next.
+int fstAllPairsMain() {
+    using namespace fstopt;
+    std::cerr << "Calculating Fst using variants from: " << vcfFile << std::endl;
+    std::cerr << "Between every pair of the populations defined in: " << popsFile << std::endl;
+    std::ifstream pf(popsFile.c_str());
+    if (!pf.is_open()) die("could not open " + popsFile);
+    std::map<string, std::vector<string>> popToIDs;
+    std::map<string, string> idToPop;
+    string line;
+    while (getline(pf, line)) {
+        line.erase(std::remove(line.begin(), line.end(), '\r'), line.end());
+        if (line.empty()) continue;
+        std::vector<string> f = split(line, '\t');
+        if (f.size() < 2) die("POPULATIONS.txt needs two tab-separated columns per line");
+        popToIDs[f[1]].push_back(f[0]); idToPop[f[0]] = f[1];
+    }
+    std::vector<string> pops;
+    std::map<string, int> popIndex;
+    for (auto &kv : popToIDs) { popIndex[kv.first] = (int)pops.size(); pops.push_back(kv.first); }
+    const int P = (int)pops.size();
+    if (P < 2) die("the all-pairs mode needs at least two populations");
+    std::vector<std::pair<int, int>> pairs;
+    for (int i = 0; i < P; ++i) for (int j = i + 1; j < P; ++j) pairs.emplace_back(i, j);
+    const size_t Q = pairs.size();
+    const int W = windowSize, g = std::gcd(windowSize, windowStep), per = W / g;
+
+    struct PairState {
+        string path, out;                               // output file and the rows waiting to be appended to it
+        string windowStartEnd = "scaffold_0\t0", windowMiddleVariant = "first\tWindow";   // fst.cpp:450-452
+        int windowStart = 0, windowEnd = 0;
+        int64_t base = 0;                               // included sites of the batches before this one
+        double carry[3] = {0, 0, 0};                    // sums behind the last complete segment
+        std::deque<std::array<double, 3>> recent;       // the last per - 1 segments {num, den, k} (overlapping windows)
+        double nn = 1;                                  // n1 * n2
+    };
+    std::vector<PairState> st(Q);
+    LineReader vcf(vcfFile);
+    Device dev;
+    Batch batch;
+    int nSamples = 0;
+    long long totalVariantNumber = 0;
+    bool haveHeader = false;
+    std::vector<int64_t> tot(Q), firstSeg(Q), nSeg(Q), base(Q);
+    std::vector<double> sNum, sDen, sK, carry(Q * 4);
+    std::vector<int32_t> sEnd;
+    std::ostringstream row;
+
+    auto flush = [&]() {
+        if (batch.n == 0) return;
+        const size_t n = batch.n;
+        dev.load(batch, EVOFST_MODE_FST, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
+        for (size_t q = 0; q < Q; ++q) base[q] = st[q].base;
+        check(dev.ctx, evofst_set_base_offsets(dev.ctx, base.data()), "set_base_offsets");
+        check(dev.ctx, evofst_run_stats(dev.ctx), "run_stats");
+        check(dev.ctx, evofst_get_included_totals(dev.ctx, tot.data()), "included_totals");
+        const size_t cap = (size_t)evofst_max_segments(dev.ctx);
+        sNum.resize(cap * Q); sDen.resize(cap * Q); sK.resize(cap * Q); sEnd.resize(cap * Q);
+        check(dev.ctx, evofst_get_segments(dev.ctx, firstSeg.data(), nSeg.data(), sNum.data(), sDen.data(), sK.data(), sEnd.data()), "segments");
+        check(dev.ctx, evofst_get_boundary(dev.ctx, carry.data()), "boundary");
+        for (size_t q = 0; q < Q; ++q) {
+            PairState &ps = st[q];
+            row.str(""); row.clear();
+            for (int64_t r = 0; r < nSeg[q]; ++r) {
+                std::array<double, 3> seg = {sNum[(size_t)r * Q + q], sDen[(size_t)r * Q + q], sK[(size_t)r * Q + q]};
+                if (r == 0) { seg[0] = ps.carry[0] + seg[0]; seg[1] = ps.carry[1] + seg[1]; seg[2] = ps.carry[2] + seg[2]; }
+                const int64_t counted = (firstSeg[q] + r + 1) * g;          // countedVariantNumber at the segment's last site
+                ps.recent.push_back(seg);
+                if ((int)ps.recent.size() > per) ps.recent.pop_front();
+                if (counted % windowStep != 0 || counted < W) continue;      // fst.cpp:638
+                double wn = 0, wd = 0, wk = 0;
+                for (auto &x : ps.recent) { wn += x[0]; wd += x[1]; wk += x[2]; }
+                if (wn != wn) wn = -__builtin_fabs(wn);                      // the sign of x86's default NaN ("-nan")
+                if (wd != wd) wd = -__builtin_fabs(wd);
+                const double windowFst = calculateFst(wn / (double)W, wd / (double)W);
+                const double sumDxy = wk / ps.nn, windowDxy = sumDxy / (double)W;
+                const int32_t e = sEnd[(size_t)r * Q + q];
+                const string &scaffold = batch.chrom[e], &loc = batch.pos[e];
+                if (windowSize == windowStep) {                              // :640-650, 682-688
+                    const size_t tab0 = ps.windowStartEnd.find('\t');
+                    const bool same = ps.windowStartEnd.compare(0, tab0, scaffold) == 0 && tab0 == scaffold.size();
+                    if (same) {
+                        ps.windowStartEnd = ps.windowStartEnd + "\t" + loc;
+                        ps.windowEnd = atoi(loc.c_str());
+                        const double dxyInc = sumDxy / (double)(ps.windowEnd - ps.windowStart);
+                        row << counted - W + 1 << "\t" << ps.windowStartEnd << "\t" << windowFst << "\t" << windowDxy << "\t" << dxyInc << "\t" << (size_t)W << std::endl;
+                        ps.windowStartEnd = scaffold + "\t" + loc;
+                        ps.windowStart = atoi(loc.c_str());
+                    } else {
+                        ps.windowStartEnd = scaffold + "\t0";
+                        ps.windowStart = 0;
+                    }
+                } else {                                                     // :662, 690
+                    row << counted - W + 1 << "\t" << ps.windowMiddleVariant << "\t" << windowFst << "\t" << windowDxy << "\t" << (size_t)W << std::endl;
+                    ps.windowMiddleVariant = scaffold + "\t" + loc;
+                }
+            }
+            if (nSeg[q] > 0) { ps.carry[0] = carry[q * 4]; ps.carry[1] = carry[q * 4 + 1]; ps.carry[2] = carry[q * 4 + 2]; }
+            else { ps.carry[0] += carry[q * 4]; ps.carry[1] += carry[q * 4 + 1]; ps.carry[2] += carry[q * 4 + 2]; }
+            ps.base += tot[q];
+            const string text = row.str();
+            if (!text.empty()) { std::ofstream f(ps.path.c_str(), std::ios::app); f << text; }
+        }
+        batch.clear();
+    };
+
+    while (vcf.getline(line)) {
+        if (line[0] == '#' && line[1] == '#') continue;
+        if (line[0] == '#' && line[1] == 'C') {
+            std::vector<string> fields = split(line, '\t');
+            std::vector<string> sampleNames;
+            nSamples = (int)fields.size() - 9;
+            if (nSamples <= 0) die("VCF header has no sample columns");
+            if (sampleNameFile.empty()) sampleNames.assign(fields.begin() + 9, fields.end());
+            else { std::ifstream sf(sampleNameFile.c_str()); string l; while (getline(sf, l)) sampleNames.push_back(l); }
+            if ((int)sampleNames.size() < nSamples) die("the -s file has fewer names than the VCF has sample columns");
+            std::vector<int32_t> sp(nSamples, -1);
+            std::vector<int> size(P, 0);
+            for (int i = 0; i < nSamples; ++i) {
+                auto it = idToPop.find(sampleNames[i]);
+                if (it != idToPop.end()) { sp[i] = popIndex[it->second]; size[sp[i]]++; }
+            }
+            for (int k = 0; k < P; ++k) if (size[k] == 0) die("population \"" + pops[k] + "\" has no sample in the VCF");
+            dev.open();
+            check(dev.ctx, evofst_set_layout(dev.ctx, nSamples, P, sp.data()), "set_layout");
+            check(dev.ctx, evofst_set_pairs(dev.ctx, nullptr, nullptr, 0), "set_pairs");
+            check(dev.ctx, evofst_set_windows(dev.ctx, windowSize, windowStep), "set_windows");
+            check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
+            for (size_t q = 0; q < Q; ++q) {
+                PairState &ps = st[q];
+                ps.nn = (double)(2 * size[pairs[q].first]) * (double)(2 * size[pairs[q].second]);
+                ps.path = runName + "_" + pops[pairs[q].first] + "_" + pops[pairs[q].second] + "_w_" + numToString(windowSize) + "_fst.txt";
+                std::ofstream f(ps.path.c_str());                            // header, fst.cpp:510-518
+                f << "var_num" << "\t" << "scaffold" << "\t" << "Start" << "\t" << "End" << "\t" << "Fst" << "\t" << "Dxy_onlyVariants" << "\t" << "Dxy_AllSites" << "\t" << "windowSize" << std::endl;
+            }
+            haveHeader = true;
+            continue;
+        }
+        if (!haveHeader) die("variant line before the #CHROM header");
+        totalVariantNumber++;
+        batch.add(line, totalVariantNumber);
+        if (batch.n == (size_t)kChunkSites) flush();
+        if (totalVariantNumber % 100000 == 0) std::cerr << totalVariantNumber << " variants processed..." << std::endl;
+    }
+    flush();
+    if (dev.ctx) evofst_destroy(dev.ctx);
+    return 0;
+}
+
 int fstMain(int argc, char **argv) {
     using namespace fstopt;
     parseFstOptions(argc, argv);
+    if (!pairsArg.empty()) return fstAllPairsMain();
     std::cerr << "Calculating Fst using variants from: " << vcfFile << std::endl;
     std::cerr << "Between the two 'populations' defined in: " << sampleSets << std::endl;
     LineReader vcf(vcfFile);

@@ -149,6 +149,65 @@ def test_cli_fstglobal_several_device_batches(tmp_path):
     _global_case(tmp_path, np.random.default_rng(22), [], 20, 10, n_sites=70000, n_samples=8, pops=["popA", "popB", "popC"])
 
 
+def _all_pairs_case(tmp_path, rng, size, step, n_sites, n_samples, pops, scaffolds):
+    """evo fst --pops --pairs=all (one pass, window sums from the device's segment table) against P (P - 1) / 2 two-set runs
+    of the oracle driver: each pair's file equals the _fst.txt of `evo fst --sets` on the two populations."""
+    vcf = str(tmp_path / "in.vcf")
+    names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=scaffolds, miss=0.08)
+    member = {}
+    pf = str(tmp_path / "pops.txt")
+    with open(pf, "w") as f:
+        for i, n in enumerate(names):
+            if i % 9 == 8:
+                continue                                          # a sample in no population
+            member.setdefault(pops[i % len(pops)], []).append(n)
+            f.write("%s\t%s\n" % (n, pops[i % len(pops)]))
+    cli_dir = tmp_path / "cli"
+    cli_dir.mkdir()
+    r = subprocess.run([EVO, "fst", "--vcf=" + vcf, "--pops=" + pf, "--pairs=all", "-n", "run", "-w", "%d,%d" % (size, step)],
+                       cwd=str(cli_dir), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sp = sorted(pops)
+    n_rows = 0
+    for a in range(len(sp)):
+        for b in range(a + 1, len(sp)):
+            od = tmp_path / ("orc_%d_%d" % (a, b))
+            od.mkdir()
+            sets = str(od / "sets.txt")
+            open(sets, "w").write(",".join(member[sp[a]]) + "\n" + ",".join(member[sp[b]]) + "\n")
+            O.fst_run(vcf, sets, str(od), run_name="run", size=size, step=step)
+            want = open(str(od / ("run_w_%d_fst.txt" % size))).read().splitlines()
+            got = open(str(cli_dir / ("run_%s_%s_w_%d_fst.txt" % (sp[a], sp[b], size)))).read().splitlines()
+            for i, (x, y) in enumerate(zip(got, want)):
+                if x == y:
+                    continue
+                # The sums are the device's (another order of additions than the reference's left-to-right one, equal to
+                # 1e-12 of a window's terms): a window whose numerator cancels to zero prints the rounding noise of its own
+                # order -- 0 against 6.4e-18, say.  Every other field, and every Fst that is not such noise, is the same text.
+                fx, fy = x.split("\t"), y.split("\t")
+                assert len(fx) == len(fy), (x, y)
+                diff = [k for k in range(len(fx)) if fx[k] != fy[k]]
+                assert all(abs(float(fx[k])) < 1e-12 and abs(float(fy[k])) < 1e-12 for k in diff), \
+                    "pair %s/%s line %d:\n cli    %r\n oracle %r" % (sp[a], sp[b], i + 1, x, y)
+            assert len(got) == len(want)
+            n_rows += len(want) - 1
+    assert n_rows > 20
+
+
+def test_cli_fst_all_pairs_equal_windows(tmp_path):
+    _all_pairs_case(tmp_path, np.random.default_rng(31), 40, 40, 4000, 27, ["zeta", "alpha", "mid", "beta"], ("scaffold_0", "chrB", "chrC"))
+
+
+def test_cli_fst_all_pairs_first_window_swallowed_and_overlap(tmp_path):
+    _all_pairs_case(tmp_path, np.random.default_rng(32), 30, 30, 2500, 18, ["p1", "p2", "p3"], ("chr1", "chr2"))
+    (tmp_path / "second").mkdir()
+    _all_pairs_case(tmp_path / "second", np.random.default_rng(33), 30, 10, 2500, 18, ["p1", "p2", "p3"], ("chr1", "chr2"))
+
+
+def test_cli_fst_all_pairs_several_device_batches(tmp_path):
+    _all_pairs_case(tmp_path, np.random.default_rng(34), 60, 20, 70000, 10, ["a", "b", "c"], ("scaffold_0", "chrB"))
+
+
 def test_cli_allele_freq(tmp_path):
     """evo alleleFreq: per-population allele frequencies straight from K1's counts, -1 where a
     population has no called allele; the file is written next to the populations file, as the reference does."""
