@@ -99,7 +99,7 @@ struct evofst_ctx {
     int64_t row_cap = 0;
 
     // fused pairs pass (evofst_fused.hip): look-back granules, ticket + error words, launch epoch
-    DevBuf d_agg0, d_agg1, d_agg2, d_fsync, d_miss;
+    DevBuf d_agg0, d_agg1, d_agg2, d_fsync, d_miss, d_dirty;
     uint32_t epoch = 0;
     bool fused_check = false;         // a fused launch has not had its error word looked at yet
     bool plain_counts = false;        // d_counts holds the counts of the loaded data (from any K1 launch)
@@ -181,7 +181,10 @@ int upload_layout(evofst_ctx *c) {
         d.flags |= (uint32_t)c->n_full[d.pop] << kSegNFullShift;
     }
     int rc;
-    if ((rc = upload_vec(c, c->d_segs, c->segs))) return rc;
+    // K1 reads the stream two entries ahead of its use: two spare entries (end of a word) behind it
+    std::vector<SegDesc> stream(c->segs);
+    for (int i = 0; i < 2; ++i) { SegDesc e{}; e.flags = kSegWordEnd; stream.push_back(e); }
+    if ((rc = upload_vec(c, c->d_segs, stream))) return rc;
     if ((rc = upload_vec(c, c->d_wss, c->word_seg_start))) return rc;
     if ((rc = upload_vec(c, c->d_nfull, c->n_full))) return rc;
     return EVOFST_OK;
@@ -478,7 +481,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles, &c->d_agg0, &c->d_agg1,
-                      &c->d_agg2, &c->d_fsync, &c->d_miss};
+                      &c->d_agg2, &c->d_fsync, &c->d_miss, &c->d_dirty};
     for (DevBuf *b : bufs) release(*b);
     for (auto &pair : c->ev)
         for (auto &e : pair)
@@ -1213,6 +1216,8 @@ int launch_k1_counts(evofst_ctx *c, int mode) {
         if ((rc = ensure(c, c->d_miss, (size_t)c->n_tiles * 8))) return rc;
         p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
         p.miss_mask = (uint64_t *)c->d_miss.p;
+        if ((rc = ensure(c, c->d_dirty, (size_t)c->n_chunks * 4))) return rc;
+        p.chunk_dirty = (uint32_t *)c->d_dirty.p;
     } else if (mode == MODE_GRAM) {
         if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 32))) return rc;
         if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
@@ -1285,11 +1290,19 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
             f.seg_cap = c->seg_cap; f.seg_rows = p.seg_rows; f.tail = p.tail; f.tail_n = p.tail_n;
             f.counts = p.counts; f.zf_masks = p.zf_masks; f.irr_mask = p.irr_mask; f.skip_mask = p.skip_mask; f.miss_mask = p.miss_mask;
             f.chunk_offsets = p.chunk_offsets;
-            const int dn = np <= 64 ? 64 : fused_threads((int)np);
-            const int per_tile = c->n_pops * kTileSites * c->count_bytes / 16;            // 16-byte vectors of one tile's counts
-            f.piece_tiles = std::max(1, std::min(std::min(4, c->chunk_tiles), 8 * dn / std::max(1, per_tile)));
-            const size_t lds = fused_lds_bytes(c->n_pops, 0, p.max_n, (int)np, f.piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, 32);
+            f.piece_tiles = std::max(1, std::min(2, c->chunk_tiles));     // two buffers of two tiles per region
+            const size_t lds = fused_lds_bytes(c->n_pops, 0, p.max_n, (int)np, 2 * f.piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, 32);
+#ifdef EVOFST_EXPERIMENTS
+            if (const char *e = getenv("EVOFST_DEBUG_WALK")) f.debug = atoi(e);
+#endif
             if (lds <= 100 * 1024) {
+                // chunks without a skipped, irregular or missing-allele site (K1 marks the others) go through the lean
+                // integer walk, the rest through the general one; each kernel leaves the other's chunks alone
+                if (c->count_bytes == 2 && !getenv("EVOFST_NO_CLEAN_WALK") &&
+                    clean_walk_lds_bytes(c->n_pops, (int)np, f.piece_tiles) <= 64 * 1024) {
+                    f.chunk_dirty = (const uint32_t *)c->d_dirty.p;
+                    HIPCHK(c, launch_clean_walk(f, c->stream));
+                }
                 HIPCHK(c, launch_fused(f, c->count_bytes, 32, 0, c->stream));
                 lds_walk = true;
             }

@@ -39,7 +39,7 @@ constexpr int kFuseWaves = 4;             // waves per workgroup in the wave-pri
 #endif
 constexpr uint32_t kSpinLimit = 1u << 22; // polls before a wait gives up (seconds; a healthy wait takes microseconds)
 
-static size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
+static __host__ __device__ constexpr size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // LDS of one region: the tables of phase B and the counts / ballots of `tiles` tiles.
 static size_t fused_region_bytes(int P, int tiles, int count_bytes, int sub) {
@@ -221,6 +221,12 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 template <typename CT, bool use_rcp, bool WP, int SUB, bool HBM>
 __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kernel(FusedParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (HBM && p.chunk_dirty != nullptr) {        // nothing to do when clean_walk_kernel takes all of this workgroup's chunks
+        bool any = false;
+        const int per = WP ? (int)(blockDim.x >> 6) : 1;
+        for (int w = 0; w < per; ++w) { const int kc_ = (int)blockIdx.x * per + w; any = any || (kc_ < p.n_chunks && p.chunk_dirty[kc_] != 0u); }
+        if (!any) return;
+    }
     constexpr int SUBP = SUB + 1;                 // row stride in entries: pop-indexed reads stay conflict-free
     constexpr int SPT = kTileSites / SUB;         // table fills per tile
     constexpr uint32_t FULL = SUB == 32 ? 0xffffffffu : ((1u << (SUB & 31)) - 1u);
@@ -231,7 +237,8 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = blockDim.x, NWV = nthreads >> 6;
-    const int TR = HBM ? p.piece_tiles : (WP ? p.chunk_tiles / NWV : p.chunk_tiles);     // tiles a region holds in LDS
+    const int TR = HBM ? p.piece_tiles : (WP ? p.chunk_tiles / NWV : p.chunk_tiles);     // tiles of a region (HBM: of one piece of it)
+    const int TRL = HBM ? 2 * TR : TR;            // tiles a region holds in LDS (HBM: the piece being walked and the one arriving)
     size_t off = 0;
     auto carve = [&](size_t bytes) { unsigned char *r = smem + off; off += (bytes + 15) & ~(size_t)15; return r; };
     RcpEntry *rcp = reinterpret_cast<RcpEntry *>(carve(use_rcp ? (size_t)(p.max_n + 1) * sizeof(RcpEntry) : 0));
@@ -243,8 +250,8 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
         lb = reinterpret_cast<uint32_t *>(carve((size_t)kFuseWaves * 3 * 64 * 4));      // [wave][level][pair] look-back partial sums
         const size_t rb = ((size_t)3 * (((size_t)P * SUBP * 8 + 15) & ~(size_t)15)) + 2 * (((size_t)P * 8 + 15) & ~(size_t)15) +
                           2 * (((size_t)P * SUBP * 4 + 15) & ~(size_t)15) + (((size_t)P * 4 + 15) & ~(size_t)15) +
-                          (((size_t)TR * P * kTileSites * sizeof(CT) + 15) & ~(size_t)15) + (((size_t)TR * 2 * P * 8 + 15) & ~(size_t)15) +
-                          3 * (((size_t)TR * 8 + 15) & ~(size_t)15);
+                          (((size_t)TRL * P * kTileSites * sizeof(CT) + 15) & ~(size_t)15) + (((size_t)TRL * 2 * P * 8 + 15) & ~(size_t)15) +
+                          3 * (((size_t)TRL * 8 + 15) & ~(size_t)15);
         off += (size_t)wave * rb;
     }
     double *pt = reinterpret_cast<double *>(carve((size_t)P * SUBP * 8));   // [P][SUB + 1] p = c / nm
@@ -255,11 +262,11 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
     uint32_t *xt = reinterpret_cast<uint32_t *>(carve((size_t)P * SUBP * 4));   // c | flags
     uint32_t *PC = reinterpret_cast<uint32_t *>(carve((size_t)P * SUBP * 4));   // sum of c
     uint32_t *carC = reinterpret_cast<uint32_t *>(carve((size_t)P * 4));
-    CT *lcnt = reinterpret_cast<CT *>(carve((size_t)TR * P * kTileSites * sizeof(CT)));   // [tile][P][64]
-    uint64_t *lzf = reinterpret_cast<uint64_t *>(carve((size_t)TR * 2 * P * 8));          // [tile][z|f][P]
-    uint64_t *lirr = reinterpret_cast<uint64_t *>(carve((size_t)TR * 8));
-    uint64_t *lskip = reinterpret_cast<uint64_t *>(carve((size_t)TR * 8));
-    uint64_t *lmiss = reinterpret_cast<uint64_t *>(carve((size_t)TR * 8));    // sites where some population has a missing allele
+    CT *lcnt = reinterpret_cast<CT *>(carve((size_t)TRL * P * kTileSites * sizeof(CT)));  // [tile][P][64]
+    uint64_t *lzf = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 2 * P * 8));         // [tile][z|f][P]
+    uint64_t *lirr = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 8));
+    uint64_t *lskip = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 8));
+    uint64_t *lmiss = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 8));   // sites where some population has a missing allele
 
     const int dtid = WP ? lane : tid;          // thread index and count of the group that shares one region
     const int dn = WP ? 64 : nthreads;
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
         const int rt0 = WP ? min(wave * TR, nt) : 0;
         // HBM: the region is K1's chunk kc
         const int kc = WP ? chunk * NWV + wave : chunk;
-        const bool kvalid = kc < p.n_chunks;
+        const bool kvalid = kc < p.n_chunks && (!HBM || p.chunk_dirty == nullptr || p.chunk_dirty[min(kc, p.n_chunks - 1)] != 0u);
         const int rg0 = HBM ? (kvalid ? kc * p.chunk_tiles : 0) : t0 + rt0;     // first tile of the region
         const int rnt = HBM ? (kvalid ? min(p.chunk_tiles, p.n_tiles - rg0) : 0) : (WP ? min(TR, nt - rt0) : nt);
 
@@ -501,64 +508,64 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
             }
         };
 
-        // HBM: the region's counts and ballots come in pieces of TR tiles, held in registers from the request to the
-        // moment the piece before has been walked
-        constexpr int NVP = 8, NVZ = 4;
-        uint4 pre[NVP];
-        uint64_t prez[NVZ], prem[3] = {0, 0, 0};
+        // HBM: the region's counts and ballots come in pieces of TR tiles, copied from HBM straight into one of two LDS
+        // buffers (global_load_lds, 16 bytes per lane, no registers in between) while the piece in the other one is walked
+        typedef __attribute__((address_space(3))) void *LdsPtr;
+        const CT *lcntp = lcnt;
+        const uint64_t *lzfp = lzf, *lirrp = lirr, *lskipp = lskip, *lmissp = lmiss;
+        uint64_t prem[3] = {0, 0, 0};
         auto piece_tiles_of = [&](int piece) { return min(TR, rnt - piece * TR); };
-        auto prefetch_piece = [&](int piece) {
-            const int g = rg0 + piece * TR, pnt = piece_tiles_of(piece);
-            const int nvp = pnt * P * kTileSites * (int)sizeof(CT) / 16, nz = pnt * 2 * P;
+        auto request_piece = [&](int piece) {
+            const int g = rg0 + piece * TR, pnt = piece_tiles_of(piece), buf = piece & 1;
+            const int v0 = WP ? 0 : wave * 64;           // first vector of this wave's row of 64; uniform
+            const int nvp = pnt * P * kTileSites * (int)sizeof(CT) / 16;
             const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)g * P * kTileSites);
-#pragma unroll
-            for (int j = 0; j < NVP; ++j) pre[j] = src[min(dtid + j * dn, nvp - 1)];
-            const uint64_t *zsrc = p.zf_masks + (size_t)g * 2 * P;
-#pragma unroll
-            for (int j = 0; j < NVZ; ++j) prez[j] = zsrc[min(dtid + j * dn, nz - 1)];
+            uint4 *dst = reinterpret_cast<uint4 *>(lcnt + (size_t)buf * TR * P * kTileSites);
+            for (int v = v0; v < nvp; v += dn)
+                if (v + lane < nvp) __builtin_amdgcn_global_load_lds(src + v + lane, (LdsPtr)(dst + v), 16, 0, 0);
+            const int nz = pnt * P;                      // 16-byte vectors of the ballots: [tile][z|f][P] u64
+            const uint4 *zsrc = reinterpret_cast<const uint4 *>(p.zf_masks + (size_t)g * 2 * P);
+            uint4 *zdst = reinterpret_cast<uint4 *>(lzf + (size_t)buf * TR * 2 * P);
+            for (int v = v0; v < nz; v += dn)
+                if (v + lane < nz) __builtin_amdgcn_global_load_lds(zsrc + v + lane, (LdsPtr)(zdst + v), 16, 0, 0);
             const int tt = g + min(dtid, pnt - 1);
             prem[0] = p.irr_mask[tt]; prem[1] = p.skip_mask[tt]; prem[2] = p.miss_mask[tt];
         };
-        auto store_piece = [&](int piece) {
-            const int g = rg0 + piece * TR, pnt = piece_tiles_of(piece);
-            const int nvp = pnt * P * kTileSites * (int)sizeof(CT) / 16, nz = pnt * 2 * P;
-            uint4 *dst = reinterpret_cast<uint4 *>(lcnt);
-#pragma unroll
-            for (int j = 0; j < NVP; ++j) { const int v = dtid + j * dn; if (v < nvp) dst[v] = pre[j]; }
-            const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)g * P * kTileSites);
-            for (int v = dtid + NVP * dn; v < nvp; v += dn) dst[v] = src[v];          // layouts too large for the registers
-#pragma unroll
-            for (int j = 0; j < NVZ; ++j) { const int v = dtid + j * dn; if (v < nz) lzf[v] = prez[j]; }
-            const uint64_t *zsrc = p.zf_masks + (size_t)g * 2 * P;
-            for (int v = dtid + NVZ * dn; v < nz; v += dn) lzf[v] = zsrc[v];
-            if (dtid < pnt) { lirr[dtid] = prem[0]; lskip[dtid] = prem[1]; lmiss[dtid] = prem[2]; }
-            for (int v = dtid + dn; v < pnt; v += dn) { lirr[v] = p.irr_mask[g + v]; lskip[v] = p.skip_mask[g + v]; lmiss[v] = p.miss_mask[g + v]; }
-        };
         const int n_pieces = HBM ? (rnt + TR - 1) / TR : 1;
-        if (HBM && rnt > 0) prefetch_piece(0);
+        if (HBM && rnt > 0) request_piece(0);
         for (int piece = 0; piece < n_pieces; ++piece) {
         const int pnt = HBM ? piece_tiles_of(piece) : rnt;     // tiles in LDS
         const int gtile0 = HBM ? rg0 + piece * TR : rg0;       // and the first of them
         if (HBM) {
-            store_piece(piece);
-            if (piece + 1 < n_pieces) prefetch_piece(piece + 1);
-            region_sync();
+            const int buf = piece & 1;
+            lcntp = lcnt + (size_t)buf * TR * P * kTileSites; lzfp = lzf + (size_t)buf * TR * 2 * P;
+            lirrp = lirr + buf * TR; lskipp = lskip + buf * TR; lmissp = lmiss + buf * TR;
+            for (int v = dtid; v < pnt; v += dn) {
+                if (v >= dn) { prem[0] = p.irr_mask[gtile0 + v]; prem[1] = p.skip_mask[gtile0 + v]; prem[2] = p.miss_mask[gtile0 + v]; }
+                lirr[buf * TR + v] = prem[0]; lskip[buf * TR + v] = prem[1]; lmiss[buf * TR + v] = prem[2];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): this thread's copies of the piece have landed
+            region_sync();                                     // ... and everybody else's
+            if (piece + 1 < n_pieces) request_piece(piece + 1);   // into the buffer whose walk ended at the last region_sync
         }
         for (int st = 0; st < SPT * pnt; ++st) {
             const int ti = st / SPT, sh = (st - ti * SPT) * SUB;
-            const uint32_t skipfill = (uint32_t)(lskip[ti] >> sh) & FULL;
-            const bool general = ((uint32_t)(lirr[ti] >> sh) & FULL) != 0u;   // uniform
-            const bool clean = kInt && ((uint32_t)((lmiss[ti] | lskip[ti] | lirr[ti]) >> sh) & FULL) == 0u;   // uniform
+            const uint32_t skipfill = (uint32_t)(lskipp[ti] >> sh) & FULL;
+            const bool general = ((uint32_t)(lirrp[ti] >> sh) & FULL) != 0u;   // uniform
+            const bool clean = kInt && ((uint32_t)((lmissp[ti] | lskipp[ti] | lirrp[ti]) >> sh) & FULL) == 0u;   // uniform
             if (!clean) {
-                const uint4 *vp = reinterpret_cast<const uint4 *>(lcnt + (size_t)ti * P * kTileSites);
+                const uint4 *vp = reinterpret_cast<const uint4 *>(lcntp + (size_t)ti * P * kTileSites);
                 for (int vi = dtid; vi < nvec; vi += dn) {
                     const int k = vi / VPR, r = vi - k * VPR;
                     derive_vec(vi, vp[k * (kTileSites / EPT) + sh / EPT + r], skipfill);
                 }
             }
             region_sync();
+#ifdef EVOFST_EXPERIMENTS
+            if (!(p.debug & 256))
+#endif
             if (active) {
-                const uint64_t *zp = lzf + (size_t)ti * 2 * P;
+                const uint64_t *zp = lzfp + (size_t)ti * 2 * P;
                 const uint32_t incl = ~(uint32_t)(((zp[pi] & zp[pj]) | (zp[P + pi] & zp[P + pj])) >> sh) & FULL;   // fst.cpp:543-544
                 int b = SUB;                                   // site of this lane's next boundary in the fill (SUB: none)
                 {
@@ -602,8 +609,8 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
                     constexpr uint32_t kOnes = 0x01010101u;
                     uint32_t wi[NW4], wj[NW4];
                     {
-                        const uint4 *ri = reinterpret_cast<const uint4 *>(lcnt + ((size_t)ti * P + pi) * kTileSites + sh);
-                        const uint4 *rj = reinterpret_cast<const uint4 *>(lcnt + ((size_t)ti * P + pj) * kTileSites + sh);
+                        const uint4 *ri = reinterpret_cast<const uint4 *>(lcntp + ((size_t)ti * P + pi) * kTileSites + sh);
+                        const uint4 *rj = reinterpret_cast<const uint4 *>(lcntp + ((size_t)ti * P + pj) * kTileSites + sh);
 #pragma unroll
                         for (int v = 0; v < SUB / 8; ++v) {       // 8 packed {c, nm} pairs -> two words of 4 c bytes
                             const uint4 x = ri[v], y = rj[v];
@@ -619,6 +626,9 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
                         tQi = __builtin_amdgcn_udot4(wi[m_], wi[m_], tQi, false); tQj = __builtin_amdgcn_udot4(wj[m_], wj[m_], tQj, false);
                     }
                     uint32_t dCC = 0, dCi = 0, dCj = 0, dQi = 0, dQj = 0;     // of them, up to the last boundary
+#ifdef EVOFST_EXPERIMENTS
+                    if (p.debug & 128) b = SUB;
+#endif
                     while (b < SUB) {
                         uint32_t pCC = 0, pCi = 0, pCj = 0, pQi = 0, pQj = 0;  // sites 0 .. b
 #pragma unroll
@@ -767,6 +777,202 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
     }
 }
 
+// =====================================================================================
+// clean_walk_kernel: the statistics walk over chunks in which no site is skipped and no population has a missing
+// allele (K1 marks the others in chunk_dirty; the walk above takes those).  There p = c / n with the population's full
+// n, so the window sums of d^2, p(1-p) and sumKij follow exactly from integer sums of c_i c_j, c and c^2 (8-bit counts,
+// four sites per v_dot4_u32_u8); none of the per-population tables of the general walk exist here, which leaves room for
+// four waves per SIMD.  Same regions, pieces, rows and tails as the walk above (its HBM mode), same arithmetic as its
+// clean fills: the two kernels are interchangeable chunk by chunk.
+// =====================================================================================
+constexpr int kCleanWps = 4;
+
+static size_t clean_region_bytes(int P, int piece_tiles) {
+    return a16((size_t)2 * piece_tiles * P * kTileSites * 2) + a16((size_t)2 * piece_tiles * 2 * P * 8);
+}
+size_t clean_walk_lds_bytes(int P, int n_pairs, int piece_tiles) {
+    return 32 * 32 + (n_pairs <= 64 ? kFuseWaves : 1) * clean_region_bytes(P, piece_tiles);
+}
+
+template <bool WP>
+__global__ __launch_bounds__(kK2Threads, kCleanWps) void clean_walk_kernel(FusedParams p) {
+    typedef uint16_t CT;
+    constexpr int SUB = 32, SPT = kTileSites / SUB, NW4 = SUB / 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int P = p.P;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NWV = blockDim.x >> 6;
+    const int TR = p.piece_tiles;
+    // prefix masks: row b holds, for each of the 8 words of a fill, the bytes of sites 0 .. b
+    uint32_t *pmask = reinterpret_cast<uint32_t *>(smem);
+    for (int i = tid; i < 32 * NW4; i += blockDim.x) {
+        const int b = i / NW4, m = i - b * NW4, nbv = b + 1 - 4 * m;
+        pmask[i] = nbv >= 4 ? 0xffffffffu : (nbv <= 0 ? 0u : ((1u << (8 * nbv)) - 1u));
+    }
+    __syncthreads();
+    const size_t cnt_bytes = a16((size_t)2 * TR * P * kTileSites * sizeof(CT));
+    unsigned char *region = smem + 32 * 32 + (WP ? (size_t)wave * (cnt_bytes + a16((size_t)2 * TR * 2 * P * 8)) : 0);
+    CT *lcnt = reinterpret_cast<CT *>(region);                            // [2][TR][P][64]
+    uint64_t *lzf = reinterpret_cast<uint64_t *>(region + cnt_bytes);     // [2][TR][z|f][P]
+    const int dtid = WP ? lane : tid, dn = WP ? 64 : (int)blockDim.x;
+    const int kc = WP ? (int)blockIdx.x * NWV + wave : (int)blockIdx.x;   // the region: K1's chunk kc
+    if (kc >= p.n_chunks || p.chunk_dirty[kc] != 0u) return;              // uniform over the threads that share the region
+    const int q = dtid;
+    const bool active = q < p.n_pairs;
+    uint32_t pi = 0, pj = 0, ni = 1, nj = 1;
+    int64_t b0 = 0, g0 = 0;
+    if (active) {
+        const uint32_t ij = p.pairs[q];
+        pi = ij & 0xffffu; pj = ij >> 16;
+        ni = (uint32_t)p.n_full[pi]; nj = (uint32_t)p.n_full[pj];
+        b0 = p.base[q];
+        g0 = p.chunk_offsets[(size_t)q * p.n_chunks + kc];
+    }
+    const int64_t first_seg = b0 / p.g;
+    const double dni = (double)ni, dnj = (double)nj;
+    const double ni2 = dni * dni, nj2 = dnj * dnj, ninj = dni * dnj;      // exact
+    const double rE = 1.0 / (ninj * ninj);                                // d^2 = (c_i n_j - c_j n_i)^2 / (n_i n_j)^2
+    const double rTi = 1.0 / ni2, rTj = 1.0 / nj2;                        // t = c (n - c) / n^2
+    const double rHi = ni > 1 ? rTi / (double)(ni - 1) : 0.0, rHj = nj > 1 ? rTj / (double)(nj - 1) : 0.0;   // h = t / (n - 1)
+    auto region_sync = [&]() {
+        if (WP) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+        else __syncthreads();
+    };
+    const int rg0 = kc * p.chunk_tiles;
+    const int rnt = min(p.chunk_tiles, p.n_tiles - rg0);
+
+    int64_t m = g0 / p.g;
+    int32_t left = p.g - (int32_t)(g0 - m * p.g);
+    const int32_t left0 = left;
+    const int32_t row0 = (int32_t)(m - first_seg);
+    size_t orow = (size_t)row0 * p.n_pairs + q;
+    int32_t nflush = 0;
+    // integer sums since the last boundary: c_i c_j, c_i, c_j, c_i^2, c_j^2.  A chunk has at most 2^14 sites and
+    // c <= 255, so every sum stays below 2^31 and every product below 2^53: the doubles below are exact integers.
+    uint32_t aCC = 0, aCi = 0, aCj = 0, aQi = 0, aQj = 0;
+    auto parts = [&](uint32_t iCC, uint32_t iCi, uint32_t iCj, uint32_t iQi, uint32_t iQj, double &num, double &den, double &k) {
+        const double CC = (double)iCC, Ci = (double)iCi, Cj = (double)iCj, Qi = (double)iQi, Qj = (double)iQj;
+        const double E = fma(nj2, Qi, fma(ni2, Qj, -2.0 * ninj * CC));    // sum (c_i n_j - c_j n_i)^2
+        const double dTi = fma(dni, Ci, -Qi), dTj = fma(dnj, Cj, -Qj);    // sum c (n - c)
+        const double dE = E * rE;
+        num = dE - dTi * rHi - dTj * rHj;
+        den = dE + dTi * rTi + dTj * rTj;
+        k = fma(dnj, Ci, fma(dni, Cj, -2.0 * CC));                        // sumKij (fst.cpp:299-321)
+    };
+
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    auto piece_tiles_of = [&](int piece) { return min(TR, rnt - piece * TR); };
+    auto request_piece = [&](int piece) {
+        const int g = rg0 + piece * TR, pnt = piece_tiles_of(piece), buf = piece & 1;
+        const int v0 = WP ? 0 : wave * 64;
+        const int nvp = pnt * P * kTileSites * (int)sizeof(CT) / 16;
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)g * P * kTileSites);
+        uint4 *dst = reinterpret_cast<uint4 *>(lcnt + (size_t)buf * TR * P * kTileSites);
+        for (int v = v0; v < nvp; v += dn)
+            if (v + lane < nvp) __builtin_amdgcn_global_load_lds(src + v + lane, (LdsPtr)(dst + v), 16, 0, 0);
+        const int nz = pnt * P;
+        const uint4 *zsrc = reinterpret_cast<const uint4 *>(p.zf_masks + (size_t)g * 2 * P);
+        uint4 *zdst = reinterpret_cast<uint4 *>(lzf + (size_t)buf * TR * 2 * P);
+        for (int v = v0; v < nz; v += dn)
+            if (v + lane < nz) __builtin_amdgcn_global_load_lds(zsrc + v + lane, (LdsPtr)(zdst + v), 16, 0, 0);
+    };
+    const int n_pieces = (rnt + TR - 1) / TR;
+    if (rnt > 0) request_piece(0);
+    for (int piece = 0; piece < n_pieces; ++piece) {
+        const int pnt = piece_tiles_of(piece), gtile0 = rg0 + piece * TR, buf = piece & 1;
+        const CT *lcntp = lcnt + (size_t)buf * TR * P * kTileSites;
+        const uint64_t *lzfp = lzf + (size_t)buf * TR * 2 * P;
+        __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0): this thread's copies of the piece have landed
+        region_sync();
+        if (piece + 1 < n_pieces) request_piece(piece + 1);
+        if (active)
+        for (int st = 0; st < SPT * pnt; ++st) {
+            const int ti = st / SPT, sh = (st - ti * SPT) * SUB;
+            const uint64_t *zp = lzfp + (size_t)ti * 2 * P;
+            const uint32_t incl = ~(uint32_t)(((zp[pi] & zp[pj]) | (zp[P + pi] & zp[P + pj])) >> sh);   // fst.cpp:543-544
+            int b = SUB;                                       // site of this lane's next boundary in the fill (SUB: none)
+            {
+                const int cnt = __popc(incl);
+                if (left <= cnt) b = nth_set_bit(incl, left);
+                else left -= cnt;
+            }
+            constexpr uint32_t kOnes = 0x01010101u;
+            uint32_t wi[NW4], wj[NW4];
+            {
+                const uint4 *ri = reinterpret_cast<const uint4 *>(lcntp + ((size_t)ti * P + pi) * kTileSites + sh);
+                const uint4 *rj = reinterpret_cast<const uint4 *>(lcntp + ((size_t)ti * P + pj) * kTileSites + sh);
+#pragma unroll
+                for (int v = 0; v < SUB / 8; ++v) {            // 8 packed {c, nm} pairs -> two words of 4 c bytes
+                    const uint4 x = ri[v], y = rj[v];
+                    wi[2 * v] = __builtin_amdgcn_perm(x.y, x.x, 0x06040200u); wi[2 * v + 1] = __builtin_amdgcn_perm(x.w, x.z, 0x06040200u);
+                    wj[2 * v] = __builtin_amdgcn_perm(y.y, y.x, 0x06040200u); wj[2 * v + 1] = __builtin_amdgcn_perm(y.w, y.z, 0x06040200u);
+                }
+            }
+            uint32_t tCC = 0, tCi = 0, tCj = 0, tQi = 0, tQj = 0;     // over the whole fill
+#pragma unroll
+            for (int m_ = 0; m_ < NW4; ++m_) {
+                tCC = __builtin_amdgcn_udot4(wi[m_], wj[m_], tCC, false);
+                tCi = __builtin_amdgcn_udot4(wi[m_], kOnes, tCi, false); tCj = __builtin_amdgcn_udot4(wj[m_], kOnes, tCj, false);
+                tQi = __builtin_amdgcn_udot4(wi[m_], wi[m_], tQi, false); tQj = __builtin_amdgcn_udot4(wj[m_], wj[m_], tQj, false);
+            }
+            uint32_t dCC = 0, dCi = 0, dCj = 0, dQi = 0, dQj = 0;     // of them, up to the last boundary
+            while (b < SUB) {
+                uint32_t pCC = 0, pCi = 0, pCj = 0, pQi = 0, pQj = 0;  // sites 0 .. b
+                const uint4 *mk4 = reinterpret_cast<const uint4 *>(pmask + b * NW4);
+                const uint4 mka = mk4[0], mkb = mk4[1];
+                const uint32_t mk[NW4] = {mka.x, mka.y, mka.z, mka.w, mkb.x, mkb.y, mkb.z, mkb.w};
+#pragma unroll
+                for (int m_ = 0; m_ < NW4; ++m_) {
+                    const uint32_t x = wi[m_] & mk[m_], y = wj[m_] & mk[m_];
+                    pCC = __builtin_amdgcn_udot4(x, y, pCC, false);
+                    pCi = __builtin_amdgcn_udot4(x, kOnes, pCi, false); pCj = __builtin_amdgcn_udot4(y, kOnes, pCj, false);
+                    pQi = __builtin_amdgcn_udot4(x, x, pQi, false); pQj = __builtin_amdgcn_udot4(y, y, pQj, false);
+                }
+                SegRow row;
+                parts(aCC + (pCC - dCC), aCi + (pCi - dCi), aCj + (pCj - dCj), aQi + (pQi - dQi), aQj + (pQj - dQj), row.num, row.den, row.k);
+                row.end = (gtile0 + ti) * kTileSites + sh + b; row.pad = 0;
+                {   // two 16-byte stores into one 32-byte sector
+                    uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(&row);
+                    dst[0] = src[0]; dst[1] = src[1];
+                }
+                aCC = aCi = aCj = aQi = aQj = 0;
+                dCC = pCC; dCi = pCi; dCj = pCj; dQi = pQi; dQj = pQj;
+                ++nflush;
+                orow += p.n_pairs;
+                const uint32_t rem = b >= SUB - 1 ? 0u : incl & ~((2u << b) - 1u);
+                const int c2 = __popc(rem);
+                if (p.g <= c2) b = nth_set_bit(rem, p.g);
+                else { left = p.g - c2; b = SUB; }
+            }
+            aCC += tCC - dCC; aCi += tCi - dCi; aCj += tCj - dCj; aQi += tQi - dQi; aQj += tQj - dQj;
+        }
+        region_sync();                                         // the buffer is free for the piece after next
+    }
+    if (active) {
+        // what the chunk holds behind its last boundary
+        const size_t cq = (size_t)kc * p.n_pairs + q;
+        const size_t plane = (size_t)p.n_pairs * p.n_chunks;
+        double num, den, k;
+        parts(aCC, aCi, aCj, aQi, aQj, num, den, k);
+        p.tail[cq] = num; p.tail[plane + cq] = den; p.tail[2 * plane + cq] = k;
+        p.tail_n[cq] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);   // {sites summed in the tail, segments completed, row of the first}
+    }
+}
+
+hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st) {
+    if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
+    if (p.n_pairs > kK2Threads || p.chunk_dirty == nullptr || p.counts == nullptr) return hipErrorInvalidValue;
+    const bool wp = p.n_pairs <= 64;
+    const int threads = fused_threads(p.n_pairs);
+    const size_t lds = clean_walk_lds_bytes(p.P, p.n_pairs, p.piece_tiles);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (wp) hipLaunchKernelGGL((clean_walk_kernel<true>), dim3((p.n_chunks + kFuseWaves - 1) / kFuseWaves), dim3(threads), lds, st, p);
+    else hipLaunchKernelGGL((clean_walk_kernel<false>), dim3(p.n_chunks), dim3(threads), lds, st, p);
+    return hipGetLastError();
+}
+
 template <typename CT, bool RCP, bool WP, int SUB, bool HBM>
 static hipError_t launch_fused_t(const FusedParams &p, size_t lds, int threads, int max_blocks, hipStream_t st) {
     const void *fn = reinterpret_cast<const void *>(&fused_pairs_kernel<CT, RCP, WP, SUB, HBM>);
@@ -805,7 +1011,7 @@ hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_
     const bool hbm = p.counts != nullptr;
     if (!hbm && wp && p.chunk_tiles % kFuseWaves != 0) return hipErrorInvalidValue;
     const int threads = fused_threads(p.n_pairs);
-    const size_t lds = fused_lds_bytes(p.P, p.n_segs, p.max_n, p.n_pairs, hbm ? p.piece_tiles * (wp ? kFuseWaves : 1) : p.chunk_tiles, count_bytes, sub);
+    const size_t lds = fused_lds_bytes(p.P, p.n_segs, p.max_n, p.n_pairs, hbm ? 2 * p.piece_tiles * (wp ? kFuseWaves : 1) : p.chunk_tiles, count_bytes, sub);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool rcp = p.max_n <= kRcpMax;
 #define EVOFST_FUSED_GO(CT, R, W_, S_) do { if (hbm) return launch_fused_t<CT, R, W_, S_, true>(p, lds, threads, max_blocks, st); \

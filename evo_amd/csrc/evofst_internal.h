@@ -89,11 +89,13 @@ struct K1Params {
     uint64_t *zf_masks;      // [n_tiles][2][P] sites with c == 0 / c == nm (skipped sites set in both)
     uint64_t *irr_mask;      // [n_tiles] sites with nm < 2 or c == nm < n_full in some population
     uint64_t *miss_mask;     // [n_tiles] sites where some population has a missing allele (pairs mode)
+    uint32_t *chunk_dirty;   // [n_chunks] != 0: the chunk holds a skipped, irregular or missing-allele site (pairs mode)
     // against-all mode
     uint2 *totals;            // [n_tiles*64] {sum alt, sum non-missing} over populationsToUse
     uint64_t *kept_mask;      // [n_tiles]
     uint64_t *skip_mask;      // [n_tiles] (both modes)
     uint32_t *chunk_used_kept;  // [2][n_chunks]
+    int32_t debug;              // timing experiments (EVOFST_EXPERIMENTS builds only; results are wrong when set)
 };
 
 // one segment of one pair: sums of the Fst numerators / denominators, sum of sumKij (dxy numerators; integers, exact),
@@ -156,6 +158,8 @@ struct FusedParams {
     const void *counts;             // K1's packed counts
     const uint64_t *zf_masks, *irr_mask, *skip_mask, *miss_mask;   // K1's ballots
     const int64_t *chunk_offsets;   // [n_pairs][n_chunks] from the scan
+    const uint32_t *chunk_dirty;    // [n_chunks] from K1, or null: the walk of evofst_fused.hip takes the chunks marked here,
+                                    // clean_walk_kernel the others
     int32_t piece_tiles;            // tiles of a region held in LDS at a time
     int32_t debug;                  // -DEVOFST_EXPERIMENTS builds only (tools/): 1 no look-back waits, 2 no phase B, 4 no tile loads
 };
@@ -310,6 +314,8 @@ int fused_threads(int n_pairs);
 int fused_tail_chunks(int n_pairs, int n_chunks);   // entries per pair of the tail table (sub-chunks when every wave owns a part of a chunk)
 // sub: sites per table fill (16 or 32); max_blocks <= 0: as many workgroups as the device holds at once (occupancy query)
 hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_blocks, hipStream_t st);
+size_t clean_walk_lds_bytes(int P, int n_pairs, int piece_tiles);
+hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st);
 size_t global_lds_bytes(int tn_max, int max_n, int n_use, int size);
 void global_rcp_split(int tn_max, int max_n, int *lo, int *hi);
 

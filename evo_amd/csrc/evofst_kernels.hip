@@ -25,29 +25,50 @@ namespace evofst {
 // (process_vcf_fst.cpp:243-280) and getBasicCounts (process_vcf_utils.cpp:62-83).
 // =====================================================================================
 //
-// One wave per chunk (a block = 4 consecutive chunks sharing the layout tables in LDS), lane = site.
+// One wave per chunk (a block = 4 consecutive chunks), lane = site.
 // A tile is W rows of 64 x 16 bytes {ALT word, MISSING word}; the wave reads them in batches of 8 rows
 // (8 KiB per batch) and requests the next batch -- of this tile or of the chunk's next tile -- before it
-// counts the current one, so a wave always has 8-16 KiB in flight and never waits for a load it has
-// only just issued.  Counting walks the (word, population) segments of the layout with wave-uniform masks.
-template <typename CT, int MODE>
+// counts the current one.  Counting walks the (word, population) descriptors of the layout, a stream in bit
+// order that comes through the scalar cache two entries ahead of its use (wave-uniform masks and flags in SGPRs,
+// scalar branches).  The counting loop holds no vector-memory instruction: with ST the packed counts of a tile
+// collect in the wave's LDS block and leave as 16-byte stores together with the tile's masks right before the
+// wave starts on its next tile, so the only wait on the vector-memory counter is the one for the next batch.
+// The zero / fixed ballots of up to 64 populations collect in four VGPRs (v_writelane, lane = population).
+typedef uint32_t SegWords __attribute__((ext_vector_type(4)));                  // {mask lo, mask hi, pop, flags | n_full << 8}
+typedef const __attribute__((address_space(4))) SegWords *SegStream;
+// v_writelane_b32: lane `lane` of the result is `val` (both wave-uniform), the other lanes keep `old`.  This clang has
+// no builtin for it; the declaration binds to the LLVM intrinsic, which also routes the lane select through M0.
+extern "C" __device__ int evofst_write_lane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ void write_lane4(int &a, int &b, int &c, int &d, uint64_t x, uint64_t y, int lane) {
+    a = evofst_write_lane((int)(uint32_t)x, lane, a); b = evofst_write_lane((int)(uint32_t)(x >> 32), lane, b);
+    c = evofst_write_lane((int)(uint32_t)y, lane, c); d = evofst_write_lane((int)(uint32_t)(y >> 32), lane, d);
+}
+
+#ifdef EVOFST_EXPERIMENTS
+#define EVOFST_K1_DBG(bit) && !(p.debug & (bit))
+#else
+#define EVOFST_K1_DBG(bit)
+#endif
+template <typename CT, int MODE, bool ST>
 __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int NW = kK1Threads / 64;
-    constexpr int NB = 8;   // rows per batch
+    constexpr int NB = 4;   // rows per batch
+    constexpr bool kBallots = MODE == MODE_PAIRS || MODE == MODE_GRAM;
+    const int P = p.P;
     // LDS: per wave [P] zero-masks, [P] fixed-masks (+ [P] nm < 2, [P] nm == 0 in Gram mode), then per wave
-    // [n_pairs] census counters
-    uint64_t *zm = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 4 * p.P;
-    uint64_t *fm = zm + p.P;
-    uint32_t *cen_all = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem) + (size_t)NW * 4 * p.P);
+    // [n_pairs] census counters, the pair list, and (ST) per wave the [P][64] packed counts of the current tile
+    uint64_t *zm = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 4 * P;
+    uint64_t *fm = zm + P;
+    uint32_t *cen_all = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem) + (size_t)NW * 4 * P);
     const int npq = MODE == MODE_PAIRS ? p.n_pairs : 0;
     uint32_t *cen = cen_all + (size_t)wave * npq;
-    // block-wide copies of the layout tables: the counting loop must not queue vector loads behind the tile loads
     uint32_t *lpairs = cen_all + (size_t)NW * npq;                                   // [n_pairs]
-    int32_t *lwss = reinterpret_cast<int32_t *>(lpairs + npq);                        // [W+1]
-    SegDesc *lsegs = reinterpret_cast<SegDesc *>(smem + (((reinterpret_cast<unsigned char *>(lwss + p.W + 1) - smem) + 15) & ~(size_t)15));
+    CT *stage = reinterpret_cast<CT *>(smem + (((reinterpret_cast<unsigned char *>(lpairs + npq) - smem) + 15) & ~(size_t)15)) +
+                (size_t)wave * P * kTileSites;
+    const SegStream segs = (SegStream)(uintptr_t)p.segs;                             // [n_segs + 2]: two spare entries behind the stream
 
     const int chunk = blockIdx.x * NW + wave;
     const bool have = chunk < p.n_chunks;
@@ -55,24 +76,34 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     const int t1 = have ? min(t0 + p.chunk_tiles, p.n_tiles) : t0;
     const int nb = (p.W + NB - 1) / NB;                 // batches per tile
     const int n_items = (t1 - t0) * nb;
-    ulonglong2 cur[NB], nxt[NB];
-    auto load_item = [&](ulonglong2 (&r)[NB], int item) {
-        const int t = t0 + item / nb, wb = (item - (item / nb) * nb) * NB;
+    // four batch buffers in turn: the one being counted and the three requested after it (12 KiB in flight per wave)
+    struct Batch { ulonglong2 r[NB]; uint32_t flag; };  // flag: site_flags of the tile, requested with its first batch
+    Batch b0, b1, b2, b3;
+    b0.flag = b1.flag = b2.flag = b3.flag = 0u;
+    // Every request is unconditional -- past the end it repeats the chunk's last batch (cache hits), without site_flags
+    // the flag byte comes from the tile itself and is ignored -- so the number of loads behind the batch a wave waits
+    // for is known at compile time and the wait is a count, not "everything outstanding".
+    const bool have_flags = p.site_flags != nullptr;
+    const uint8_t *flag_base = have_flags ? p.site_flags : reinterpret_cast<const uint8_t *>(p.tiles);
+    const int64_t flag_last = have_flags ? p.n_sites - 1 : 0;
+    auto load_item = [&](Batch &b, int item) {
+        const int it = max(min(item, n_items - 1), 0);
+        const int ti = it / nb, bi = it - ti * nb;
+        const int t = t0 + ti, wb = bi * NB;
         const ulonglong2 *tp = p.tiles + (size_t)t * p.W * kTileSites + lane;
 #pragma unroll
-        for (int u = 0; u < NB; ++u)   // unconditional (clamped) so that all loads of a batch are in flight together
-            r[u] = tp[(size_t)min(wb + u, p.W - 1) * kTileSites];
+        for (int u = 0; u < NB; ++u)   // clamped rows: all loads of a batch are in flight together
+            b.r[u] = tp[(size_t)min(wb + u, p.W - 1) * kTileSites];
+        b.flag = flag_base[max(min((int64_t)t * kTileSites + lane, flag_last), (int64_t)0)];
     };
-    if (n_items > 0) load_item(cur, 0);                 // first batch goes out before the tables are staged
-
-    for (int i = threadIdx.x; i < npq; i += kK1Threads) lpairs[i] = p.pairs[i];
-    for (int i = threadIdx.x; i <= p.W; i += kK1Threads) lwss[i] = p.word_seg_start[i];
-    for (int i = threadIdx.x; i <= p.n_segs; i += kK1Threads) {
-        SegDesc e{}; e.flags = kSegWordEnd;            // the spare entry behind the stream
-        lsegs[i] = i < p.n_segs ? p.segs[i] : e;
-    }
-    if (MODE == MODE_PAIRS)
+    load_item(b0, 0);                                   // the first batches go out before the pair list is staged
+    load_item(b1, 1);
+    load_item(b2, 2);
+    if (MODE == MODE_PAIRS) {
+        if ((int)threadIdx.x < npq) lpairs[threadIdx.x] = p.pairs[threadIdx.x];       // one round trip for up to 256 pairs
+        for (int i = threadIdx.x + kK1Threads; i < npq; i += kK1Threads) lpairs[i] = p.pairs[i];
         for (int q = lane; q < p.n_pairs; q += 64) cen[q] = 0;
+    }
     uint32_t used_cnt = 0, kept_cnt = 0;
     __syncthreads();
 
@@ -81,51 +112,134 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     uint32_t Tc = 0, Tn = 0, c0 = 0, nm0 = 0;
     bool irregular = false, skip = false, anymiss = false;
     uint64_t skipmask = 0;
-    const uint4 *lsegs4 = reinterpret_cast<const uint4 *>(lsegs);
+    bool dirty = false;                                 // wave-uniform: the chunk has a site clean_walk_kernel cannot take
+    int zlo = 0, zhi = 0, flo = 0, fhi = 0, ylo1 = 0, yhi1 = 0, ylo0 = 0, yhi0 = 0;   // ballots by population, lane = pop & 63
+    auto wave_lds_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto flush_ballots = [&](int base, int n) {         // populations base .. base + n - 1 -> the wave's mask tables
+        if (lane < n) {
+            zm[base + lane] = ((uint64_t)(uint32_t)zhi << 32) | (uint32_t)zlo;
+            fm[base + lane] = ((uint64_t)(uint32_t)fhi << 32) | (uint32_t)flo;
+            if (MODE == MODE_GRAM) {
+                zm[2 * P + base + lane] = ((uint64_t)(uint32_t)yhi1 << 32) | (uint32_t)ylo1;
+                zm[3 * P + base + lane] = ((uint64_t)(uint32_t)yhi0 << 32) | (uint32_t)ylo0;
+            }
+        }
+    };
+    // Everything a finished tile writes to HBM.  With ST (P * sizeof(CT) <= 64) the number of store instructions is
+    // bounded at compile time, so the wait for the next batch stays a count (not "everything outstanding").
+    auto epilogue = [&](int t) {
+        if (kBallots) { const int base = ((P - 1) >> 6) << 6; flush_ballots(base, P - base); }
+        if (ST || kBallots) wave_lds_sync();
+        if (ST) {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(stage);
+            uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<CT *>(p.counts) + (size_t)t * P * kTileSites);
+            const int nv = P * kTileSites * (int)sizeof(CT) / 16;     // <= 256
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int v = lane + 64 * j; if (v < nv EVOFST_K1_DBG(4)) dst[v] = s4[v]; }
+        }
+        if (MODE == MODE_GRAM) {
+            const uint64_t im = __ballot(irregular && !skip);
+            if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
+            if (ST) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { const int i = lane + 64 * j; if (i < 4 * P) p.zf_masks[(size_t)t * 4 * P + i] = zm[i]; }
+            } else {
+                for (int i = lane; i < 4 * P; i += 64) p.zf_masks[(size_t)t * 4 * P + i] = zm[i];   // [tile][z|f|b1|b0][P]
+            }
+        }
+        if (MODE == MODE_PAIRS) {
+            const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss);
+            if (lane == 0 EVOFST_K1_DBG(8)) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; p.miss_mask[t] = mm; }
+            dirty = dirty || (im | mm | skipmask) != 0;
+            // [tile][z|f][P]: zm, fm are adjacent
+            if (ST) { if (lane < 2 * P EVOFST_K1_DBG(16)) p.zf_masks[(size_t)t * 2 * P + lane] = zm[lane]; }
+            else for (int i = lane; i < 2 * P; i += 64) p.zf_masks[(size_t)t * 2 * P + i] = zm[i];
+            // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
+            // (i,j) iff both counts are 0 or both pops are fixed for ALT (or the site is skipped).
+            for (int q = lane; q < p.n_pairs; q += 64) {
+                const uint32_t ij = lpairs[q];
+                const uint32_t i = ij & 0xffffu, j = ij >> 16;
+                const uint64_t ex = (zm[i] & zm[j]) | (fm[i] & fm[j]);
+                cen[q] += 64u - (uint32_t)__popcll(ex);
+            }
+        }
+        if (MODE == MODE_GLOBAL) {
+            // evo_FstAgainstAll.cpp:198-203 on populationsToUse[0], in exact integer form:
+            // AAF == 0 <=> nm > 0 && c == 0 ; AAF == 1 <=> nm > 0 && c == nm (0/0 is NaN, -1 if own nm == 0)
+            const uint32_t cc = Tc - c0, cn = Tn - nm0;
+            const bool both0 = (nm0 > 0 && c0 == 0) && (cn > 0 && cc == 0);
+            const bool both1 = (nm0 > 0 && c0 == nm0) && (cn > 0 && cc == cn);
+            const bool kept = !skip && !both0 && !both1;
+            const uint64_t km = __ballot(kept);
+            p.totals[(int64_t)t * kTileSites + lane] = make_uint2(Tc, Tn);
+            if (lane == 0) { p.kept_mask[t] = km; p.skip_mask[t] = skipmask; }
+            used_cnt += 64u - (uint32_t)__popcll(skipmask);
+            kept_cnt += (uint32_t)__popcll(km);
+        }
+        if (ST || kBallots) wave_lds_sync();
+    };
+
     int sidx = 0;
-    uint4 d = lsegs4[0];
-    for (int item = 0; item < n_items; ++item) {
+    SegWords d = segs[0], dn = segs[1];
+    // One batch: the finished tile's stores first, then the request for the batch three ahead (into the buffer that was
+    // counted last), then the counting -- so what is outstanding behind the batch waited for is only ever younger loads.
+    auto step = [&](Batch &cur, Batch &spare, int item) {
         const int ti = item / nb, bi = item - ti * nb;
         const int t = t0 + ti, wb = bi * NB;
-        const int64_t site = (int64_t)t * kTileSites + lane;
-        if (item + 1 < n_items) load_item(nxt, item + 1);
         if (bi == 0) {
-            skip = site >= p.n_sites;
-            if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
+#ifdef EVOFST_EXPERIMENTS
+            if (!(p.debug & 2))
+#endif
+            if (item > 0) epilogue(t - 1);
+            skip = (int64_t)t * kTileSites + lane >= p.n_sites || (have_flags && (cur.flag & 1u) != 0);
             skipmask = __ballot(skip);
             c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false; anymiss = false;
+            sidx = 0; d = segs[0]; dn = segs[1];
         }
-        CT *cp = reinterpret_cast<CT *>(p.counts) + (size_t)t * p.P * kTileSites + lane;
-        if (bi == 0) { sidx = 0; d = lsegs4[0]; }
+        load_item(spare, item + 3);
+        // the flag byte is the last load of its batch: taking it here marks the whole batch as arrived, including rows
+        // past W that nothing reads (their registers would otherwise count as outstanding when they are reused)
+        asm volatile("" :: "v"(cur.flag));
+        CT *cp = reinterpret_cast<CT *>(p.counts) + (size_t)t * P * kTileSites + lane;
+#ifdef EVOFST_EXPERIMENTS
+        if (p.debug & 1) { c += (uint32_t)cur.r[0].x ^ (uint32_t)cur.r[1].y ^ (uint32_t)cur.r[2].x ^ (uint32_t)cur.r[3].y; return; }
+#endif
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             if (wb + u < p.W) {
-                const uint32_t xlo = (uint32_t)cur[u].x, xhi = (uint32_t)(cur[u].x >> 32);
-                const uint32_t ylo = (uint32_t)cur[u].y, yhi = (uint32_t)(cur[u].y >> 32);
+                const uint32_t xlo = (uint32_t)cur.r[u].x, xhi = (uint32_t)(cur.r[u].x >> 32);
+                const uint32_t ylo = (uint32_t)cur.r[u].y, yhi = (uint32_t)(cur.r[u].y >> 32);
                 bool more = true;
                 while (more) {
-                    // the descriptors {mask lo, mask hi, pop, flags | n_full << 8} are a stream in bit order, read one ahead of
-                    // its use (the table ends with a spare entry)
-                    const uint4 dn = lsegs4[sidx + 1];
+                    const SegWords dnn = segs[sidx + 2];
                     c = __popc(xlo & d.x) + c; c = __popc(xhi & d.y) + c;
                     mc = __popc(ylo & d.x) + mc; mc = __popc(yhi & d.y) + mc;
                     const uint32_t fl = d.w, pop = d.z;
                     if (fl & kSegLast) {
                         const uint32_t nfull = fl >> kSegNFullShift;
                         const uint32_t nm = nfull - mc;
-                        cp[(size_t)pop * kTileSites] = (CT)(c | (nm << CountTraits<CT>::shift));
-                        if (MODE == MODE_GRAM) {
-                            const uint64_t b1 = __ballot(nm < 2) & ~skipmask, b0 = __ballot(nm == 0) & ~skipmask;
-                            if (lane == 0) { zm[2 * p.P + pop] = b1; zm[3 * p.P + pop] = b0; }
-                        }
-                        if (MODE == MODE_PAIRS || MODE == MODE_GRAM) {
+                        const CT packed = (CT)(c | (nm << CountTraits<CT>::shift));
+                        if (ST) stage[pop * kTileSites + lane] = packed;
+                        else cp[(size_t)pop * kTileSites] = packed;
+                        if (kBallots) {
+                            const int pl = (int)(pop & 63u);
                             const uint64_t z = __ballot(c == 0) | skipmask;
                             const uint64_t f = __ballot(c == nm) | skipmask;
-                            if (lane == 0) { zm[pop] = z; fm[pop] = f; }
-                            // sites K2 must take through its general loop: a NaN in the reference (nm < 2) or an
-                            // excluded site with a dxy term (fixed with missing alleles)
-                            irregular = irregular || nm < 2 || (c == nm && nm < nfull);
-                            anymiss = anymiss || mc != 0;
+                            write_lane4(zlo, zhi, flo, fhi, z, f, pl);
+                            if (MODE == MODE_GRAM) {
+                                const uint64_t b1 = __ballot(nm < 2) & ~skipmask, b0_ = __ballot(nm == 0) & ~skipmask;
+                                write_lane4(ylo1, yhi1, ylo0, yhi0, b1, b0_, pl);
+                            }
+                            if (pl == 63) flush_ballots((int)pop - 63, 64);
+                            // sites K2 must take through its general loop: a NaN in the reference (nm < 2) or an excluded
+                            // site with a dxy term (fixed with missing alleles).  Both need a missing allele unless n_full < 2.
+                            const bool anym = mc != 0;
+                            if (__any(anym) || nfull < 2u) {
+                                irregular = irregular || nm < 2 || (c == nm && nm < nfull);
+                                anymiss = anymiss || anym;
+                            }
                         }
                         if (MODE == MODE_GLOBAL) {
                             if (fl & kSegUse) { Tc += c; Tn += nm; }
@@ -134,55 +248,26 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                         c = 0; mc = 0;
                     }
                     more = (fl & kSegWordEnd) == 0u;
-                    d = dn; ++sidx;
+                    d = dn; dn = dnn; ++sidx;
                 }
             }
         }
-        if (bi == nb - 1) {   // the tile is complete
-            if (MODE == MODE_GRAM) {
-                const uint64_t im = __ballot(irregular && !skip);
-                if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
-                __builtin_amdgcn_wave_barrier();
-                for (int i = lane; i < 4 * p.P; i += 64) p.zf_masks[(size_t)t * 4 * p.P + i] = zm[i];   // [tile][z|f|b1|b0][P]
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (MODE == MODE_PAIRS) {
-                const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss);
-                if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; p.miss_mask[t] = mm; }
-                // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
-                // (i,j) iff both counts are 0 or both pops are fixed for ALT (or the site is skipped).
-                __builtin_amdgcn_wave_barrier();
-                for (int i = lane; i < 2 * p.P; i += 64) p.zf_masks[(size_t)t * 2 * p.P + i] = zm[i];   // [tile][z|f][P]: zm, fm are adjacent
-                for (int q = lane; q < p.n_pairs; q += 64) {
-                    const uint32_t ij = lpairs[q];
-                    const uint32_t i = ij & 0xffffu, j = ij >> 16;
-                    const uint64_t ex = (zm[i] & zm[j]) | (fm[i] & fm[j]);
-                    cen[q] += 64u - (uint32_t)__popcll(ex);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (MODE == MODE_GLOBAL) {
-                // evo_FstAgainstAll.cpp:198-203 on populationsToUse[0], in exact integer form:
-                // AAF == 0 <=> nm > 0 && c == 0 ; AAF == 1 <=> nm > 0 && c == nm (0/0 is NaN, -1 if own nm == 0)
-                const uint32_t cc = Tc - c0, cn = Tn - nm0;
-                const bool both0 = (nm0 > 0 && c0 == 0) && (cn > 0 && cc == 0);
-                const bool both1 = (nm0 > 0 && c0 == nm0) && (cn > 0 && cc == cn);
-                const bool kept = !skip && !both0 && !both1;
-                const uint64_t km = __ballot(kept);
-                p.totals[site] = make_uint2(Tc, Tn);
-                if (lane == 0) { p.kept_mask[t] = km; p.skip_mask[t] = skipmask; }
-                used_cnt += 64u - (uint32_t)__popcll(skipmask);
-                kept_cnt += (uint32_t)__popcll(km);
-            }
-        }
-        if (item + 1 < n_items) {
-#pragma unroll
-            for (int u = 0; u < NB; ++u) cur[u] = nxt[u];
-        }
+    };
+    for (int item = 0; item < n_items; item += 4) {
+        step(b0, b3, item);
+        if (item + 1 >= n_items) break;
+        step(b1, b0, item + 1);
+        if (item + 2 >= n_items) break;
+        step(b2, b1, item + 2);
+        if (item + 3 >= n_items) break;
+        step(b3, b2, item + 3);
     }
+    if (n_items > 0) epilogue(t1 - 1);
     if (have) {
-        if (MODE == MODE_PAIRS)
+        if (MODE == MODE_PAIRS) {
             for (int q = lane; q < p.n_pairs; q += 64) p.chunk_census[(size_t)q * p.n_chunks + chunk] = cen[q];
+            if (lane == 0) p.chunk_dirty[chunk] = dirty ? 1u : 0u;
+        }
         if (MODE == MODE_GLOBAL && lane == 0) {
             p.chunk_used_kept[chunk] = used_cnt;
             p.chunk_used_kept[(size_t)p.n_chunks + chunk] = kept_cnt;
@@ -190,19 +275,29 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     }
 }
 
-hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t st) {
-    if (p.n_chunks <= 0) return hipSuccess;
+hipError_t launch_k1(const K1Params &p_, int count_bytes, int mode, hipStream_t st) {
+    if (p_.n_chunks <= 0) return hipSuccess;
+    K1Params p = p_;
+    p.debug = 0;
+#ifdef EVOFST_EXPERIMENTS
+    if (const char *e = getenv("EVOFST_DEBUG_K1")) p.debug = atoi(e);
+#endif
     constexpr int NW = kK1Threads / 64;
     const size_t npq = mode == MODE_PAIRS ? p.n_pairs : 0;
-    size_t lds = (size_t)NW * 4 * p.P * 8 + (NW + 1) * npq * 4 + (size_t)(p.W + 1) * 4 + 16 + (size_t)(p.n_segs + 1) * sizeof(SegDesc) + 64;
-    if (lds > 150 * 1024) return hipErrorInvalidValue;   // layouts with thousands of populations / words: not expected
+    const size_t base = (size_t)NW * 4 * p.P * 8 + (NW + 1) * npq * 4 + 16;
+    const size_t stage = (size_t)NW * p.P * kTileSites * count_bytes;
+    // staged: a tile's counts leave as at most four 16-byte stores per lane (more populations: they go out as they complete)
+    const bool staged = (size_t)p.P * count_bytes <= 64;
+    const size_t lds = base + (staged ? stage : 0) + 64;
+    if (lds > 150 * 1024) return hipErrorInvalidValue;   // layouts with thousands of populations: not expected
     dim3 grid((p.n_chunks + NW - 1) / NW), block(kK1Threads);
-#define EVOFST_K1(CT, M) do { \
+#define EVOFST_K1S(CT, M, S) do { \
         if (lds > 48 * 1024) { \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_count_kernel<CT, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_count_kernel<CT, M, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return e_; \
         } \
-        hipLaunchKernelGGL((k1_count_kernel<CT, M>), grid, block, lds, st, p); } while (0)
+        hipLaunchKernelGGL((k1_count_kernel<CT, M, S>), grid, block, lds, st, p); } while (0)
+#define EVOFST_K1(CT, M) do { if (staged) EVOFST_K1S(CT, M, true); else EVOFST_K1S(CT, M, false); } while (0)
     if (count_bytes == 2) {
         if (mode == MODE_COUNTS) EVOFST_K1(uint16_t, MODE_COUNTS);
         else if (mode == MODE_PAIRS) EVOFST_K1(uint16_t, MODE_PAIRS);
@@ -215,6 +310,7 @@ hipError_t launch_k1(const K1Params &p, int count_bytes, int mode, hipStream_t s
         else EVOFST_K1(uint32_t, MODE_GLOBAL);
     }
 #undef EVOFST_K1
+#undef EVOFST_K1S
     return hipGetLastError();
 }
 
