@@ -145,7 +145,7 @@ def hbm_leg(device, steps=10):
             "kernel": "k1_count_kernel", "algorithmic_bytes": k1_bytes, "achieved": k1_bytes / (k[0] * 1e-3) / 1e9 if k[0] > 0 else 0.0,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_bytes / (k[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if k[0] > 0 else 0.0,
             "pipeline_GBps": S * (N / 2.0 + 4.0) / dt / 1e9, "pipeline_frac": S * (N / 2.0 + 4.0) / dt / 1e9 / HBM_PEAK_GBS,
-            "kernels_ms": {"k1_count_kernel": float(k[0]), "scan_kernel": float(k[1]), "fused_pairs_kernel(counts from HBM)": float(k[2]), "stitch_kernel": float(k[3])},
+            "kernels_ms": {"k1_count_kernel": float(k[0]), "scan_kernel": float(k[1]), "walk(clean_walk_kernel + fused_pairs_kernel on K1 counts)": float(k[2]), "stitch_kernel": float(k[3])},
             "command": "python bench.py --config cfg4s"}
 
 
@@ -396,7 +396,7 @@ def main():
     else:
         k2_bytes = S * P * cb + S * 8.0 + (S / cfg["step"]) * P * 16.0
     names = ["k1_count_kernel", "scan_kernel",
-             {"pairs": "fused_pairs_kernel(counts from HBM)", "gram": "gram_kernel"}.get(cfg["mode"], "global_window_kernel"), "stitch_kernel",
+             {"pairs": "walk(clean_walk_kernel + fused_pairs_kernel on K1 counts)", "gram": "gram_kernel"}.get(cfg["mode"], "global_window_kernel"), "stitch_kernel",
              "fused_pairs_kernel"]
     if cfg["mode"] == "gram":
         kavg[2] = float(np.sum(gram_ms))          # popsums + gram launches of every batch of one step

@@ -221,10 +221,11 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 template <typename CT, bool use_rcp, bool WP, int SUB, bool HBM>
 __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kernel(FusedParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    if (HBM && p.chunk_dirty != nullptr) {        // nothing to do when clean_walk_kernel takes all of this workgroup's chunks
-        bool any = false;
+    if (HBM && p.chunk_dirty != nullptr) {        // before anything is set up: does this workgroup's stride hold a marked chunk at all?
         const int per = WP ? (int)(blockDim.x >> 6) : 1;
-        for (int w = 0; w < per; ++w) { const int kc_ = (int)blockIdx.x * per + w; any = any || (kc_ < p.n_chunks && p.chunk_dirty[kc_] != 0u); }
+        bool any = false;
+        for (int kc_ = (int)blockIdx.x * per; kc_ < p.n_chunks && !any; kc_ += (int)gridDim.x * per)
+            for (int w = 0; w < per; ++w) any = any || (kc_ + w < p.n_chunks && p.chunk_dirty[kc_ + w] != 0u);
         if (!any) return;
     }
     constexpr int SUBP = SUB + 1;                 // row stride in entries: pop-indexed reads stay conflict-free
@@ -309,10 +310,19 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
     };
 
     for (int iter = 0;; ++iter) {
+        if (HBM) {                                     // regions in turn, a grid's stride apart; no ticket, nothing to wait for
+            const int region = (int)blockIdx.x + iter * (int)gridDim.x, per = WP ? NWV : 1;
+            if (region >= (p.n_chunks + per - 1) / per) break;
+            if (p.chunk_dirty != nullptr) {            // clean_walk_kernel takes the chunks K1 left unmarked
+                bool any = false;
+                for (int w = 0; w < per; ++w) { const int kc_ = region * per + w; any = any || (kc_ < p.n_chunks && p.chunk_dirty[kc_] != 0u); }
+                if (!any) continue;
+            }
+        }
         __syncthreads();                               // the tables above; the previous chunk's readers of lmisc / LDS
-        if (HBM && iter > 0) break;                    // one chunk (or four of K1's) per workgroup
         if (tid == 0) {
             int32_t chunk = (int32_t)blockIdx.x;       // first chunk: the workgroup's own index (the grid is not larger than n_chunks)
+            if (HBM) chunk += iter * (int32_t)gridDim.x;   // HBM: regions (one chunk, or four of K1's) in turn, a grid's stride apart
             if (!HBM && iter > 0) {
                 // n_chunks draws in all: every workgroup draws until its chunk is past the end
                 const uint32_t t = __hip_atomic_fetch_add((gu32 *)p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
         __syncthreads();
         const int chunk = lmisc[0];
         dead = dead || lmisc[1] != 0;
-        if (!HBM && chunk >= p.n_chunks) break;
+        if (chunk >= (HBM && WP ? (p.n_chunks + NWV - 1) / NWV : p.n_chunks)) break;
         if (dead) continue;
         const int t0 = chunk * p.chunk_tiles;
         const int nt = min(p.chunk_tiles, p.n_tiles - t0);           // tiles of the chunk
@@ -981,7 +991,6 @@ static hipError_t launch_fused_t(const FusedParams &p, size_t lds, int threads, 
         if (e != hipSuccess) return e;
     }
     int grid = max_blocks;
-    if (HBM) grid = WP ? (p.n_chunks + kFuseWaves - 1) / kFuseWaves : p.n_chunks;
     if (grid <= 0) {
         // workgroups the device holds at once; asked once per shape (the query costs more than a launch)
         static thread_local struct { const void *fn; int threads; size_t lds; int dev; int grid; } memo = {nullptr, 0, 0, -1, 0};
@@ -996,7 +1005,7 @@ static hipError_t launch_fused_t(const FusedParams &p, size_t lds, int threads, 
         }
         grid = memo.grid;
     }
-    grid = std::max(1, std::min(grid, p.n_chunks));
+    grid = std::max(1, std::min(grid, HBM && WP ? (p.n_chunks + kFuseWaves - 1) / kFuseWaves : p.n_chunks));
     hipLaunchKernelGGL((fused_pairs_kernel<CT, RCP, WP, SUB, HBM>), dim3(grid), dim3(threads), lds, st, p);
     return hipGetLastError();
 }

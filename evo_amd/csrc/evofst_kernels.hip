@@ -80,21 +80,23 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     struct Batch { ulonglong2 r[NB]; uint32_t flag; };  // flag: site_flags of the tile, requested with its first batch
     Batch b0, b1, b2, b3;
     b0.flag = b1.flag = b2.flag = b3.flag = 0u;
-    // Every request is unconditional -- past the end it repeats the chunk's last batch (cache hits), without site_flags
-    // the flag byte comes from the tile itself and is ignored -- so the number of loads behind the batch a wave waits
-    // for is known at compile time and the wait is a count, not "everything outstanding".
+    // Every request is unconditional -- rows past W, batches past the chunk's end and the flag byte of a run without
+    // site_flags all read the first bytes of the tile array (one cache line per instruction, results ignored) -- so the
+    // number of loads behind the batch a wave waits for is known at compile time and the wait is a count, not
+    // "everything outstanding".
     const bool have_flags = p.site_flags != nullptr;
-    const uint8_t *flag_base = have_flags ? p.site_flags : reinterpret_cast<const uint8_t *>(p.tiles);
-    const int64_t flag_last = have_flags ? p.n_sites - 1 : 0;
     auto load_item = [&](Batch &b, int item) {
-        const int it = max(min(item, n_items - 1), 0);
+        const bool past = item >= n_items;
+        const int it = past ? 0 : item;
         const int ti = it / nb, bi = it - ti * nb;
         const int t = t0 + ti, wb = bi * NB;
         const ulonglong2 *tp = p.tiles + (size_t)t * p.W * kTileSites + lane;
 #pragma unroll
-        for (int u = 0; u < NB; ++u)   // clamped rows: all loads of a batch are in flight together
-            b.r[u] = tp[(size_t)min(wb + u, p.W - 1) * kTileSites];
-        b.flag = flag_base[max(min((int64_t)t * kTileSites + lane, flag_last), (int64_t)0)];
+        for (int u = 0; u < NB; ++u)
+            b.r[u] = (past || wb + u >= p.W) ? p.tiles[0] : tp[(size_t)(wb + u) * kTileSites];
+        const int64_t site = (int64_t)t * kTileSites + lane;
+        const uint8_t *fp = (have_flags && !past && site < p.n_sites) ? p.site_flags + site : reinterpret_cast<const uint8_t *>(p.tiles);
+        b.flag = *fp;
     };
     load_item(b0, 0);                                   // the first batches go out before the pair list is staged
     load_item(b1, 1);

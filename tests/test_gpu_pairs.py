@@ -186,6 +186,23 @@ def test_snp_windows_without_missing_alleles(engine, S, N, P, size, step, dirty)
     _check_windows(engine, sp, codes, None, P, size, step, tag="snp_windows_clean")
 
 
+@pytest.mark.parametrize("S,N,P,dirty", [(200_000, 40, 4, 900), (100_000, 48, 12, 500)])
+def test_snp_windows_clean_and_dirty_chunks(engine, monkeypatch, S, N, P, dirty):
+    """One-tile chunks, a few hundred of them with a missing allele: clean_walk_kernel takes the chunks K1 left unmarked,
+    the general walk strides over the marked ones with a grid smaller than the number of regions, and every window
+    straddles chunks of both kinds (6 pairs: a wave per chunk; 66 pairs: a workgroup per chunk)."""
+    monkeypatch.setenv("EVOFST_CHUNK_TILES", "1")
+    rng = np.random.default_rng(S + dirty)
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=0.0, edge=False)
+    for s_ in rng.choice(S, dirty, replace=False):
+        codes[s_, rng.choice(2 * N, 2, replace=False)] = 2
+    engine.set_layout(sp, P)
+    engine.upload(engine.pack_codes(codes), S)
+    engine.set_pairs()
+    _check_windows(engine, sp, codes, None, P, 100, 50, tag="snp_windows_clean_and_dirty_chunks")
+
+
 def test_snp_windows_many_pairs(engine):
     """435 pairs: more than one K2 block per chunk (blockIdx.y > 0), each deriving the same tables."""
     rng = np.random.default_rng(435)

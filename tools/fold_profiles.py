@@ -23,6 +23,11 @@ for cfg in sys.argv[1:]:
             e["hbm_read_bytes"] = v["fetch_size_raw_per_launch"] * 1024 * 2
             e["hbm_write_bytes"] = v["write_size_raw_per_launch"] * 1024
         out[short] = e
+    # bench.py's "walk" line is the two statistics kernels together (clean chunks / the rest)
+    parts = [out[k] for k in ("clean_walk_kernel", "fused_pairs_kernel") if k in out]
+    if parts:
+        out["walk"] = {k: sum(x.get(k, 0) for x in parts) for k in ("avg_ns", "hbm_read_bytes", "hbm_write_bytes")}
+        out["walk"]["calls"] = parts[0]["calls"]
     traffic[cfg] = out
     stats = glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
