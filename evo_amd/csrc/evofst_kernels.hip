@@ -1888,6 +1888,28 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     uint4 nxt_tot[TV];
     tot_at(th, 0, nxt_tot);
     uint32_t urem = (uint32_t)(used % p.step);         // used modulo STEP, carried in 32 bits
+    const int size = p.size, nu = p.n_use;
+    const uint32_t ustep = (uint32_t)p.step;
+    double *my_n = ring_n + u, *my_d = ring_d + u;      // this lane's column of the two rings
+    // window row of this lane's population: the deque oldest -> newest as vector_average walks it, i.e. ring slots
+    // hd .. size-1, then 0 .. hd-1 (two straight runs, loads of four slots ahead of their adds)
+    auto window_row = [&](int hd, int64_t row_) {
+        double an = 0.0, ad = 0.0;
+        auto run = [&](int from, int to) {
+            int i = from;
+            for (; i + 4 <= to; i += 4) {
+                const double n0 = my_n[i * nu], n1 = my_n[(i + 1) * nu], n2 = my_n[(i + 2) * nu], n3 = my_n[(i + 3) * nu];
+                const double d0 = my_d[i * nu], d1 = my_d[(i + 1) * nu], d2 = my_d[(i + 2) * nu], d3 = my_d[(i + 3) * nu];
+                an += n0; an += n1; an += n2; an += n3;
+                ad += d0; ad += d1; ad += d2; ad += d3;
+            }
+            for (; i < to; ++i) { an += my_n[i * nu]; ad += my_d[i * nu]; }
+        };
+        run(hd, size);
+        run(0, hd);
+        p.row_num[(size_t)row_ * nu + u] = an / (double)size;
+        p.row_den[(size_t)row_ * nu + u] = ad / (double)size;
+    };
     for (int t = th; t < t1; ++t) {
         const uint64_t km = p.kept_mask[t], sm = p.skip_mask[t];
         const bool replay = t < t0;
@@ -1906,7 +1928,7 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
             const uint32_t kb = (uint32_t)(km >> (j * EPT)) & ((1u << EPT) - 1u);
             const uint32_t sb = (uint32_t)(sm >> (j * EPT)) & ((1u << EPT) - 1u);
             if (kb == 0u) {                       // nothing kept among these sites: only the used counter moves
-                if (!replay) { const uint32_t n = EPT - __popc(sb); used += n; urem = (urem + n) % (uint32_t)p.step; }
+                if (!replay) { const uint32_t n = EPT - __popc(sb); used += n; urem = (urem + n) % ustep; }
                 continue;
             }
             // 1) the EPT sites' values, independent of each other (no branches: the chains overlap)
@@ -1921,32 +1943,48 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
                     global_eval<RCP>(v & CountTraits<CT>::mask, v >> CountTraits<CT>::shift, Tc, Tn, thr, rcp, numv[e], denv[e]);
                 }
             }
-            // 2) the deque walk, in site order
+            // 2a) the usual vector -- every site kept, none skipped, windows longer than it: the EPT inserts with one
+            // wave-uniform test per site (at most one window ends inside the vector)
+            if (!replay && kb == ((1u << EPT) - 1u) && sb == 0u && size > EPT && ustep >= (uint32_t)EPT) {
+                const int estar = (int)(ustep - 1u - urem);        // the site of the vector that completes a STEP, if < EPT
+                const bool emits = estar < EPT && (used + estar + 1 > size || size == (int)ustep);
+                const int site0 = t * kTileSites + j * EPT;
+                int start_site = 0;
+                if (emits && threadIdx.x == 0) {                   // the window's oldest site, before its slot is reused below
+                    int os = head + estar + 1; if (os >= size) os -= size;
+                    start_site = ring_s[os];
+                }
+                if (threadIdx.x < EPT) { int hs = head + (int)threadIdx.x; if (hs >= size) hs -= size; ring_s[hs] = site0 + (int)threadIdx.x; }
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    int h = head + e; if (h >= size) h -= size;
+                    if (active) { my_n[h * nu] = numv[e]; my_d[h * nu] = denv[e]; }
+                    if (emits && e == estar) {
+                        if (active) window_row(h + 1 == size ? 0 : h + 1, row);
+                        if (threadIdx.x == 0) { p.row_start[row] = start_site; p.row_end[row] = site0 + e; }
+                        ++row;
+                    }
+                }
+                head += EPT; if (head >= size) head -= size;
+                used += EPT; urem += EPT; if (urem >= ustep) urem -= ustep;
+                continue;
+            }
+            // 2b) the deque walk, in site order (LDS offsets in 32 bits; the ring is walked as its two straight runs)
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 if ((sb >> e) & 1u) continue;
-                if (!replay) { ++used; urem = urem + 1 == (uint32_t)p.step ? 0u : urem + 1; }
+                if (!replay) { ++used; urem = urem + 1 == ustep ? 0u : urem + 1; }
                 if (!((kb >> e) & 1u)) continue;
                 if (replay && drop > 0) { --drop; continue; }
                 const int site = t * kTileSites + j * EPT + e;
                 if (active) {
-                    ring_n[(size_t)head * p.n_use + u] = numv[e];
-                    ring_d[(size_t)head * p.n_use + u] = denv[e];
+                    my_n[head * nu] = numv[e];
+                    my_d[head * nu] = denv[e];
                 }
                 if (threadIdx.x == 0) ring_s[head] = site;
-                head = head + 1 == p.size ? 0 : head + 1;
-                if (!replay && (used > p.size || p.size == p.step) && urem == 0u) {
-                    if (active) {
-                        double an = 0.0, ad = 0.0;
-                        int idx = head;
-                        for (int i = 0; i < p.size; ++i) {      // oldest -> newest, as vector_average on the deque
-                            an += ring_n[(size_t)idx * p.n_use + u];
-                            ad += ring_d[(size_t)idx * p.n_use + u];
-                            idx = idx + 1 == p.size ? 0 : idx + 1;
-                        }
-                        p.row_num[(size_t)row * p.n_use + u] = an / (double)p.size;
-                        p.row_den[(size_t)row * p.n_use + u] = ad / (double)p.size;
-                    }
+                head = head + 1 == size ? 0 : head + 1;
+                if (!replay && (used > size || size == (int)ustep) && urem == 0u) {
+                    if (active) window_row(head, row);
                     if (threadIdx.x == 0) {
                         p.row_start[row] = ring_s[head];
                         p.row_end[row] = site;
