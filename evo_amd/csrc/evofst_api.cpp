@@ -99,7 +99,7 @@ struct evofst_ctx {
     int64_t row_cap = 0;
 
     // fused pairs pass (evofst_fused.hip): look-back granules, ticket + error words, launch epoch
-    DevBuf d_agg0, d_agg1, d_agg2, d_fsync, d_miss, d_dirty;
+    DevBuf d_agg0, d_agg1, d_agg2, d_fsync, d_miss, d_dirty, d_poison;
     uint32_t epoch = 0;
     bool fused_check = false;         // a fused launch has not had its error word looked at yet
     bool plain_counts = false;        // d_counts holds the counts of the loaded data (from any K1 launch)
@@ -481,7 +481,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles, &c->d_agg0, &c->d_agg1,
-                      &c->d_agg2, &c->d_fsync, &c->d_miss, &c->d_dirty};
+                      &c->d_agg2, &c->d_fsync, &c->d_miss, &c->d_dirty, &c->d_poison};
     for (DevBuf *b : bufs) release(*b);
     for (auto &pair : c->ev)
         for (auto &e : pair)
@@ -1222,7 +1222,9 @@ int launch_k1_counts(evofst_ctx *c, int mode) {
         if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 32))) return rc;
         if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
         if ((rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8))) return rc;
+        if ((rc = ensure(c, c->d_poison, (size_t)c->n_tiles * 4))) return rc;
         p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
+        p.tile_poison = (uint32_t *)c->d_poison.p;
         c->gram_missing = -1;
     } else if (mode == MODE_GLOBAL) {
         if ((rc = ensure(c, c->d_gtotals, (size_t)c->n_tiles * kTileSites * 8))) return rc;
@@ -1378,6 +1380,7 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.masks = (const uint64_t *)c->d_zf.p; p.skip_mask = (const uint64_t *)c->d_skip.p;
+    p.tile_poison = (const uint32_t *)c->d_poison.p;
     p.win_start = (const int64_t *)c->d_win.p;
     p.first_window = first_window; p.n_windows = (int32_t)n_windows;
     p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p;

@@ -89,6 +89,7 @@ struct K1Params {
     uint64_t *zf_masks;      // [n_tiles][2][P] sites with c == 0 / c == nm (skipped sites set in both)
     uint64_t *irr_mask;      // [n_tiles] sites with nm < 2 or c == nm < n_full in some population
     uint64_t *miss_mask;     // [n_tiles] sites where some population has a missing allele (pairs mode)
+    uint32_t *tile_poison;   // [n_tiles] Gram mode: != 0 when a population has fewer than two called alleles at some site of the tile
     uint32_t *chunk_dirty;   // [n_chunks] != 0: the chunk holds a skipped, irregular or missing-allele site (pairs mode)
     // against-all mode
     uint2 *totals;            // [n_tiles*64] {sum alt, sum non-missing} over populationsToUse
@@ -260,6 +261,7 @@ struct GramParams {
     const int32_t *n_full;
     const uint64_t *masks;       // [n_tiles][4][P] from K1 (Gram mode): c == 0, c == nm, nm < 2, nm == 0
     const uint64_t *skip_mask;   // [n_tiles]
+    const uint32_t *tile_poison; // [n_tiles] from K1 (Gram mode): != 0 when one of the nm < 2 / nm == 0 masks of the tile has a bit set
     const int64_t *win_start;    // [n_windows_total + 1] first site of every window (device)
     int64_t first_window;        // this launch covers windows [first_window, first_window + n_windows)
     int32_t n_windows;

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     bool irregular = false, skip = false, anymiss = false;
     uint64_t skipmask = 0;
     bool dirty = false;                                 // wave-uniform: the chunk has a site clean_walk_kernel cannot take
+    bool poison = false;                                // wave-uniform, Gram mode: the tile has a site where a population has < 2 called alleles
     int zlo = 0, zhi = 0, flo = 0, fhi = 0, ylo1 = 0, yhi1 = 0, ylo0 = 0, yhi0 = 0;   // ballots by population, lane = pop & 63
     auto wave_lds_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                 zm[3 * P + base + lane] = ((uint64_t)(uint32_t)yhi0 << 32) | (uint32_t)ylo0;
             }
         }
+        if (MODE == MODE_GRAM) poison = poison || __any(lane < n && (ylo1 | yhi1 | ylo0 | yhi0) != 0);
     };
     // Everything a finished tile writes to HBM.  With ST (P * sizeof(CT) <= 64) the number of store instructions is
     // bounded at compile time, so the wait for the next batch stays a count (not "everything outstanding").
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
         }
         if (MODE == MODE_GRAM) {
             const uint64_t im = __ballot(irregular && !skip);
-            if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; }
+            if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; p.tile_poison[t] = poison ? 1u : 0u; }
             if (ST) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { const int i = lane + 64 * j; if (i < 4 * P) p.zf_masks[(size_t)t * 4 * P + i] = zm[i]; }
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             if (item > 0) epilogue(t - 1);
             skip = (int64_t)t * kTileSites + lane >= p.n_sites || (have_flags && (cur.flag & 1u) != 0);
             skipmask = __ballot(skip);
-            c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false; anymiss = false;
+            c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false; anymiss = false; poison = false;
             sidx = 0; d = segs[0]; dn = segs[1];
         }
         load_item(spare, item + 3);
@@ -1018,12 +1020,18 @@ constexpr int kGramMaskTiles = 4;    // tiles of a window whose masks are staged
 
 // TAB (every population has <= 31 chromosomes): the operands of a packed count {c, nm} come from a 1024-entry LDS
 // table {p, q}, {c, F nm}, [c == nm] instead of being derived with ~25 VALU instructions per element.
-template <typename CT, bool MISS, bool TAB>
+// I8 (8-bit counts, every population has <= 127 chromosomes): the integer contractions -- sum c_i c_j and the
+// fixed-with-missing term of sumKij -- run on the int8 matrix cores (v_mfma_i32_16x16x32_i8, one instruction per 32
+// sites and tile pair, exact in 32 bits), which leaves the FP64 cores the two streams of the denominator.
+typedef int int4_t __attribute__((ext_vector_type(4)));
+template <typename CT, bool MISS, bool TAB, bool I8>
 __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
+    __shared__ uint64_t spread[I8 ? 256 : 1];            // bit e of the index -> byte e 0xff
     __shared__ double rcp[TAB ? 2 : 2048];
     __shared__ double2 tab_pq[TAB ? 1024 : 1], tab_cf[TAB ? 1024 : 1];
     __shared__ double tab_fi[TAB ? 1024 : 1];
     __shared__ uint64_t lmask[kGramMaskTiles][4][128];   // [tile][z|f|nm<2|nm==0][64 row pops, 64 column pops]
+    __shared__ double lU[128], lC[128], lN[128];         // U, C of the window and n_full, same 128 populations
     constexpr int EV = 8;                               // sites per lane and step
     constexpr int NVEC = sizeof(CT) == 2 ? 1 : 2;       // 16-byte vectors per 8 packed counts
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -1035,6 +1043,12 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     const int bj = bi + rem;
     const int r0 = bi * 64 + (wave >> 1) * 32, c0 = bj * 64 + (wave & 1) * 32;
     const bool use_rcp = p.max_n < 2048;
+    if (I8)
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+            uint64_t m = 0;
+            for (int e = 0; e < 8; ++e) if ((i >> e) & 1) m |= 0xffull << (8 * e);
+            spread[i] = m;
+        }
     if (TAB) {
         for (int i = threadIdx.x; i < 1024; i += blockDim.x) {      // entry (nm << 5) | c; impossible ones (c > nm) are 0: entry 1 serves sites outside the window
             const int c = i & 31, nm = i >> 5;
@@ -1046,6 +1060,10 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         }
     } else if (use_rcp) {
         for (int i = threadIdx.x; i <= p.max_n; i += blockDim.x) rcp[i] = i ? 1.0 / (double)i : 0.0;
+    }
+    if (threadIdx.x < 128) {
+        const int x = threadIdx.x, pop_ = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
+        lN[x] = pop_ < p.P ? (double)p.n_full[pop_] : 0.0;
     }
     const bool idle = r0 > c0 + 31 || r0 >= p.P || c0 >= p.P;   // a wave below the diagonal or outside: only joins the barriers
     int pop[4];                                          // row tile 0, 1, column tile 0, 1
@@ -1063,15 +1081,33 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     const int64_t a = p.win_start[p.first_window + w], b = min(p.win_start[p.first_window + w + 1], p.n_sites);
     const int tw0 = (int)(a >> 6), tw1 = b > a ? (int)((b - 1) >> 6) : tw0 - 1;
     // K1's masks of the block's 128 populations for ng tiles from tile tg on
-    auto stage_masks = [&](int tg, int ng) {
-        for (int i = threadIdx.x; i < ng * 4 * 128; i += blockDim.x) {
-            const int t = i / 512, m = (i >> 7) & 3, x = i & 127;
+    // (m_first = 2: only the two masks behind the NaN poison; returns whether one of them has a bit set)
+    auto stage_masks = [&](int tg, int ng, int m_first, int m_count) {
+        bool any = false;
+        for (int i = threadIdx.x; i < ng * m_count * 128; i += blockDim.x) {
+            const int x = i & 127, mt = i >> 7;
+            const int t = mt / m_count, m = m_first + (mt - t * m_count);
             const int pop = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
-            lmask[t][m][x] = pop < p.P ? p.masks[((size_t)(tg + t) * 4 + m) * p.P + pop] : ~0ull;
+            const uint64_t v = pop < p.P ? p.masks[((size_t)(tg + t) * 4 + m) * p.P + pop] : (m < 2 ? ~0ull : 0ull);
+            lmask[t][m][x] = v;
+            any = any || (m >= 2 && v != 0ull);
         }
+        return any;
     };
-    if (wi) __syncthreads();                             // the previous window's epilogue is done with lmask
-    stage_masks(tw0, min(kGramMaskTiles, tw1 - tw0 + 1));
+    // I8: the included sites of every pair come out of the int8 contraction below; K1's masks are only needed where the
+    // reference would poison a window with NaN (a population with fewer than two called alleles at an included site),
+    // which the two masks behind it announce -- all zero in all but pathological windows
+    bool masks_needed = !I8;
+    if (I8 && MISS)
+        for (int t = tw0; t <= tw1; ++t) masks_needed = masks_needed || p.tile_poison[t] != 0u;   // uniform over the block
+    if (wi) __syncthreads();                             // the previous window's epilogue is done with lmask, lU, lC
+    // the window's per-population sums of the block's 128 populations, for the epilogue (requested here, read there)
+    if (threadIdx.x < 128) {
+        const int x = threadIdx.x, pop_ = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
+        lU[x] = pop_ < p.P ? p.U[(size_t)w * p.P + pop_] : 0.0;
+        lC[x] = pop_ < p.P ? p.C[(size_t)w * p.P + pop_] : 0.0;
+    }
+    if (masks_needed) stage_masks(tw0, min(kGramMaskTiles, tw1 - tw0 + 1), 0, 4);
     __syncthreads();
 
     // included sites and NaN poison of every pair from K1's masks, kGramMaskTiles tiles at a time through LDS.  The
@@ -1113,9 +1149,16 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
             }
         }
     };
-    if (!idle && !(p.debug & 2)) count_group(tw0, min(kGramMaskTiles, tw1 - tw0 + 1));
+    if (!idle && masks_needed && !(p.debug & 2)) count_group(tw0, min(kGramMaskTiles, tw1 - tw0 + 1));
 
     double4_t acc_den[2][2], acc_cc[2][2], acc_m[2][2];
+    int4_t icc[2][2], im[2][2], iex[2][2];               // I8: the integer sums (C/D layout: col = lane & 15, row = 4 (lane >> 4) + v);
+                                                         // iex: sites of the window the filter excludes for the pair
+    uint32_t vcount = 0;                                 // this lane's valid (in the window, not skipped) sites
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { icc[i][j] = int4_t{0, 0, 0, 0}; im[i][j] = int4_t{0, 0, 0, 0}; iex[i][j] = int4_t{0, 0, 0, 0}; }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1123,9 +1166,11 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
 
     const int64_t base0 = a & ~(int64_t)7;
     uint4 nxt[4][NVEC];
+    uint64_t nxt_skip = 0;                               // skip mask of the tile of those sites, requested with them
     auto fetch = [&](int64_t base) {                     // the 4 populations' count vectors of this lane's 8 sites
         const int64_t sv = base + (int64_t)kq * EV;
         const int t = (int)min(sv >> 6, (int64_t)p.n_tiles - 1), o = (int)(sv & 63);
+        nxt_skip = p.skip_mask[t];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const CT *src = cb + ((size_t)t * p.P + min(pop[x], p.P - 1)) * kTileSites + o;
@@ -1137,13 +1182,13 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     if (base0 < bend) fetch(base0);
     for (int64_t base = base0; base < bend; base += 4 * EV) {
         const int64_t sv = base + (int64_t)kq * EV;      // this lane's 8 sites (inside one tile)
-        const int t = (int)min(sv >> 6, (int64_t)p.n_tiles - 1), o = (int)(sv & 63);
+        const int o = (int)(sv & 63);
         // sites of the vector that belong to the window and are not skipped
         uint32_t valid = 0;
         if (sv < b && sv + EV > a) {
             const uint32_t lo = sv < a ? (uint32_t)(a - sv) : 0u, hi = sv + EV > b ? (uint32_t)(b - sv) : (uint32_t)EV;
             valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            valid &= ~(uint32_t)(p.skip_mask[t] >> o);
+            valid &= ~(uint32_t)(nxt_skip >> o);
         }
         uint32_t cnt[4][EV];                             // packed counts of the 4 populations
 #pragma unroll
@@ -1157,6 +1202,50 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 cnt[x][0] = v0.x; cnt[x][1] = v0.y; cnt[x][2] = v0.z; cnt[x][3] = v0.w;
                 cnt[x][4] = v1.x; cnt[x][5] = v1.y; cnt[x][6] = v1.z; cnt[x][7] = v1.w;
             }
+        }
+        if (I8 && __builtin_amdgcn_ballot_w64(valid != 0u) != 0) {
+            // the step's 32 sites at once: lane = population (lane & 15), bytes = its 8 sites
+            long C8[4], FN8[4], FM8[4], Z8[4], F8[4], B8[4], BN8[4];
+            vcount += (uint32_t)__popc(valid);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const uint4 v = nxt[x][0];
+                const uint64_t vm = pop[x] < p.P ? spread[valid] : 0ull;
+                const uint32_t vlo = (uint32_t)vm, vhi = (uint32_t)(vm >> 32);
+                const uint32_t clo = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u) & vlo, chi = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u) & vhi;
+                C8[x] = (long)(((uint64_t)chi << 32) | clo);
+                auto fixed_bytes = [](uint32_t t) {               // 0xff in the bytes of t that are zero
+                    const uint32_t nz = (((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
+                    return ((nz ^ 0x80808080u) >> 7) * 0xffu;
+                };
+                const uint32_t nlo = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u) & vlo, nhi = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u) & vhi;
+                const uint32_t flo = fixed_bytes(clo ^ nlo) & vlo, fhi = fixed_bytes(chi ^ nhi) & vhi;   // F = [c == nm], sites of the window only
+                {   // the site filter (process_vcf_fst.cpp:543-544) as 0/1 bytes: excluded = z_i z_j + f_i f_j - (z f)_i (z f)_j
+                    const uint32_t zlo = fixed_bytes(clo) & vlo, zhi = fixed_bytes(chi) & vhi;            // Z = [c == 0]
+                    Z8[x] = (long)(((uint64_t)(zhi & 0x01010101u) << 32) | (zlo & 0x01010101u));
+                    F8[x] = (long)(((uint64_t)(fhi & 0x01010101u) << 32) | (flo & 0x01010101u));
+                    B8[x] = Z8[x] & F8[x];
+                    BN8[x] = (long)(((uint64_t)(zhi & fhi) << 32) | (zlo & flo));                          // -1 where both
+                }
+                if (MISS) {
+                    const uint32_t n4 = nfull[x] * 0x01010101u;
+                    FN8[x] = (long)(((uint64_t)(nhi & fhi) << 32) | (nlo & flo));                        // F nm
+                    FM8[x] = (long)(((uint64_t)((n4 - nhi) & fhi) << 32) | ((n4 - nlo) & flo));          // F (n - nm); bytewise, no borrows
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    icc[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(C8[i], C8[2 + j], icc[i][j], 0, 0, 0);
+                    iex[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(Z8[i], Z8[2 + j], iex[i][j], 0, 0, 0);
+                    iex[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(F8[i], F8[2 + j], iex[i][j], 0, 0, 0);
+                    iex[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(BN8[i], B8[2 + j], iex[i][j], 0, 0, 0);
+                    if (MISS) {
+                        im[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(FN8[i], FM8[2 + j], im[i][j], 0, 0, 0);
+                        im[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(FM8[i], FN8[2 + j], im[i][j], 0, 0, 0);
+                    }
+                }
         }
         if (base + 4 * EV < b) fetch(base + 4 * EV);     // the next step's vectors travel while this one is contracted
 #pragma unroll
@@ -1199,6 +1288,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 for (int j = 0; j < 2; ++j) {
                     acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(P_[i], Q_[2 + j], acc_den[i][j], 0, 0, 0);
                     acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(Q_[i], P_[2 + j], acc_den[i][j], 0, 0, 0);
+                    if (I8) continue;
                     acc_cc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(C_[i], C_[2 + j], acc_cc[i][j], 0, 0, 0);
                     if (MISS) {
                         acc_m[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(FN[i], FM[2 + j], acc_m[i][j], 0, 0, 0);
@@ -1211,42 +1301,62 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     // ---- epilogue: C/D layout col = lane & 15, row = (lane >> 4) + 4 v
     if (p.debug & 2) {                                   // timing experiment: keep the accumulators alive, nothing else
         double s = 0;
-        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 4; ++v) s += acc_den[i][j][v] + acc_cc[i][j][v] + acc_m[i][j][v];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 4; ++v) s += acc_den[i][j][v] + acc_cc[i][j][v] + acc_m[i][j][v] + (double)(icc[i][j][v] + im[i][j][v] + iex[i][j][v]);
         if (s == 1.2345e-300) p.out_num[0] = s;
         continue;
     }
+    if (masks_needed)
     for (int tg = tw0 + kGramMaskTiles; tg <= tw1; tg += kGramMaskTiles) {   // windows longer than one group of tiles
         const int ng = min(kGramMaskTiles, tw1 - tg + 1);
         __syncthreads();
-        stage_masks(tg, ng);
+        stage_masks(tg, ng, 0, 4);
         __syncthreads();
         if (!idle) count_group(tg, ng);
     }
-    const size_t wp = (size_t)w * p.P;
+    const size_t wq = (size_t)w * p.n_pairs;
+    uint32_t nvalid = vcount;                            // over the four lanes that hold the same population: the window's valid sites
+    nvalid += __shfl_xor(nvalid, 16); nvalid += __shfl_xor(nvalid, 32);
+    const int lrow = (wave >> 1) * 32, lcol = 64 + (wave & 1) * 32;   // this wave's rows / columns inside lU, lC, lN
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pj = c0 + j * 16 + r;
-        const double Uj = pj < p.P ? p.U[wp + pj] : 0.0, Cj = pj < p.P ? p.C[wp + pj] : 0.0;
-        const double nj = pj < p.P ? (double)p.n_full[pj] : 0.0;
+        const double Uj = lU[lcol + j * 16 + r], Cj = lC[lcol + j * 16 + r], nj = lN[lcol + j * 16 + r];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int pi = r0 + i * 16 + kq + 4 * v;
+                const int li = lrow + i * 16 + kq + 4 * v, pi = r0 + i * 16 + kq + 4 * v;
                 if (pi < pj && pj < p.P) {
                     const uint32_t bit = 1u << ((j * 2 + i) * 4 + v);
                     const double den = acc_den[i][j][v];
-                    const double num = den - p.U[wp + pi] - Uj;
-                    double kk = nj * p.C[wp + pi] + (double)p.n_full[pi] * Cj - 2.0 * acc_cc[i][j][v];
-                    if (MISS) kk -= acc_m[i][j][v];
-                    const size_t q = (size_t)pi * (2 * (size_t)p.P - pi - 1) / 2 + (size_t)(pj - pi - 1);
-                    const size_t o = (size_t)w * p.n_pairs + q;
+                    const double num = den - lU[li] - Uj;
+                    const uint32_t q = (uint32_t)pi * (2u * (uint32_t)p.P - (uint32_t)pi - 1u) / 2u + (uint32_t)(pj - pi - 1);   // P < 2^16
+                    const size_t o = wq + q;
                     p.out_num[o] = (poison_n & bit) ? kNaN : num;
                     p.out_den[o] = (poison_d & bit) ? kNaN : den;
-                    p.out_k[o] = kk;
-                    p.out_cnt[o] = (double)cnt_in[j][i][v];
+                    if (!I8) {
+                        double kk = nj * lC[li] + lN[li] * Cj - 2.0 * acc_cc[i][j][v];
+                        if (MISS) kk -= acc_m[i][j][v];
+                        p.out_k[o] = kk;
+                        p.out_cnt[o] = (double)cnt_in[j][i][v];
+                    }
                 }
             }
+        if (I8) {                                          // the 32-bit accumulators hold rows 4 kq + v
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int li = lrow + i * 16 + 4 * kq + v, pi = r0 + i * 16 + 4 * kq + v;
+                    if (pi < pj && pj < p.P) {
+                        double kk = nj * lC[li] + lN[li] * Cj - 2.0 * (double)icc[i][j][v];
+                        if (MISS) kk -= (double)im[i][j][v];
+                        const uint32_t q = (uint32_t)pi * (2u * (uint32_t)p.P - (uint32_t)pi - 1u) / 2u + (uint32_t)(pj - pi - 1);
+                        p.out_k[wq + q] = kk;
+                        p.out_cnt[wq + q] = (double)((int)nvalid - iex[i][j][v]);
+                    }
+                }
+        }
     }
     }   // windows of this block
 }
@@ -1262,18 +1372,25 @@ hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, h
     }
     const int nblk = (p.P + 63) / 64;
     dim3 grid((p.n_windows + kGramWPB - 1) / kGramWPB, nblk * (nblk + 1) / 2), block(256);
+    bool i8 = count_bytes == 2 && p.max_n <= 127;
+#ifdef EVOFST_EXPERIMENTS
+    if (getenv("EVOFST_GRAM_NO_I8")) i8 = false;
+#endif
+#define EVOFST_GRAM_GO(CT, M, T) do { if (i8) hipLaunchKernelGGL((gram_kernel<CT, M, T, sizeof(CT) == 2>), grid, block, 0, st, p); \
+                                      else hipLaunchKernelGGL((gram_kernel<CT, M, T, false>), grid, block, 0, st, p); } while (0)
     if (count_bytes == 2) {
         if (p.max_n <= 31) {
-            if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true, true>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((gram_kernel<uint16_t, false, true>), grid, block, 0, st, p);
+            if (has_missing) EVOFST_GRAM_GO(uint16_t, true, true);
+            else EVOFST_GRAM_GO(uint16_t, false, true);
         } else {
-            if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true, false>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((gram_kernel<uint16_t, false, false>), grid, block, 0, st, p);
+            if (has_missing) EVOFST_GRAM_GO(uint16_t, true, false);
+            else EVOFST_GRAM_GO(uint16_t, false, false);
         }
     } else {
-        if (has_missing) hipLaunchKernelGGL((gram_kernel<uint32_t, true, false>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gram_kernel<uint32_t, false, false>), grid, block, 0, st, p);
+        if (has_missing) hipLaunchKernelGGL((gram_kernel<uint32_t, true, false, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gram_kernel<uint32_t, false, false, false>), grid, block, 0, st, p);
     }
+#undef EVOFST_GRAM_GO
     return hipGetLastError();
 }
 
