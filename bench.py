@@ -429,20 +429,30 @@ def main():
                 "algorithmic_bytes": dom_bytes}
 
     if cfg["mode"] == "gram" and kavg[2] > 0:
-        # flops of the dominant kernel: 2 S Ppad^2 per Gram matrix over the blocks on or above the diagonal;
-        # 3 MFMA streams without missing alleles (p q^T, q p^T, c c^T), 5 with (two more for the fixed-with-missing term)
+        # SURVEY 8d counts 2 S flops per pair and contraction.  Of the contractions behind a window's sums only the two of
+        # the Hudson denominator (p q^T, q p^T) need doubles and run on the FP64 matrix cores; the integer ones (c c^T,
+        # the fixed-with-missing term, the site filter's exclusions) run on the int8 cores (exact in 32 bits).  "frac" is
+        # the FP64 MFMA rate on the flops of those two over the pairs (no padding of P to 64, no diagonal blocks);
+        # issued_* counts the padded 64 x 64 blocks on or above the diagonal.  What bounds the kernel at 100-site windows
+        # is the table of results it writes (hbm_write_GBps), not the matrix cores.
         Pp = 64 * ((P + 63) // 64)
         nblk = Pp // 64
-        n_mm = 5 if cfg["miss"] > 0 else 3
-        flops = 2.0 * S * (64 * 64) * (nblk * (nblk + 1) / 2) * n_mm
-        ach = flops / (kavg[2] * 1e-3) / 1e12
-        # the same kernel on the flops SURVEY 8d counts as useful: 2 S per pair and contraction, no padding of P to 64, no
-        # diagonal blocks (2 S pairs streams); "frac" is quoted on these
-        useful = 2.0 * S * e.n_pairs * n_mm
-        ach_u = useful / (kavg[2] * 1e-3) / 1e12
+        n_f64 = 2
+        n_i8 = 6 if cfg["miss"] > 0 else 4
+        t_s = kavg[2] * 1e-3
+        useful = 2.0 * S * e.n_pairs * n_f64
+        issued = 2.0 * S * (64 * 64) * (nblk * (nblk + 1) / 2) * n_f64
+        n_win = (S + cfg["size"] - 1) // cfg["size"]
+        written = float(n_win) * (nblk * (nblk + 1) / 2) * 4096 * 32.0
+        ach_u = useful / t_s / 1e12
         roofline.update({"bound": "mfma", "kernel": "gram_kernel", "achieved": ach_u, "peak": F64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach_u / F64_MFMA_PEAK_TFLOPS, "algorithmic_flops": useful,
-                         "issued_flops": flops, "issued_TFLOPs": ach, "issued_frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": None})
+                         "issued_flops": issued, "issued_TFLOPs": issued / t_s / 1e12,
+                         "issued_frac": issued / t_s / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                         "streams": {"f64_mfma": n_f64, "int8_mfma": n_i8},
+                         "all_contractions_as_f64_TFLOPs": 2.0 * S * e.n_pairs * (5 if cfg["miss"] > 0 else 3) / t_s / 1e12,
+                         "hbm_write_bytes": written, "hbm_write_GBps": written / t_s / 1e9,
+                         "hbm_write_frac": written / t_s / 1e9 / HBM_PEAK_GBS, "traffic": None})
     out = {
         "metric": "site x pop-pair Fst+dxy evaluations/sec",
         "value": value, "unit": "site*pair/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

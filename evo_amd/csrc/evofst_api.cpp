@@ -82,7 +82,7 @@ struct evofst_ctx {
 
     // pairs-mode work buffers
     DevBuf d_census, d_offsets, d_incl_totals, d_seg_rows, d_seg_num, d_seg_den, d_seg_k, d_seg_end, d_zf, d_irr,
-        d_tail, d_tail_n, d_carry, d_win, d_halo_num, d_halo_den, d_halo_tag, d_gU, d_gC, d_gnum, d_gden, d_gk, d_gcnt,
+        d_tail, d_tail_n, d_carry, d_win, d_halo_num, d_halo_den, d_halo_tag, d_gU, d_gC, d_gnum, d_gden, d_gk, d_gcnt, d_graw,
         d_nrows, d_totals;
     int64_t seg_cap = 0;
     std::vector<int64_t> win_start;   // Gram mode: site windows
@@ -477,7 +477,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
     DevBuf *bufs[] = {&c->d_segs, &c->d_wss, &c->d_nfull, &c->d_pairs, &c->d_use, &c->d_thr, &c->d_base, &c->d_first_seg,
                       &c->d_tiles, &c->d_flags, &c->d_pos, &c->d_counts, &c->d_census, &c->d_offsets, &c->d_incl_totals,
                       &c->d_seg_rows, &c->d_seg_num, &c->d_seg_den, &c->d_seg_k, &c->d_seg_end, &c->d_zf, &c->d_irr,
-                      &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_halo_num, &c->d_halo_den, &c->d_halo_tag, &c->d_gU, &c->d_gC, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_carry,
+                      &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_halo_num, &c->d_halo_den, &c->d_halo_tag, &c->d_gU, &c->d_gC, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_graw, &c->d_carry,
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles, &c->d_agg0, &c->d_agg1,
@@ -1372,9 +1372,7 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     const int64_t P = c->n_pops, np = P * (P - 1) / 2;
     if ((rc = ensure(c, c->d_gU, (size_t)n_windows * P * 8))) return rc;
     if ((rc = ensure(c, c->d_gC, (size_t)n_windows * P * 8))) return rc;
-    const size_t out_bytes = (size_t)n_windows * np * 8;
-    if ((rc = ensure(c, c->d_gnum, out_bytes)) || (rc = ensure(c, c->d_gden, out_bytes)) ||
-        (rc = ensure(c, c->d_gk, out_bytes)) || (rc = ensure(c, c->d_gcnt, out_bytes))) return rc;
+    if ((rc = ensure(c, c->d_graw, gram_raw_bytes(c->n_pops, n_windows)))) return rc;
     GramParams p{};
     p.counts = c->d_counts.p; p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.P = c->n_pops;
     p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
@@ -1385,7 +1383,7 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     p.first_window = first_window; p.n_windows = (int32_t)n_windows;
     p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p;
     p.n_pairs = np;
-    p.out_num = (double *)c->d_gnum.p; p.out_den = (double *)c->d_gden.p; p.out_k = (double *)c->d_gk.p; p.out_cnt = (double *)c->d_gcnt.p;
+    p.out_raw = (double2 *)c->d_graw.p;
 #ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_DEBUG_GRAM")) p.debug = atoi(e);
 #endif
@@ -1405,6 +1403,12 @@ extern "C" int evofst_get_gram(evofst_ctx *c, double *sum_num, double *sum_den, 
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = (size_t)c->gram_windows * ((size_t)c->n_pops * (c->n_pops - 1) / 2);
     int rc;
+    // the kernel's table of results -> the four arrays of the interface
+    if ((rc = ensure(c, c->d_gnum, n * 8)) || (rc = ensure(c, c->d_gden, n * 8)) || (rc = ensure(c, c->d_gk, n * 8)) ||
+        (rc = ensure(c, c->d_gcnt, n * 8))) return rc;
+    HIPCHK(c, launch_gram_unpack((const double2 *)c->d_graw.p, c->n_pops, c->gram_windows,
+                                 gram_uses_i8(c->count_bytes, *std::max_element(c->n_full.begin(), c->n_full.end())),
+                                 (double *)c->d_gnum.p, (double *)c->d_gden.p, (double *)c->d_gk.p, (double *)c->d_gcnt.p, c->stream));
     if ((rc = d2h(c, sum_num, c->d_gnum.p, n)) || (rc = d2h(c, sum_den, c->d_gden.p, n)) ||
         (rc = d2h(c, sum_dxy_k, c->d_gk.p, n)) || (rc = d2h(c, n_included, c->d_gcnt.p, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -267,7 +267,10 @@ struct GramParams {
     int32_t n_windows;
     double *U, *C;               // [n_windows][P] per-population sums of t + h and of c over the window
     int64_t n_pairs;             // P (P - 1) / 2, pair (i < j) at i (2P - i - 1) / 2 + j - i - 1
-    double *out_num, *out_den, *out_k, *out_cnt;   // [n_windows][n_pairs]
+    // results as the workgroups hold them: [n_windows][block pairs][A|B][wave 4][slot 16][lane 64] x 16 bytes, A = {num, den},
+    // B = {k, n_included}; every store instruction of the epilogue writes 1 KiB of consecutive, aligned bytes
+    // (gram_unpack_kernel turns the table into the four [n_windows][n_pairs] arrays the getter hands out)
+    double2 *out_raw;
     int32_t debug;               // EVOFST_DEBUG_GRAM (timing experiments): 1 no contraction loop, 2 no epilogue, 4 no popsums
 };
 
@@ -309,6 +312,9 @@ hipError_t launch_global_rows(const uint64_t *kept_mask, const uint64_t *skip_ma
 hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st);
 hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
+size_t gram_raw_bytes(int P, int64_t n_windows);
+hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, double *num, double *den, double *k, double *cnt, hipStream_t st);
+bool gram_uses_i8(int count_bytes, int max_n);
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st);
 size_t k2_lds_bytes(int P, int max_n);
 size_t fused_lds_bytes(int P, int n_segs, int max_n, int n_pairs, int chunk_tiles, int count_bytes, int sub);

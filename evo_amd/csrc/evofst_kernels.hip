@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     if (p.debug & 2) {                                   // timing experiment: keep the accumulators alive, nothing else
         double s = 0;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 4; ++v) s += acc_den[i][j][v] + acc_cc[i][j][v] + acc_m[i][j][v] + (double)(icc[i][j][v] + im[i][j][v] + iex[i][j][v]);
-        if (s == 1.2345e-300) p.out_num[0] = s;
+        if (s == 1.2345e-300) p.out_raw[0].x = s;
         continue;
     }
     if (masks_needed)
@@ -1313,52 +1313,85 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         __syncthreads();
         if (!idle) count_group(tg, ng);
     }
-    const size_t wq = (size_t)w * p.n_pairs;
     uint32_t nvalid = vcount;                            // over the four lanes that hold the same population: the window's valid sites
     nvalid += __shfl_xor(nvalid, 16); nvalid += __shfl_xor(nvalid, 32);
+    if (idle) continue;                                  // (uniform over the wave; the barriers are at the top of the loop)
     const int lrow = (wave >> 1) * 32, lcol = 64 + (wave & 1) * 32;   // this wave's rows / columns inside lU, lC, lN
+    const int nbp = nblk * (nblk + 1) / 2;
+    double2 *rawA = p.out_raw + (((size_t)w * nbp + blockIdx.y) * 2 * 4 + wave) * 1024 + lane;
+    double2 *rawB = rawA + 4 * 1024;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int pj = c0 + j * 16 + r;
         const double Uj = lU[lcol + j * 16 + r], Cj = lC[lcol + j * 16 + r], nj = lN[lcol + j * 16 + r];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int li = lrow + i * 16 + kq + 4 * v, pi = r0 + i * 16 + kq + 4 * v;
-                if (pi < pj && pj < p.P) {
-                    const uint32_t bit = 1u << ((j * 2 + i) * 4 + v);
-                    const double den = acc_den[i][j][v];
-                    const double num = den - lU[li] - Uj;
-                    const uint32_t q = (uint32_t)pi * (2u * (uint32_t)p.P - (uint32_t)pi - 1u) / 2u + (uint32_t)(pj - pi - 1);   // P < 2^16
-                    const size_t o = wq + q;
-                    p.out_num[o] = (poison_n & bit) ? kNaN : num;
-                    p.out_den[o] = (poison_d & bit) ? kNaN : den;
-                    if (!I8) {
-                        double kk = nj * lC[li] + lN[li] * Cj - 2.0 * acc_cc[i][j][v];
-                        if (MISS) kk -= acc_m[i][j][v];
-                        p.out_k[o] = kk;
-                        p.out_cnt[o] = (double)cnt_in[j][i][v];
-                    }
+                const int slot = (j * 2 + i) * 4 + v;
+                const int li = lrow + i * 16 + kq + 4 * v;          // FP64 accumulators: row kq + 4 v
+                const uint32_t bit = 1u << slot;
+                const double den = acc_den[i][j][v];
+                const double num = den - lU[li] - Uj;
+                rawA[slot * 64] = make_double2((poison_n & bit) ? kNaN : num, (poison_d & bit) ? kNaN : den);
+                if (!I8) {
+                    double kk = nj * lC[li] + lN[li] * Cj - 2.0 * acc_cc[i][j][v];
+                    if (MISS) kk -= acc_m[i][j][v];
+                    rawB[slot * 64] = make_double2(kk, (double)cnt_in[j][i][v]);
+                } else {
+                    const int l8 = lrow + i * 16 + 4 * kq + v;      // 32-bit accumulators: row 4 kq + v
+                    double kk = nj * lC[l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
+                    if (MISS) kk -= (double)im[i][j][v];
+                    rawB[slot * 64] = make_double2(kk, (double)((int)nvalid - iex[i][j][v]));
                 }
             }
-        if (I8) {                                          // the 32-bit accumulators hold rows 4 kq + v
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int li = lrow + i * 16 + 4 * kq + v, pi = r0 + i * 16 + 4 * kq + v;
-                    if (pi < pj && pj < p.P) {
-                        double kk = nj * lC[li] + lN[li] * Cj - 2.0 * (double)icc[i][j][v];
-                        if (MISS) kk -= (double)im[i][j][v];
-                        const uint32_t q = (uint32_t)pi * (2u * (uint32_t)p.P - (uint32_t)pi - 1u) / 2u + (uint32_t)(pj - pi - 1);
-                        p.out_k[wq + q] = kk;
-                        p.out_cnt[wq + q] = (double)((int)nvalid - iex[i][j][v]);
-                    }
-                }
-        }
     }
     }   // windows of this block
+}
+
+// [n_windows][block pairs][A|B][wave][slot][lane] -> the four [n_windows][n_pairs] arrays (pair (i < j) at
+// i (2P - i - 1) / 2 + j - i - 1).  i8: B's rows follow the 32-bit accumulator layout (row 4 kq + v), else the FP64 one.
+__global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restrict__ raw, int P, int64_t n_windows, bool i8,
+                                                           double *__restrict__ num, double *__restrict__ den,
+                                                           double *__restrict__ k, double *__restrict__ cnt) {
+    const int pj = blockIdx.x * blockDim.x + threadIdx.x, pi = blockIdx.y;
+    const int64_t w = blockIdx.z;
+    if (pj >= P || pi >= pj) return;
+    const int nblk = (P + 63) / 64, nbp = nblk * (nblk + 1) / 2;
+    const int bi = pi >> 6, bj = pj >> 6;
+    const int bp = bi * nblk - bi * (bi - 1) / 2 + (bj - bi);
+    const int rho = pi & 63, chi = pj & 63;
+    const int wave = (rho >> 5) * 2 + (chi >> 5);
+    const int i = (rho >> 4) & 1, j = (chi >> 4) & 1, r16 = rho & 15, r = chi & 15;
+    const size_t base = (((size_t)w * nbp + bp) * 2 * 4 + wave) * 1024;
+    const int slotA = (j * 2 + i) * 4 + (r16 >> 2), laneA = (r16 & 3) * 16 + r;             // row kq + 4 v
+    const int slotB = i8 ? (j * 2 + i) * 4 + (r16 & 3) : slotA, laneB = i8 ? (r16 >> 2) * 16 + r : laneA;   // row 4 kq + v
+    const double2 a = raw[base + slotA * 64 + laneA], b = raw[base + 4 * 1024 + slotB * 64 + laneB];
+    const size_t np = (size_t)P * (P - 1) / 2;
+    const size_t o = (size_t)w * np + (size_t)pi * (2 * (size_t)P - pi - 1) / 2 + (size_t)(pj - pi - 1);
+    num[o] = a.x; den[o] = a.y; k[o] = b.x; cnt[o] = b.y;
+}
+
+size_t gram_raw_bytes(int P, int64_t n_windows) {
+    const size_t nblk = (P + 63) / 64;
+    return (size_t)n_windows * (nblk * (nblk + 1) / 2) * 2 * 4 * 1024 * sizeof(double2);
+}
+bool gram_uses_i8(int count_bytes, int max_n) {
+    bool i8 = count_bytes == 2 && max_n <= 127;
+#ifdef EVOFST_EXPERIMENTS
+    if (getenv("EVOFST_GRAM_NO_I8")) i8 = false;
+#endif
+    return i8;
+}
+hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, double *num, double *den, double *k, double *cnt, hipStream_t st) {
+    if (n_windows <= 0 || P < 2) return hipSuccess;
+    for (int64_t w0 = 0; w0 < n_windows; w0 += 65535) {          // gridDim.z
+        const int64_t nw = std::min<int64_t>(65535, n_windows - w0);
+        const size_t nblk = (P + 63) / 64, per_w = (nblk * (nblk + 1) / 2) * 2 * 4 * 1024, np = (size_t)P * (P - 1) / 2;
+        dim3 grid((P + 255) / 256, P, (unsigned)nw), block(256);
+        hipLaunchKernelGGL(gram_unpack_kernel, grid, block, 0, st, raw + (size_t)w0 * per_w, P, nw, i8, num + (size_t)w0 * np, den + (size_t)w0 * np,
+                           k + (size_t)w0 * np, cnt + (size_t)w0 * np);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st) {
@@ -1372,10 +1405,7 @@ hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, h
     }
     const int nblk = (p.P + 63) / 64;
     dim3 grid((p.n_windows + kGramWPB - 1) / kGramWPB, nblk * (nblk + 1) / 2), block(256);
-    bool i8 = count_bytes == 2 && p.max_n <= 127;
-#ifdef EVOFST_EXPERIMENTS
-    if (getenv("EVOFST_GRAM_NO_I8")) i8 = false;
-#endif
+    const bool i8 = gram_uses_i8(count_bytes, p.max_n);
 #define EVOFST_GRAM_GO(CT, M, T) do { if (i8) hipLaunchKernelGGL((gram_kernel<CT, M, T, sizeof(CT) == 2>), grid, block, 0, st, p); \
                                       else hipLaunchKernelGGL((gram_kernel<CT, M, T, false>), grid, block, 0, st, p); } while (0)
     if (count_bytes == 2) {
