@@ -180,6 +180,9 @@ def main():
                     help="no GPU work: the ranks only meet (gloo, CPU) and rank 0 prints how many there are -- tests the launch path")
     ap.add_argument("--batches", type=int, default=0,
                     help="resident synthetic batches the timed loop rotates over (0 = enough to exceed the 256 MiB Infinity Cache)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the resident batches are spread over (1: the steps run one after the other; more: "
+                         "independent batches overlap, as a run that keeps several batches in flight would)")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the short cfg4-shard run behind roofline_hbm")
     ap.add_argument("--sites", type=int, default=0, help="experiments only: another number of sites per GPU (the label says so)")
     args = ap.parse_args()
@@ -263,11 +266,14 @@ def main():
     # "HBM" rate would be a cache rate.  One stream for all of them: the steps run one after the other.
     tiles_bytes = e.tiles_bytes(S)
     n_batches = args.batches if args.batches > 0 else int(min(8, max(1, -(-640 * 2**20 // tiles_bytes))))
+    if args.batches <= 0 and args.streams > 1:
+        n_batches = max(n_batches, 2)          # two batches at least, so that one's counting overlaps the other's walk
     if multi or cfg["mode"] == "gram":
         n_batches = 1
     es = [e]
     if n_batches > 1:
-        shared = torch.cuda.Stream()
+        streams = [torch.cuda.Stream() for _ in range(max(1, min(args.streams, n_batches)))]
+        shared = streams[0]
         e.set_stream(shared.cuda_stream)
         for b in range(1, n_batches):
             eb = EvoFst(local_rank)
@@ -277,7 +283,7 @@ def main():
             else:
                 eb.set_against_all(np.arange(P, dtype=np.int32), np.full(P, N // P, np.int64))
             eb.set_windows(cfg["size"], cfg["step"])
-            eb.set_stream(shared.cuda_stream)
+            eb.set_stream(streams[b % len(streams)].cuda_stream)
             eb.reserve(S)
             eb.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=(rank * n_batches + b) * S)
             eb.sync()
@@ -460,7 +466,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["label"], "sites_per_gpu": S, "samples": N, "pops": P,
                    "units_per_site": units_per_site, "sharding": "contiguous site shards, one per GPU",
-                   "resident_batches": n_batches,
+                   "resident_batches": n_batches, "streams": min(args.streams, n_batches) if n_batches > 1 else 1,
                    "rccl_ranks": dist.get_world_size() if multi else 1},
         "roofline": roofline,
     }
