@@ -81,10 +81,11 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     Batch b0, b1, b2, b3;
     b0.flag = b1.flag = b2.flag = b3.flag = 0u;
     // Every request is unconditional -- rows past W, batches past the chunk's end and the flag byte of a run without
-    // site_flags all read the first bytes of the tile array (one cache line per instruction, results ignored) -- so the
+    // site_flags all read the first bytes of the wave's chunk (one cache line per instruction, results ignored) -- so the
     // number of loads behind the batch a wave waits for is known at compile time and the wait is a count, not
     // "everything outstanding".
     const bool have_flags = p.site_flags != nullptr;
+    const ulonglong2 *dummy = p.tiles + (size_t)t0 * p.W * kTileSites;   // the wave's own first line: no address shared by all waves
     auto load_item = [&](Batch &b, int item) {
         const bool past = item >= n_items;
         const int it = past ? 0 : item;
@@ -93,9 +94,9 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
         const ulonglong2 *tp = p.tiles + (size_t)t * p.W * kTileSites + lane;
 #pragma unroll
         for (int u = 0; u < NB; ++u)
-            b.r[u] = (past || wb + u >= p.W) ? p.tiles[0] : tp[(size_t)(wb + u) * kTileSites];
+            b.r[u] = (past || wb + u >= p.W) ? *dummy : tp[(size_t)(wb + u) * kTileSites];
         const int64_t site = (int64_t)t * kTileSites + lane;
-        const uint8_t *fp = (have_flags && !past && site < p.n_sites) ? p.site_flags + site : reinterpret_cast<const uint8_t *>(p.tiles);
+        const uint8_t *fp = (have_flags && !past && site < p.n_sites) ? p.site_flags + site : reinterpret_cast<const uint8_t *>(dummy);
         b.flag = *fp;
     };
     load_item(b0, 0);                                   // the first batches go out before the pair list is staged
@@ -325,18 +326,18 @@ hipError_t launch_k1(const K1Params &p_, int count_bytes, int mode, hipStream_t 
 // =====================================================================================
 constexpr int kScanThreads = 1024, kScanPer = 4;
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const uint32_t *__restrict__ census,
-                                                            const int64_t *__restrict__ base,
+                                                            const int64_t *base,      // may be base_out (run_scan passes d_base for both)
                                                             int64_t *__restrict__ offsets,
                                                             int64_t *__restrict__ totals, int n_chunks, int n_cols,
                                                             int64_t g, int64_t *__restrict__ first_seg,
                                                             const int64_t *__restrict__ gathered, int64_t row_stride, int n_rows,
-                                                            int64_t *__restrict__ base_out, int64_t *__restrict__ totals_copy) {
+                                                            int64_t *base_out, int64_t *__restrict__ totals_copy) {
     __shared__ uint32_t wsum[kScanThreads / 64];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int q = blockIdx.x;
     const uint32_t *in = census + (size_t)q * n_chunks;
     int64_t *out = offsets + (size_t)q * n_chunks;
-    int64_t b0 = base ? base[q] : 0;
+    int64_t b0 = (base && !gathered) ? base[q] : 0;
     if (gathered) {   // the base offset is the sum of the earlier ranks' totals, straight from the all-gather buffer
         b0 = 0;
         for (int r = 0; r < n_rows; ++r) b0 += gathered[(size_t)r * row_stride + q];

@@ -44,6 +44,7 @@ def main():
         host.append((engine.segments(), engine.boundary().copy()))
     # device forms: nothing between run_counts and copy_boundary waits on the host
     t_all = torch.zeros(n_shards * nq, dtype=torch.int64, device="cuda")
+    stream.wait_stream(torch.cuda.current_stream())      # the fill above ran on torch's current stream
     with torch.cuda.stream(stream):
         for r in range(n_shards):
             load(r)
@@ -51,6 +52,7 @@ def main():
     stream.synchronize()
     assert np.array_equal(t_all.cpu().numpy().reshape(n_shards, nq), np.array(totals))
     t_carry = torch.zeros(nq * 4, dtype=torch.float64, device="cuda")
+    stream.wait_stream(torch.cuda.current_stream())
     for r in range(n_shards):
         with torch.cuda.stream(stream):
             load(r)
@@ -71,6 +73,7 @@ def main():
     # first, as bench.py's message is laid out), shard r sums rows 0 .. r-1
     t_msg = torch.full((n_shards, 5 * nq), 7_777, dtype=torch.int64, device="cuda")
     t_msg[:, :nq] = t_all.view(n_shards, nq)
+    stream.wait_stream(torch.cuda.current_stream())
     for r in range(n_shards):
         with torch.cuda.stream(stream):
             load(r)
