@@ -26,6 +26,8 @@ CONFIGS = {
     # name: (sites per GPU, samples, pops, mode, size, step, missing)
     "cfg2": dict(sites=1_000_000, samples=200, pops=10, mode="pairs", size=100, step=100, miss=0.0,
                  label="synthetic 1M sites x 200 diploid samples, 10 pops (45 pairs), SNP windows 100,100"),
+    "cfg2m": dict(sites=1_000_000, samples=200, pops=10, mode="pairs", size=100, step=100, miss=0.02,
+                 label="cfg2 with 2% missing calls (diagnostic: every chunk takes the general walk)"),
     "cfg2nw": dict(sites=1_000_000, samples=200, pops=10, mode="pairs", size=0, step=0, miss=0.0,
                   label="cfg2 without windows (totals only; diagnostic)"),
     "cfg3s": dict(sites=2_000_000, samples=1000, pops=100, mode="global", size=20, step=10, miss=0.0,

@@ -99,7 +99,7 @@ struct evofst_ctx {
     int64_t row_cap = 0;
 
     // fused pairs pass (evofst_fused.hip): look-back granules, ticket + error words, launch epoch
-    DevBuf d_agg0, d_agg1, d_agg2, d_fsync, d_miss, d_dirty, d_poison;
+    DevBuf d_agg0, d_agg1, d_agg2, d_fsync, d_miss, d_dirty, d_poison, d_nan;
     uint32_t epoch = 0;
     bool fused_check = false;         // a fused launch has not had its error word looked at yet
     bool plain_counts = false;        // d_counts holds the counts of the loaded data (from any K1 launch)
@@ -481,7 +481,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles, &c->d_agg0, &c->d_agg1,
-                      &c->d_agg2, &c->d_fsync, &c->d_miss, &c->d_dirty, &c->d_poison};
+                      &c->d_agg2, &c->d_fsync, &c->d_miss, &c->d_dirty, &c->d_poison, &c->d_nan};
     for (DevBuf *b : bufs) release(*b);
     for (auto &pair : c->ev)
         for (auto &e : pair)
@@ -1218,6 +1218,8 @@ int launch_k1_counts(evofst_ctx *c, int mode) {
         p.miss_mask = (uint64_t *)c->d_miss.p;
         if ((rc = ensure(c, c->d_dirty, (size_t)c->n_chunks * 4))) return rc;
         p.chunk_dirty = (uint32_t *)c->d_dirty.p;
+        if ((rc = ensure(c, c->d_nan, (size_t)c->n_tiles * 8))) return rc;
+        p.nan_mask = (uint64_t *)c->d_nan.p;
     } else if (mode == MODE_GRAM) {
         if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 32))) return rc;
         if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
@@ -1292,6 +1294,7 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
             f.seg_cap = c->seg_cap; f.seg_rows = p.seg_rows; f.tail = p.tail; f.tail_n = p.tail_n;
             f.counts = p.counts; f.zf_masks = p.zf_masks; f.irr_mask = p.irr_mask; f.skip_mask = p.skip_mask; f.miss_mask = p.miss_mask;
             f.chunk_offsets = p.chunk_offsets;
+            f.nan_mask = (const uint64_t *)c->d_nan.p;
             f.piece_tiles = std::max(1, std::min(2, c->chunk_tiles));     // two buffers of two tiles per region
             const size_t lds = fused_lds_bytes(c->n_pops, 0, p.max_n, (int)np, 2 * f.piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, 32);
 #ifdef EVOFST_EXPERIMENTS

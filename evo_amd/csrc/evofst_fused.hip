@@ -51,7 +51,7 @@ static size_t fused_region_bytes(int P, int tiles, int count_bytes, int sub) {
     b += a16((size_t)P * 4);                    // carC
     b += a16((size_t)tiles * P * kTileSites * count_bytes);
     b += a16((size_t)tiles * 2 * P * 8);        // zero / fixed ballots
-    b += 3 * a16((size_t)tiles * 8);            // irregular, skip, any-missing
+    b += 4 * a16((size_t)tiles * 8);            // irregular, skip, any-missing, NaN sites
     return b;
 }
 
@@ -130,7 +130,7 @@ __device__ __forceinline__ bool sum_granule_rows(const FusedParams &p, int chunk
 template <typename CT>
 __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane, int n_my, int tile_first, int tile_stride,
                                                  int slot_first, int slot_stride, CT *lcnt, uint64_t *lzf, uint64_t *lirr,
-                                                 uint64_t *lskip, uint64_t *lmiss, const uint4 *lsegs) {
+                                                 uint64_t *lskip, uint64_t *lmiss, uint64_t *lnan, const uint4 *lsegs) {
     const int P = p.P;
     const int nb = (p.W + kFuseNB - 1) / kFuseNB;      // load batches per tile
     const int n_items = n_my * nb;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 #endif
     if (n_items > 0) EVOFST_FUSED_LOAD(cur, 0);
     uint32_t c = 0, mc = 0;
-    bool irregular = false, skip = false, anymiss = false;
+    bool irregular = false, skip = false, anymiss = false, nanany = false;
     uint64_t skipmask = 0;
     int sidx = 0;                          // next descriptor of the stream
     uint4 d = lsegs[0];                    // {mask lo, mask hi, pop, flags | n_full << 8}
@@ -166,7 +166,7 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
             skip = site >= p.n_sites;
             if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
             skipmask = __ballot(skip);
-            c = 0; mc = 0; irregular = false; anymiss = false;
+            c = 0; mc = 0; irregular = false; anymiss = false; nanany = false;
             sidx = 0; d = lsegs[0];
         }
         CT *cp = lcnt + (size_t)slot * P * kTileSites + lane;
@@ -195,6 +195,7 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
                         // sites phase B must take through its general loop: a NaN in the reference (nm < 2) or an
                         // excluded site with a dxy term (fixed with missing alleles)
                         irregular = irregular || nm < 2 || (c == nm && nm < nfull);
+                        nanany = nanany || nm < 2;
                         anymiss = anymiss || mc != 0;
                         c = 0; mc = 0;
                     }
@@ -204,8 +205,8 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
             }
         }
         if (bi == nb - 1) {
-            const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss);
-            if (lane == 0) { lirr[slot] = im; lskip[slot] = skipmask; lmiss[slot] = mm; }
+            const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss), nn = __ballot(nanany && !skip);
+            if (lane == 0) { lirr[slot] = im; lskip[slot] = skipmask; lmiss[slot] = mm; lnan[slot] = nn; }
         }
         if (item + 1 < n_items) {
 #pragma unroll
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
         const size_t rb = ((size_t)3 * (((size_t)P * SUBP * 8 + 15) & ~(size_t)15)) + 2 * (((size_t)P * 8 + 15) & ~(size_t)15) +
                           2 * (((size_t)P * SUBP * 4 + 15) & ~(size_t)15) + (((size_t)P * 4 + 15) & ~(size_t)15) +
                           (((size_t)TRL * P * kTileSites * sizeof(CT) + 15) & ~(size_t)15) + (((size_t)TRL * 2 * P * 8 + 15) & ~(size_t)15) +
-                          3 * (((size_t)TRL * 8 + 15) & ~(size_t)15);
+                          4 * (((size_t)TRL * 8 + 15) & ~(size_t)15);
         off += (size_t)wave * rb;
     }
     double *pt = reinterpret_cast<double *>(carve((size_t)P * SUBP * 8));   // [P][SUB + 1] p = c / nm
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
     uint64_t *lirr = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 8));
     uint64_t *lskip = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 8));
     uint64_t *lmiss = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 8));   // sites where some population has a missing allele
+    uint64_t *lnan = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 8));    // sites where some population has fewer than two called alleles
 
     const int dtid = WP ? lane : tid;          // thread index and count of the group that shares one region
     const int dn = WP ? 64 : nthreads;
@@ -353,8 +355,8 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
         if (!(p.debug & 8))
 #endif
         if (!HBM) {
-            if (WP) count_wave_tiles<CT>(p, lane, rnt, t0 + rt0, 1, 0, 1, lcnt, lzf, lirr, lskip, lmiss, lsegs);
-            else count_wave_tiles<CT>(p, lane, wave < nt ? (nt - wave + NWV - 1) / NWV : 0, t0 + wave, NWV, wave, NWV, lcnt, lzf, lirr, lskip, lmiss, lsegs);
+            if (WP) count_wave_tiles<CT>(p, lane, rnt, t0 + rt0, 1, 0, 1, lcnt, lzf, lirr, lskip, lmiss, lnan, lsegs);
+            else count_wave_tiles<CT>(p, lane, wave < nt ? (nt - wave + NWV - 1) / NWV : 0, t0 + wave, NWV, wave, NWV, lcnt, lzf, lirr, lskip, lmiss, lnan, lsegs);
         }
         for (int i = dtid; i < P; i += dn) { carH[i] = 0.0; carT[i] = 0.0; carC[i] = 0u; }
         region_sync();
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
         double prevN = 0.0, prevD = 0.0;      // their values at the last boundary
         uint32_t prevCi = 0, prevCj = 0, prevBn = 0, prevBd = 0;
         uint64_t prevCC = 0;
+        uint64_t kx = 0, prevKx = 0;          // sumKij terms of excluded sites the regular loop's sums include (fixed in both, alleles missing)
         int32_t nflush = 0;
         uint64_t aCC = 0, aCi = 0, aCj = 0, aQi = 0, aQj = 0;   // clean fills since the last boundary: sums of c_i c_j, c, c^2
         const int nvec = P * VPR;
@@ -522,8 +525,8 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
         // buffers (global_load_lds, 16 bytes per lane, no registers in between) while the piece in the other one is walked
         typedef __attribute__((address_space(3))) void *LdsPtr;
         const CT *lcntp = lcnt;
-        const uint64_t *lzfp = lzf, *lirrp = lirr, *lskipp = lskip, *lmissp = lmiss;
-        uint64_t prem[3] = {0, 0, 0};
+        const uint64_t *lzfp = lzf, *lirrp = lirr, *lskipp = lskip, *lmissp = lmiss, *lnanp = lnan;
+        uint64_t prem[4] = {0, 0, 0, 0};
         auto piece_tiles_of = [&](int piece) { return min(TR, rnt - piece * TR); };
         auto request_piece = [&](int piece) {
             const int g = rg0 + piece * TR, pnt = piece_tiles_of(piece), buf = piece & 1;
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
             for (int v = v0; v < nz; v += dn)
                 if (v + lane < nz) __builtin_amdgcn_global_load_lds(zsrc + v + lane, (LdsPtr)(zdst + v), 16, 0, 0);
             const int tt = g + min(dtid, pnt - 1);
-            prem[0] = p.irr_mask[tt]; prem[1] = p.skip_mask[tt]; prem[2] = p.miss_mask[tt];
+            prem[0] = p.irr_mask[tt]; prem[1] = p.skip_mask[tt]; prem[2] = p.miss_mask[tt]; prem[3] = p.nan_mask[tt];
         };
         const int n_pieces = HBM ? (rnt + TR - 1) / TR : 1;
         if (HBM && rnt > 0) request_piece(0);
@@ -549,10 +552,10 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
         if (HBM) {
             const int buf = piece & 1;
             lcntp = lcnt + (size_t)buf * TR * P * kTileSites; lzfp = lzf + (size_t)buf * TR * 2 * P;
-            lirrp = lirr + buf * TR; lskipp = lskip + buf * TR; lmissp = lmiss + buf * TR;
+            lirrp = lirr + buf * TR; lskipp = lskip + buf * TR; lmissp = lmiss + buf * TR; lnanp = lnan + buf * TR;
             for (int v = dtid; v < pnt; v += dn) {
-                if (v >= dn) { prem[0] = p.irr_mask[gtile0 + v]; prem[1] = p.skip_mask[gtile0 + v]; prem[2] = p.miss_mask[gtile0 + v]; }
-                lirr[buf * TR + v] = prem[0]; lskip[buf * TR + v] = prem[1]; lmiss[buf * TR + v] = prem[2];
+                if (v >= dn) { prem[0] = p.irr_mask[gtile0 + v]; prem[1] = p.skip_mask[gtile0 + v]; prem[2] = p.miss_mask[gtile0 + v]; prem[3] = p.nan_mask[gtile0 + v]; }
+                lirr[buf * TR + v] = prem[0]; lskip[buf * TR + v] = prem[1]; lmiss[buf * TR + v] = prem[2]; lnan[buf * TR + v] = prem[3];
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): this thread's copies of the piece have landed
             region_sync();                                     // ... and everybody else's
@@ -561,7 +564,11 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
         for (int st = 0; st < SPT * pnt; ++st) {
             const int ti = st / SPT, sh = (st - ti * SPT) * SUB;
             const uint32_t skipfill = (uint32_t)(lskipp[ti] >> sh) & FULL;
-            const bool general = ((uint32_t)(lirrp[ti] >> sh) & FULL) != 0u;   // uniform
+            // general: a site of the fill is NaN in the reference (a population with fewer than two called alleles).  Sites
+            // both populations are fixed at with alleles missing -- excluded, but with a sumKij term -- are taken out of the
+            // regular loop's sums afterwards (kx below)
+            const bool general = ((uint32_t)(lnanp[ti] >> sh) & FULL) != 0u;   // uniform
+            const bool fill_missing = ((uint32_t)(lmissp[ti] >> sh) & FULL) != 0u;   // uniform
             const bool clean = kInt && ((uint32_t)((lmissp[ti] | lskipp[ti] | lirrp[ti]) >> sh) & FULL) == 0u;   // uniform
             if (!clean) {
                 const uint4 *vp = reinterpret_cast<const uint4 *>(lcntp + (size_t)ti * P * kTileSites);
@@ -585,12 +592,12 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
                 }
                 // emit: the accumulators right after boundary site b -> one row of the segment table, then the next boundary.
                 // H, T, PCi, PCj: the per-population prefix sums at b; i*: the integer sums of the segment's clean fills.
-                auto emit = [&](double cD, uint64_t ccc, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd, double H, double T,
+                auto emit = [&](double cD, uint64_t ccc, uint64_t ckx, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd, double H, double T,
                                 uint32_t PCi, uint32_t PCj, uint64_t iCC, uint64_t iCi, uint64_t iCj, uint64_t iQi, uint64_t iQj) {
                     const uint32_t Ci = PCi - cexi, Cj = PCj - cexj;
                     const double cumN = cD - H, cumD = cD + T;
                     // sumKij (fst.cpp:299-321) of the segment, exact: differences are taken modulo 2^32 / 2^64
-                    uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC);
+                    uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC) - (ckx - prevKx);
                     double numI = 0.0, denI = 0.0;
                     if (kInt) int_parts(iCC, iCi, iCj, iQi, iQj, numI, denI, kk);
                     SegRow row;
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
                         const uint4 *src = reinterpret_cast<const uint4 *>(&row);
                         dst[0] = src[0]; dst[1] = src[1];
                     }
-                    prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevBn = cbn; prevBd = cbd;
+                    prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevKx = ckx; prevBn = cbn; prevBd = cbd;
                     ++nflush;
                     orow += p.n_pairs;
                     const uint32_t rem = b >= SUB - 1 ? 0u : incl & ~((2u << b) - 1u);
@@ -650,13 +657,26 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
                             pCi = __builtin_amdgcn_udot4(x, kOnes, pCi, false); pCj = __builtin_amdgcn_udot4(y, kOnes, pCj, false);
                             pQi = __builtin_amdgcn_udot4(x, x, pQi, false); pQj = __builtin_amdgcn_udot4(y, y, pQj, false);
                         }
-                        emit(D, cc, exi, exj, bn, bd, carH[pi] + carH[pj], carT[pi] + carT[pj], carC[pi], carC[pj],
+                        emit(D, cc, kx, exi, exj, bn, bd, carH[pi] + carH[pj], carT[pi] + carT[pj], carC[pi], carC[pj],
                              aCC + (pCC - dCC), aCi + (pCi - dCi), aCj + (pCj - dCj), aQi + (pQi - dQi), aQj + (pQj - dQj));
                         aCC = aCi = aCj = aQi = aQj = 0;
                         dCC = pCC; dCi = pCi; dCj = pCj; dQi = pQi; dQj = pQj;
                     }
                     aCC += tCC - dCC; aCi += tCi - dCi; aCj += tCj - dCj; aQi += tQi - dQi; aQj += tQj - dQj;
                 } else {
+                // sites of the fill both populations are fixed at (c == nm), where the fill has missing alleles at all
+                const uint32_t E = (!general && fill_missing) ? ((uint32_t)((zp[P + pi] & zp[P + pj]) >> sh) & FULL) : 0u;
+                const uint64_t kx0 = kx;
+                auto kx_sum = [&](uint32_t bits) {             // their sumKij terms (0 where no allele is missing: c = n)
+                    uint64_t sum = 0;
+                    while (bits) {
+                        const int e_ = __ffs((int)bits) - 1;
+                        bits &= bits - 1u;
+                        const uint64_t ci = xt[io + e_] & kXMask, cj = xt[jo + e_] & kXMask;
+                        sum += (uint64_t)nj * ci + (uint64_t)ni * cj - 2ull * ci * cj;
+                    }
+                    return sum;
+                };
                 const int bgrp = b & ~(kGrp - 1);
                 double sD = D;                                 // snapshots at the end of the boundary's group
                 uint64_t scc = cc;
@@ -708,7 +728,8 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
                     }
                 }
                 auto emit_general = [&](double cD, uint64_t ccc, uint32_t cexi, uint32_t cexj, uint32_t cbn, uint32_t cbd) {
-                    emit(cD, ccc, cexi, cexj, cbn, cbd, PH[io + b] + PH[jo + b], PT[io + b] + PT[jo + b], PC[io + b], PC[jo + b],
+                    const uint64_t ckx = E ? kx0 + kx_sum(E & (b >= 31 ? 0xffffffffu : ((2u << b) - 1u))) : kx0;   // up to the boundary
+                    emit(cD, ccc, ckx, cexi, cexj, cbn, cbd, PH[io + b] + PH[jo + b], PT[io + b] + PT[jo + b], PC[io + b], PC[jo + b],
                          aCC, aCi, aCj, aQi, aQj);
                     aCC = aCi = aCj = aQi = aQj = 0;
                 };
@@ -763,6 +784,7 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
                         emit_general(cD, ccc, cexi, cexj, cbn, cbd);
                     }
                 }
+                if (E) kx = kx0 + kx_sum(E);                   // the whole fill
                 }   // general fill
             }
             region_sync();
@@ -776,7 +798,7 @@ __global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kern
             const size_t plane = (size_t)p.n_pairs * n_sub;
             const double H = carH[pi] + carH[pj], T = carT[pi] + carT[pj];
             const uint32_t Ci = carC[pi] - exi, Cj = carC[pj] - exj;
-            uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (cc - prevCC);
+            uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (cc - prevCC) - (kx - prevKx);
             double numI = 0.0, denI = 0.0;
             if (kInt) int_parts(aCC, aCi, aCj, aQi, aQj, numI, denI, kk);
             p.tail[cq] = bn != prevBn ? kNaN : ((D - H) - prevN) + numI;

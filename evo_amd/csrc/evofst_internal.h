@@ -89,6 +89,7 @@ struct K1Params {
     uint64_t *zf_masks;      // [n_tiles][2][P] sites with c == 0 / c == nm (skipped sites set in both)
     uint64_t *irr_mask;      // [n_tiles] sites with nm < 2 or c == nm < n_full in some population
     uint64_t *miss_mask;     // [n_tiles] sites where some population has a missing allele (pairs mode)
+    uint64_t *nan_mask;      // [n_tiles] sites where some population has fewer than two called alleles (pairs mode)
     uint32_t *tile_poison;   // [n_tiles] Gram mode: != 0 when a population has fewer than two called alleles at some site of the tile
     uint32_t *chunk_dirty;   // [n_chunks] != 0: the chunk holds a skipped, irregular or missing-allele site (pairs mode)
     // against-all mode
@@ -158,6 +159,7 @@ struct FusedParams {
     // statistics half on its own (counts != null): a region is one of K1's n_chunks chunks of chunk_tiles tiles
     const void *counts;             // K1's packed counts
     const uint64_t *zf_masks, *irr_mask, *skip_mask, *miss_mask;   // K1's ballots
+    const uint64_t *nan_mask;       // K1: sites where some population has fewer than two called alleles
     const int64_t *chunk_offsets;   // [n_pairs][n_chunks] from the scan
     const uint32_t *chunk_dirty;    // [n_chunks] from K1, or null: the walk of evofst_fused.hip takes the chunks marked here,
                                     // clean_walk_kernel the others

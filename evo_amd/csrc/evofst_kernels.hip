@@ -116,6 +116,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     bool irregular = false, skip = false, anymiss = false;
     uint64_t skipmask = 0;
     bool dirty = false;                                 // wave-uniform: the chunk has a site clean_walk_kernel cannot take
+    bool nanany = false;                                // this lane's site: some population has fewer than two called alleles
     bool poison = false;                                // wave-uniform, Gram mode: the tile has a site where a population has < 2 called alleles
     int zlo = 0, zhi = 0, flo = 0, fhi = 0, ylo1 = 0, yhi1 = 0, ylo0 = 0, yhi0 = 0;   // ballots by population, lane = pop & 63
     auto wave_lds_sync = [&]() {
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             }
         }
         if (MODE == MODE_PAIRS) {
-            const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss);
-            if (lane == 0 EVOFST_K1_DBG(8)) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; p.miss_mask[t] = mm; }
+            const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss), nn = __ballot(nanany && !skip);
+            if (lane == 0 EVOFST_K1_DBG(8)) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; p.miss_mask[t] = mm; p.nan_mask[t] = nn; }
             dirty = dirty || (im | mm | skipmask) != 0;
             // [tile][z|f][P]: zm, fm are adjacent
             if (ST) { if (lane < 2 * P EVOFST_K1_DBG(16)) p.zf_masks[(size_t)t * 2 * P + lane] = zm[lane]; }
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             if (item > 0) epilogue(t - 1);
             skip = (int64_t)t * kTileSites + lane >= p.n_sites || (have_flags && (cur.flag & 1u) != 0);
             skipmask = __ballot(skip);
-            c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false; anymiss = false; poison = false;
+            c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false; anymiss = false; poison = false; nanany = false;
             sidx = 0; d = segs[0]; dn = segs[1];
         }
         load_item(spare, item + 3);
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                             const bool anym = mc != 0;
                             if (__any(anym) || nfull < 2u) {
                                 irregular = irregular || nm < 2 || (c == nm && nm < nfull);
+                                nanany = nanany || nm < 2;
                                 anymiss = anymiss || anym;
                             }
                         }
