@@ -270,7 +270,7 @@ def main():
     n_batches = args.batches if args.batches > 0 else int(min(8, max(1, -(-640 * 2**20 // tiles_bytes))))
     if args.batches <= 0 and args.streams > 1:
         n_batches = max(n_batches, 2)          # two batches at least, so that one's counting overlaps the other's walk
-    if multi or cfg["mode"] == "gram":
+    if cfg["mode"] == "gram" or (multi and cfg["mode"] != "pairs"):
         n_batches = 1
     es = [e]
     if n_batches > 1:
@@ -298,16 +298,22 @@ def main():
     from evo_amd import shard
     ag = shard.torch_all_gather(device="cuda") if multi else None
     if multi and cfg["mode"] == "pairs":
-        # the whole pass stays on one stream: kernels, device-to-device copies and the two all-gathers (RCCL)
-        stream = torch.cuda.Stream()
-        e.set_stream(stream.cuda_stream)
+        # a pass stays on one stream: kernels, device-to-device copies and the all-gather (RCCL; every rank issues the
+        # passes, hence the collectives, in the same order).  The resident batches take the streams in turn, as in the
+        # one-rank run, so one batch's exchange and statistics overlap the next one's counting.
+        if n_batches == 1:
+            streams = [torch.cuda.Stream()]
+            e.set_stream(streams[0].cuda_stream)
+        pass_streams = [streams[b % len(streams)] for b in range(n_batches)]
         nq = e.n_pairs
         # one message per rank and pass: [included-site totals of this pass (nq x i64) | carries of the pass before
         # (nq x 4 f64, bit patterns)].  The totals are needed before K2; the carries only by the host after the
-        # pass, so they ride with the next pass's totals and one more gather after the last pass delivers the rest.
-        msg = shard.PairsPassMessage(nq, world, rank, "cuda")
-        p_tot, p_carry, p_recv = msg.totals_ptr(), msg.carry_ptr(), msg.recv_ptr()
-        stream.wait_stream(torch.cuda.current_stream())      # the message tensors were filled on torch's current stream
+        # pass, so they ride with the batch's next pass and one more gather per batch after the last pass delivers
+        # the rest.
+        msgs = [shard.PairsPassMessage(nq, world, rank, "cuda") for _ in range(n_batches)]
+        msg = msgs[0]
+        for st_ in set(pass_streams):
+            st_.wait_stream(torch.cuda.current_stream())     # the message tensors were filled on torch's current stream
 
     e_prof = [False]
 
@@ -333,19 +339,23 @@ def main():
             # travel in the next pass's message (one collective per pass instead of two).
             # Nothing in this step waits on the host; what the gathered carries are used for (completing the
             # windows that straddle the left edge, evo_amd.shard.carry_in) is host bookkeeping after the pass.
-            with torch.cuda.stream(stream):
-                e.run_counts()
-                e.copy_included_totals(p_tot)
-                msg.gather(dist)
-                e.set_base_offsets_gathered(p_recv, msg.row, rank)     # sum of the earlier ranks' totals
-                e.run_stats()
-                e.copy_boundary(p_carry)
+            b = turn[0] % n_batches
+            turn[0] += 1
+            eb_, mb_ = es[b], msgs[b]
+            with torch.cuda.stream(pass_streams[b]):
+                eb_.run_counts()
+                eb_.copy_included_totals(mb_.totals_ptr())
+                mb_.gather(dist)
+                eb_.set_base_offsets_gathered(mb_.recv_ptr(), mb_.row, rank)     # sum of the earlier ranks' totals
+                eb_.run_stats()
+                eb_.copy_boundary(mb_.carry_ptr())
 
     def flush():
         # the carries of the last pass (multi-rank pairs mode): one more gather, inside the timed region
         if multi and cfg["mode"] == "pairs":
-            with torch.cuda.stream(stream):
-                msg.gather(dist)
+            for b in range(n_batches):
+                with torch.cuda.stream(pass_streams[b]):
+                    msgs[b].gather(dist)
 
     def fence():
         for x in es:
@@ -373,7 +383,7 @@ def main():
     for x in es:
         x.set_profiling(True)
     for i in range(reps):
-        cur = es[turn[0] % n_batches] if not multi and cfg["mode"] != "gram" else e
+        cur = es[turn[0] % n_batches] if cfg["mode"] != "gram" and (not multi or cfg["mode"] == "pairs") else e
         step()
         cur.sync()
         for k in range(5):
