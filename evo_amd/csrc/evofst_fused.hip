@@ -1000,6 +1000,11 @@ hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st) {
     const int threads = fused_threads(p.n_pairs);
     const size_t lds = clean_walk_lds_bytes(p.P, p.n_pairs, p.piece_tiles);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+        const void *fn = wp ? reinterpret_cast<const void *>(&clean_walk_kernel<true>) : reinterpret_cast<const void *>(&clean_walk_kernel<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (wp) hipLaunchKernelGGL((clean_walk_kernel<true>), dim3((p.n_chunks + kFuseWaves - 1) / kFuseWaves), dim3(threads), lds, st, p);
     else hipLaunchKernelGGL((clean_walk_kernel<false>), dim3(p.n_chunks), dim3(threads), lds, st, p);
     return hipGetLastError();

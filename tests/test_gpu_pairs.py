@@ -170,7 +170,9 @@ def test_snp_windows(engine, S, N, P, miss, size, step):
 
 
 @pytest.mark.parametrize("S,N,P,size,step,dirty", [(6000, 200, 10, 100, 100, 0), (5000, 40, 4, 20, 10, 0), (4096, 60, 5, 7, 7, 40),
-                                                     (3000, 250, 2, 50, 25, 3)])
+                                                     (3000, 250, 2, 50, 25, 3), (2500, 40, 4, 1, 1, 0), (2500, 36, 3, 3, 1, 2),
+                                                     (1500, 100, 25, 40, 40, 0),      # 25 populations: the lean walk's LDS block is above 48 KB
+                                                     (1500, 180, 90, 40, 40, 0)])     # 90 populations, 4005 pairs: beyond the walk, K2
 def test_snp_windows_without_missing_alleles(engine, S, N, P, size, step, dirty):
     """No missing allele (but for `dirty` sites spread over the input): half tiles without one take the exact integer sums
     (v_dot4_u32_u8) instead of the per-population tables, the others the tables, and segments mix both."""
@@ -182,6 +184,12 @@ def test_snp_windows_without_missing_alleles(engine, S, N, P, size, step, dirty)
         codes[s_, rng.choice(2 * N, 3, replace=False)] = 2
     engine.set_layout(sp, P)
     engine.upload(engine.pack_codes(codes), S)
+    if P == 25:                                            # a short pair list: a wave per chunk with 25 populations' counts
+        pi = np.array([0, 3, 24, 17, 5, 23, 20, 1, 2, 11], np.int32)
+        pj = np.array([24, 4, 1, 18, 21, 22, 19, 13, 9, 12], np.int32)
+        engine.set_pairs(pi, pj)
+        _check_windows(engine, sp, codes, None, P, size, step, pairs=(pi, pj), tag="snp_windows_clean")
+        return
     engine.set_pairs()
     _check_windows(engine, sp, codes, None, P, size, step, tag="snp_windows_clean")
 
