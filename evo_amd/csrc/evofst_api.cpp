@@ -1296,7 +1296,11 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
             f.chunk_offsets = p.chunk_offsets;
             f.nan_mask = (const uint64_t *)c->d_nan.p;
             f.piece_tiles = std::max(1, std::min(2, c->chunk_tiles));     // two buffers of two tiles per region
-            const size_t lds = fused_lds_bytes(c->n_pops, 0, p.max_n, (int)np, 2 * f.piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, 32);
+            int wsub = 32;
+#ifdef EVOFST_EXPERIMENTS
+            if (const char *e = getenv("EVOFST_WALK_SUB")) wsub = atoi(e) == 16 ? 16 : 32;
+#endif
+            const size_t lds = fused_lds_bytes(c->n_pops, 0, p.max_n, (int)np, 2 * f.piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, wsub);
 #ifdef EVOFST_EXPERIMENTS
             if (const char *e = getenv("EVOFST_DEBUG_WALK")) f.debug = atoi(e);
 #endif
@@ -1308,7 +1312,7 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
                     f.chunk_dirty = (const uint32_t *)c->d_dirty.p;
                     HIPCHK(c, launch_clean_walk(f, c->stream));
                 }
-                HIPCHK(c, launch_fused(f, c->count_bytes, 32, 0, c->stream));
+                HIPCHK(c, launch_fused(f, c->count_bytes, wsub, 0, c->stream));
                 lds_walk = true;
             }
         }

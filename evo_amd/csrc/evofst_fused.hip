@@ -219,8 +219,11 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 // HBM: the statistics half on its own (evofst_run_stats after evofst_run_counts, the multi-GPU pass): a region is one of
 // K1's chunks, its counts and ballots come from HBM in pieces of a few tiles (the next piece is requested before the
 // current one is walked) and its offsets from the scan kernel; no phase A, no look-back, no tickets.
+#ifndef EVOFST_WALK_WPS
+#define EVOFST_WALK_WPS 2
+#endif
 template <typename CT, bool use_rcp, bool WP, int SUB, bool HBM>
-__global__ __launch_bounds__(kK2Threads, EVOFST_FUSED_WPS) void fused_pairs_kernel(FusedParams p) {
+__global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WPS) void fused_pairs_kernel(FusedParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (HBM && p.chunk_dirty != nullptr) {        // before anything is set up: does this workgroup's stride hold a marked chunk at all?
         const int per = WP ? (int)(blockDim.x >> 6) : 1;

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             else for (int i = lane; i < 2 * P; i += 64) p.zf_masks[(size_t)t * 2 * P + i] = zm[i];
             // census of the site filter (process_vcf_fst.cpp:543-544): a site is excluded for pair
             // (i,j) iff both counts are 0 or both pops are fixed for ALT (or the site is skipped).
-            for (int q = lane; q < p.n_pairs; q += 64) {
+            for (int q = lane; q < p.n_pairs EVOFST_K1_DBG(32); q += 64) {
                 const uint32_t ij = lpairs[q];
                 const uint32_t i = ij & 0xffffu, j = ij >> 16;
                 const uint64_t ex = (zm[i] & zm[j]) | (fm[i] & fm[j]);
