@@ -14,7 +14,7 @@
 // window state machines over those per-site values, so that the text outputs -- including the
 // reference's load-bearing quirks -- are byte-identical.  Output goes
 // through iostreams with default formatting, exactly like the reference.
-// Not carried over: --annot, --ancSets, --accessibleGenomeBED, --ms*, --eigen (host-side
+// Not carried over: --annot, --ancSets, --ms*, --eigen (fst: --accessibleGenomeBED is) (host-side
 // consumers / other modes, out of scope).
 #include <getopt.h>
 #include <zlib.h>
@@ -266,8 +266,46 @@ struct Device {
 
 // ============================================================================================ fst
 
+// --accessibleGenomeBED (process_vcf_fst.cpp:414-419, 593-595, 613-616; AccessibleGenome / BedCoordinateFeatures,
+// process_vcf_annotation_tools.h:340-530).  Host bookkeeping next to the device path: per scaffold the feature starts and
+// ends in file order (a scaffold that comes back later in the file replaces its earlier entry, as the reference's map
+// assignment does), and the bases of a 1-based region the features cover, counted with the reference's four overlap rules
+// (a feature that begins before the region adds one base more than its overlap).
+struct AccessibleBed {
+    std::map<string, std::pair<std::vector<int>, std::vector<int>>> features;
+    void load(const string &path) {
+        std::ifstream in(path.c_str());
+        if (!in) die("could not open " + path);
+        string line, previous;
+        std::vector<int> starts, ends;
+        while (getline(in, line)) {
+            std::vector<string> f = split(line, '\t');
+            if (f.size() < 3) continue;
+            if (f[0] != previous && !previous.empty()) { features[previous] = std::make_pair(starts, ends); starts.clear(); ends.clear(); }
+            starts.push_back(atoi(f[1].c_str())); ends.push_back(atoi(f[2].c_str()));
+            previous = f[0];
+        }
+        features[previous] = std::make_pair(starts, ends);
+    }
+    int basesIn(const string &scaffold, int start, int end) const {
+        auto it = features.find(scaffold);
+        if (it == features.end()) return 0;
+        const std::vector<int> &s = it->second.first, &e = it->second.second;
+        size_t i = (size_t)(std::lower_bound(e.begin(), e.end(), start) - e.begin());   // first feature that ends at or behind `start`
+        int bases = 0;
+        for (; i < s.size() && s[i] <= end; ++i) {
+            const bool before = s[i] < start, beyond = e[i] > end;
+            if (before && !beyond) bases += e[i] - start + 1;
+            else if (!before && !beyond) bases += e[i] - s[i];
+            else if (!before && beyond) bases += end - s[i];
+            else bases += end - start + 1;
+        }
+        return bases;
+    }
+};
+
 namespace fstopt {
-string vcfFile, sampleSets, sampleNameFile, runName = "", popsFile, pairsArg;
+string vcfFile, sampleSets, sampleNameFile, runName = "", popsFile, pairsArg, accessibleBed;
 int windowSize = 0, windowStep = 0, physicalWindowSize = 10000;
 double regAbove = 0;
 }
@@ -286,9 +324,11 @@ const char *FST_USAGE =
     "                                               populations in one pass over the VCF, one RUN_<POP1>_<POP2>_w_<SIZE>_fst.txt per\n"
     "                                               pair = the _fst.txt file of `evo fst --sets` on those two populations (-w SIZE,STEP\n"
     "                                               with SIZE > 1 required; no heterozygosity / fixed-window files in this mode)\n"
-    "       --physicalWindowSize=SIZE               (optional; default 10000bp)\n\n";
+    "       --physicalWindowSize=SIZE               (optional; default 10000bp)\n"
+    "       --accessibleGenomeBED=BEDfile.bed       (optional) regions of the genome where SNPs could be called: the fixed-window\n"
+    "                                               file reports and divides by the accessible bases of each window\n\n";
 
-enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS };
+enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS, OPT_ACC_BED };
 
 void parseFstOptions(int argc, char **argv) {
     static const struct option longopts[] = {
@@ -299,7 +339,7 @@ void parseFstOptions(int argc, char **argv) {
         {"pops", required_argument, NULL, OPT_POPS}, {"pairs", required_argument, NULL, OPT_PAIRS},
         {"ancSets", required_argument, NULL, OPT_UNSUPPORTED}, {"annot", required_argument, NULL, OPT_UNSUPPORTED},
         {"ms", required_argument, NULL, OPT_UNSUPPORTED}, {"eigen", required_argument, NULL, OPT_UNSUPPORTED},
-        {"accessibleGenomeBED", required_argument, NULL, OPT_UNSUPPORTED}, {NULL, 0, NULL, 0}};
+        {"accessibleGenomeBED", required_argument, NULL, OPT_ACC_BED}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
     std::vector<string> ws;
     for (int c; (c = getopt_long(argc, argv, "hn:s:w:", longopts, NULL)) != -1;) {
@@ -316,6 +356,7 @@ void parseFstOptions(int argc, char **argv) {
                 break;
             case OPT_REG_ABOVE: arg >> fstopt::regAbove; break;
             case OPT_PHYS: arg >> fstopt::physicalWindowSize; break;
+            case OPT_ACC_BED: arg >> fstopt::accessibleBed; break;
             case 's': arg >> fstopt::sampleNameFile; break;
             case 'n': arg >> fstopt::runName; break;
             case OPT_UNSUPPORTED: die("this option belongs to a mode the GPU build does not carry (see evo_main.cpp header)");
@@ -510,6 +551,9 @@ int fstMain(int argc, char **argv) {
     std::ofstream regionsAboveFstFile; bool inRegAbove = false;
     if (regAbove > 0) regionsAboveFstFile.open((runName + "_w_" + numToString(windowSize) + "_fst_above" + numToString(regAbove) + ".txt").c_str());
     std::ofstream pFst((runName + "_w_" + numToString(windowSize) + "_fst.txt").c_str());
+    AccessibleBed bed;
+    const bool haveBed = !accessibleBed.empty();
+    if (haveBed) { std::cerr << "Loading the accessible genome annotation" << std::endl; bed.load(accessibleBed); std::cerr << "Done" << std::endl; }
     std::ofstream fwFile((runName + "_w_" + numToString(physicalWindowSize) + "_fixedWindowStats.txt").c_str());
     std::ofstream pHet((runName + "_w_" + numToString(windowSize) + "_heterozygosity.txt").c_str());
     fwFile << "scaffold" << "\t" << "Start" << "\t" << "End" << "\t" << "Fst" << "\t" << "Dxy" << "\t" << "Set1_pi" << "\t" << "Set2_pi" << "\t" << "Accessible_bp" << "\t" << "Set1_VariantDensity" << "\t" << "Set2_VariantDensity" << std::endl;
@@ -567,6 +611,7 @@ int fstMain(int argc, char **argv) {
             if (len0 == scaffold.size() && windowStartEnd.compare(0, len0, scaffold) == 0) {
                 if (atoi(loc.c_str()) > (fixedWindowStart + physicalWindowSize)) {
                     int acc = physicalWindowSize;
+                    if (haveBed) acc = bed.basesIn(scaffold, fixedWindowStart, fixedWindowStart + physicalWindowSize);
                     double fDxy = vector_tail_with_region(fwDxy, fwDxy.size(), acc);
                     double fFst = calculateFst(vector_average(fwNum), vector_average(fwDen));
                     double fPi1 = vector_tail_with_region(fwPi1, fwPi1.size(), acc);
@@ -577,8 +622,10 @@ int fstMain(int argc, char **argv) {
                     fwDxy.clear(); fwNum.clear(); fwDen.clear(); fwPi1.clear(); fwPi2.clear();
                     int without = 0;
                     while (atoi(loc.c_str()) > (fixedWindowStart + physicalWindowSize)) {
-                        if (without > 0)
-                            fwFile << scaffold << "\t" << fixedWindowStart << "\t" << fixedWindowStart + physicalWindowSize << "\t" << "NA" << "\t" << 0 << "\t" << 0 << "\t" << 0 << "\t" << physicalWindowSize << "\t" << 0 << "\t" << 0 << std::endl;
+                        if (without > 0) {
+                            const int acc0 = haveBed ? bed.basesIn(scaffold, fixedWindowStart, fixedWindowStart + physicalWindowSize) : physicalWindowSize;
+                            fwFile << scaffold << "\t" << fixedWindowStart << "\t" << fixedWindowStart + physicalWindowSize << "\t" << "NA" << "\t" << 0 << "\t" << 0 << "\t" << 0 << "\t" << acc0 << "\t" << 0 << "\t" << 0 << std::endl;
+                        }
                         fixedWindowStart = fixedWindowStart + physicalWindowSize;
                         without++;
                     }

@@ -564,6 +564,93 @@ static int first_field_is(const char *s, const char *scaffold, char **second_fie
     return strlen(scaffold) == l && strncmp(s, scaffold, l) == 0;
 }
 
+/* --accessibleGenomeBED: BedCoordinateFeatures / AccessibleGenome, process_vcf_annotation_tools.h:340-530 ------------- */
+
+/* getNumBPinRegion (:360-402) on the features of one scaffold, starts / ends in file order: the first feature whose end
+ * is >= start by std::lower_bound on the ends (the halving search of libstdc++, so unsorted files behave alike), then
+ * the four overlap cases summed until a feature starts behind `end`.  Left coordinates are 0-based (BED), the query
+ * 1-based; cases 3 and 6 add one base, cases 4 and 5 do not -- restated as written. */
+int orc_accessible_bp(const int *starts, const int *ends, int n, int start, int end) {
+    int first = 0, len = n;
+    while (len > 0) {
+        int half = len >> 1, mid = first + half;
+        if (ends[mid] < start) { first = mid + 1; len = len - half - 1; }
+        else len = half;
+    }
+    int numBP = 0;
+    for (int index = first; index < n && starts[index] <= end; index++) {
+        if (starts[index] < start && ends[index] <= end) numBP = numBP + (ends[index] - start) + 1;
+        else if (starts[index] >= start && ends[index] <= end) numBP = numBP + (ends[index] - starts[index]);
+        else if (starts[index] >= start && ends[index] > end) numBP = numBP + (end - starts[index]);
+        else if (starts[index] < start && ends[index] > end) numBP = numBP + (end - start) + 1;
+    }
+    return numBP;
+}
+
+typedef struct { char *name; int *starts, *ends; int n, cap; } bed_scaffold;
+struct orc_bed { bed_scaffold *sc; int n, cap; };
+
+static bed_scaffold *bed_find(const orc_bed *b, const char *name) {
+    for (int i = 0; i < b->n; i++) if (strcmp(b->sc[i].name, name) == 0) return &b->sc[i];
+    return NULL;
+}
+
+/* BedFeatureMap[previousScaffold] = features: an assignment, so a scaffold that comes back later in the file replaces
+ * its earlier entry (:479-481, :491-493) */
+static void bed_store(orc_bed *b, const char *name, int *starts, int *ends, int n) {
+    bed_scaffold *e = bed_find(b, name);
+    if (!e) {
+        if (b->n == b->cap) { b->cap = b->cap ? 2 * b->cap : 16; b->sc = (bed_scaffold *)realloc(b->sc, sizeof(bed_scaffold) * (size_t)b->cap); }
+        e = &b->sc[b->n++];
+        e->name = strdup(name); e->starts = NULL; e->ends = NULL;
+    } else { free(e->starts); free(e->ends); }
+    e->n = e->cap = n;
+    e->starts = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1)); e->ends = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+    memcpy(e->starts, starts, sizeof(int) * (size_t)n); memcpy(e->ends, ends, sizeof(int) * (size_t)n);
+}
+
+/* loadBedFeatureMap (:461-496): tab-separated scaffold, start, end; consecutive lines of one scaffold form its entry */
+orc_bed *orc_bed_load(const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    orc_bed *b = (orc_bed *)calloc(1, sizeof(orc_bed));
+    int *st = NULL, *en = NULL, n = 0, cap = 0;
+    char *prev = strdup("");
+    char *line = NULL; size_t lcap = 0; ssize_t ln;
+    while ((ln = getline(&line, &lcap, f)) >= 0) {
+        if (ln && line[ln - 1] == '\n') line[ln - 1] = '\0';
+        char **fld = NULL; int fcap = 0;
+        int nf = split_inplace(line, '\t', &fld, &fcap);
+        if (nf >= 3) {
+            if (strcmp(fld[0], prev) != 0 && prev[0] != '\0') { bed_store(b, prev, st, en, n); n = 0; }
+            if (n == cap) { cap = cap ? 2 * cap : 1024; st = (int *)realloc(st, sizeof(int) * (size_t)cap); en = (int *)realloc(en, sizeof(int) * (size_t)cap); }
+            st[n] = atoi(fld[1]); en[n] = atoi(fld[2]); n++;
+            free(prev); prev = strdup(fld[0]);
+        }
+        free(fld);
+    }
+    free(line);
+    fclose(f);
+    bed_store(b, prev, st, en, n);                     /* final scaffold (:491-493) */
+    free(prev); free(st); free(en);
+    return b;
+}
+
+void orc_bed_free(orc_bed *b) {
+    if (!b) return;
+    for (int i = 0; i < b->n; i++) { free(b->sc[i].name); free(b->sc[i].starts); free(b->sc[i].ends); }
+    free(b->sc); free(b);
+}
+
+/* AccessibleGenome::getAccessibleBPinRegion (:510-512); a scaffold the file does not name has 0 accessible bases (:398-401) */
+int orc_bed_accessible_bp(const orc_bed *b, const char *scaffold, int start, int end) {
+    const bed_scaffold *e = bed_find(b, scaffold);
+    if (!e) return 0;
+    return orc_accessible_bp(e->starts, e->ends, e->n, start, end);
+}
+
+static const orc_bed *g_fst_bed = NULL;                /* set by orc_fst_run_bed for the duration of one run */
+
 int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples_path,
                 int windowSize, int windowStep, int physicalWindowSize, double regAbove,
                 const char *run_name, const char *out_dir, double *summary) {
@@ -688,6 +775,7 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
                 if (first_field_is(windowStartEnd, scaffold, NULL)) {
                     if (atoi(loc) > (fixedWindowStart + physicalWindowSize)) {
                         int acc = physicalWindowSize;
+                        if (g_fst_bed) acc = orc_bed_accessible_bp(g_fst_bed, scaffold, fixedWindowStart, fixedWindowStart + physicalWindowSize);   /* :593-595 */
                         double fDxy = orc_vector_average_with_region(fwDxy.v, fwDxy.n, acc);
                         double fFst = orc_calculate_fst(fwNum.v, fwDen.v, fwNum.n);
                         double fPi1 = orc_vector_average_with_region(fwPi1.v, fwPi1.n, acc);
@@ -703,8 +791,10 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
                         int without = 0;
                         while (atoi(loc) > (fixedWindowStart + physicalWindowSize)) {
                             if (without > 0) {
+                                int acc0 = physicalWindowSize;
+                                if (g_fst_bed) acc0 = orc_bed_accessible_bp(g_fst_bed, scaffold, fixedWindowStart, fixedWindowStart + physicalWindowSize);   /* :613-616 */
                                 fprintf(fw, "%s\t%d\t%d\tNA\t0\t0\t0\t%d\t0\t0\n", scaffold, fixedWindowStart,
-                                        fixedWindowStart + physicalWindowSize, physicalWindowSize);
+                                        fixedWindowStart + physicalWindowSize, acc0);
                             }
                             fixedWindowStart = fixedWindowStart + physicalWindowSize;
                             without++;
@@ -789,6 +879,23 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
     free(set1); free(set2); free(set1String); free(set2String);
     free(windowMiddleVariant); free(windowStartEnd); free(fields);
     return 0;
+}
+
+/* orc_fst_run with --accessibleGenomeBED=bed_path (process_vcf_fst.cpp:414-419, :593-595, :613-616): the fixed-window
+ * file divides by, and reports, the accessible bases of each window instead of its length. */
+int orc_fst_run_bed(const char *vcf_path, const char *sets_path, const char *samples_path,
+                    int windowSize, int windowStep, int physicalWindowSize, double regAbove,
+                    const char *run_name, const char *out_dir, double *summary, const char *bed_path) {
+    orc_bed *bed = NULL;
+    if (bed_path && bed_path[0]) {
+        bed = orc_bed_load(bed_path);
+        if (!bed) { fprintf(stderr, "Error: could not open %s\n", bed_path); return -4; }
+    }
+    g_fst_bed = bed;
+    int rc = orc_fst_run(vcf_path, sets_path, samples_path, windowSize, windowStep, physicalWindowSize, regAbove, run_name, out_dir, summary);
+    g_fst_bed = NULL;
+    orc_bed_free(bed);
+    return rc;
 }
 
 /* ===================================================================== */

@@ -178,6 +178,17 @@ int64_t orc_global_windows(const uint8_t *kept, const uint8_t *site_flags,
 int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples_path,
                 int window_size, int window_step, int physical_window_size, double reg_above,
                 const char *run_name, const char *out_dir, double *summary);
+/* the same with --accessibleGenomeBED (bed_path may be NULL or ""), and the pieces behind it:
+ * BedCoordinateFeatures / AccessibleGenome, process_vcf_annotation_tools.h:340-530 */
+int orc_fst_run_bed(const char *vcf_path, const char *sets_path, const char *samples_path,
+                    int windowSize, int windowStep, int physicalWindowSize, double regAbove,
+                    const char *run_name, const char *out_dir, double *summary, const char *bed_path);
+typedef struct orc_bed orc_bed;
+orc_bed *orc_bed_load(const char *path);
+void orc_bed_free(orc_bed *b);
+int orc_bed_accessible_bp(const orc_bed *b, const char *scaffold, int start, int end);
+int orc_accessible_bp(const int *starts, const int *ends, int n, int start, int end);
+
 
 /* `evo FstGlobal [-w] [-f] [-n] VCF POPS` (FstGlobalMain, evo_FstAgainstAll.cpp:62-308)
  * without --annot. */

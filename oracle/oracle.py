@@ -16,6 +16,7 @@ _REF_PBS = os.path.join(_HERE, "_ref", "libevo_refpbs.so")
 _REF_ABS = os.path.join(_HERE, "_ref", "libevo_refabs.so")
 _REF_DIFFS = os.path.join(_HERE, "_ref", "libevo_refdiffs.so")
 _REF_DIST = os.path.join(_HERE, "_ref", "libevo_refdist.so")
+_REF_BED = os.path.join(_HERE, "_ref", "libevo_refbed.so")
 
 _dp = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -184,6 +185,53 @@ def ref_dist():
         R.ref_DxyPerSNPfromAFs.argtypes = [C.c_double, C.c_double]
         _ref_dist = R
     return _ref_dist
+
+
+_ref_bed = None
+
+
+def ref_bed():
+    """The reference's own AccessibleGenome::getAccessibleBPinRegion (process_vcf_annotation_tools.h:360-402, 510-512)
+    behind ref_accessible_bp(starts, ends, n, start, end, scaffold_absent), or None when oracle/_ref was never built."""
+    global _ref_bed
+    if _ref_bed is None:
+        build()
+        if not os.path.exists(_REF_BED):
+            return None
+        R = C.CDLL(_REF_BED)
+        ip = C.POINTER(C.c_int)
+        R.ref_accessible_bp.restype = C.c_int
+        R.ref_accessible_bp.argtypes = [ip, ip, C.c_int, C.c_int, C.c_int, C.c_int]
+        _ref_bed = R
+    return _ref_bed
+
+
+def accessible_bp(starts, ends, start, end):
+    """Accessible bases of the 1-based region [start, end] given one scaffold's BED features in file order."""
+    st = np.ascontiguousarray(starts, np.int32); en = np.ascontiguousarray(ends, np.int32)
+    L = lib()
+    ip = C.POINTER(C.c_int)
+    L.orc_accessible_bp.restype = C.c_int
+    L.orc_accessible_bp.argtypes = [ip, ip, C.c_int, C.c_int, C.c_int]
+    return int(L.orc_accessible_bp(st.ctypes.data_as(ip), en.ctypes.data_as(ip), len(st), int(start), int(end)))
+
+
+def bed_accessible_bp(bed_path, scaffold, start, end):
+    """The same through the BED loader (loadBedFeatureMap, process_vcf_annotation_tools.h:461-496)."""
+    L = lib()
+    L.orc_bed_load.restype = C.c_void_p
+    L.orc_bed_load.argtypes = [C.c_char_p]
+    L.orc_bed_free.restype = None
+    L.orc_bed_free.argtypes = [C.c_void_p]
+    L.orc_bed_accessible_bp.restype = C.c_int
+    L.orc_bed_accessible_bp.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    b = L.orc_bed_load(bed_path.encode())
+    if not b:
+        raise RuntimeError("could not open " + bed_path)
+    try:
+        return int(L.orc_bed_accessible_bp(b, scaffold.encode(), int(start), int(end)))
+    finally:
+        L.orc_bed_free(b)
 
 
 _ref_abs = None
@@ -431,10 +479,14 @@ def global_windows(kept, num, den, size, step, site_flags=None):
     return dict(start_site=ss[:n], end_site=es[:n], fst=fst[:n])
 
 
-def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_above=0.0, samples=None):
+def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_above=0.0, samples=None, bed=None):
     summ = np.zeros(7)
-    rc = lib().orc_fst_run(vcf.encode(), sets.encode(), (samples or "").encode(), size, step, phys,
-                           reg_above, run_name.encode(), out_dir.encode(), _p(summ, _dp))
+    L = lib()
+    L.orc_fst_run_bed.restype = C.c_int
+    L.orc_fst_run_bed.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_double, C.c_char_p, C.c_char_p, _dp, C.c_char_p]
+    rc = L.orc_fst_run_bed(vcf.encode(), sets.encode(), (samples or "").encode(), size, step, phys,
+                           reg_above, run_name.encode(), out_dir.encode(), _p(summ, _dp), (bed or "").encode())
     if rc != 0:
         raise RuntimeError("orc_fst_run failed: %d" % rc)
     return summ

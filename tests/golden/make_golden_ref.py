@@ -4,6 +4,7 @@ the shims of oracle/_ref (compiled from /root/reference where it lies; see oracl
     calculatePBSfromAFs                             evo_PBS.cpp:69-98
     calculateABSfromAFs                             evo_ABS.cpp:58-106
     diffs_between_individuals[_with_multialleleics] process_vcf_stats_functions.cpp:180-281
+    AccessibleGenome::getAccessibleBPinRegion       process_vcf_annotation_tools.h:360-402
     calculateAlleleFrequencies, calculateFstNumerator / Denominator, calculateExpectedHeterozygositySimple / Nei78
                                                     process_vcf_utils.h:272-275, process_vcf_fst.h:19-45
 Doubles are stored as the hex of their 64 bits, so the fixture pins NaN signs too.  Needs /root/reference (run in the
@@ -63,6 +64,26 @@ for c1, n1, c2, n2 in quads:
             R.ref_calculateExpectedHeterozygositySimple(p1.value), R.ref_calculateExpectedHeterozygosityNei78(p1.value, n1)]
     rows_in.append([c1, n1, c2, n2]); rows_out.append(bits(vals))
 out["fst_math"] = {"c1_n1_c2_n2": rows_in, "p1_p2_num_den_het_hetNei78": rows_out}
+Rb = O.ref_bed()
+assert Rb is not None
+ip = C.POINTER(C.c_int)
+bed_cases = []
+for case in range(90):                       # after everything else: the earlier sections keep their random numbers
+    n = int(rng.integers(0, 25)); kind = case % 3
+    if kind == 0:
+        cuts = np.sort(rng.choice(4000, 2 * n, replace=False)) if n else np.zeros(0, np.int64)
+        st, en = cuts[0::2], cuts[1::2]
+    elif kind == 1:
+        st = np.sort(rng.integers(0, 4000, n)); en = st + rng.integers(0, 300, n)
+    else:
+        st = rng.integers(0, 4000, n); en = st + rng.integers(1, 250, n)
+    st = np.ascontiguousarray(st, np.int32); en = np.ascontiguousarray(en, np.int32)
+    qs = []
+    for _ in range(12):
+        a = int(rng.integers(0, 4200)); b = a + int(rng.integers(1, 1200))
+        qs.append([a, b, int(Rb.ref_accessible_bp(st.ctypes.data_as(ip), en.ctypes.data_as(ip), n, a, b, 0))])
+    bed_cases.append({"starts": st.tolist(), "ends": en.tolist(), "start_end_bp": qs})
+out["accessible_bp"] = bed_cases
 p = os.path.join(ROOT, "tests", "golden", "ref_consumer_vectors.json")
 json.dump(out, open(p, "w"), separators=(",", ":"))
 print(p, os.path.getsize(p), "bytes;", len(pbs_in), "PBS,", len(abs_in), "ABS cases")

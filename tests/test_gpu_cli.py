@@ -35,7 +35,7 @@ def _same_files(a_dir, b_dir):
 
 
 def _fst_case(tmp_path, rng, args, size, step, n_sites=900, n_samples=24, scaffolds=("scaffold_0", "chrB"),
-              crlf=False, gz=False, overlap=False, samples_file=False, phys=10000, reg_above=0.0):
+              crlf=False, gz=False, overlap=False, samples_file=False, phys=10000, reg_above=0.0, bed_rows=None):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=scaffolds, crlf=crlf, miss=0.08)
     if gz:
@@ -58,9 +58,15 @@ def _fst_case(tmp_path, rng, args, size, step, n_sites=900, n_samples=24, scaffo
     cmd = [EVO, "fst", "--vcf=" + vcf, "--sets=" + sets, "-n", "run"] + args
     if sf:
         cmd += ["-s", sf]
+    bed = None
+    if bed_rows is not None:
+        bed = str(tmp_path / "accessible.bed")
+        open(bed, "w").write("".join("%s\t%d\t%d\n" % row for row in bed_rows))
+        cmd += ["--accessibleGenomeBED=" + bed]
     r = subprocess.run(cmd, cwd=str(cli_dir), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
-    O.fst_run(vcf, sets, str(orc_dir), run_name="run", size=size, step=step, phys=phys, reg_above=reg_above, samples=sf)
+    O.fst_run(vcf, sets, str(orc_dir), run_name="run", size=size, step=step, phys=phys, reg_above=reg_above, samples=sf,
+              bed=bed)
     _same_files(str(cli_dir), str(orc_dir))
     return r
 
@@ -89,6 +95,24 @@ def test_cli_fst_no_windows_gz_crlf(tmp_path):
 def test_cli_fst_sets_overlap_samples_file_regions_above(tmp_path):
     _fst_case(tmp_path, np.random.default_rng(6), ["-w", "30,30", "--regions-above=0.05"], 30, 30, overlap=True,
               samples_file=True, reg_above=0.05, scaffolds=("scaffold_0",))
+
+
+def test_cli_fst_accessible_genome_bed(tmp_path):
+    """--accessibleGenomeBED (evo_Fst.cpp:498-505 through getAccessibleBPinRegion): intervals that start and end
+    inside windows, one that spans several windows, a stretch of windows with no accessible base, touching
+    intervals, and a scaffold the BED does not name."""
+    rows = [("scaffold_0", 0, 1200), ("scaffold_0", 1200, 1900), ("scaffold_0", 4100, 4990), ("scaffold_0", 4995, 5005),
+            ("scaffold_0", 9000, 23017), ("scaffold_0", 41000, 41001), ("scaffold_0", 44999, 45000),
+            ("scaffold_0", 45000, 45001), ("scaffold_0", 52000, 90000), ("other", 0, 100000)]
+    _fst_case(tmp_path, np.random.default_rng(41), ["-w", "50,50", "--physicalWindowSize=5000"], 50, 50, phys=5000,
+              bed_rows=rows)
+
+
+def test_cli_fst_accessible_genome_bed_no_snp_windows(tmp_path):
+    """Fixed windows that hold no SNP take their accessible length from the BED too (evo_Fst.cpp:486-497)."""
+    rows = [("chr7", 100, 2500), ("chr7", 3000, 3100), ("chr7", 7990, 8010), ("chr8", 500, 61000)]
+    _fst_case(tmp_path, np.random.default_rng(42), ["-w", "40,40", "--physicalWindowSize=1000"], 40, 40, phys=1000,
+              scaffolds=("chr7", "chr8"), n_sites=300, bed_rows=rows)
 
 
 def test_cli_fst_sc3749(tmp_path):

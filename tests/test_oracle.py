@@ -205,6 +205,49 @@ def test_dxy_from_afs_bit_equal_to_reference():
     assert_same_bits(got, want, "DxyPerSNPfromAFs (random)")
 
 
+@pytest.mark.skipif(O.ref_bed() is None, reason="oracle/_ref not built (no /root/reference here)")
+def test_accessible_bp_equal_to_reference():
+    """orc_accessible_bp vs the reference's own getAccessibleBPinRegion (process_vcf_annotation_tools.h:360-402) compiled
+    from /root/reference: sorted disjoint features, abutting and overlapping ones, unsorted files, queries that start or
+    end inside, before and behind the features, and a scaffold the map does not hold."""
+    R = O.ref_bed()
+    ip = C.POINTER(C.c_int)
+    rng = np.random.default_rng(11)
+    n_checked = 0
+    for case in range(300):
+        n = int(rng.integers(0, 40))
+        kind = case % 3
+        if kind == 0:                                              # sorted, disjoint
+            cuts = np.sort(rng.choice(5000, 2 * n, replace=False)) if n else np.zeros(0, np.int64)
+            st, en = cuts[0::2], cuts[1::2]
+        elif kind == 1:                                            # sorted starts, lengths at random: overlaps and abutting
+            st = np.sort(rng.integers(0, 5000, n)); en = st + rng.integers(0, 400, n)
+        else:                                                      # unsorted file
+            st = rng.integers(0, 5000, n); en = st + rng.integers(1, 300, n)
+        st = np.ascontiguousarray(st, np.int32); en = np.ascontiguousarray(en, np.int32)
+        for _ in range(40):
+            a = int(rng.integers(0, 5200)); b = a + int(rng.integers(1, 1500))
+            want = R.ref_accessible_bp(st.ctypes.data_as(ip), en.ctypes.data_as(ip), n, a, b, 0)
+            assert O.accessible_bp(st, en, a, b) == want, (case, a, b)
+            n_checked += 1
+    st = np.array([0, 100], np.int32); en = np.array([50, 200], np.int32)
+    assert R.ref_accessible_bp(st.ctypes.data_as(ip), en.ctypes.data_as(ip), 2, 1, 1000, 1) == 0
+    assert n_checked == 12000
+
+
+def test_bed_loader_quirks(tmp_path):
+    """loadBedFeatureMap (process_vcf_annotation_tools.h:461-496): consecutive lines of a scaffold form its entry, a
+    scaffold that comes back later replaces its earlier entry, an unknown scaffold has no accessible bases."""
+    bed = tmp_path / "acc.bed"
+    bed.write_text("s1\t0\t100\ns1\t200\t300\ns2\t10\t20\ns1\t1000\t1100\n")
+    assert O.bed_accessible_bp(str(bed), "s2", 1, 1000) == 10
+    assert O.bed_accessible_bp(str(bed), "s1", 1, 5000) == 100          # only the last run of s1 is left
+    assert O.bed_accessible_bp(str(bed), "s3", 1, 5000) == 0
+    bed.write_text("s1\t0\t100\ns1\t200\t300\n")
+    assert O.bed_accessible_bp(str(bed), "s1", 1, 5000) == O.accessible_bp([0, 200], [100, 300], 1, 5000) == 200
+    assert O.bed_accessible_bp(str(bed), "s1", 51, 250) == (100 - 51 + 1) + (250 - 200)
+
+
 def test_dist_windows_against_numpy():
     """orc_dist_windows (evo_distanceToOutgroups.cpp:274-294) against a direct numpy evaluation, incl. carry."""
     rng = np.random.default_rng(9)
@@ -325,6 +368,12 @@ def test_golden_vectors_of_the_reference_functions():
         w = np.array([int(x, 16) for x in d[k]], np.uint64).reshape(n, n)
         assert np.array_equal(r[k].view(np.uint64), w), k
     assert np.array_equal(r["miss"].ravel(), d["miss"])
+    n_q = 0
+    for case in g["accessible_bp"]:
+        for a, b, want_bp in case["start_end_bp"]:
+            assert O.accessible_bp(case["starts"], case["ends"], a, b) == want_bp, (case, a, b)
+            n_q += 1
+    assert n_q == 1080
 
 
 def test_rcp_division_identity():
