@@ -1328,7 +1328,7 @@ int branchMain(const int arity, int argc, char **argv) {
 // ================================================================================== DistOutgroups
 
 namespace dopt {
-string vcfFile, setsFile, outgroupFile, ingroupFile, runName = "";
+string vcfFile, setsFile, outgroupFile, ingroupFile, runName = "", accessibleBed = "";
 int fixedWindowSize = 10000;
 }
 
@@ -1338,9 +1338,10 @@ const char *DISTOUT_USAGE =
     "population (one per line in INGROUPS.txt) in fixed windows; writes OUTGROUP_DIST_RUN_FWsize.txt per outgroup\n"
     "       -h, --help                              display this help and exit\n"
     "       -f, --fixedW size                       fixed (physical) window size (default: 10000)\n"
-    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n\n";
+    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n"
+    "       --accessibleGenomeBED=BEDfile.bed           (optional) a bed file specifying the regions of the genome where we could call SNPs\n\n";
 
-// evo DistOutgroups (DistOutMain, evo_distanceToOutgroups.cpp:68-306) without -i and --accessibleGenomeBED.  The host
+// evo DistOutgroups (DistOutMain, evo_distanceToOutgroups.cpp:68-306) without -i.  The host
 // replays the fixed-window state machine on the coordinates alone to find where rows are emitted, the device adds up
 // the per-site dxy of every (outgroup, ingroup) pair between two emissions in site order, the host turns the sums
 // into rows.  A window left open at the end of a device batch is continued by the next batch (carry_first).
@@ -1349,7 +1350,7 @@ int DistOutMain(int argc, char **argv) {
     static const struct option longopts[] = {{"fixedW", required_argument, NULL, 'f'}, {"help", no_argument, NULL, 'h'},
                                              {"run-name", required_argument, NULL, 'n'},
                                              {"allow-indels-and-multiallelics", no_argument, NULL, 'i'},
-                                             {"accessibleGenomeBED", required_argument, NULL, OPT_UNSUPPORTED}, {NULL, 0, NULL, 0}};
+                                             {"accessibleGenomeBED", required_argument, NULL, OPT_ACC_BED}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
     for (int c; (c = getopt_long(argc, argv, "hn:f:i", longopts, NULL)) != -1;) {
         std::istringstream arg(optarg != NULL ? optarg : "");
@@ -1358,7 +1359,7 @@ int DistOutMain(int argc, char **argv) {
             case 'f': arg >> fixedWindowSize; break;
             case 'n': arg >> runName; break;
             case 'i': die("-i (indels and multiallelics) is not carried by the GPU build");
-            case OPT_UNSUPPORTED: die("--accessibleGenomeBED is not carried by the GPU build");
+            case OPT_ACC_BED: arg >> accessibleBed; break;
             case 'h': std::cout << DISTOUT_USAGE; exit(EXIT_SUCCESS);
         }
     }
@@ -1409,6 +1410,9 @@ int DistOutMain(int argc, char **argv) {
     }
     const size_t nOut = outgroups.size(), nIn = ingroups.size();
     if (nOut == 0) die("no outgroup in " + outgroupFile);
+    AccessibleBed bed;                                               // :121-127
+    const bool haveBed = !accessibleBed.empty();
+    if (haveBed) { std::cerr << "Loading the accessible genome annotation" << std::endl; bed.load(accessibleBed); std::cerr << "Done" << std::endl; }
 
     int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
     int totalVariantNumber = 0;
@@ -1416,7 +1420,7 @@ int DistOutMain(int argc, char **argv) {
     Batch batch;
     int nSamples = 0;
     bool haveHeader = false;
-    struct Emission { int64_t site; string chr; int wStart, wEnd; };
+    struct Emission { int64_t site; string chr; int wStart, wEnd, accessible; };
     std::vector<Emission> rows;
     std::vector<int64_t> winOff;
     std::vector<double> sum, carrySum(nOut * nIn, 0.0), averaged(nIn);
@@ -1431,7 +1435,10 @@ int DistOutMain(int argc, char **argv) {
             if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :194-202
             double coordDouble; { std::stringstream ss(batch.pos[s]); ss >> coordDouble; }
             if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {
-                rows.push_back(Emission{(int64_t)s, batch.chrom[s], currentWindowStart, currentWindowEnd});
+                int accessible = fixedWindowSize;                    // :223-230: asked of the scaffold of the line that closes the window
+                if (haveBed) accessible = coordDouble > currentWindowEnd ? bed.basesIn(batch.chrom[s], currentWindowStart, currentWindowStart + fixedWindowSize)
+                                                                         : bed.basesIn(batch.chrom[s], 0, fixedWindowSize);
+                rows.push_back(Emission{(int64_t)s, batch.chrom[s], currentWindowStart, currentWindowEnd, accessible});
                 if (coordDouble > currentWindowEnd) { currentWindowStart = currentWindowStart + fixedWindowSize; currentWindowEnd = currentWindowEnd + fixedWindowSize; }
                 else if (coordDouble < currentWindowStart) { currentWindowStart = 0; currentWindowEnd = 0 + fixedWindowSize; }
             }
@@ -1448,7 +1455,7 @@ int DistOutMain(int argc, char **argv) {
         check(dev.ctx, evofst_get_dist_windows(dev.ctx, (int)W, winOff.data(), (int)nOut, outIdx.data(), (int)nIn, inIdx.data(), 1,
                                                sum.data(), nsnp.data(), miss.data(), usedV.data(), missingV.data()), "get_dist_windows");
         for (size_t w = 0; w + 1 < W; ++w) {
-            const int accessibleInThisWindow = fixedWindowSize;      // :223 (no BED file)
+            const int accessibleInThisWindow = rows[w].accessible;
             for (size_t i = 0; i != nOut; i++) {                     // :232-254
                 for (size_t j = 0; j != nIn; j++) {
                     const size_t o = (w * nOut + i) * nIn + j;

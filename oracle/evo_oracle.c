@@ -1681,10 +1681,17 @@ void orc_dist_windows(const int32_t *alt, const int32_t *nm, int n_pops, const u
         }
 }
 
-/* `evo DistOutgroups [-f FW] [-n RUN] VCF POPS OUTGROUPS INGROUPS` (DistOutMain, evo_distanceToOutgroups.cpp:68-306)
- * without -i and --accessibleGenomeBED.  Output files go to out_dir. */
+/* `evo DistOutgroups [-f FW] [-n RUN] [--accessibleGenomeBED=BED] VCF POPS OUTGROUPS INGROUPS` (DistOutMain,
+ * evo_distanceToOutgroups.cpp:68-306) without -i.  Output files go to out_dir; bed_path may be NULL. */
 int orc_distout_run(const char *vcf_path, const char *pops_path, const char *outgroups_path, const char *ingroups_path,
                     int fixedWindowSize, const char *run_name, const char *out_dir) {
+    return orc_distout_run_bed(vcf_path, pops_path, outgroups_path, ingroups_path, fixedWindowSize, run_name, out_dir, NULL);
+}
+
+int orc_distout_run_bed(const char *vcf_path, const char *pops_path, const char *outgroups_path, const char *ingroups_path,
+                        int fixedWindowSize, const char *run_name, const char *out_dir, const char *bed_path) {
+    struct orc_bed *ag = NULL;                                               /* :121-127 */
+    if (bed_path && *bed_path) { ag = orc_bed_load(bed_path); if (!ag) { fprintf(stderr, "Error: could not open %s\n", bed_path); return -1; } }
     lreader vcf;
     if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
     popfile_t pf;
@@ -1742,6 +1749,10 @@ int orc_distout_run(const char *vcf_path, const char *pops_path, const char *out
                                alt, alleles, aaf, allelesC, aafC);
             if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {                    /* :221-269 */
                 int accessibleInThisWindow = fixedWindowSize;
+                if (ag) {                                                    /* :224-230: the scaffold of THIS line is asked */
+                    if (coordDouble > currentWindowEnd) accessibleInThisWindow = orc_bed_accessible_bp(ag, chr, currentWindowStart, currentWindowStart + fixedWindowSize);
+                    else if (coordDouble < currentWindowStart) accessibleInThisWindow = orc_bed_accessible_bp(ag, chr, 0, fixedWindowSize);
+                }
                 for (int i = 0; i < n_out; i++) {
                     for (int j = 0; j < n_in; j++) {
                         dvec *v = &perSNP[i * n_in + j];
@@ -1789,6 +1800,7 @@ int orc_distout_run(const char *vcf_path, const char *pops_path, const char *out
     for (int i = 0; i < n_out; i++) free(outgroups[i]);
     free(ingroups); free(outgroups);
     popfile_free(&pf);
+    if (ag) orc_bed_free(ag);
     return rc;
 }
 

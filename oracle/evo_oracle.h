@@ -230,6 +230,8 @@ void orc_dist_windows(const int32_t *alt, const int32_t *nm, int n_pops, const u
                       int carry_first, double *sum, int32_t *nsnp, int32_t *miss, int32_t *used, int32_t *missing_vars);
 int orc_distout_run(const char *vcf_path, const char *pops_path, const char *outgroups_path, const char *ingroups_path,
                     int fixedWindowSize, const char *run_name, const char *out_dir);
+int orc_distout_run_bed(const char *vcf_path, const char *pops_path, const char *outgroups_path, const char *ingroups_path,
+                        int fixedWindowSize, const char *run_name, const char *out_dir, const char *bed_path);
 
 /* stats --diff-matrix: getThisVariantCountsSimple (process_vcf_utils.cpp:358-408), the two per-site matrix updates
  * (process_vcf_stats_functions.cpp:180-281) literally, the same as five counts per pair (what the device returns), and

@@ -547,12 +547,12 @@ def dist_windows(alt, nm, win_off, out_idx, in_idx, site_flags=None, carry=None)
     return r
 
 
-def distout_run(vcf, pops, outgroups, ingroups, out_dir, run_name="", fixed=10000):
+def distout_run(vcf, pops, outgroups, ingroups, out_dir, run_name="", fixed=10000, bed=None):
     L = lib()
-    L.orc_distout_run.restype = C.c_int
-    L.orc_distout_run.argtypes = [C.c_char_p] * 4 + [C.c_int, C.c_char_p, C.c_char_p]
-    rc = L.orc_distout_run(vcf.encode(), pops.encode(), outgroups.encode(), ingroups.encode(), fixed, run_name.encode(),
-                           out_dir.encode())
+    L.orc_distout_run_bed.restype = C.c_int
+    L.orc_distout_run_bed.argtypes = [C.c_char_p] * 4 + [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+    rc = L.orc_distout_run_bed(vcf.encode(), pops.encode(), outgroups.encode(), ingroups.encode(), fixed, run_name.encode(),
+                               out_dir.encode(), bed.encode() if bed else None)
     if rc != 0:
         raise RuntimeError("orc_distout_run failed: %d" % rc)
 

@@ -317,7 +317,7 @@ def test_cli_abs_windows_crlf_batches(tmp_path):
     _pbs_case(tmp_path, np.random.default_rng(52), ["-w", "9,4"], 9, 4, crlf=True, miss=0.12, n_sites=40000, n_samples=14, quartets=True)
 
 
-def _dist_case(tmp_path, rng, args, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.3):
+def _dist_case(tmp_path, rng, args, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.3, bed_rows=None):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=miss)
     pf, of, inf = str(tmp_path / "pops.txt"), str(tmp_path / "outgroups.txt"), str(tmp_path / "ingroups.txt")
@@ -332,10 +332,15 @@ def _dist_case(tmp_path, rng, args, fixed=10000, n_sites=3000, n_samples=25, crl
     open(inf, "w").write("popA\npopB\npopC\nsolo\npopD\n")
     cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
     cli_dir.mkdir(); orc_dir.mkdir()
+    bed = None
+    if bed_rows is not None:
+        bed = str(tmp_path / "accessible.bed")
+        open(bed, "w").write("".join("%s\t%d\t%d\n" % row for row in bed_rows))
+        args = args + ["--accessibleGenomeBED=" + bed]
     r = subprocess.run([EVO, "DistOutgroups", "-n", "d"] + args + [vcf, pf, of, inf], cwd=str(cli_dir), capture_output=True, text=True,
                        timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
-    O.distout_run(vcf, pf, of, inf, str(orc_dir), run_name="d", fixed=fixed)
+    O.distout_run(vcf, pf, of, inf, str(orc_dir), run_name="d", fixed=fixed, bed=bed)
     _same_files(str(cli_dir), str(orc_dir))
     return cli_dir
 
@@ -352,6 +357,17 @@ def test_cli_distoutgroups_default(tmp_path):
 def test_cli_distoutgroups_small_windows_crlf_batches(tmp_path):
     d = _dist_case(tmp_path, np.random.default_rng(62), ["-f", "2000"], fixed=2000, n_sites=70000, n_samples=12, crlf=True, miss=0.4)
     assert "\tnan" in (d / "out2_DIST_d_FW2000.txt").read_text()       # windows where an ingroup is mostly missing
+
+
+def test_cli_distoutgroups_accessible_genome_bed(tmp_path):
+    """--accessibleGenomeBED (evo_distanceToOutgroups.cpp:223-230): the divisor of a window comes from the BED; the row that
+    closes a scaffold asks the NEXT scaffold's features, as the reference does; windows without an accessible base
+    divide by 0 (inf / nan rows)."""
+    rows = [("chr1", 0, 3000), ("chr1", 3500, 9000), ("chr1", 12000, 12001), ("chr1", 30000, 150000), ("chr1", 160000, 200000),
+            ("chr2", 100, 1100), ("chr2", 4000, 100000)]
+    d = _dist_case(tmp_path, np.random.default_rng(63), ["-f", "4000"], fixed=4000, bed_rows=rows)
+    sizes = {r.split("\t")[5] for r in (d / "out2_DIST_d_FW4000.txt").read_text().splitlines()[1:]}
+    assert len(sizes) > 3 and "4000" in sizes and "0" in sizes
 
 
 def _stats_case(tmp_path, rng, args, block=0, accessible=-1, n_sites=3000, n_samples=19, crlf=False, miss=0.1):
