@@ -191,10 +191,14 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     SegWords d = segs[0], dn = segs[1];
     // One batch: the finished tile's stores first, then the request for the batch three ahead (into the buffer that was
     // counted last), then the counting -- so what is outstanding behind the batch waited for is only ever younger loads.
+    // Past the chunk's end (the last round of four) a step still requests and takes its batch: with `break`s between
+    // the steps the loop header is reached with the buffers requested in different orders, and the compiler's wait there
+    // becomes "everything outstanding" (two of the three batches in flight drained at every fourth batch).
     auto step = [&](Batch &cur, Batch &spare, int item) {
+        const bool live = item < n_items;
         const int ti = item / nb, bi = item - ti * nb;
         const int t = t0 + ti, wb = bi * NB;
-        if (bi == 0) {
+        if (bi == 0 && live) {
 #ifdef EVOFST_EXPERIMENTS
             if (!(p.debug & 2))
 #endif
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
         // the flag byte is the last load of its batch: taking it here marks the whole batch as arrived, including rows
         // past W that nothing reads (their registers would otherwise count as outstanding when they are reused)
         asm volatile("" :: "v"(cur.flag));
+        if (!live) return;
         CT *cp = reinterpret_cast<CT *>(p.counts) + (size_t)t * P * kTileSites + lane;
 #ifdef EVOFST_EXPERIMENTS
         if (p.debug & 1) { c += (uint32_t)cur.r[0].x ^ (uint32_t)cur.r[1].y ^ (uint32_t)cur.r[2].x ^ (uint32_t)cur.r[3].y; return; }
@@ -262,11 +267,8 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     };
     for (int item = 0; item < n_items; item += 4) {
         step(b0, b3, item);
-        if (item + 1 >= n_items) break;
         step(b1, b0, item + 1);
-        if (item + 2 >= n_items) break;
         step(b2, b1, item + 2);
-        if (item + 3 >= n_items) break;
         step(b3, b2, item + 3);
     }
     if (n_items > 0) epilogue(t1 - 1);
