@@ -304,8 +304,74 @@ struct AccessibleBed {
     }
 };
 
+// --annot (process_vcf_fst.cpp:394-402, 558-562; Annotation, process_vcf_annotation_tools.h:177-327 and
+// process_vcf_annotation_tools.cpp:84-109): the category of an included SNP -- "exon", "intron" or "other non-coding".
+// Per scaffold the kept transcripts in file order with the four strings the lookup compares.  The reference's behaviour
+// is kept where it is surprising: positions compare as strings; only the first line of a transcript counts as its
+// exon; a partial transcript ("X-name" in column 5) is dropped together with the transcript before it; the last
+// transcript of a scaffold is stored when another scaffold follows, so the file's last scaffold never is; a scaffold
+// that comes back replaces its entry; two transcripts of one name share the later one's exon line.
+struct GeneAnnotation {
+    struct Transcript { string name, start, end, exonStart, exonEnd; };
+    std::map<string, std::vector<Transcript>> scaffolds;
+    static string transcriptName(const string &geneColumn, bool &partial) {
+        std::vector<string> parts = split(geneColumn, '-');
+        if (parts.size() == 2) { partial = true; return parts[1]; }
+        return parts.size() == 1 ? geneColumn : string();
+    }
+    void store(const string &scaffold, std::vector<std::vector<string>> &transcripts) {
+        std::vector<Transcript> kept;
+        std::map<string, size_t> lastOfName;
+        for (size_t i = 0; i < transcripts.size(); ++i) {
+            std::vector<string> first = split(transcripts[i].front(), '\t'), last = split(transcripts[i].back(), '\t');
+            if (first.size() < 5 || last.size() < 3) die("annotation lines need five tab-separated columns");
+            Transcript t;
+            t.name = first[4];
+            if (first[3] == "+") { t.start = first[1]; t.end = last[2]; } else { t.end = first[2]; t.start = last[1]; }
+            t.exonStart = first[1]; t.exonEnd = first[2];
+            lastOfName[t.name] = i;
+            kept.push_back(t);
+        }
+        for (Transcript &t : kept) { const Transcript &l = kept[lastOfName[t.name]]; const string a = l.exonStart, b = l.exonEnd; t.exonStart = a; t.exonEnd = b; }
+        scaffolds[scaffold] = kept;
+        transcripts.clear();
+    }
+    void load(const string &path) {
+        std::ifstream in(path.c_str());
+        if (!in) die("could not open " + path);
+        string line, scaffold, name;
+        std::vector<std::vector<string>> transcripts;
+        std::vector<string> current;
+        bool partial = false, first = true;
+        while (getline(in, line)) {
+            std::vector<string> f = split(line, '\t');
+            if (f.size() < 5) die("annotation lines need five tab-separated columns");
+            bool linePartial = false;
+            const string lineName = transcriptName(f[4], linePartial);
+            if (first) { current.push_back(line); scaffold = f[0]; name = lineName; partial = linePartial; first = false; continue; }
+            if (linePartial) partial = true;
+            if (f[0] == scaffold && lineName == name) { current.push_back(line); continue; }
+            if (!partial) transcripts.push_back(current);
+            if (f[0] != scaffold) { store(scaffold, transcripts); scaffold = f[0]; }
+            current.assign(1, line); name = lineName; partial = linePartial;
+        }
+        if (first) die("empty annotation file " + path);
+    }
+    const char *category(const string &scaffold, const string &locus) const {
+        const char *c = "other non-coding";
+        auto it = scaffolds.find(scaffold);
+        if (it == scaffolds.end()) return c;
+        for (const Transcript &t : it->second)
+            if (locus >= t.start && locus <= t.end) {
+                c = "intron";
+                if (locus >= t.exonStart && locus <= t.exonEnd) return "exon";
+            }
+        return c;
+    }
+};
+
 namespace fstopt {
-string vcfFile, sampleSets, sampleNameFile, runName = "", popsFile, pairsArg, accessibleBed;
+string vcfFile, sampleSets, sampleNameFile, runName = "", popsFile, pairsArg, accessibleBed, annotFile;
 int windowSize = 0, windowStep = 0, physicalWindowSize = 10000;
 double regAbove = 0;
 }
@@ -326,9 +392,11 @@ const char *FST_USAGE =
     "                                               with SIZE > 1 required; no heterozygosity / fixed-window files in this mode)\n"
     "       --physicalWindowSize=SIZE               (optional; default 10000bp)\n"
     "       --accessibleGenomeBED=BEDfile.bed       (optional) regions of the genome where SNPs could be called: the fixed-window\n"
-    "                                               file reports and divides by the accessible bases of each window\n\n";
+    "                                               file reports and divides by the accessible bases of each window\n"
+    "       --annot=ANNOTATION.gffExtract           (optional) gene annotation (scaffold, start, end, strand, transcript per line):\n"
+    "                                               writes RUN_NAMESNPcategory_fst.txt with the category, Fst and dxy of every SNP\n\n";
 
-enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS, OPT_ACC_BED };
+enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS, OPT_ACC_BED, OPT_ANNOT };
 
 void parseFstOptions(int argc, char **argv) {
     static const struct option longopts[] = {
@@ -337,7 +405,7 @@ void parseFstOptions(int argc, char **argv) {
         {"physicalWindowSize", required_argument, NULL, OPT_PHYS}, {"samples", required_argument, NULL, 's'},
         {"run-name", required_argument, NULL, 'n'}, {"help", no_argument, NULL, 'h'},
         {"pops", required_argument, NULL, OPT_POPS}, {"pairs", required_argument, NULL, OPT_PAIRS},
-        {"ancSets", required_argument, NULL, OPT_UNSUPPORTED}, {"annot", required_argument, NULL, OPT_UNSUPPORTED},
+        {"ancSets", required_argument, NULL, OPT_UNSUPPORTED}, {"annot", required_argument, NULL, OPT_ANNOT},
         {"ms", required_argument, NULL, OPT_UNSUPPORTED}, {"eigen", required_argument, NULL, OPT_UNSUPPORTED},
         {"accessibleGenomeBED", required_argument, NULL, OPT_ACC_BED}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
@@ -357,6 +425,7 @@ void parseFstOptions(int argc, char **argv) {
             case OPT_REG_ABOVE: arg >> fstopt::regAbove; break;
             case OPT_PHYS: arg >> fstopt::physicalWindowSize; break;
             case OPT_ACC_BED: arg >> fstopt::accessibleBed; break;
+            case OPT_ANNOT: arg >> fstopt::annotFile; break;
             case 's': arg >> fstopt::sampleNameFile; break;
             case 'n': arg >> fstopt::runName; break;
             case OPT_UNSUPPORTED: die("this option belongs to a mode the GPU build does not carry (see evo_main.cpp header)");
@@ -554,6 +623,14 @@ int fstMain(int argc, char **argv) {
     AccessibleBed bed;
     const bool haveBed = !accessibleBed.empty();
     if (haveBed) { std::cerr << "Loading the accessible genome annotation" << std::endl; bed.load(accessibleBed); std::cerr << "Done" << std::endl; }
+    GeneAnnotation annotation;                                       // fst.cpp:394-402
+    std::ofstream snpCategoryFstFile;
+    const bool haveAnnot = !annotFile.empty();
+    if (haveAnnot) {
+        annotation.load(annotFile);
+        snpCategoryFstFile.open((runName + "SNPcategory_fst.txt").c_str());
+        snpCategoryFstFile << "SNPcategory" << "\t" << "thisSNPFst" << "\t" << "thisSNPDxy" << "\t" << "scaffold" << "\t" << "position" << std::endl;
+    }
     std::ofstream fwFile((runName + "_w_" + numToString(physicalWindowSize) + "_fixedWindowStats.txt").c_str());
     std::ofstream pHet((runName + "_w_" + numToString(windowSize) + "_heterozygosity.txt").c_str());
     fwFile << "scaffold" << "\t" << "Start" << "\t" << "End" << "\t" << "Fst" << "\t" << "Dxy" << "\t" << "Set1_pi" << "\t" << "Set2_pi" << "\t" << "Accessible_bp" << "\t" << "Set1_VariantDensity" << "\t" << "Set2_VariantDensity" << std::endl;
@@ -604,6 +681,8 @@ int fstMain(int argc, char **argv) {
             pi1V.push_back(pi[s]); pi2V.push_back(pi[n + s]);
             het1S.push_back(het[s]); het2S.push_back(het[n + s]);
             het1N.push_back(hetNei[s]); het2N.push_back(hetNei[n + s]);
+            if (haveAnnot)                                          // fst.cpp:558-562
+                snpCategoryFstFile << annotation.category(scaffold, loc) << "\t" << FstNumerator / FstDenominator << "\t" << thisSNPDxy << "\t" << scaffold << "\t" << loc << std::endl;
             // physical windows, fst.cpp:589-629
             // (the reference splits windowStartEnd at every site to compare its first field; the comparison alone is enough)
             const size_t tab0 = windowStartEnd.find('\t');

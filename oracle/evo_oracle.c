@@ -651,6 +651,150 @@ int orc_bed_accessible_bp(const orc_bed *b, const char *scaffold, int start, int
 
 static const orc_bed *g_fst_bed = NULL;                /* set by orc_fst_run_bed for the duration of one run */
 
+/* ---- Annotation (process_vcf_annotation_tools.h:177-327, process_vcf_annotation_tools.cpp:84-109), as far as
+ * getCategoryOfSNP needs it.  A restatement (its loader calls split() of the unbuildable process_vcf_utils.cpp):
+ * parity unpinned.  Kept from the reference: a transcript is the run of consecutive lines with one name in column 5
+ * ("X-name" marks a partial transcript, which is dropped -- and a partial line also drops the transcript BEFORE it,
+ * because the flag is raised before the line is told apart, :268-270); the last transcript of a scaffold is stored
+ * only when another scaffold follows, so the last scaffold of the file is never stored (:282-294); a scaffold that
+ * comes back replaces its entry; positions are compared as STRINGS (:196, :205); only the first line of a transcript
+ * is tried as an exon (:203-209, the break); the exon lines are looked up by transcript name, so of two transcripts
+ * with one name in a scaffold the later one's lines serve both (:100).  The reference leaves the partial flag of the
+ * file's first transcript uninitialized unless its first line is partial (:265); it is taken as false here. */
+typedef struct { char *name, *start, *end, *exon_start, *exon_end; } annot_tr;
+typedef struct { char *name; annot_tr *tr; int n; } annot_scaffold;
+struct orc_annot { annot_scaffold *sc; int n, cap; };
+
+static char *annot_field(const char *line, int k) {          /* field k of split(line, '\t'), NULL when absent */
+    char *tmp = strdup(line); char **f = NULL; int cap = 0;
+    int nf = split_inplace(tmp, '\t', &f, &cap);
+    char *r = k < nf ? strdup(f[k]) : NULL;
+    free(f); free(tmp);
+    return r;
+}
+/* getTranscriptName (:242-252) */
+static char *annot_transcript_name(const char *geneColumn, int *partial) {
+    char *tmp = strdup(geneColumn); char **f = NULL; int cap = 0;
+    int nf = split_inplace(tmp, '-', &f, &cap);
+    char *r;
+    if (nf == 2) { *partial = 1; r = strdup(f[1]); }
+    else if (nf == 1) r = strdup(geneColumn);
+    else r = strdup("");
+    free(f); free(tmp);
+    return r;
+}
+typedef struct { char **lines; int n, cap; } annot_lines;       /* one transcript */
+typedef struct { annot_lines *t; int n, cap; } annot_trs;       /* the transcripts of the scaffold being read */
+static void annot_lines_push(annot_lines *t, const char *l) {
+    if (t->n == t->cap) { t->cap = t->cap ? 2 * t->cap : 8; t->lines = (char **)realloc(t->lines, sizeof(char *) * (size_t)t->cap); }
+    t->lines[t->n++] = strdup(l);
+}
+static void annot_trs_push(annot_trs *a, annot_lines *t) {      /* takes the lines over */
+    if (a->n == a->cap) { a->cap = a->cap ? 2 * a->cap : 64; a->t = (annot_lines *)realloc(a->t, sizeof(annot_lines) * (size_t)a->cap); }
+    a->t[a->n++] = *t; t->lines = NULL; t->n = t->cap = 0;
+}
+static void annot_lines_clear(annot_lines *t) { for (int i = 0; i < t->n; i++) free(t->lines[i]); free(t->lines); t->lines = NULL; t->n = t->cap = 0; }
+static void annot_scaffold_free(annot_scaffold *e) {
+    for (int i = 0; i < e->n; i++) { free(e->tr[i].name); free(e->tr[i].start); free(e->tr[i].end); free(e->tr[i].exon_start); free(e->tr[i].exon_end); }
+    free(e->tr); free(e->name);
+}
+/* annotationMap[scaffold] = annotation (:285) followed by annotateGeneStartsEnds (annotation_tools.cpp:84-109) */
+static int annot_store(orc_annot *a, const char *scaffold, annot_trs *trs) {
+    annot_scaffold e; e.name = strdup(scaffold); e.n = trs->n; e.tr = (annot_tr *)calloc((size_t)trs->n + 1, sizeof(annot_tr));
+    int bad = 0;
+    for (int i = 0; i < trs->n; i++) {
+        const char *first = trs->t[i].lines[0], *last = trs->t[i].lines[trs->t[i].n - 1];
+        char *strand = annot_field(first, 3);
+        e.tr[i].name = annot_field(first, 4);
+        if (strand && strcmp(strand, "+") == 0) { e.tr[i].start = annot_field(first, 1); e.tr[i].end = annot_field(last, 2); }
+        else { e.tr[i].end = annot_field(first, 2); e.tr[i].start = annot_field(last, 1); }
+        if (!strand || !e.tr[i].name || !e.tr[i].start || !e.tr[i].end) bad = 1;
+        free(strand);
+    }
+    for (int i = 0; i < trs->n && !bad; i++) {                    /* exons by name: the last transcript of that name (:100) */
+        int k = i;
+        for (int j = trs->n - 1; j > i; j--) if (strcmp(e.tr[j].name, e.tr[i].name) == 0) { k = j; break; }
+        e.tr[i].exon_start = annot_field(trs->t[k].lines[0], 1); e.tr[i].exon_end = annot_field(trs->t[k].lines[0], 2);
+    }
+    for (int i = 0; i < trs->n; i++) annot_lines_clear(&trs->t[i]);
+    trs->n = 0;
+    if (bad) { annot_scaffold_free(&e); return -1; }
+    for (int i = 0; i < a->n; i++)
+        if (strcmp(a->sc[i].name, scaffold) == 0) { annot_scaffold_free(&a->sc[i]); a->sc[i] = e; return 0; }
+    if (a->n == a->cap) { a->cap = a->cap ? 2 * a->cap : 16; a->sc = (annot_scaffold *)realloc(a->sc, sizeof(annot_scaffold) * (size_t)a->cap); }
+    a->sc[a->n++] = e;
+    return 0;
+}
+void orc_annot_free(orc_annot *a) {
+    if (!a) return;
+    for (int i = 0; i < a->n; i++) annot_scaffold_free(&a->sc[i]);
+    free(a->sc); free(a);
+}
+/* Annotation(geneFile, false): loadAnnotationMap (:255-295) */
+orc_annot *orc_annot_load(const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    orc_annot *a = (orc_annot *)calloc(1, sizeof(orc_annot));
+    annot_trs trs = {0}; annot_lines cur = {0};
+    char *line = NULL; size_t lcap = 0; ssize_t ln;
+    char *currentScaffold = NULL, *currentTranscriptName = NULL;
+    int thisPartial = 0, first = 1, bad = 0;
+    while (!bad && (ln = getline(&line, &lcap, f)) >= 0) {
+        if (ln && line[ln - 1] == '\n') line[ln - 1] = '\0';
+        char *sc = annot_field(line, 0), *gene = annot_field(line, 4);
+        if (!sc || !gene) { free(sc); free(gene); bad = 1; break; }       /* the reference would index out of range */
+        int linePartial = 0;
+        char *name = annot_transcript_name(gene, &linePartial);
+        if (first) {                                                      /* :260-265 */
+            annot_lines_push(&cur, line);
+            currentScaffold = sc; currentTranscriptName = name; thisPartial = linePartial; first = 0;
+            free(gene);
+            continue;
+        }
+        if (linePartial) thisPartial = 1;                                 /* :269-270, before the line is told apart */
+        if (strcmp(sc, currentScaffold) == 0) {
+            if (strcmp(name, currentTranscriptName) == 0) { annot_lines_push(&cur, line); free(name); }
+            else {
+                if (!thisPartial) annot_trs_push(&trs, &cur); else annot_lines_clear(&cur);
+                annot_lines_push(&cur, line);
+                free(currentTranscriptName); currentTranscriptName = name; thisPartial = linePartial;
+            }
+            free(sc);
+        } else {
+            if (!thisPartial) annot_trs_push(&trs, &cur); else annot_lines_clear(&cur);
+            if (annot_store(a, currentScaffold, &trs) != 0) bad = 1;
+            annot_lines_push(&cur, line);
+            free(currentScaffold); currentScaffold = sc;
+            free(currentTranscriptName); currentTranscriptName = name; thisPartial = linePartial;
+        }
+        free(gene);
+    }
+    /* end of file: the open transcript and the open scaffold are dropped (:293-294) */
+    annot_lines_clear(&cur);
+    for (int i = 0; i < trs.n; i++) annot_lines_clear(&trs.t[i]);
+    free(trs.t); free(line); free(currentScaffold); free(currentTranscriptName);
+    fclose(f);
+    if (bad || first) { orc_annot_free(a); return NULL; }
+    return a;
+}
+static int annot_str_ge(const char *x, const char *y) { return strcmp(x, y) >= 0; }   /* std::string >=: bytes, then length */
+/* getCategoryOfSNP (:190-214) */
+const char *orc_annot_category(const orc_annot *a, const char *scaffold, const char *locus) {
+    const char *category = "other non-coding";
+    const annot_scaffold *e = NULL;
+    for (int i = 0; i < a->n; i++) if (strcmp(a->sc[i].name, scaffold) == 0) e = &a->sc[i];
+    if (!e) return category;
+    for (int i = 0; i < e->n; i++) {
+        if (annot_str_ge(locus, e->tr[i].start) && annot_str_ge(e->tr[i].end, locus)) {
+            category = "intron";
+            if (annot_str_ge(locus, e->tr[i].exon_start) && annot_str_ge(e->tr[i].exon_end, locus)) return "exon";
+        }
+    }
+    return category;
+}
+static const orc_annot *g_fst_annot = NULL;            /* set by orc_fst_run_opts for the duration of one run */
+static FILE *g_fst_annot_out = NULL;
+
 int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples_path,
                 int windowSize, int windowStep, int physicalWindowSize, double regAbove,
                 const char *run_name, const char *out_dir, double *summary) {
@@ -770,6 +914,9 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
                 dv_push(&pi1V, pi1); dv_push(&pi2V, pi2);
                 dv_push(&het1S, h1); dv_push(&het2S, h2);
                 dv_push(&het1N, hn1); dv_push(&het2N, hn2);
+                if (g_fst_annot)                                /* :558-562 */
+                    fprintf(g_fst_annot_out, "%s\t%g\t%g\t%s\t%s\n", orc_annot_category(g_fst_annot, scaffold, loc),
+                            FstNumerator / FstDenominator, thisSNPDxy, scaffold, loc);
 
                 /* physical windows, :589-629 */
                 if (first_field_is(windowStartEnd, scaffold, NULL)) {
@@ -895,6 +1042,29 @@ int orc_fst_run_bed(const char *vcf_path, const char *sets_path, const char *sam
     int rc = orc_fst_run(vcf_path, sets_path, samples_path, windowSize, windowStep, physicalWindowSize, regAbove, run_name, out_dir, summary);
     g_fst_bed = NULL;
     orc_bed_free(bed);
+    return rc;
+}
+
+/* orc_fst_run with --accessibleGenomeBED and --annot=annot_path (process_vcf_fst.cpp:394-402, :558-562): every included
+ * site adds a row {category, Fst of the site, dxy, scaffold, position} to <run_name>SNPcategory_fst.txt. */
+int orc_fst_run_opts(const char *vcf_path, const char *sets_path, const char *samples_path,
+                     int windowSize, int windowStep, int physicalWindowSize, double regAbove,
+                     const char *run_name, const char *out_dir, double *summary, const char *bed_path, const char *annot_path) {
+    orc_annot *an = NULL;
+    if (annot_path && annot_path[0]) {
+        an = orc_annot_load(annot_path);
+        if (!an) { fprintf(stderr, "Error: could not read %s\n", annot_path); return -5; }
+        char name[512];
+        snprintf(name, sizeof name, "%sSNPcategory_fst.txt", run_name);      /* :399 */
+        char *p = path_join(out_dir, name); g_fst_annot_out = fopen(p, "w"); free(p);
+        if (!g_fst_annot_out) { orc_annot_free(an); return -3; }
+        fprintf(g_fst_annot_out, "SNPcategory\tthisSNPFst\tthisSNPDxy\tscaffold\tposition\n");
+    }
+    g_fst_annot = an;
+    int rc = orc_fst_run_bed(vcf_path, sets_path, samples_path, windowSize, windowStep, physicalWindowSize, regAbove, run_name, out_dir, summary, bed_path);
+    g_fst_annot = NULL;
+    if (g_fst_annot_out) { fclose(g_fst_annot_out); g_fst_annot_out = NULL; }
+    orc_annot_free(an);
     return rc;
 }
 

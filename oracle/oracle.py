@@ -479,17 +479,33 @@ def global_windows(kept, num, den, size, step, site_flags=None):
     return dict(start_site=ss[:n], end_site=es[:n], fst=fst[:n])
 
 
-def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_above=0.0, samples=None, bed=None):
+def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_above=0.0, samples=None, bed=None, annot=None):
     summ = np.zeros(7)
     L = lib()
-    L.orc_fst_run_bed.restype = C.c_int
-    L.orc_fst_run_bed.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
-                                  C.c_double, C.c_char_p, C.c_char_p, _dp, C.c_char_p]
-    rc = L.orc_fst_run_bed(vcf.encode(), sets.encode(), (samples or "").encode(), size, step, phys,
-                           reg_above, run_name.encode(), out_dir.encode(), _p(summ, _dp), (bed or "").encode())
+    L.orc_fst_run_opts.restype = C.c_int
+    L.orc_fst_run_opts.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_double, C.c_char_p, C.c_char_p, _dp, C.c_char_p, C.c_char_p]
+    rc = L.orc_fst_run_opts(vcf.encode(), sets.encode(), (samples or "").encode(), size, step, phys,
+                            reg_above, run_name.encode(), out_dir.encode(), _p(summ, _dp), (bed or "").encode(),
+                            (annot or "").encode())
     if rc != 0:
         raise RuntimeError("orc_fst_run failed: %d" % rc)
     return summ
+
+
+def annot_categories(annot_path, queries):
+    """getCategoryOfSNP (process_vcf_annotation_tools.h:190-214) of (scaffold, position string) pairs."""
+    L = lib()
+    L.orc_annot_load.restype = C.c_void_p; L.orc_annot_load.argtypes = [C.c_char_p]
+    L.orc_annot_free.argtypes = [C.c_void_p]
+    L.orc_annot_category.restype = C.c_char_p; L.orc_annot_category.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    a = L.orc_annot_load(annot_path.encode())
+    if not a:
+        raise RuntimeError("orc_annot_load failed")
+    try:
+        return [L.orc_annot_category(a, sc.encode(), str(loc).encode()).decode() for sc, loc in queries]
+    finally:
+        L.orc_annot_free(a)
 
 
 def pbs_site_stats(alt, nm, trios, site_flags=None):

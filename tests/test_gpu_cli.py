@@ -35,7 +35,7 @@ def _same_files(a_dir, b_dir):
 
 
 def _fst_case(tmp_path, rng, args, size, step, n_sites=900, n_samples=24, scaffolds=("scaffold_0", "chrB"),
-              crlf=False, gz=False, overlap=False, samples_file=False, phys=10000, reg_above=0.0, bed_rows=None):
+              crlf=False, gz=False, overlap=False, samples_file=False, phys=10000, reg_above=0.0, bed_rows=None, annot_text=None):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=scaffolds, crlf=crlf, miss=0.08)
     if gz:
@@ -63,10 +63,15 @@ def _fst_case(tmp_path, rng, args, size, step, n_sites=900, n_samples=24, scaffo
         bed = str(tmp_path / "accessible.bed")
         open(bed, "w").write("".join("%s\t%d\t%d\n" % row for row in bed_rows))
         cmd += ["--accessibleGenomeBED=" + bed]
+    annot = None
+    if annot_text is not None:
+        annot = str(tmp_path / "genes.gffExtract")
+        open(annot, "w").write(annot_text)
+        cmd += ["--annot=" + annot]
     r = subprocess.run(cmd, cwd=str(cli_dir), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     O.fst_run(vcf, sets, str(orc_dir), run_name="run", size=size, step=step, phys=phys, reg_above=reg_above, samples=sf,
-              bed=bed)
+              bed=bed, annot=annot)
     _same_files(str(cli_dir), str(orc_dir))
     return r
 
@@ -113,6 +118,27 @@ def test_cli_fst_accessible_genome_bed_no_snp_windows(tmp_path):
     rows = [("chr7", 100, 2500), ("chr7", 3000, 3100), ("chr7", 7990, 8010), ("chr8", 500, 61000)]
     _fst_case(tmp_path, np.random.default_rng(42), ["-w", "40,40", "--physicalWindowSize=1000"], 40, 40, phys=1000,
               scaffolds=("chr7", "chr8"), n_sites=300, bed_rows=rows)
+
+
+def test_cli_fst_annot_snp_categories(tmp_path):
+    """--annot (process_vcf_fst.cpp:558-562): runSNPcategory_fst.txt with the category of every included SNP.  The
+    annotation has transcripts on both strands, a partial transcript, overlapping transcripts, positions of three to five
+    digits (the reference compares them as strings) and a last scaffold, which the reference's loader never stores."""
+    rows = []
+    for k in range(12):                                   # scaffold_0: two-exon transcripts every 5 kb, alternating strands
+        a = 900 + 5000 * k
+        ex = [(a, a + 400), (a + 1500, a + 2100)]
+        if k % 2:
+            ex.reverse()
+        name = "gene.%d.1.1.1" % k if k % 3 else "g%d" % k
+        if k == 7:
+            name = "5partial-" + name
+        rows += ["scaffold_0\t%d\t%d\t%s\t%s" % (s, e, "-" if k % 2 else "+", name) for s, e in ex]
+    rows += ["scaffold_0\t20000\t30000\t+\tlong.1", "scaffold_0\t95\t99\t+\ttiny"]
+    rows += ["chrB\t100\t60000\t+\twhole", "chrB\t200\t300\t+\twhole", "chrZ\t1\t10\t+\tlast"]
+    r = _fst_case(tmp_path, np.random.default_rng(43), ["-w", "20,20"], 20, 20, annot_text="\n".join(rows) + "\n")
+    cats = [l.split("\t")[0] for l in (tmp_path / "cli" / "runSNPcategory_fst.txt").read_text().splitlines()[1:]]
+    assert {"exon", "intron", "other non-coding"} <= set(cats) and len(cats) > 500
 
 
 def test_cli_fst_sc3749(tmp_path):

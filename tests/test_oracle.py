@@ -248,6 +248,31 @@ def test_bed_loader_quirks(tmp_path):
     assert O.bed_accessible_bp(str(bed), "s1", 51, 250) == (100 - 51 + 1) + (250 - 200)
 
 
+def test_annotation_category_quirks(tmp_path):
+    """getCategoryOfSNP / loadAnnotationMap (process_vcf_annotation_tools.h:190-214, 255-295) as restated (parity
+    unpinned): string comparison of positions, first line of a transcript as its only exon, partial transcripts, the
+    dropped last scaffold."""
+    an = tmp_path / "a.gffExtract"
+    an.write_text("s1\t1000\t1200\t+\tg.1.1.1.1\n"        # transcript A: 1000..2500 (+), first exon 1000..1200
+                  "s1\t2000\t2500\t+\tg.1.1.1.1\n"
+                  "s1\t5000\t5200\t-\tg2\n"               # transcript B (-): start = last line's start 4000, end = first line's end 5200
+                  "s1\t4000\t4100\t-\tg2\n"
+                  "s1\t7000\t7100\t+\tg3\n"               # dropped: the partial line after it raises the flag first
+                  "s1\t8000\t8100\t+\t5partial-g4\n"      # partial: dropped
+                  "s1\t9000\t9100\t+\tg5\n"               # last transcript of s1: stored because s2 follows
+                  "s2\t100\t900\t+\th1\n"
+                  "s3\t100\t900\t+\tk1\n")                # last scaffold of the file: never stored (so s2 is, s3 is not)
+    q = [("s1", 1100), ("s1", 1500), ("s1", 2200), ("s1", 3000), ("s1", 4050), ("s1", 5100), ("s1", 7050), ("s1", 8050),
+         ("s1", 9050), ("s2", 500), ("s3", 500), ("nowhere", 5), ("s1", 15), ("s1", 100), ("s2", 1000), ("s2", 95)]
+    got = O.annot_categories(str(an), q)
+    assert got == ["exon", "intron", "intron", "other non-coding", "intron", "exon", "other non-coding", "other non-coding",
+                   "exon", "exon", "other non-coding", "other non-coding",
+                   "intron",               # "15" >= "1000" and "15" <= "2500" as strings; not <= "1200"
+                   "other non-coding",     # "100" < "1000" (a prefix is smaller)
+                   "exon",                 # s2: "1000" lies between "100" and "900"
+                   "other non-coding"]     # "95" > "900"
+
+
 def test_dist_windows_against_numpy():
     """orc_dist_windows (evo_distanceToOutgroups.cpp:274-294) against a direct numpy evaluation, incl. carry."""
     rng = np.random.default_rng(9)
