@@ -371,7 +371,7 @@ struct GeneAnnotation {
 };
 
 namespace fstopt {
-string vcfFile, sampleSets, sampleNameFile, runName = "", popsFile, pairsArg, accessibleBed, annotFile;
+string vcfFile, sampleSets, sampleNameFile, runName = "", popsFile, pairsArg, accessibleBed, annotFile, ancSets;
 int windowSize = 0, windowStep = 0, physicalWindowSize = 10000;
 double regAbove = 0;
 }
@@ -393,10 +393,12 @@ const char *FST_USAGE =
     "       --physicalWindowSize=SIZE               (optional; default 10000bp)\n"
     "       --accessibleGenomeBED=BEDfile.bed       (optional) regions of the genome where SNPs could be called: the fixed-window\n"
     "                                               file reports and divides by the accessible bases of each window\n"
+    "       --ancSets=ANCESTRAL_SAMPLE_SETS.txt     (optional) two sets of samples that form outgroup populations to the two populations:\n"
+    "                                               writes RUN_NAMEancestralSNPs_fst.txt (needs AA=allele as the last INFO entry)\n"
     "       --annot=ANNOTATION.gffExtract           (optional) gene annotation (scaffold, start, end, strand, transcript per line):\n"
     "                                               writes RUN_NAMESNPcategory_fst.txt with the category, Fst and dxy of every SNP\n\n";
 
-enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS, OPT_ACC_BED, OPT_ANNOT };
+enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS, OPT_ACC_BED, OPT_ANNOT, OPT_ANC_SETS };
 
 void parseFstOptions(int argc, char **argv) {
     static const struct option longopts[] = {
@@ -405,7 +407,7 @@ void parseFstOptions(int argc, char **argv) {
         {"physicalWindowSize", required_argument, NULL, OPT_PHYS}, {"samples", required_argument, NULL, 's'},
         {"run-name", required_argument, NULL, 'n'}, {"help", no_argument, NULL, 'h'},
         {"pops", required_argument, NULL, OPT_POPS}, {"pairs", required_argument, NULL, OPT_PAIRS},
-        {"ancSets", required_argument, NULL, OPT_UNSUPPORTED}, {"annot", required_argument, NULL, OPT_ANNOT},
+        {"ancSets", required_argument, NULL, OPT_ANC_SETS}, {"annot", required_argument, NULL, OPT_ANNOT},
         {"ms", required_argument, NULL, OPT_UNSUPPORTED}, {"eigen", required_argument, NULL, OPT_UNSUPPORTED},
         {"accessibleGenomeBED", required_argument, NULL, OPT_ACC_BED}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
@@ -426,6 +428,7 @@ void parseFstOptions(int argc, char **argv) {
             case OPT_PHYS: arg >> fstopt::physicalWindowSize; break;
             case OPT_ACC_BED: arg >> fstopt::accessibleBed; break;
             case OPT_ANNOT: arg >> fstopt::annotFile; break;
+            case OPT_ANC_SETS: arg >> fstopt::ancSets; break;
             case 's': arg >> fstopt::sampleNameFile; break;
             case 'n': arg >> fstopt::runName; break;
             case OPT_UNSUPPORTED: die("this option belongs to a mode the GPU build does not carry (see evo_main.cpp header)");
@@ -631,6 +634,33 @@ int fstMain(int argc, char **argv) {
         snpCategoryFstFile.open((runName + "SNPcategory_fst.txt").c_str());
         snpCategoryFstFile << "SNPcategory" << "\t" << "thisSNPFst" << "\t" << "thisSNPDxy" << "\t" << "scaffold" << "\t" << "position" << std::endl;
     }
+    // --ancSets, fst.cpp:403-413: per included SNP the derived-allele frequency difference of the two sets and whether the two
+    // ancestral sets segregate.  Host bookkeeping on the line's text, as in the reference (getFourSetVariantCounts,
+    // process_vcf_utils.cpp:577-627, counts the characters '1' whatever the ALT column says, so the device's counts of
+    // the Fst rules are not the same thing on lines with a '*' allele).
+    std::ofstream ancSetsOutFile;
+    std::vector<string> ancSet1, ancSet2;
+    std::vector<size_t> ancSet1Loci, ancSet2Loci;
+    const bool haveAnc = !ancSets.empty();
+    if (haveAnc) {
+        std::ifstream ancSetsFile(ancSets.c_str());
+        if (!ancSetsFile.is_open()) die("could not open " + ancSets);
+        ancSetsOutFile.open((runName + "ancestralSNPs_fst.txt").c_str());
+        ancSetsOutFile << "scaffold" << "\t" << "position" << "\t" << "AncAllelePopulation" << "\t" << "Fst" << "\t" << "ancSet1_segregating" << "\t" << "ancSet2_segregating" << std::endl;
+        string a1, a2;
+        getline(ancSetsFile, a1); getline(ancSetsFile, a2);
+        ancSet1 = split(a1, ','); ancSet2 = split(a2, ',');
+        std::sort(ancSet1.begin(), ancSet1.end()); std::sort(ancSet2.begin(), ancSet2.end());
+    }
+    auto altCharacters = [](const std::vector<string> &fields, const std::vector<size_t> &loci) {
+        int alt = 0;
+        for (size_t i = 9; i < fields.size(); ++i) {
+            if (std::find(loci.begin(), loci.end(), i - 9) == loci.end()) continue;
+            if (fields[i].size() > 0 && fields[i][0] == '1') alt++;
+            if (fields[i].size() > 2 && fields[i][2] == '1') alt++;
+        }
+        return alt;
+    };
     std::ofstream fwFile((runName + "_w_" + numToString(physicalWindowSize) + "_fixedWindowStats.txt").c_str());
     std::ofstream pHet((runName + "_w_" + numToString(windowSize) + "_heterozygosity.txt").c_str());
     fwFile << "scaffold" << "\t" << "Start" << "\t" << "End" << "\t" << "Fst" << "\t" << "Dxy" << "\t" << "Set1_pi" << "\t" << "Set2_pi" << "\t" << "Accessible_bp" << "\t" << "Set1_VariantDensity" << "\t" << "Set2_VariantDensity" << std::endl;
@@ -681,6 +711,31 @@ int fstMain(int argc, char **argv) {
             pi1V.push_back(pi[s]); pi2V.push_back(pi[n + s]);
             het1S.push_back(het[s]); het2S.push_back(het[n + s]);
             het1N.push_back(hetNei[s]); het2N.push_back(hetNei[n + s]);
+            if (haveAnc) {                                          // fst.cpp:563-588
+                double thisSNPFst = FstNumerator / FstDenominator;
+                if (thisSNPFst < 0) thisSNPFst = 0;
+                const std::vector<string> fields = split(batch.lines[s], '\t');
+                const std::vector<string> info = split(fields[7], ';');
+                const std::vector<string> lastInfo = info.empty() ? info : split(info.back(), '=');
+                if (lastInfo.size() < 2) die("--ancSets needs AA=<allele> as the last INFO entry (line of " + scaffold + ":" + loc + ")");
+                const string &AA = lastInfo[1];
+                const int a1 = altCharacters(fields, set1Loci), a2 = altCharacters(fields, set2Loci);
+                const int a3 = altCharacters(fields, ancSet1Loci), a4 = altCharacters(fields, ancSet2Loci);
+                const double m1 = (double)(set1Loci.size() * 2), m2 = (double)(set2Loci.size() * 2);
+                const double m3 = (double)(ancSet1Loci.size() * 2), m4 = (double)(ancSet2Loci.size() * 2);
+                double f3, f4;
+                if (AA == fields[3]) {
+                    f3 = a3 / m3; f4 = a4 / m4;
+                    ancSetsOutFile << scaffold << "\t" << fields[1] << "\t" << a1 / m1 - a2 / m2 << "\t" << thisSNPFst << "\t";
+                } else if (AA == fields[4]) {
+                    f3 = (double)((int)m3 - a3) / m3; f4 = (double)((int)m4 - a4) / m4;
+                    ancSetsOutFile << scaffold << "\t" << fields[1] << "\t" << (double)((int)m1 - a1) / m1 - (double)((int)m2 - a2) / m2 << "\t" << thisSNPFst << "\t";
+                } else {
+                    f3 = a3 / m3; f4 = a4 / m4;
+                    ancSetsOutFile << scaffold << "\t" << fields[1] << "\t" << "-888" << "\t" << thisSNPFst << "\t";
+                }
+                ancSetsOutFile << (((f3 > 0) & (f3 < 1)) ? "1" : "0") << "\t" << (((f4 > 0) & (f4 < 1)) ? "1" : "0") << std::endl;
+            }
             if (haveAnnot)                                          // fst.cpp:558-562
                 snpCategoryFstFile << annotation.category(scaffold, loc) << "\t" << FstNumerator / FstDenominator << "\t" << thisSNPDxy << "\t" << scaffold << "\t" << loc << std::endl;
             // physical windows, fst.cpp:589-629
@@ -771,6 +826,7 @@ int fstMain(int argc, char **argv) {
             else { std::ifstream sf(sampleNameFile.c_str()); string l; while (getline(sf, l)) sampleNames.push_back(l); }
             set1Loci = locateSet(sampleNames, set1); set2Loci = locateSet(sampleNames, set2);
             if (set1Loci.empty() || set2Loci.empty()) die("a sample set has no samples in the VCF");
+            if (haveAnc) { ancSet1Loci = locateSet(sampleNames, ancSet1); ancSet2Loci = locateSet(sampleNames, ancSet2); }   // fst.cpp:497-505
             for (size_t i : set1Loci) virt.push_back(i);
             for (size_t i : set2Loci) virt.push_back(i);
             for (size_t i : virt) if ((int)i >= nSamples) die("sample index beyond the VCF columns (check the -s file)");

@@ -794,6 +794,21 @@ const char *orc_annot_category(const orc_annot *a, const char *scaffold, const c
 }
 static const orc_annot *g_fst_annot = NULL;            /* set by orc_fst_run_opts for the duration of one run */
 static FILE *g_fst_annot_out = NULL;
+static const char *g_fst_anc_sets = NULL;              /* --ancSets file, likewise */
+
+/* The counts getFourSetVariantCounts (process_vcf_utils.cpp:577-627) takes from one line: genotype characters 0 and 2
+ * equal to '1', per set; a sample counts once per character however often its column is listed. */
+static int four_set_alt(const char *const *genotypes, int n_samples, const size_t *loci, int n_loci) {
+    int alt = 0;
+    for (int i = 0; i < n_samples; i++) {
+        int in = 0;
+        for (int k = 0; k < n_loci; k++) if (loci[k] == (size_t)i) { in = 1; break; }
+        if (!in) continue;
+        if (genotypes[i][0] == '1') alt++;
+        if (genotypes[i][0] != '\0' && genotypes[i][1] != '\0' && genotypes[i][2] == '1') alt++;
+    }
+    return alt;
+}
 
 int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples_path,
                 int windowSize, int windowStep, int physicalWindowSize, double regAbove,
@@ -826,6 +841,23 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
     int nset2 = split_inplace(set2String, ',', &set2, &c2cap);
     qsort(set1, (size_t)nset1, sizeof(char *), cmp_str);
     qsort(set2, (size_t)nset2, sizeof(char *), cmp_str);
+    /* --ancSets, :403-413 */
+    FILE *ancOut = NULL; char *anc1String = NULL, *anc2String = NULL; char **anc1 = NULL, **anc2 = NULL;
+    int nanc1 = 0, nanc2 = 0, lenA1 = 0, lenA2 = 0; size_t *anc1Loci = NULL, *anc2Loci = NULL;
+    if (g_fst_anc_sets) {
+        FILE *af = fopen(g_fst_anc_sets, "r");
+        if (!af) { lr_close(&vcf); return -2; }
+        snprintf(name, sizeof name, "%sancestralSNPs_fst.txt", run_name);
+        char *pa = path_join(out_dir, name); ancOut = fopen(pa, "w"); free(pa);
+        if (!ancOut) { fclose(af); lr_close(&vcf); return -3; }
+        fprintf(ancOut, "scaffold\tposition\tAncAllelePopulation\tFst\tancSet1_segregating\tancSet2_segregating\n");
+        anc1String = read_line_dup(af); anc2String = read_line_dup(af); fclose(af);
+        int c1 = 0, c2 = 0;
+        nanc1 = split_inplace(anc1String, ',', &anc1, &c1); nanc2 = split_inplace(anc2String, ',', &anc2, &c2);
+        qsort(anc1, (size_t)nanc1, sizeof(char *), cmp_str); qsort(anc2, (size_t)nanc2, sizeof(char *), cmp_str);
+        anc1Loci = (size_t *)malloc(sizeof(size_t) * (size_t)(nanc1 + 1)); anc2Loci = (size_t *)malloc(sizeof(size_t) * (size_t)(nanc2 + 1));
+    }
+    int anc_rc = 0;
 
     int totalVariantNumber = 0, countedVariantNumber = 0;
     char *windowMiddleVariant = strdup("first\tWindow");   /* :451 */
@@ -865,6 +897,10 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
             len1 = locate_set(sampleNames, nNames, set1, nset1, set1Loci);
             len2 = locate_set(sampleNames, nNames, set2, nset2, set2Loci);
             n1 = len1 * 2; n2 = len2 * 2;                   /* :491 */
+            if (ancOut) {                                   /* :497-505 */
+                lenA1 = locate_set(sampleNames, nNames, anc1, nanc1, anc1Loci);
+                lenA2 = locate_set(sampleNames, nNames, anc2, nanc2, anc2Loci);
+            }
             s1indiv = (int *)malloc(sizeof(int) * (size_t)(len1 + 1));
             s2indiv = (int *)malloc(sizeof(int) * (size_t)(len2 + 1));
             s1hap = (int *)malloc(sizeof(int) * (size_t)(n1 + 2));
@@ -892,6 +928,7 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
             const char *scaffold = fields[0];
             const char *loc = fields[1];
             if (strlen(fields[3]) > 1) continue;            /* :529-532 */
+            char *infoCopy = ancOut ? strdup(fields[7]) : NULL;   /* :526 */
             orc_setcounts c;
             orc_fst_variant_counts(fields[4], (const char *const *)(fields + 9), set1Loci, len1, set2Loci, len2,
                                    &c, s1indiv, s2indiv, s1hap, s2hap);
@@ -914,6 +951,36 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
                 dv_push(&pi1V, pi1); dv_push(&pi2V, pi2);
                 dv_push(&het1S, h1); dv_push(&het2S, h2);
                 dv_push(&het1N, hn1); dv_push(&het2N, hn2);
+                if (ancOut) {                                   /* :563-588 */
+                    double thisSNPFst = FstNumerator / FstDenominator;
+                    if (thisSNPFst < 0) thisSNPFst = 0;
+                    char **info = NULL, **kv = NULL; int icap = 0, kcap = 0;
+                    int ni = split_inplace(infoCopy, ';', &info, &icap);
+                    int nk = ni > 0 ? split_inplace(info[ni - 1], '=', &kv, &kcap) : 0;
+                    if (nk < 2) anc_rc = -7;                    /* the reference indexes [1] of that split regardless */
+                    else {
+                        const char *AA = kv[1];
+                        const char *const *gt = (const char *const *)(fields + 9);
+                        int ns = nf - 9;
+                        int a1 = four_set_alt(gt, ns, set1Loci, len1), a2 = four_set_alt(gt, ns, set2Loci, len2);
+                        int a3 = four_set_alt(gt, ns, anc1Loci, lenA1), a4 = four_set_alt(gt, ns, anc2Loci, lenA2);
+                        double f3, f4;
+                        if (strcmp(AA, fields[3]) == 0) {       /* derived = ALT */
+                            double d1 = (double)a1 / (len1 * 2), d2 = (double)a2 / (len2 * 2);
+                            f3 = (double)a3 / (lenA1 * 2); f4 = (double)a4 / (lenA2 * 2);
+                            fprintf(ancOut, "%s\t%s\t%g\t%g\t", scaffold, loc, d1 - d2, thisSNPFst);
+                        } else if (strcmp(AA, fields[4]) == 0) { /* derived = REF */
+                            double d1 = (double)(len1 * 2 - a1) / (len1 * 2), d2 = (double)(len2 * 2 - a2) / (len2 * 2);
+                            f3 = (double)(lenA1 * 2 - a3) / (lenA1 * 2); f4 = (double)(lenA2 * 2 - a4) / (lenA2 * 2);
+                            fprintf(ancOut, "%s\t%s\t%g\t%g\t", scaffold, loc, d1 - d2, thisSNPFst);
+                        } else {
+                            f3 = (double)a3 / (lenA1 * 2); f4 = (double)a4 / (lenA2 * 2);
+                            fprintf(ancOut, "%s\t%s\t-888\t%g\t", scaffold, loc, thisSNPFst);
+                        }
+                        fprintf(ancOut, "%s\t%s\n", (f3 > 0) & (f3 < 1) ? "1" : "0", (f4 > 0) & (f4 < 1) ? "1" : "0");
+                    }
+                    free(info); free(kv);
+                }
                 if (g_fst_annot)                                /* :558-562 */
                     fprintf(g_fst_annot_out, "%s\t%g\t%g\t%s\t%s\n", orc_annot_category(g_fst_annot, scaffold, loc),
                             FstNumerator / FstDenominator, thisSNPDxy, scaffold, loc);
@@ -1007,6 +1074,7 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
                     }
                 }
             }
+            free(infoCopy);
         }
     }
     double Fst = orc_calculate_fst(fstNumerators.v, fstDenominators.v, fstNumerators.n);   /* :701 */
@@ -1025,7 +1093,9 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
     free(set1Loci); free(set2Loci); free(s1indiv); free(s2indiv); free(s1hap); free(s2hap);
     free(set1); free(set2); free(set1String); free(set2String);
     free(windowMiddleVariant); free(windowStartEnd); free(fields);
-    return 0;
+    if (ancOut) fclose(ancOut);
+    free(anc1); free(anc2); free(anc1String); free(anc2String); free(anc1Loci); free(anc2Loci);
+    return anc_rc;
 }
 
 /* orc_fst_run with --accessibleGenomeBED=bed_path (process_vcf_fst.cpp:414-419, :593-595, :613-616): the fixed-window
@@ -1045,24 +1115,30 @@ int orc_fst_run_bed(const char *vcf_path, const char *sets_path, const char *sam
     return rc;
 }
 
-/* orc_fst_run with --accessibleGenomeBED and --annot=annot_path (process_vcf_fst.cpp:394-402, :558-562): every included
- * site adds a row {category, Fst of the site, dxy, scaffold, position} to <run_name>SNPcategory_fst.txt. */
+/* orc_fst_run with --accessibleGenomeBED, --annot=annot_path (process_vcf_fst.cpp:394-402, :558-562: every included
+ * site adds a row {category, Fst of the site, dxy, scaffold, position} to <run_name>SNPcategory_fst.txt) and
+ * --ancSets=anc_sets_path (:403-413, :497-505, :563-588: two more sample sets; every included site adds a row
+ * {scaffold, position, derived-allele frequency difference of the two sets or -888, Fst clamped at 0, whether each of the
+ * two ancestral sets segregates} to <run_name>ancestralSNPs_fst.txt; the ancestral allele is the value of the last INFO
+ * entry; returns -7 where that entry has no '=', which the reference does not survive). */
 int orc_fst_run_opts(const char *vcf_path, const char *sets_path, const char *samples_path,
                      int windowSize, int windowStep, int physicalWindowSize, double regAbove,
-                     const char *run_name, const char *out_dir, double *summary, const char *bed_path, const char *annot_path) {
+                     const char *run_name, const char *out_dir, double *summary, const char *bed_path, const char *annot_path,
+                     const char *anc_sets_path) {
     orc_annot *an = NULL;
+    g_fst_anc_sets = anc_sets_path && anc_sets_path[0] ? anc_sets_path : NULL;
     if (annot_path && annot_path[0]) {
         an = orc_annot_load(annot_path);
-        if (!an) { fprintf(stderr, "Error: could not read %s\n", annot_path); return -5; }
+        if (!an) { fprintf(stderr, "Error: could not read %s\n", annot_path); g_fst_anc_sets = NULL; return -5; }
         char name[512];
         snprintf(name, sizeof name, "%sSNPcategory_fst.txt", run_name);      /* :399 */
         char *p = path_join(out_dir, name); g_fst_annot_out = fopen(p, "w"); free(p);
-        if (!g_fst_annot_out) { orc_annot_free(an); return -3; }
+        if (!g_fst_annot_out) { orc_annot_free(an); g_fst_anc_sets = NULL; return -3; }
         fprintf(g_fst_annot_out, "SNPcategory\tthisSNPFst\tthisSNPDxy\tscaffold\tposition\n");
     }
     g_fst_annot = an;
     int rc = orc_fst_run_bed(vcf_path, sets_path, samples_path, windowSize, windowStep, physicalWindowSize, regAbove, run_name, out_dir, summary, bed_path);
-    g_fst_annot = NULL;
+    g_fst_annot = NULL; g_fst_anc_sets = NULL;
     if (g_fst_annot_out) { fclose(g_fst_annot_out); g_fst_annot_out = NULL; }
     orc_annot_free(an);
     return rc;

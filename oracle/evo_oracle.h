@@ -183,11 +183,12 @@ int orc_fst_run(const char *vcf_path, const char *sets_path, const char *samples
 int orc_fst_run_bed(const char *vcf_path, const char *sets_path, const char *samples_path,
                     int windowSize, int windowStep, int physicalWindowSize, double regAbove,
                     const char *run_name, const char *out_dir, double *summary, const char *bed_path);
-/* the same with --annot as well (annot_path may be NULL or ""): Annotation::getCategoryOfSNP,
+/* the same with --annot and --ancSets as well (paths may be NULL or ""): Annotation::getCategoryOfSNP,
  * process_vcf_annotation_tools.h:177-327 */
 int orc_fst_run_opts(const char *vcf_path, const char *sets_path, const char *samples_path,
                      int windowSize, int windowStep, int physicalWindowSize, double regAbove,
-                     const char *run_name, const char *out_dir, double *summary, const char *bed_path, const char *annot_path);
+                     const char *run_name, const char *out_dir, double *summary, const char *bed_path, const char *annot_path,
+                     const char *anc_sets_path);
 typedef struct orc_annot orc_annot;
 orc_annot *orc_annot_load(const char *path);
 void orc_annot_free(orc_annot *a);

@@ -479,15 +479,15 @@ def global_windows(kept, num, den, size, step, site_flags=None):
     return dict(start_site=ss[:n], end_site=es[:n], fst=fst[:n])
 
 
-def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_above=0.0, samples=None, bed=None, annot=None):
+def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_above=0.0, samples=None, bed=None, annot=None, anc_sets=None):
     summ = np.zeros(7)
     L = lib()
     L.orc_fst_run_opts.restype = C.c_int
     L.orc_fst_run_opts.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
-                                   C.c_double, C.c_char_p, C.c_char_p, _dp, C.c_char_p, C.c_char_p]
+                                   C.c_double, C.c_char_p, C.c_char_p, _dp, C.c_char_p, C.c_char_p, C.c_char_p]
     rc = L.orc_fst_run_opts(vcf.encode(), sets.encode(), (samples or "").encode(), size, step, phys,
                             reg_above, run_name.encode(), out_dir.encode(), _p(summ, _dp), (bed or "").encode(),
-                            (annot or "").encode())
+                            (annot or "").encode(), (anc_sets or "").encode())
     if rc != 0:
         raise RuntimeError("orc_fst_run failed: %d" % rc)
     return summ

@@ -52,7 +52,7 @@ def assert_same_bits(a, b, what=""):
                              (what, int(bad.sum()), a.size, tuple(k), a[tuple(k)], b[tuple(k)]))
 
 
-def write_vcf(path, rng, n_sites, n_samples, scaffolds=("scaffold_0", "chr2"), miss=0.05, crlf=False, weird=True):
+def write_vcf(path, rng, n_sites, n_samples, scaffolds=("scaffold_0", "chr2"), miss=0.05, crlf=False, weird=True, vary_aa=False):
     """Small seeded VCF with the cases the reference's parsers treat specially: half calls, '*' ALT
     in either position, indels, multi-allelics, long REF, several scaffolds, extra FORMAT fields."""
     names = ["S%03d" % i for i in range(n_samples)]
@@ -85,7 +85,10 @@ def write_vcf(path, rng, n_sites, n_samples, scaffolds=("scaffold_0", "chr2"), m
                 elif r < miss * 1.3: a[int(rng.integers(0, 2))] = "."
                 sep = "|" if rng.random() < 0.3 else "/"
                 gts.append(a[0] + sep + a[1] + ":%d:%d" % (rng.integers(0, 60), rng.integers(0, 99)))
-            f.write("\t".join([scaf, str(pos), ".", ref, alt, "999", ".", "DP=10;AA=A", "GT:DP:GQ"] + gts) + eol)
+            aa = "A"
+            if vary_aa:                                     # ancestral allele = REF, ALT or neither, by a draw of its own
+                aa = (ref, alt, "N", "T")[(si * 2654435761 >> 7) % 4]
+            f.write("\t".join([scaf, str(pos), ".", ref, alt, "999", ".", "DP=10;AA=" + aa, "GT:DP:GQ"] + gts) + eol)
     return names
 
 

@@ -35,15 +35,20 @@ def _same_files(a_dir, b_dir):
 
 
 def _fst_case(tmp_path, rng, args, size, step, n_sites=900, n_samples=24, scaffolds=("scaffold_0", "chrB"),
-              crlf=False, gz=False, overlap=False, samples_file=False, phys=10000, reg_above=0.0, bed_rows=None, annot_text=None):
+              crlf=False, gz=False, overlap=False, samples_file=False, phys=10000, reg_above=0.0, bed_rows=None, annot_text=None, anc=False):
     vcf = str(tmp_path / "in.vcf")
-    names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=scaffolds, crlf=crlf, miss=0.08)
+    names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=scaffolds, crlf=crlf, miss=0.08, vary_aa=anc)
     if gz:
         with open(vcf, "rb") as f, gzip.open(vcf + ".gz", "wb") as g:
             shutil.copyfileobj(f, g)
         vcf += ".gz"
     half = n_samples // 2
     s1, s2 = names[:half], names[half:]
+    anc_sets = None
+    if anc:                                # the last samples of each half form the two ancestral sets (one also sits in set 2)
+        anc_sets = str(tmp_path / "anc.txt")
+        open(anc_sets, "w").write(",".join(s1[-3:]) + "\n" + ",".join(s2[-2:] + ["NOT_THERE"]) + "\n")
+        s1, s2 = s1[:-3], s2[:-1]
     if overlap:
         s2 = s2 + names[:2]           # samples that sit in both sets
         s1 = s1 + ["NOT_THERE"]       # and a name the VCF does not have
@@ -63,6 +68,8 @@ def _fst_case(tmp_path, rng, args, size, step, n_sites=900, n_samples=24, scaffo
         bed = str(tmp_path / "accessible.bed")
         open(bed, "w").write("".join("%s\t%d\t%d\n" % row for row in bed_rows))
         cmd += ["--accessibleGenomeBED=" + bed]
+    if anc_sets:
+        cmd += ["--ancSets=" + anc_sets]
     annot = None
     if annot_text is not None:
         annot = str(tmp_path / "genes.gffExtract")
@@ -71,7 +78,7 @@ def _fst_case(tmp_path, rng, args, size, step, n_sites=900, n_samples=24, scaffo
     r = subprocess.run(cmd, cwd=str(cli_dir), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     O.fst_run(vcf, sets, str(orc_dir), run_name="run", size=size, step=step, phys=phys, reg_above=reg_above, samples=sf,
-              bed=bed, annot=annot)
+              bed=bed, annot=annot, anc_sets=anc_sets)
     _same_files(str(cli_dir), str(orc_dir))
     return r
 
@@ -139,6 +146,14 @@ def test_cli_fst_annot_snp_categories(tmp_path):
     r = _fst_case(tmp_path, np.random.default_rng(43), ["-w", "20,20"], 20, 20, annot_text="\n".join(rows) + "\n")
     cats = [l.split("\t")[0] for l in (tmp_path / "cli" / "runSNPcategory_fst.txt").read_text().splitlines()[1:]]
     assert {"exon", "intron", "other non-coding"} <= set(cats) and len(cats) > 500
+
+
+def test_cli_fst_anc_sets(tmp_path):
+    """--ancSets (process_vcf_fst.cpp:563-588): runancestralSNPs_fst.txt; ancestral allele = REF, = ALT, and neither
+    ("-888"), on lines with '*' alleles and missing calls too."""
+    _fst_case(tmp_path, np.random.default_rng(44), ["-w", "25,25"], 25, 25, anc=True)
+    rows = [l.split("\t") for l in (tmp_path / "cli" / "runancestralSNPs_fst.txt").read_text().splitlines()[1:]]
+    assert len(rows) > 500 and {r[2] for r in rows} >= {"-888", "0"} and {r[4] for r in rows} == {"0", "1"}
 
 
 def test_cli_fst_sc3749(tmp_path):
