@@ -14,8 +14,9 @@
 // window state machines over those per-site values, so that the text outputs -- including the
 // reference's load-bearing quirks -- are byte-identical.  Output goes
 // through iostreams with default formatting, exactly like the reference.
-// Not carried over: --annot, --ancSets, --ms*, --eigen (fst: --accessibleGenomeBED is) (host-side
-// consumers / other modes, out of scope).
+// The optional host-side consumers of the per-site values are carried too: --annot (fst, FstGlobal), --ancSets,
+// --accessibleGenomeBED (fst, DistOutgroups), --regions-above.  Not carried over: the --ms* / --eigen modes of `evo fst`
+// (text post-processing of other programs' output, out of scope), PBS --annot / --af.
 #include <getopt.h>
 #include <zlib.h>
 
@@ -312,7 +313,7 @@ struct AccessibleBed {
 // transcript of a scaffold is stored when another scaffold follows, so the file's last scaffold never is; a scaffold
 // that comes back replaces its entry; two transcripts of one name share the later one's exon line.
 struct GeneAnnotation {
-    struct Transcript { string name, start, end, exonStart, exonEnd; };
+    struct Transcript { string name, start, end, exonStart, exonEnd, strand; std::vector<std::pair<int, int>> exons; };
     std::map<string, std::vector<Transcript>> scaffolds;
     static string transcriptName(const string &geneColumn, bool &partial) {
         std::vector<string> parts = split(geneColumn, '-');
@@ -328,11 +329,19 @@ struct GeneAnnotation {
             Transcript t;
             t.name = first[4];
             if (first[3] == "+") { t.start = first[1]; t.end = last[2]; } else { t.end = first[2]; t.start = last[1]; }
-            t.exonStart = first[1]; t.exonEnd = first[2];
+            t.exonStart = first[1]; t.exonEnd = first[2]; t.strand = first[3];
+            for (const string &l : transcripts[i]) {
+                std::vector<string> f = split(l, '\t');
+                if (f.size() < 3) die("annotation lines need five tab-separated columns");
+                t.exons.emplace_back(atoi(f[1].c_str()), atoi(f[2].c_str()));
+            }
             lastOfName[t.name] = i;
             kept.push_back(t);
         }
-        for (Transcript &t : kept) { const Transcript &l = kept[lastOfName[t.name]]; const string a = l.exonStart, b = l.exonEnd; t.exonStart = a; t.exonEnd = b; }
+        for (size_t i = 0; i < kept.size(); ++i) {
+            const size_t l = lastOfName[kept[i].name];
+            if (l != i) { kept[i].exonStart = kept[l].exonStart; kept[i].exonEnd = kept[l].exonEnd; kept[i].exons = kept[l].exons; }
+        }
         scaffolds[scaffold] = kept;
         transcripts.clear();
     }
@@ -367,6 +376,25 @@ struct GeneAnnotation {
                 if (locus >= t.exonStart && locus <= t.exonEnd) return "exon";
             }
         return c;
+    }
+    // getSNPgeneDetails (process_vcf_annotation_tools.cpp:39-80), the lookup of FstGlobal --annot: integers here, every
+    // line of the transcript, promoters 3 kb upstream by strand; the first transcript that holds the locus decides
+    const char *geneDetails(const string &scaffold, int locus, const string *&gene) const {
+        static const string none;
+        gene = &none;
+        auto it = scaffolds.find(scaffold);
+        if (it == scaffolds.end()) return "nonCoding";
+        for (const Transcript &t : it->second) {
+            const int geneStart = atoi(t.start.c_str()), geneEnd = atoi(t.end.c_str());
+            if (t.strand == "+") { if (locus >= geneStart - 3000 && locus < geneStart) { gene = &t.name; return "promoter"; } }
+            else if (t.strand == "-") { if (locus > geneEnd && locus <= geneEnd + 3000) { gene = &t.name; return "promoter"; } }
+            if (locus >= geneStart && locus <= geneEnd) {
+                gene = &t.name;
+                for (const auto &ex : t.exons) if (locus >= ex.first && locus <= ex.second) return "exon";
+                return "intron";
+            }
+        }
+        return "nonCoding";
     }
 };
 
@@ -875,7 +903,7 @@ int fstMain(int argc, char **argv) {
 // ====================================================================================== FstGlobal
 
 namespace gopt {
-string vcfFile, setsFile, runName = "";
+string vcfFile, setsFile, runName = "", annotFile;
 int fixedWindowSize = 10000, windowSize = 20, windowStep = 10;
 }
 
@@ -885,11 +913,12 @@ const char *FSTGLOBAL_USAGE =
     "       -h, --help                              display this help and exit\n"
     "       -f, --fixedW sizeKb                     fixed window size (default: 10kb)\n"
     "       -w SIZE,STEP --window=SIZE,STEP         sliding window: SIZE SNPs, moving by STEP (default: 20,10)\n"
-    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file name\n\n";
+    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file name\n"
+    "       --annot=ANNOTATION.gffExtract           (optional) gene annotation: writes RUN_FstGlobalGenes_RUN_SIZE_STEP.txt, one row per gene\n\n";
 
 void parseFstGlobalOptions(int argc, char **argv) {
     static const struct option longopts[] = {{"fixedW", required_argument, NULL, 'f'}, {"window", required_argument, NULL, 'w'},
-                                             {"annot", required_argument, NULL, OPT_UNSUPPORTED}, {"help", no_argument, NULL, 'h'},
+                                             {"annot", required_argument, NULL, OPT_ANNOT}, {"help", no_argument, NULL, 'h'},
                                              {"run-name", required_argument, NULL, 'n'}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
     std::vector<string> ws;
@@ -904,7 +933,7 @@ void parseFstGlobalOptions(int argc, char **argv) {
                 gopt::windowSize = atoi(ws[0].c_str()); gopt::windowStep = atoi(ws[1].c_str());
                 break;
             case 'n': arg >> gopt::runName; break;
-            case OPT_UNSUPPORTED: die("--annot is not carried by the GPU build");
+            case OPT_ANNOT: arg >> gopt::annotFile; break;
             case 'h': std::cout << FSTGLOBAL_USAGE; exit(EXIT_SUCCESS);
         }
     }
@@ -948,6 +977,22 @@ int FstGlobalMain(int argc, char **argv) {
     outFW << std::endl;
 
     const size_t nUse = populationsToUse.size();
+    // --annot (FstAgainstAll.cpp:66-72, 107-116, 215-219, 267-297): per gene the kept SNPs in its exons, introns and promoter
+    // and each population's Fst over them.  A row is written when a SNP of another gene arrives, after that SNP's own
+    // values have joined the sums -- the reference's order, kept.
+    GeneAnnotation annotation;
+    const bool haveAnnot = !annotFile.empty();
+    std::ofstream outFileGenes;
+    std::vector<std::vector<double>> geneNum(nUse * 3), geneDen(nUse * 3);   // [population][exon | intron | promoter]
+    string currentGene, previousGene;
+    if (haveAnnot) {
+        annotation.load(annotFile);
+        outFileGenes.open((runName + "_FstGlobalGenes_" + runName + "_" + numToString(windowSize) + "_" + numToString(windowStep) + ".txt").c_str());
+        outFileGenes << "gene\t" << "numSNPsExons\tnumSNPsIntrons\tnumSNPs3kbPromoter";
+        for (size_t i = 0; i < nUse; i++) outFileGenes << "\t" << populationsToUse[i] << "_exons" << "\t" << populationsToUse[i] << "_wIntrons" << "\t" << populationsToUse[i] << "_promoter";
+        outFileGenes << std::endl;
+    }
+    std::vector<double> numAll, denAll;
     int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
     int totalVariantNumber = 0;
     int64_t usedBefore = 0, keptBefore = 0;          // used / kept sites of the batches before this one (:189, :204)
@@ -1002,6 +1047,11 @@ int FstGlobalMain(int argc, char **argv) {
         }
         // kept sites in order: the fixed-window table, and the deque contents behind this batch
         kept.resize(n);
+        if (haveAnnot) {
+            numAll.resize(nUse * n); denAll.resize(nUse * n);
+            check(dev.ctx, evofst_get_global_site_stats(dev.ctx, 0, (int64_t)n, numAll.data(), denAll.data(), kept.data()), "global_site_stats");
+            x86_nan_sign(numAll); x86_nan_sign(denAll);
+        } else
         check(dev.ctx, evofst_get_global_site_stats(dev.ctx, 0, (int64_t)n, nullptr, nullptr, kept.data()), "global_site_stats");
         size_t tailFrom = n; int tailKept = 0;
         for (size_t s = n; s-- > 0 && tailKept < windowSize;)
@@ -1010,6 +1060,31 @@ int FstGlobalMain(int argc, char **argv) {
             if ((batch.flags[s] & EVOFST_SITE_SKIP) || !kept[s]) continue;
             const string &chr = batch.chrom[s];
             double coordDouble; { std::stringstream ss(batch.pos[s]); ss >> coordDouble; }
+            if (haveAnnot) {                                         // :215-219, 267-275, 283-297
+                const string *gene;
+                const string category = annotation.geneDetails(chr, atoi(batch.pos[s].c_str()), gene);
+                if (!gene->empty()) {
+                    currentGene = *gene;
+                    if (previousGene.empty()) previousGene = currentGene;
+                    const int cat = category == "exon" ? 0 : category == "intron" ? 1 : category == "promoter" ? 2 : -1;
+                    if (cat >= 0)
+                        for (size_t i = 0; i < nUse; ++i) { geneNum[i * 3 + cat].push_back(numAll[i * n + s]); geneDen[i * 3 + cat].push_back(denAll[i * n + s]); }
+                }
+                if (!previousGene.empty() && currentGene != previousGene) {
+                    const int nExonSNPs = (int)geneNum[0].size(), nIntronSNPs = (int)geneNum[1].size(), nPromoterSNPs = (int)geneNum[2].size();
+                    const int counts[3] = {nExonSNPs, nIntronSNPs, nPromoterSNPs};
+                    outFileGenes << previousGene << "\t" << nExonSNPs << "\t" << nIntronSNPs << "\t" << nPromoterSNPs;
+                    for (size_t i = 0; i < nUse; i++)
+                        for (int c3 = 0; c3 < 3; ++c3) {
+                            double f = counts[c3] > 0 ? vector_average(geneNum[i * 3 + c3]) / vector_average(geneDen[i * 3 + c3]) : 0;
+                            if (f < 0) f = 0;
+                            outFileGenes << "\t" << f;
+                            geneNum[i * 3 + c3].clear(); geneDen[i * 3 + c3].clear();
+                        }
+                    outFileGenes << std::endl;
+                    previousGene = currentGene;
+                }
+            }
             if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {   // :222-235
                 outFW << chr << "\t" << currentWindowStart << "\t" << currentWindowEnd << "\t" << 0;
                 for (size_t i = 0; i != nUse; i++) { double FstFW = 0; outFW << "\t" << FstFW; }

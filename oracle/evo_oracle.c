@@ -661,7 +661,7 @@ static const orc_bed *g_fst_bed = NULL;                /* set by orc_fst_run_bed
  * is tried as an exon (:203-209, the break); the exon lines are looked up by transcript name, so of two transcripts
  * with one name in a scaffold the later one's lines serve both (:100).  The reference leaves the partial flag of the
  * file's first transcript uninitialized unless its first line is partial (:265); it is taken as false here. */
-typedef struct { char *name, *start, *end, *exon_start, *exon_end; } annot_tr;
+typedef struct { char *name, *start, *end, *exon_start, *exon_end, *strand; int *ex_s, *ex_e, n_ex; } annot_tr;   /* ex_*: every line of the transcript's exon entry, as atoi reads it */
 typedef struct { char *name; annot_tr *tr; int n; } annot_scaffold;
 struct orc_annot { annot_scaffold *sc; int n, cap; };
 
@@ -695,7 +695,8 @@ static void annot_trs_push(annot_trs *a, annot_lines *t) {      /* takes the lin
 }
 static void annot_lines_clear(annot_lines *t) { for (int i = 0; i < t->n; i++) free(t->lines[i]); free(t->lines); t->lines = NULL; t->n = t->cap = 0; }
 static void annot_scaffold_free(annot_scaffold *e) {
-    for (int i = 0; i < e->n; i++) { free(e->tr[i].name); free(e->tr[i].start); free(e->tr[i].end); free(e->tr[i].exon_start); free(e->tr[i].exon_end); }
+    for (int i = 0; i < e->n; i++) { free(e->tr[i].name); free(e->tr[i].start); free(e->tr[i].end); free(e->tr[i].exon_start); free(e->tr[i].exon_end);
+                                     free(e->tr[i].strand); free(e->tr[i].ex_s); free(e->tr[i].ex_e); }
     free(e->tr); free(e->name);
 }
 /* annotationMap[scaffold] = annotation (:285) followed by annotateGeneStartsEnds (annotation_tools.cpp:84-109) */
@@ -709,12 +710,20 @@ static int annot_store(orc_annot *a, const char *scaffold, annot_trs *trs) {
         if (strand && strcmp(strand, "+") == 0) { e.tr[i].start = annot_field(first, 1); e.tr[i].end = annot_field(last, 2); }
         else { e.tr[i].end = annot_field(first, 2); e.tr[i].start = annot_field(last, 1); }
         if (!strand || !e.tr[i].name || !e.tr[i].start || !e.tr[i].end) bad = 1;
-        free(strand);
+        e.tr[i].strand = strand;
     }
     for (int i = 0; i < trs->n && !bad; i++) {                    /* exons by name: the last transcript of that name (:100) */
         int k = i;
         for (int j = trs->n - 1; j > i; j--) if (strcmp(e.tr[j].name, e.tr[i].name) == 0) { k = j; break; }
         e.tr[i].exon_start = annot_field(trs->t[k].lines[0], 1); e.tr[i].exon_end = annot_field(trs->t[k].lines[0], 2);
+        e.tr[i].n_ex = trs->t[k].n;
+        e.tr[i].ex_s = (int *)malloc(sizeof(int) * (size_t)trs->t[k].n); e.tr[i].ex_e = (int *)malloc(sizeof(int) * (size_t)trs->t[k].n);
+        for (int x = 0; x < trs->t[k].n; x++) {
+            char *a = annot_field(trs->t[k].lines[x], 1), *b = annot_field(trs->t[k].lines[x], 2);
+            e.tr[i].ex_s[x] = a ? atoi(a) : 0; e.tr[i].ex_e[x] = b ? atoi(b) : 0;
+            if (!a || !b) bad = 1;
+            free(a); free(b);
+        }
     }
     for (int i = 0; i < trs->n; i++) annot_lines_clear(&trs->t[i]);
     trs->n = 0;
@@ -791,6 +800,30 @@ const char *orc_annot_category(const orc_annot *a, const char *scaffold, const c
         }
     }
     return category;
+}
+/* Annotation::getSNPgeneDetails (process_vcf_annotation_tools.cpp:39-80): positions as integers here; the first
+ * transcript of the scaffold whose promoter (3 kb upstream, by strand) or body holds the locus decides.  *gene = its
+ * name ("" when none), returns "promoter", "exon", "intron" or "nonCoding". */
+const char *orc_annot_gene_details(const orc_annot *a, const char *scaffold, int locus, const char **gene) {
+    *gene = "";
+    const annot_scaffold *e = NULL;
+    for (int i = 0; i < a->n; i++) if (strcmp(a->sc[i].name, scaffold) == 0) e = &a->sc[i];
+    if (!e) return "nonCoding";
+    for (int i = 0; i < e->n; i++) {
+        const annot_tr *t = &e->tr[i];
+        int geneStart = atoi(t->start), geneEnd = atoi(t->end);
+        if (strcmp(t->strand, "+") == 0) {
+            if (locus >= geneStart - 3000 && locus < geneStart) { *gene = t->name; return "promoter"; }
+        } else if (strcmp(t->strand, "-") == 0) {
+            if (locus > geneEnd && locus <= geneEnd + 3000) { *gene = t->name; return "promoter"; }
+        }
+        if (locus >= geneStart && locus <= geneEnd) {
+            *gene = t->name;
+            for (int x = 0; x < t->n_ex; x++) if (locus >= t->ex_s[x] && locus <= t->ex_e[x]) return "exon";
+            return "intron";
+        }
+    }
+    return "nonCoding";
 }
 static const orc_annot *g_fst_annot = NULL;            /* set by orc_fst_run_opts for the duration of one run */
 static FILE *g_fst_annot_out = NULL;
@@ -1154,6 +1187,18 @@ static int cmp_pop(const void *a, const void *b) {
     return strcmp(((const pop_t *)a)->name, ((const pop_t *)b)->name);
 }
 
+static const char *g_global_annot_path = NULL;         /* set by orc_fstglobal_run_annot for the duration of one run */
+/* the same with --annot (evo_FstAgainstAll.cpp:66-72, :107-116, :215-219, :267-275, :283-297): a row per gene in
+ * <run>_FstGlobalGenes_<run>_<SIZE>_<STEP>.txt, written when a SNP of another gene arrives -- after that SNP's own
+ * values have joined the vectors, so it is averaged into the gene before it and lost to its own (:267-297). */
+int orc_fstglobal_run_annot(const char *vcf_path, const char *pops_path, int windowSize, int windowStep, int fixedWindowSize,
+                            const char *run_name, const char *out_dir, const char *annot_path) {
+    g_global_annot_path = annot_path && annot_path[0] ? annot_path : NULL;
+    int rc = orc_fstglobal_run(vcf_path, pops_path, windowSize, windowStep, fixedWindowSize, run_name, out_dir);
+    g_global_annot_path = NULL;
+    return rc;
+}
+
 int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
                       int windowSize, int windowStep, int fixedWindowSize,
                       const char *run_name, const char *out_dir) {
@@ -1212,6 +1257,20 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
     fprintf(outFW, "chr\tpos1\tpos2\tnSNPs");                /* :104: pop names go to outFile (sic) */
     for (int u = 0; u < n_use; u++) fprintf(outFile, "\t%s", pops[use_idx[u]].name);
     fprintf(outFW, "\n");
+    orc_annot *an = NULL; FILE *outGenes = NULL;             /* :66-72, :107-116 */
+    dvec *geneN = NULL, *geneD = NULL;                       /* [n_use][3]: exon, intron, promoter */
+    char *currentGene = strdup(""), *previousGene = strdup("");
+    if (g_global_annot_path) {
+        an = orc_annot_load(g_global_annot_path);
+        if (!an) { fprintf(stderr, "Error: could not read %s\n", g_global_annot_path); lr_close(&vcf); return -5; }
+        snprintf(name, sizeof name, "%s_FstGlobalGenes_%s_%d_%d.txt", run_name, run_name, windowSize, windowStep);
+        char *p3 = path_join(out_dir, name); outGenes = fopen(p3, "w"); free(p3);
+        if (!outGenes) { lr_close(&vcf); return -3; }
+        fprintf(outGenes, "gene\tnumSNPsExons\tnumSNPsIntrons\tnumSNPs3kbPromoter");
+        for (int u = 0; u < n_use; u++) fprintf(outGenes, "\t%s_exons\t%s_wIntrons\t%s_promoter", pops[use_idx[u]].name, pops[use_idx[u]].name, pops[use_idx[u]].name);
+        fprintf(outGenes, "\n");
+        geneN = (dvec *)calloc((size_t)n_use * 3 + 1, sizeof(dvec)); geneD = (dvec *)calloc((size_t)n_use * 3 + 1, sizeof(dvec));
+    }
 
     size_t nu = (size_t)n_use;
     double *dqN = (double *)calloc((size_t)windowSize * (nu + 1), sizeof(double));
@@ -1268,6 +1327,14 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
             int k0 = use_idx[0];
             if (aaf[k0] == 0 && aafC[k0] == 0) continue;     /* :198-203 */
             if (aaf[k0] == 1 && aafC[k0] == 1) continue;
+            const char *snpGene = "", *snpCategory = "nonCoding";                        /* :215-219 */
+            if (an) {
+                snpCategory = orc_annot_gene_details(an, chr, atoi(coord), &snpGene);
+                if (snpGene[0]) {
+                    free(currentGene); currentGene = strdup(snpGene);
+                    if (!previousGene[0]) { free(previousGene); previousGene = strdup(currentGene); }
+                }
+            }
 
             if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {   /* :222-235 */
                 fprintf(outFW, "%s\t%d\t%d\t%d", chr, currentWindowStart, currentWindowEnd, 0);
@@ -1297,6 +1364,10 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
                 } else { FstNum = 0; FstDenom = 0; }
                 dqN[(size_t)newest * (nu + 1) + (size_t)u] = FstNum;
                 dqD[(size_t)newest * (nu + 1) + (size_t)u] = FstDenom;
+                if (an && snpGene[0]) {                          /* :267-275 */
+                    int cat = strcmp(snpCategory, "exon") == 0 ? 0 : strcmp(snpCategory, "intron") == 0 ? 1 : strcmp(snpCategory, "promoter") == 0 ? 2 : -1;
+                    if (cat >= 0) { dv_push(&geneN[u * 3 + cat], FstNum); dv_push(&geneD[u * 3 + cat], FstDenom); }
+                }
                 if (emit) {
                     double sn = 0, sd = 0;
                     for (int t = 0; t < windowSize; t++) {
@@ -1309,9 +1380,27 @@ int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
                     fprintf(outFile, "\t%g", Fst);
                 }
             }
+            if (an && previousGene[0] && strcmp(currentGene, previousGene) != 0) {   /* :283-297 */
+                int nEx = (int)geneN[0].n, nIn = (int)geneN[1].n, nPr = (int)geneN[2].n;
+                fprintf(outGenes, "%s\t%d\t%d\t%d", previousGene, nEx, nIn, nPr);
+                for (int u = 0; u < n_use; u++) {
+                    double f[3]; int cnt[3] = {nEx, nIn, nPr};
+                    for (int c3 = 0; c3 < 3; c3++) {
+                        f[c3] = cnt[c3] > 0 ? orc_vector_average(geneN[u * 3 + c3].v, geneN[u * 3 + c3].n) / orc_vector_average(geneD[u * 3 + c3].v, geneD[u * 3 + c3].n) : 0;
+                        if (f[c3] < 0) f[c3] = 0;
+                        dv_clear(&geneN[u * 3 + c3]); dv_clear(&geneD[u * 3 + c3]);
+                    }
+                    fprintf(outGenes, "\t%g\t%g\t%g", f[0], f[1], f[2]);
+                }
+                fprintf(outGenes, "\n");
+                free(previousGene); previousGene = strdup(currentGene);
+            }
             if (emit) fprintf(outFile, "\n");
         }
     }
+    if (outGenes) fclose(outGenes);
+    if (geneN) { for (int i = 0; i < n_use * 3; i++) { dv_free(&geneN[i]); dv_free(&geneD[i]); } free(geneN); free(geneD); }
+    orc_annot_free(an); free(currentGene); free(previousGene);
     fclose(outFile); fclose(outFW); lr_close(&vcf);
     for (int i = 0; i < windowSize; i++) free(coordDeque[i]);
     free(coordDeque); free(dqN); free(dqD); free(fields); free(sample_pop);

@@ -205,6 +205,10 @@ int orc_accessible_bp(const int *starts, const int *ends, int n, int start, int 
 int orc_fstglobal_run(const char *vcf_path, const char *pops_path,
                       int window_size, int window_step, int fixed_window_size,
                       const char *run_name, const char *out_dir);
+/* with --annot (annot_path may be NULL or ""): one row per gene, evo_FstAgainstAll.cpp:107-116, 215-219, 267-297 */
+int orc_fstglobal_run_annot(const char *vcf_path, const char *pops_path, int window_size, int window_step, int fixed_window_size,
+                            const char *run_name, const char *out_dir, const char *annot_path);
+const char *orc_annot_gene_details(const orc_annot *a, const char *scaffold, int locus, const char **gene);
 
 /* calculatePBSfromAFs (evo_PBS.cpp:69-98) and the per-site rules of PBSmain (:304-322) on counts:
  * pbs [n_trios][3][n_sites], used [n_trios][n_sites].  No reference build or fixture covers these: parity unpinned. */

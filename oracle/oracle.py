@@ -493,6 +493,27 @@ def fst_run(vcf, sets, out_dir, run_name="", size=0, step=0, phys=10000, reg_abo
     return summ
 
 
+def annot_gene_details(annot_path, queries):
+    """getSNPgeneDetails (process_vcf_annotation_tools.cpp:39-80) of (scaffold, position) pairs: [(gene, category)]."""
+    L = lib()
+    L.orc_annot_load.restype = C.c_void_p; L.orc_annot_load.argtypes = [C.c_char_p]
+    L.orc_annot_free.argtypes = [C.c_void_p]
+    L.orc_annot_gene_details.restype = C.c_char_p
+    L.orc_annot_gene_details.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p)]
+    a = L.orc_annot_load(annot_path.encode())
+    if not a:
+        raise RuntimeError("orc_annot_load failed")
+    try:
+        out = []
+        for sc, loc in queries:
+            g = C.c_char_p()
+            cat = L.orc_annot_gene_details(a, sc.encode(), int(loc), C.byref(g)).decode()
+            out.append((g.value.decode(), cat))
+        return out
+    finally:
+        L.orc_annot_free(a)
+
+
 def annot_categories(annot_path, queries):
     """getCategoryOfSNP (process_vcf_annotation_tools.h:190-214) of (scaffold, position string) pairs."""
     L = lib()
@@ -579,10 +600,13 @@ def af_run(vcf, pops, out_dir, run_name="out"):
         raise RuntimeError("orc_af_run failed: %d" % rc)
 
 
-def fstglobal_run(vcf, pops, out_dir, run_name="", size=20, step=10, fixed=10000):
+def fstglobal_run(vcf, pops, out_dir, run_name="", size=20, step=10, fixed=10000, annot=None):
     if size <= 0 or step <= 0:
         raise ValueError("FstGlobal needs positive window size and step")
-    rc = lib().orc_fstglobal_run(vcf.encode(), pops.encode(), size, step, fixed,
-                                 run_name.encode(), out_dir.encode())
+    L = lib()
+    L.orc_fstglobal_run_annot.restype = C.c_int
+    L.orc_fstglobal_run_annot.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+    rc = L.orc_fstglobal_run_annot(vcf.encode(), pops.encode(), size, step, fixed, run_name.encode(), out_dir.encode(),
+                                   (annot or "").encode())
     if rc != 0:
         raise RuntimeError("orc_fstglobal_run failed: %d" % rc)

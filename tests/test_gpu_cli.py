@@ -169,7 +169,7 @@ def test_cli_fst_sc3749(tmp_path):
     assert "Fst: 0.0962099" in r.stderr
 
 
-def _global_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=1200, n_samples=36, crlf=False, pops=None):
+def _global_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=1200, n_samples=36, crlf=False, pops=None, annot_text=None):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=0.1)
     pops = pops or ["popA", "popB", "Outgroup", "popC"]
@@ -182,11 +182,17 @@ def _global_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=1200, n_s
         f.write("GHOST\t%s\n" % pops[0])                          # ID the VCF does not have
     cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
     cli_dir.mkdir(); orc_dir.mkdir()
+    annot = None
+    if annot_text is not None:
+        annot = str(tmp_path / "genes.gffExtract")
+        open(annot, "w").write(annot_text)
+        args = args + ["--annot=" + annot]
     r = subprocess.run([EVO, "FstGlobal", "-n", "g"] + args + [vcf, pf], cwd=str(cli_dir), capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
-    O.fstglobal_run(vcf, pf, str(orc_dir), run_name="g", size=size, step=step, fixed=fixed)
+    O.fstglobal_run(vcf, pf, str(orc_dir), run_name="g", size=size, step=step, fixed=fixed, annot=annot)
     _same_files(str(cli_dir), str(orc_dir))
+    return cli_dir
 
 
 def test_cli_fstglobal_default(tmp_path):
@@ -195,6 +201,25 @@ def test_cli_fstglobal_default(tmp_path):
 
 def test_cli_fstglobal_equal_windows_crlf(tmp_path):
     _global_case(tmp_path, np.random.default_rng(8), ["-w", "25,25", "-f", "3000"], 25, 25, fixed=3000, crlf=True)
+
+
+def test_cli_fstglobal_annot_gene_rows(tmp_path):
+    """FstGlobal --annot (evo_FstAgainstAll.cpp:215-219, 267-297): one row per gene with its exon / intron / promoter SNP
+    counts and every population's Fst over them; genes on both strands, genes without a kept SNP in some category, a
+    partial transcript, and the first SNP of a gene going into the row of the gene before it."""
+    rows = []
+    for k in range(14):
+        a = 4000 + 5500 * k
+        ex = [(a, a + 300), (a + 900, a + 1300), (a + 2000, a + 2400)]
+        if k % 2:
+            ex.reverse()
+        name = ("5partial-" if k == 5 else "") + "tr%d" % k
+        rows += ["chr1\t%d\t%d\t%s\t%s" % (s, e, "-" if k % 2 else "+", name) for s, e in ex]
+    rows += ["chr2\t1000\t30000\t+\tbig.1", "chr2\t40000\t40100\t-\tsmall", "chr2\t45000\t45100\t-\tsmall",
+             "chrZ\t1\t10\t+\tlast"]
+    d = _global_case(tmp_path, np.random.default_rng(71), ["-w", "20,10"], 20, 10, annot_text="\n".join(rows) + "\n")
+    genes = (d / "g_FstGlobalGenes_g_20_10.txt").read_text().splitlines()
+    assert len(genes) > 10 and genes[0].startswith("gene\tnumSNPsExons")
 
 
 def test_cli_fstglobal_outgroup_sorts_first(tmp_path):

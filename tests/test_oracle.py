@@ -271,6 +271,14 @@ def test_annotation_category_quirks(tmp_path):
                    "other non-coding",     # "100" < "1000" (a prefix is smaller)
                    "exon",                 # s2: "1000" lies between "100" and "900"
                    "other non-coding"]     # "95" > "900"
+    # getSNPgeneDetails (process_vcf_annotation_tools.cpp:39-80) compares integers, looks through every line of the
+    # transcript, knows promoters (3 kb upstream by strand) and stops at the first transcript that holds the locus
+    q = [("s1", 999), ("s1", 1100), ("s1", 1500), ("s1", 2200), ("s1", 2600), ("s1", 5300), ("s1", 8201), ("s1", 4050),
+         ("s1", 4500), ("s1", 15), ("s2", 95), ("s2", 1000), ("s3", 500)]
+    assert O.annot_gene_details(str(an), q) == [
+        ("g.1.1.1.1", "promoter"), ("g.1.1.1.1", "exon"), ("g.1.1.1.1", "intron"), ("g.1.1.1.1", "exon"),
+        ("", "nonCoding"), ("g2", "promoter"), ("g5", "promoter"), ("g2", "exon"), ("g2", "intron"), ("g.1.1.1.1", "promoter"),
+        ("h1", "promoter"), ("", "nonCoding"), ("", "nonCoding")]
 
 
 def test_dist_windows_against_numpy():
