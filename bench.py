@@ -141,7 +141,8 @@ def hbm_leg(device, steps=10):
     k = km.mean(axis=0)
     cb = e.geometry().count_bytes
     g = np.gcd(cfg["size"], cfg["step"])
-    k1_bytes = S * (N / 2.0) + S * P * cb + S / 64.0 * (2 * P + 3) * 8.0
+    cbw = 1 if cb == 2 and not cfg.get("miss") else cb     # clean chunks leave one byte per count (K1Params::compact)
+    k1_bytes = S * (N / 2.0) + S * P * cbw + S / 64.0 * (2 * P + 3) * 8.0
     e.close()
     return {"workload": cfg["label"], "ms_per_step": dt * 1e3, "site_pairs_per_s": S * 190 / dt, "bound": "hbm",
             "kernel": "k1_count_kernel", "algorithmic_bytes": k1_bytes, "achieved": k1_bytes / (k[0] * 1e-3) / 1e9 if k[0] > 0 else 0.0,
@@ -409,8 +410,10 @@ def main():
         k2_bytes = 0.0
     elif cfg["mode"] == "pairs":
         g = np.gcd(cfg["size"], cfg["step"]) if cfg["size"] else 10**9
-        k1_bytes += S / 64.0 * (2 * P + 2) * 8.0         # zero / fixed / irregular / skip masks written
-        k2_bytes = S * P * cb + S / 64.0 * (2 * P + 2) * 8.0 + (S / g) * e.n_pairs * 28.0   # counts + masks read, segment rows written
+        # data without missing calls: every chunk is clean and holds one byte per count (K1Params::compact)
+        cbw = 1 if cb == 2 and not cfg.get("miss") and e.n_pairs <= 256 else cb
+        k1_bytes += S * P * (cbw - cb) + S / 64.0 * (2 * P + 2) * 8.0         # zero / fixed / irregular / skip masks written
+        k2_bytes = S * P * cbw + S / 64.0 * (2 * P + 2) * 8.0 + (S / g) * e.n_pairs * 28.0   # counts + masks read, segment rows written
     else:
         k2_bytes = S * P * cb + S * 8.0 + (S / cfg["step"]) * P * 16.0
     names = ["k1_count_kernel", "scan_kernel",

@@ -102,7 +102,9 @@ struct evofst_ctx {
     DevBuf d_agg0, d_agg1, d_agg2, d_fsync, d_miss, d_dirty, d_poison, d_nan;
     uint32_t epoch = 0;
     bool fused_check = false;         // a fused launch has not had its error word looked at yet
-    bool plain_counts = false;        // d_counts holds the counts of the loaded data (from any K1 launch)
+    bool plain_counts = false;        // d_counts holds the packed counts of the loaded data, every tile (from any K1 launch)
+    bool compact_counts = false;      // d_counts comes from a pairs-mode K1 that left one byte per count in its clean chunks
+    bool prefer_plain = false;        // a getter has asked for per-site values on this context: K1 keeps to packed counts
     bool counts_done = false, stats_done = false;
     bool profiling = false;
     hipEvent_t ev[kNumKernels][2] = {};
@@ -424,7 +426,19 @@ int launch_k1_counts(evofst_ctx *c, int mode);
 int need_counts(evofst_ctx *c, const char *who) {
     if (c->plain_counts) return EVOFST_OK;
     if (c->n_sites == 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, std::string(who) + ": no data");
+    if (c->compact_counts) c->prefer_plain = true;   // this caller reads per-site values: later batches skip the one-byte form
     return launch_k1_counts(c, MODE_COUNTS);
+}
+
+// The walk of run_stats that takes K1's clean chunks (clean_walk_kernel): the condition K1 and run_stats share.
+bool clean_walk_applies(const evofst_ctx *c) {
+    const size_t np = c->pairs.size();
+    if (c->mode != MODE_PAIRS || c->count_bytes != 2 || np == 0 || np > (size_t)kK2Threads) return false;
+    if (getenv("EVOFST_OLD_K2") || getenv("EVOFST_NO_CLEAN_WALK")) return false;
+    const int piece_tiles = std::max(1, std::min(2, c->chunk_tiles));
+    const int max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
+    if (fused_lds_bytes(c->n_pops, 0, max_n, (int)np, 2 * piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, 32) > 100 * 1024) return false;
+    return clean_walk_lds_bytes(c->n_pops, (int)np, piece_tiles, false) <= 64 * 1024;
 }
 
 }  // namespace
@@ -511,6 +525,7 @@ extern "C" int evofst_set_layout(evofst_ctx *c, int n_samples, int n_pops, const
     if (!c) return EVOFST_ERR_ARG;
     if (n_samples <= 0 || n_pops <= 0 || !sample_pop) return fail(c, EVOFST_ERR_ARG, "set_layout: bad arguments");
     if (n_pops > EVOFST_MAX_POPS) return fail(c, EVOFST_ERR_UNSUPPORTED, "set_layout: too many populations");
+    c->prefer_plain = false;          // a new job: K1 may leave one-byte counts until a getter asks for per-site values
     std::vector<int32_t> size(n_pops, 0);
     for (int i = 0; i < n_samples; ++i) {
         if (sample_pop[i] >= n_pops) return fail(c, EVOFST_ERR_ARG, "set_layout: population index out of range");
@@ -564,7 +579,7 @@ extern "C" int evofst_set_layout(evofst_ctx *c, int n_samples, int n_pops, const
     c->mode = MODE_COUNTS;
     c->pairs.clear(); c->use_idx.clear(); c->thresholds.clear();
     c->counts_done = c->stats_done = false;
-    c->plain_counts = false;
+    c->plain_counts = false; c->compact_counts = false;
     c->cap_sites = 0; c->n_sites = 0;
     if (c->host_only) return EVOFST_OK;
     return upload_layout(c);
@@ -899,7 +914,7 @@ static int begin_data(evofst_ctx *c, int64_t n_sites) {
     if ((int64_t)n_tiles_of(n_sites) * kTileSites > (int64_t)INT_MAX) return fail(c, EVOFST_ERR_UNSUPPORTED, "too many sites for one shard");
     HIPCHK(c, hipSetDevice(c->device));
     c->counts_done = c->stats_done = false;
-    c->plain_counts = false;
+    c->plain_counts = false; c->compact_counts = false;
     c->offsets_dirty = true;
     c->n_multi = 0;
     return EVOFST_OK;
@@ -1220,6 +1235,7 @@ int launch_k1_counts(evofst_ctx *c, int mode) {
         p.chunk_dirty = (uint32_t *)c->d_dirty.p;
         if ((rc = ensure(c, c->d_nan, (size_t)c->n_tiles * 8))) return rc;
         p.nan_mask = (uint64_t *)c->d_nan.p;
+        p.compact = !c->prefer_plain && (size_t)c->n_pops * c->count_bytes <= 64 && clean_walk_applies(c) ? 1 : 0;
     } else if (mode == MODE_GRAM) {
         if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 32))) return rc;
         if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8))) return rc;
@@ -1239,7 +1255,8 @@ int launch_k1_counts(evofst_ctx *c, int mode) {
     record(c, 0, 0);
     HIPCHK(c, launch_k1(p, c->count_bytes, mode, c->stream));
     record(c, 0, 1);
-    c->plain_counts = true;
+    c->plain_counts = !p.compact;
+    c->compact_counts = p.compact != 0;
     if (mode == MODE_COUNTS && c->stats_done) { c->chunk_tiles = keep_ct; c->n_chunks = keep_nc; }
     return EVOFST_OK;
 }
@@ -1270,6 +1287,8 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
     int rc;
     if (c->offsets_dirty && (rc = run_scan(c))) return rc;
     if (c->mode == MODE_PAIRS) {
+        // K1's one-byte counts are for clean_walk_kernel alone: should it not run after all, the counts are made again
+        if (c->compact_counts && !clean_walk_applies(c) && (rc = launch_k1_counts(c, MODE_COUNTS))) return rc;
         const size_t np = c->pairs.size();
         const int64_t g = c->g;
         c->seg_cap = c->n_sites / g + 2;
@@ -1307,9 +1326,9 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
             if (lds <= 100 * 1024) {
                 // chunks without a skipped, irregular or missing-allele site (K1 marks the others) go through the lean
                 // integer walk, the rest through the general one; each kernel leaves the other's chunks alone
-                if (c->count_bytes == 2 && !getenv("EVOFST_NO_CLEAN_WALK") &&
-                    clean_walk_lds_bytes(c->n_pops, (int)np, f.piece_tiles) <= 64 * 1024) {
+                if (clean_walk_applies(c)) {
                     f.chunk_dirty = (const uint32_t *)c->d_dirty.p;
+                    f.compact = c->compact_counts ? 1 : 0;
                     HIPCHK(c, launch_clean_walk(f, c->stream));
                 }
                 HIPCHK(c, launch_fused(f, c->count_bytes, wsub, 0, c->stream));

@@ -822,16 +822,18 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
 // =====================================================================================
 constexpr int kCleanWps = 4;
 
-static size_t clean_region_bytes(int P, int piece_tiles) {
-    return a16((size_t)2 * piece_tiles * P * kTileSites * 2) + a16((size_t)2 * piece_tiles * 2 * P * 8);
+static size_t clean_region_bytes(int P, int piece_tiles, bool compact) {
+    return a16((size_t)2 * piece_tiles * P * kTileSites * (compact ? 1 : 2)) + a16((size_t)2 * piece_tiles * 2 * P * 8);
 }
-size_t clean_walk_lds_bytes(int P, int n_pairs, int piece_tiles) {
-    return 32 * 32 + (n_pairs <= 64 ? kFuseWaves : 1) * clean_region_bytes(P, piece_tiles);
+size_t clean_walk_lds_bytes(int P, int n_pairs, int piece_tiles, bool compact) {
+    return 32 * 32 + (n_pairs <= 64 ? kFuseWaves : 1) * clean_region_bytes(P, piece_tiles, compact);
 }
 
-template <bool WP>
+// CB = bytes per count in the chunks this kernel takes: 2 = K1's packed {c, nm}, 1 = c alone, the chunk's tiles back to
+// back from the chunk's first byte (K1Params::compact)
+template <bool WP, int CB>
 __global__ __launch_bounds__(kK2Threads, kCleanWps) void clean_walk_kernel(FusedParams p) {
-    typedef uint16_t CT;
+    typedef unsigned char CT;                          // LDS and HBM offsets below are in bytes
     constexpr int SUB = 32, SPT = kTileSites / SUB, NW4 = SUB / 4;
     extern __shared__ __align__(16) unsigned char smem[];
     const int P = p.P;
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(kK2Threads, kCleanWps) void clean_walk_kernel(Fused
         pmask[i] = nbv >= 4 ? 0xffffffffu : (nbv <= 0 ? 0u : ((1u << (8 * nbv)) - 1u));
     }
     __syncthreads();
-    const size_t cnt_bytes = a16((size_t)2 * TR * P * kTileSites * sizeof(CT));
+    const size_t cnt_bytes = a16((size_t)2 * TR * P * kTileSites * CB);
     unsigned char *region = smem + 32 * 32 + (WP ? (size_t)wave * (cnt_bytes + a16((size_t)2 * TR * 2 * P * 8)) : 0);
     CT *lcnt = reinterpret_cast<CT *>(region);                            // [2][TR][P][64]
     uint64_t *lzf = reinterpret_cast<uint64_t *>(region + cnt_bytes);     // [2][TR][z|f][P]
@@ -901,9 +903,11 @@ __global__ __launch_bounds__(kK2Threads, kCleanWps) void clean_walk_kernel(Fused
     auto request_piece = [&](int piece) {
         const int g = rg0 + piece * TR, pnt = piece_tiles_of(piece), buf = piece & 1;
         const int v0 = WP ? 0 : wave * 64;
-        const int nvp = pnt * P * kTileSites * (int)sizeof(CT) / 16;
-        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) + (size_t)g * P * kTileSites);
-        uint4 *dst = reinterpret_cast<uint4 *>(lcnt + (size_t)buf * TR * P * kTileSites);
+        const int nvp = pnt * P * kTileSites * CB / 16;
+        // one-byte tiles lie back to back from the chunk's first byte, packed ones at their tile's own place
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const CT *>(p.counts) +
+                                                           (CB == 1 ? (size_t)rg0 * P * kTileSites * 2 + (size_t)piece * TR * P * kTileSites : (size_t)g * P * kTileSites * 2));
+        uint4 *dst = reinterpret_cast<uint4 *>(lcnt + (size_t)buf * TR * P * kTileSites * CB);
         for (int v = v0; v < nvp; v += dn)
             if (v + lane < nvp) __builtin_amdgcn_global_load_lds(src + v + lane, (LdsPtr)(dst + v), 16, 0, 0);
         const int nz = pnt * P;
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(kK2Threads, kCleanWps) void clean_walk_kernel(Fused
     if (rnt > 0) request_piece(0);
     for (int piece = 0; piece < n_pieces; ++piece) {
         const int pnt = piece_tiles_of(piece), gtile0 = rg0 + piece * TR, buf = piece & 1;
-        const CT *lcntp = lcnt + (size_t)buf * TR * P * kTileSites;
+        const CT *lcntp = lcnt + (size_t)buf * TR * P * kTileSites * CB;
         const uint64_t *lzfp = lzf + (size_t)buf * TR * 2 * P;
         __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0): this thread's copies of the piece have landed
         region_sync();
@@ -934,9 +938,18 @@ __global__ __launch_bounds__(kK2Threads, kCleanWps) void clean_walk_kernel(Fused
             }
             constexpr uint32_t kOnes = 0x01010101u;
             uint32_t wi[NW4], wj[NW4];
-            {
+            if (CB == 1) {
                 const uint4 *ri = reinterpret_cast<const uint4 *>(lcntp + ((size_t)ti * P + pi) * kTileSites + sh);
                 const uint4 *rj = reinterpret_cast<const uint4 *>(lcntp + ((size_t)ti * P + pj) * kTileSites + sh);
+#pragma unroll
+                for (int v = 0; v < SUB / 16; ++v) {           // 16 counts a vector, as the dot products want them
+                    const uint4 x = ri[v], y = rj[v];
+                    wi[4 * v] = x.x; wi[4 * v + 1] = x.y; wi[4 * v + 2] = x.z; wi[4 * v + 3] = x.w;
+                    wj[4 * v] = y.x; wj[4 * v + 1] = y.y; wj[4 * v + 2] = y.z; wj[4 * v + 3] = y.w;
+                }
+            } else {
+                const uint4 *ri = reinterpret_cast<const uint4 *>(lcntp + (((size_t)ti * P + pi) * kTileSites + sh) * 2);
+                const uint4 *rj = reinterpret_cast<const uint4 *>(lcntp + (((size_t)ti * P + pj) * kTileSites + sh) * 2);
 #pragma unroll
                 for (int v = 0; v < SUB / 8; ++v) {            // 8 packed {c, nm} pairs -> two words of 4 c bytes
                     const uint4 x = ri[v], y = rj[v];
@@ -996,21 +1009,24 @@ __global__ __launch_bounds__(kK2Threads, kCleanWps) void clean_walk_kernel(Fused
     }
 }
 
+template <bool WP, int CB>
+static hipError_t launch_clean_walk_t(const FusedParams &p, size_t lds, int threads, hipStream_t st) {
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&clean_walk_kernel<WP, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((clean_walk_kernel<WP, CB>), dim3(WP ? (p.n_chunks + kFuseWaves - 1) / kFuseWaves : p.n_chunks), dim3(threads), lds, st, p);
+    return hipGetLastError();
+}
 hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
     if (p.n_pairs > kK2Threads || p.chunk_dirty == nullptr || p.counts == nullptr) return hipErrorInvalidValue;
     const bool wp = p.n_pairs <= 64;
     const int threads = fused_threads(p.n_pairs);
-    const size_t lds = clean_walk_lds_bytes(p.P, p.n_pairs, p.piece_tiles);
+    const size_t lds = clean_walk_lds_bytes(p.P, p.n_pairs, p.piece_tiles, p.compact != 0);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    if (lds > 48 * 1024) {
-        const void *fn = wp ? reinterpret_cast<const void *>(&clean_walk_kernel<true>) : reinterpret_cast<const void *>(&clean_walk_kernel<false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    if (wp) hipLaunchKernelGGL((clean_walk_kernel<true>), dim3((p.n_chunks + kFuseWaves - 1) / kFuseWaves), dim3(threads), lds, st, p);
-    else hipLaunchKernelGGL((clean_walk_kernel<false>), dim3(p.n_chunks), dim3(threads), lds, st, p);
-    return hipGetLastError();
+    if (p.compact) return wp ? launch_clean_walk_t<true, 1>(p, lds, threads, st) : launch_clean_walk_t<false, 1>(p, lds, threads, st);
+    return wp ? launch_clean_walk_t<true, 2>(p, lds, threads, st) : launch_clean_walk_t<false, 2>(p, lds, threads, st);
 }
 
 template <typename CT, bool RCP, bool WP, int SUB, bool HBM>

@@ -98,6 +98,11 @@ struct K1Params {
     uint64_t *skip_mask;      // [n_tiles] (both modes)
     uint32_t *chunk_used_kept;  // [2][n_chunks]
     int32_t debug;              // timing experiments (EVOFST_EXPERIMENTS builds only; results are wrong when set)
+    // pairs mode, 16-bit counts: a chunk without a skipped, irregular or missing-allele site leaves one byte per count
+    // (c alone: nm is the population's n_full there), its tiles back to back from the chunk's first byte
+    // ([chunk_tiles][P][64] bytes at counts + chunk * chunk_tiles * P * 128); every other chunk the packed form above.
+    // chunk_dirty tells the two apart.  Writes are what K1 pays most for.
+    int32_t compact;
 };
 
 // one segment of one pair: sums of the Fst numerators / denominators, sum of sumKij (dxy numerators; integers, exact),
@@ -164,6 +169,7 @@ struct FusedParams {
     const uint32_t *chunk_dirty;    // [n_chunks] from K1, or null: the walk of evofst_fused.hip takes the chunks marked here,
                                     // clean_walk_kernel the others
     int32_t piece_tiles;            // tiles of a region held in LDS at a time
+    int32_t compact;                // the chunks clean_walk_kernel takes hold one byte per count (K1Params::compact)
     int32_t debug;                  // -DEVOFST_EXPERIMENTS builds only (tools/): 1 no look-back waits, 2 no phase B, 4 no tile loads
 };
 
@@ -324,7 +330,7 @@ int fused_threads(int n_pairs);
 int fused_tail_chunks(int n_pairs, int n_chunks);   // entries per pair of the tail table (sub-chunks when every wave owns a part of a chunk)
 // sub: sites per table fill (16 or 32); max_blocks <= 0: as many workgroups as the device holds at once (occupancy query)
 hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_blocks, hipStream_t st);
-size_t clean_walk_lds_bytes(int P, int n_pairs, int piece_tiles);
+size_t clean_walk_lds_bytes(int P, int n_pairs, int piece_tiles, bool compact);
 hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st);
 size_t global_lds_bytes(int tn_max, int max_n, int n_use, int size);
 void global_rcp_split(int tn_max, int max_n, int *lo, int *hi);

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     bool irregular = false, skip = false, anymiss = false;
     uint64_t skipmask = 0;
     bool dirty = false;                                 // wave-uniform: the chunk has a site clean_walk_kernel cannot take
+    int n_compact = 0;                                  // wave-uniform: the chunk's tiles so far, all written one byte per count
     bool nanany = false;                                // this lane's site: some population has fewer than two called alleles
     bool poison = false;                                // wave-uniform, Gram mode: the tile has a site where a population has < 2 called alleles
     int zlo = 0, zhi = 0, flo = 0, fhi = 0, ylo1 = 0, yhi1 = 0, ylo0 = 0, yhi0 = 0;   // ballots by population, lane = pop & 63
@@ -138,12 +139,65 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     auto epilogue = [&](int t) {
         if (kBallots) { const int base = ((P - 1) >> 6) << 6; flush_ballots(base, P - base); }
         if (ST || kBallots) wave_lds_sync();
+        uint64_t pim = 0, pmm = 0, pnn = 0;                 // pairs mode: the tile's irregular / missing / NaN sites
+        bool compact_tile = false;
+        if (MODE == MODE_PAIRS) {
+            pim = __ballot(irregular && !skip); pmm = __ballot(anymiss); pnn = __ballot(nanany && !skip);
+            const bool was_dirty = dirty;
+            dirty = dirty || (pim | pmm | skipmask) != 0;
+            if (ST && sizeof(CT) == 2 && p.compact) {
+                compact_tile = !dirty;
+                // the chunk's first dirty tile: the tiles before it become packed counts again, last one first (the
+                // packed tile k lies behind every one-byte tile below k).  A wave reads back what it stored itself, after
+                // its stores have been acknowledged, with loads that pass the CU's cache by.
+                if (dirty && !was_dirty && n_compact > 0) {
+                    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+                    unsigned char *cbase = reinterpret_cast<unsigned char *>(p.counts) + (size_t)t0 * P * kTileSites * 2;
+                    const int ndw = P * kTileSites / 4;     // one-byte tile in dwords, <= 512
+                    for (int k = n_compact - 1; k >= 0; --k) {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(cbase + (size_t)k * P * kTileSites);
+                        uint2 *dst = reinterpret_cast<uint2 *>(cbase + (size_t)k * P * kTileSites * 2);
+                        uint32_t r[8], nf[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int dw = lane + 64 * j;
+                            r[j] = dw < ndw ? __hip_atomic_load(src + dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                            nf[j] = dw < ndw ? (uint32_t)p.n_full[dw >> 4] : 0u;
+                        }
+                        asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));   // every load before the first store
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int dw = lane + 64 * j;
+                            const uint32_t hi = (nf[j] << 8) * 0x00010001u;
+                            if (dw < ndw) dst[dw] = make_uint2(hi | (r[j] & 0xffu) | ((r[j] & 0xff00u) << 8), hi | ((r[j] >> 16) & 0xffu) | ((r[j] >> 8) & 0xff0000u));
+                        }
+                        __builtin_amdgcn_s_waitcnt(0x0f70); // the packed tile k is out before the tile below it is read
+                    }
+                    n_compact = 0;
+                }
+            }
+        }
         if (ST) {
             const uint4 *s4 = reinterpret_cast<const uint4 *>(stage);
-            uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<CT *>(p.counts) + (size_t)t * P * kTileSites);
-            const int nv = P * kTileSites * (int)sizeof(CT) / 16;     // <= 256
+            if (compact_tile) {
+                uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(p.counts) + (size_t)t0 * P * kTileSites * 2 + (size_t)(t - t0) * P * kTileSites);
+                const int nv = P * kTileSites / 16;                   // <= 128
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int v = lane + 64 * j; if (v < nv EVOFST_K1_DBG(4)) dst[v] = s4[v]; }
+                for (int j = 0; j < 2; ++j) {
+                    const int v = lane + 64 * j;
+                    if (v < nv EVOFST_K1_DBG(4)) {
+                        const uint4 a = s4[2 * v], b = s4[2 * v + 1];   // 16 packed counts -> their 16 low bytes
+                        dst[v] = make_uint4(__builtin_amdgcn_perm(a.y, a.x, 0x06040200u), __builtin_amdgcn_perm(a.w, a.z, 0x06040200u),
+                                            __builtin_amdgcn_perm(b.y, b.x, 0x06040200u), __builtin_amdgcn_perm(b.w, b.z, 0x06040200u));
+                    }
+                }
+                ++n_compact;
+            } else {
+                uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<CT *>(p.counts) + (size_t)t * P * kTileSites);
+                const int nv = P * kTileSites * (int)sizeof(CT) / 16;     // <= 256
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int v = lane + 64 * j; if (v < nv EVOFST_K1_DBG(4)) dst[v] = s4[v]; }
+            }
         }
         if (MODE == MODE_GRAM) {
             const uint64_t im = __ballot(irregular && !skip);
@@ -156,9 +210,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             }
         }
         if (MODE == MODE_PAIRS) {
-            const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss), nn = __ballot(nanany && !skip);
-            if (lane == 0 EVOFST_K1_DBG(8)) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; p.miss_mask[t] = mm; p.nan_mask[t] = nn; }
-            dirty = dirty || (im | mm | skipmask) != 0;
+            if (lane == 0 EVOFST_K1_DBG(8)) { p.irr_mask[t] = pim; p.skip_mask[t] = skipmask; p.miss_mask[t] = pmm; p.nan_mask[t] = pnn; }
             // [tile][z|f][P]: zm, fm are adjacent
             if (ST) { if (lane < 2 * P EVOFST_K1_DBG(16)) p.zf_masks[(size_t)t * 2 * P + lane] = zm[lane]; }
             else for (int i = lane; i < 2 * P; i += 64) p.zf_masks[(size_t)t * 2 * P + i] = zm[i];

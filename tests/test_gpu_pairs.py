@@ -211,6 +211,56 @@ def test_snp_windows_clean_and_dirty_chunks(engine, monkeypatch, S, N, P, dirty)
     _check_windows(engine, sp, codes, None, P, 100, 50, tag="snp_windows_clean_and_dirty_chunks")
 
 
+@pytest.mark.parametrize("chunk_tiles", [4, 16])
+def test_one_byte_counts_of_clean_chunks(monkeypatch, chunk_tiles):
+    """K1 leaves one byte per count in chunks without a skipped, irregular or missing-allele site (pairs mode, 16-bit
+    counts).  Same data through a context that walks them (run, segments) and one that was asked for per-site values
+    first (which keeps K1 to packed counts): segments, totals and boundary bit-identical; the per-site getters after the
+    walk (K1 runs again behind them) equal the other context's.  Chunks that turn dirty at their first, a middle and
+    their last tile cover the return of already written one-byte tiles to packed counts."""
+    from evo_amd import EvoFst
+    monkeypatch.setenv("EVOFST_CHUNK_TILES", str(chunk_tiles))
+    rng = np.random.default_rng(1000 + chunk_tiles)
+    S, N, P = 64 * chunk_tiles * 9 + 37, 60, 6
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=0.0, edge=False)
+    cs = 64 * chunk_tiles                                        # sites per chunk
+    for chunk, tile in ((1, 0), (3, chunk_tiles // 2), (5, chunk_tiles - 1), (6, 1)):
+        codes[chunk * cs + tile * 64 + 5, 3] = 2                 # one missing allele
+    fl = np.zeros(S, np.uint8); fl[7 * cs + 64 * (chunk_tiles - 2) + 9] = 1      # and one skipped site
+    out = []
+    for ask_first in (False, True):
+        e = EvoFst(0)
+        try:
+            e.set_layout(sp, P)
+            e.upload(e.pack_codes(codes), S, site_flags=fl)
+            e.set_pairs()
+            e.set_windows(50, 25)
+            if ask_first:
+                e.run_counts()
+                c0 = e.counts()
+            e.run()
+            seg, tot, bnd = e.segments(), e.totals(), e.boundary()
+            alt, nm = e.counts()
+            st = e.site_stats()
+            out.append((seg, tot, bnd, alt, nm, st))
+            _check_windows_once(e, sp, codes, fl, P, 50, 25, None, "one_byte_counts")
+        finally:
+            e.close()
+    a, b = out
+    assert np.array_equal(a[0]["first_segment"], b[0]["first_segment"]) and np.array_equal(a[0]["n_segments"], b[0]["n_segments"])
+    for q, n in enumerate(a[0]["n_segments"]):                   # rows behind a pair's last segment are not written
+        assert n > 50
+        for k in ("sum_num", "sum_den", "sum_dxy_k", "end_site"):
+            assert np.array_equal(a[0][k][:n, q], b[0][k][:n, q], equal_nan=True), (k, q)
+    assert np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2], equal_nan=True)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    oalt, onm = O.counts_from_codes(codes, sp, P)
+    assert np.array_equal(a[3], oalt) and np.array_equal(a[4], onm)
+    for x, y in zip(a[5], b[5]):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
 def test_snp_windows_many_pairs(engine):
     """435 pairs: more than one K2 block per chunk (blockIdx.y > 0), each deriving the same tables."""
     rng = np.random.default_rng(435)
