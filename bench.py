@@ -174,8 +174,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-sites", type=int, default=-1, help="sites of the CPU baseline sample (0 = skip)")
     ap.add_argument("--dist-path", action="store_true", help="rehearsal: take the multi-rank step even with one rank")
