@@ -1284,7 +1284,7 @@ int AFmain(int argc, char **argv) {
 // ====================================================================================== PBS, ABS
 
 namespace bopt {
-string vcfFile, setsFile, tuplesFile, runName = "";
+string vcfFile, setsFile, tuplesFile, runName = "", annotFile;
 int fixedWindowSize = 10000, windowSize = 20, windowStep = 10;
 }
 
@@ -1295,7 +1295,8 @@ const char *PBS_USAGE =
     "       -h, --help                              display this help and exit\n"
     "       -f, --fixedW size                       fixed (physical) window size (default: 10000)\n"
     "       -w SIZE,STEP --window=SIZE,STEP         sliding window: SIZE SNPs, moving by STEP (default: 20,10)\n"
-    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n\n";
+    "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n"
+    "       --annot=ANNOTATION.gffExtract           (optional) gene annotation: writes P1_P2_P3_PBSGenes_RUN_SIZE_STEP.txt, one row per gene\n\n";
 
 const char *ABS_USAGE =
     "Usage: evo ABS [OPTIONS] INPUT_FILE.vcf POPULATIONS.txt ABS_quartets.txt\n"
@@ -1317,8 +1318,7 @@ const uint8_t kPbsNanNegative[8] = {0, 4, 3, 0, 7, 4, 3, 0};
 const uint8_t kAbsNanNegative[64] = {0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 3, 2, 0, 0, 0, 0,
                                      3, 0, 3, 0, 1, 0, 0, 0, 3, 2, 3, 0, 1, 0, 1, 0, 3, 0, 3, 0, 1, 0, 1, 0, 0, 2, 3, 2, 1, 0, 1, 0};
 
-// evo PBS (PBSmain, evo_PBS.cpp:126-369, without --annot, --af and -i) and evo ABS (ABSmain, evo_ABS.cpp:109-293,
-// without --annot): the reference's two mains are one loop over a different per-site statistic.  Per-site values of
+// evo PBS (PBSmain, evo_PBS.cpp:126-369, without --af and -i) and evo ABS (ABSmain, evo_ABS.cpp:109-293): the reference's two mains are one loop over a different per-site statistic.  Per-site values of
 // every trio / quartet come from the device; the sliding windows (and, for PBS, the fixed windows) are replayed on the
 // host in file order.  Line citations are PBSmain's unless marked.
 int branchMain(const int arity, int argc, char **argv) {
@@ -1327,7 +1327,7 @@ int branchMain(const int arity, int argc, char **argv) {
     const int nVal = pbsMode ? 3 : 2;
     const char *usage = pbsMode ? PBS_USAGE : ABS_USAGE;
     static const struct option longopts[] = {{"fixedW", required_argument, NULL, 'f'}, {"window", required_argument, NULL, 'w'},
-                                             {"annot", required_argument, NULL, OPT_UNSUPPORTED}, {"af", required_argument, NULL, OPT_UNSUPPORTED},
+                                             {"annot", required_argument, NULL, OPT_ANNOT}, {"af", required_argument, NULL, OPT_UNSUPPORTED},
                                              {"allow-indels-and-multiallelics", no_argument, NULL, 'i'},
                                              {"help", no_argument, NULL, 'h'}, {"run-name", required_argument, NULL, 'n'}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
@@ -1344,7 +1344,8 @@ int branchMain(const int arity, int argc, char **argv) {
                 break;
             case 'n': arg >> runName; break;
             case 'i': if (!pbsMode) { dieFlag = true; break; } die("-i (indels and multiallelics) is not carried by the GPU build");
-            case OPT_UNSUPPORTED: die("--annot and --af are not carried by the GPU build");
+            case OPT_ANNOT: arg >> annotFile; break;
+            case OPT_UNSUPPORTED: die("--af is not carried by the GPU build");
             case 'h': std::cout << usage; exit(EXIT_SUCCESS);
         }
     }
@@ -1373,6 +1374,13 @@ int branchMain(const int arity, int argc, char **argv) {
     std::cerr << "There are " << populations.size() << " populations " << std::endl;
     const size_t P = populations.size();
 
+    // --annot (:130-136): PBS writes a row per gene and trio (:176-181, 282-286, 333-361); ABS loads the file and does
+    // nothing with it (its gene rows are commented out in the reference, ABS.cpp:267-285)
+    GeneAnnotation annotation;
+    const bool haveAnnot = !annotFile.empty();
+    if (haveAnnot) annotation.load(annotFile);
+    std::vector<std::ofstream> outFilesGenes;
+    string currentGene, previousGene;
     std::vector<std::ofstream> outFiles, outFilesFixedWindow;        // :163-183, ABS.cpp:146-156
     std::vector<int32_t> tuples;
     while (getline(tuplesF, line)) {
@@ -1393,6 +1401,11 @@ int branchMain(const int arity, int argc, char **argv) {
             outFiles.back() << "chr\twStart\twEnd\t" << names[0] << "\t" << names[1] << "\t" << names[2] << std::endl;
             outFilesFixedWindow.back() << "chr\twStart\twEnd\t" << names[0] << "\t" << names[1] << "\t" << names[2] << "\t"
                                        << "nFwSNPs1" << "\t" << "nFwSNPs2" << "\t" << "nFwSNPs3" << std::endl;
+            if (haveAnnot) {
+                outFilesGenes.emplace_back((names[0] + "_" + names[1] + "_" + names[2] + "_PBSGenes_" + runName + "_" + numToString(windowSize) + "_" + numToString(windowStep) + ".txt").c_str());
+                outFilesGenes.back() << "gene\t" << "numSNPsExons\tnumSNPsIntrons\tnumSNPs3kbPromoter\t" << names[0] << "_exons\t" << names[1] << "_exons\t" << names[2] << "_exons\t"
+                                     << names[0] << "_wIntrons\t" << names[1] << "_wIntrons\t" << names[2] << "_wIntrons\t" << names[0] << "_promoter\t" << names[1] << "_promoter\t" << names[2] << "_promoter" << std::endl;
+            }
         } else {
             outFiles.back() << "chr\tpos1\tpos2\tABS\tABSalt" << std::endl;
         }
@@ -1403,6 +1416,7 @@ int branchMain(const int arity, int argc, char **argv) {
     std::deque<double> initDeq(windowSize, 0.0);                     // :186-192: nVal value deques + one of coordinates
     std::vector<std::vector<std::deque<double>>> results(T, std::vector<std::deque<double>>(nVal + 1, initDeq));
     std::vector<std::vector<std::vector<double>>> fixedWindowResults(T, std::vector<std::vector<double>>(3));
+    std::vector<std::vector<std::vector<double>>> geneResults(T, std::vector<std::vector<double>>(9));   // exon x3, intron x3, promoter x3
     int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
     std::vector<int> usedVars(T, 0);
     int totalVariantNumber = 0;
@@ -1462,6 +1476,16 @@ int branchMain(const int arity, int argc, char **argv) {
             const string &chr = batch.chrom[s];
             const string &coord = batch.pos[s];
             double coordDouble; { std::stringstream ss(coord); ss >> coordDouble; }
+            int geneCategory = -1;                                   // :282-286
+            if (pbsMode && haveAnnot) {
+                const string *gene;
+                const string category = annotation.geneDetails(chr, atoi(coord.c_str()), gene);
+                if (!gene->empty()) {
+                    currentGene = *gene;
+                    if (previousGene.empty()) previousGene = currentGene;
+                    geneCategory = category == "exon" ? 0 : category == "intron" ? 1 : category == "promoter" ? 2 : -1;
+                }
+            }
             if (pbsMode && (coordDouble > currentWindowEnd || coordDouble < currentWindowStart)) {   // :289-303 (PBS only)
                 for (size_t i = 0; i != T; i++) {
                     std::vector<std::vector<double>> &fw = fixedWindowResults[i];
@@ -1484,6 +1508,7 @@ int branchMain(const int arity, int argc, char **argv) {
                     const double v = val[(i * nVal + x) * n + s];
                     r[x].push_back(v); r[x].pop_front();
                     if (pbsMode) fixedWindowResults[i][x].push_back(v);
+                    if (geneCategory >= 0) geneResults[i][3 * geneCategory + x].push_back(v);   // :333-341
                 }
                 r[nVal].push_back(coordDouble); r[nVal].pop_front();
                 if (usedVars[i] > windowSize && (usedVars[i] % windowStep == 0)) {
@@ -1496,6 +1521,17 @@ int branchMain(const int arity, int argc, char **argv) {
                     if (pbsMode) outFiles[i] << chr << "\t" << (int)r[3][0] << "\t" << coord << "\t" << av[0] << "\t" << av[1] << "\t" << av[2] << std::endl;
                     else outFiles[i] << chr << "\t" << r[2][0] << "\t" << coord << "\t" << av[0] << "\t" << av[1] << std::endl;   // ABS.cpp:275: a double
                 }
+            }
+            if (pbsMode && haveAnnot && !previousGene.empty() && currentGene != previousGene) {   // :348-361
+                for (size_t i = 0; i != T; i++) {
+                    std::vector<std::vector<double>> &g = geneResults[i];
+                    const int counts[3] = {(int)g[0].size(), (int)g[3].size(), (int)g[6].size()};
+                    outFilesGenes[i] << previousGene << "\t" << counts[0] << "\t" << counts[1] << "\t" << counts[2];
+                    for (int y = 0; y < 9; ++y) { const double a = counts[y / 3] > 0 ? vector_average(g[y]) : 0; outFilesGenes[i] << "\t" << a; }
+                    outFilesGenes[i] << std::endl;
+                    for (int y = 0; y < 9; ++y) g[y].clear();
+                }
+                previousGene = currentGene;
             }
         }
         batch.clear();

@@ -1538,9 +1538,18 @@ void orc_abs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, 
  * --af and -i, and `evo ABS [-w SIZE,STEP] [-n RUN] VCF POPS QUARTETS` (ABSmain, evo_ABS.cpp:109-293) without --annot.
  * The two mains are the same loop over a different statistic (arity 3 with fixed windows, arity 4 without); the
  * citations below are PBSmain's, ABSmain's lines are noted where the behaviour differs.  Output files go to out_dir. */
+static const char *g_pbs_annot_path = NULL;            /* set by orc_pbs_run_annot for the duration of one run */
 static int branch_run(int arity, const char *vcf_path, const char *pops_path, const char *trios_path,
                       int windowSize, int windowStep, int fixedWindowSize, const char *run_name, const char *out_dir) {
     const int nval = arity == 3 ? 3 : 2;                         /* values per site: PBS x3, or ABS and ABSalt */
+    /* PBS --annot (evo_PBS.cpp:130-136, :176-181, :282-286, :333-341, :348-361): a row per gene and trio */
+    orc_annot *an = NULL;
+    if (arity == 3 && g_pbs_annot_path) {
+        an = orc_annot_load(g_pbs_annot_path);
+        if (!an) { fprintf(stderr, "Error: could not read %s\n", g_pbs_annot_path); return -7; }
+    }
+    FILE **outGenes = NULL; dvec *geneRes = NULL;            /* [trio][9]: exon x3, intron x3, promoter x3 */
+    char *currentGene = strdup(""), *previousGene = strdup("");
     lreader vcf;
     if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
     FILE *sf = fopen(pops_path, "r");
@@ -1594,7 +1603,9 @@ static int branch_run(int arity, const char *vcf_path, const char *pops_path, co
                 tcap = tcap ? tcap * 2 : 8;
                 trio = (int *)realloc(trio, sizeof(int) * 4 * (size_t)tcap);
                 outW = (FILE **)realloc(outW, sizeof(FILE *) * (size_t)tcap); outFW = (FILE **)realloc(outFW, sizeof(FILE *) * (size_t)tcap);
+                outGenes = (FILE **)realloc(outGenes, sizeof(FILE *) * (size_t)tcap);
             }
+            outGenes[n_trios] = NULL;
             for (int x = 0; x < arity; x++) {
                 int k = -1;
                 for (int i = 0; i < n_pops; i++) if (strcmp(pops[i].name, nm4[x]) == 0) k = i;
@@ -1611,6 +1622,13 @@ static int branch_run(int arity, const char *vcf_path, const char *pops_path, co
                 if (!outW[n_trios] || !outFW[n_trios]) { rc = -3; n_trios++; break; }
                 fprintf(outW[n_trios], "chr\twStart\twEnd\t%s\t%s\t%s\n", nm4[0], nm4[1], nm4[2]);
                 fprintf(outFW[n_trios], "chr\twStart\twEnd\t%s\t%s\t%s\tnFwSNPs1\tnFwSNPs2\tnFwSNPs3\n", nm4[0], nm4[1], nm4[2]);
+                if (an) {
+                    snprintf(name, sizeof name, "%s_%s_%s_PBSGenes_%s_%d_%d.txt", nm4[0], nm4[1], nm4[2], run_name, windowSize, windowStep);
+                    char *p3 = path_join(out_dir, name); outGenes[n_trios] = fopen(p3, "w"); free(p3);
+                    if (!outGenes[n_trios]) { rc = -3; n_trios++; break; }
+                    fprintf(outGenes[n_trios], "gene\tnumSNPsExons\tnumSNPsIntrons\tnumSNPs3kbPromoter\t%s_exons\t%s_exons\t%s_exons\t%s_wIntrons\t%s_wIntrons\t%s_wIntrons\t%s_promoter\t%s_promoter\t%s_promoter\n",
+                            nm4[0], nm4[1], nm4[2], nm4[0], nm4[1], nm4[2], nm4[0], nm4[1], nm4[2]);
+                }
             } else {                                              /* ABS.cpp:153-154 */
                 snprintf(name, sizeof name, "%s_%s_%s_%s_ABS_%s_%d_%d.txt", nm4[0], nm4[1], nm4[2], nm4[3], run_name, windowSize, windowStep);
                 char *p1 = path_join(out_dir, name); outW[n_trios] = fopen(p1, "w"); free(p1);
@@ -1627,6 +1645,7 @@ static int branch_run(int arity, const char *vcf_path, const char *pops_path, co
     int *head = (int *)calloc((size_t)n_trios + 1, sizeof(int));
     dvec *fw = (dvec *)calloc((size_t)(n_trios + 1) * 3, sizeof(dvec));
     int *usedVars = (int *)calloc((size_t)n_trios + 1, sizeof(int));
+    if (an) geneRes = (dvec *)calloc((size_t)n_trios * 9 + 1, sizeof(dvec));
     int currentWindowStart = 0, currentWindowEnd = currentWindowStart + fixedWindowSize;
     uint8_t *use_pop = (uint8_t *)calloc((size_t)n_pops + 1, 1);
     int32_t *sample_pop = NULL; int n_samples = 0;
@@ -1666,6 +1685,14 @@ static int branch_run(int arity, const char *vcf_path, const char *pops_path, co
             if (strcmp(fields[4], "*") == 0 || strlen(fields[3]) > 1 || strlen(fields[4]) > 1) continue;
             orc_general_counts((const char *const *)(fields + 9), n_samples, sample_pop, n_pops, use_pop,
                                alt, alleles, aaf, allelesC, aafC);
+            const char *snpGene = "", *snpCategory = "nonCoding";                                /* :282-286 */
+            if (an) {
+                snpCategory = orc_annot_gene_details(an, chr, atoi(coord), &snpGene);
+                if (snpGene[0]) {
+                    free(currentGene); currentGene = strdup(snpGene);
+                    if (!previousGene[0]) { free(previousGene); previousGene = strdup(currentGene); }
+                }
+            }
             if (arity == 3 && (coordDouble > currentWindowEnd || coordDouble < currentWindowStart)) {   /* :288-303; ABS has no fixed windows */
                 for (int i = 0; i < n_trios; i++) {
                     dvec *f0 = &fw[3 * i];
@@ -1700,6 +1727,10 @@ static int branch_run(int arity, const char *vcf_path, const char *pops_path, co
                 d[3 * W + (size_t)h] = coordDouble;
                 head[i] = h = (h + 1) % (int)W;                                                  /* push_back + pop_front */
                 if (arity == 3) for (int x = 0; x < 3; x++) dv_push(&fw[3 * i + x], val[x]);
+                if (an && snpGene[0]) {                                                           /* :333-341 */
+                    int cat = strcmp(snpCategory, "exon") == 0 ? 0 : strcmp(snpCategory, "intron") == 0 ? 1 : strcmp(snpCategory, "promoter") == 0 ? 2 : -1;
+                    if (cat >= 0) for (int x = 0; x < 3; x++) dv_push(&geneRes[9 * i + 3 * cat + x], val[x]);
+                }
                 if (usedVars[i] > windowSize && (usedVars[i] % windowStep == 0)) {
                     double av[3];
                     for (int x = 0; x < nval; x++) {
@@ -1711,8 +1742,25 @@ static int branch_run(int arity, const char *vcf_path, const char *pops_path, co
                     else fprintf(outW[i], "%s\t%g\t%s\t%g\t%g\n", chr, d[3 * W + (size_t)h], coord, av[0], av[1]);   /* ABS.cpp:275: the coordinate stays a double */
                 }
             }
+            if (an && previousGene[0] && strcmp(currentGene, previousGene) != 0) {                /* :348-361 */
+                for (int i = 0; i < n_trios; i++) {
+                    dvec *g = &geneRes[9 * i];
+                    int cnt[3] = {(int)g[0].n, (int)g[3].n, (int)g[6].n};
+                    fprintf(outGenes[i], "%s\t%d\t%d\t%d", previousGene, cnt[0], cnt[1], cnt[2]);
+                    for (int y = 0; y < 9; y++) fprintf(outGenes[i], "\t%g", cnt[y / 3] > 0 ? orc_vector_average(g[y].v, g[y].n) : 0.0);
+                    fprintf(outGenes[i], "\n");
+                    for (int y = 0; y < 9; y++) dv_clear(&g[y]);
+                }
+                free(previousGene); previousGene = strdup(currentGene);
+            }
         }
     }
+    if (an) {
+        for (int i = 0; i < n_trios; i++) if (outGenes[i]) fclose(outGenes[i]);
+        for (int i = 0; i < 9 * n_trios; i++) dv_free(&geneRes[i]);
+        free(geneRes); orc_annot_free(an);
+    }
+    free(outGenes); free(currentGene); free(previousGene);
     for (int i = 0; i < n_trios; i++) { if (outW[i]) fclose(outW[i]); if (outFW[i]) fclose(outFW[i]); }
     for (int i = 0; i < 3 * n_trios; i++) dv_free(&fw[i]);
     lr_close(&vcf);
@@ -1731,6 +1779,14 @@ static int branch_run(int arity, const char *vcf_path, const char *pops_path, co
 int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_path,
                 int windowSize, int windowStep, int fixedWindowSize, const char *run_name, const char *out_dir) {
     return branch_run(3, vcf_path, pops_path, trios_path, windowSize, windowStep, fixedWindowSize, run_name, out_dir);
+}
+/* with --annot (annot_path may be NULL or ""): P1_P2_P3_PBSGenes_<run>_<SIZE>_<STEP>.txt per trio */
+int orc_pbs_run_annot(const char *vcf_path, const char *pops_path, const char *trios_path, int windowSize, int windowStep,
+                      int fixedWindowSize, const char *run_name, const char *out_dir, const char *annot_path) {
+    g_pbs_annot_path = annot_path && annot_path[0] ? annot_path : NULL;
+    int rc = branch_run(3, vcf_path, pops_path, trios_path, windowSize, windowStep, fixedWindowSize, run_name, out_dir);
+    g_pbs_annot_path = NULL;
+    return rc;
 }
 
 int orc_abs_run(const char *vcf_path, const char *pops_path, const char *quartets_path,

@@ -543,11 +543,12 @@ def pbs_site_stats(alt, nm, trios, site_flags=None):
     return pbs, used
 
 
-def pbs_run(vcf, pops, trios, out_dir, run_name="", size=20, step=10, fixed=10000):
+def pbs_run(vcf, pops, trios, out_dir, run_name="", size=20, step=10, fixed=10000, annot=None):
     L = lib()
-    L.orc_pbs_run.restype = C.c_int
-    L.orc_pbs_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
-    rc = L.orc_pbs_run(vcf.encode(), pops.encode(), trios.encode(), size, step, fixed, run_name.encode(), out_dir.encode())
+    L.orc_pbs_run_annot.restype = C.c_int
+    L.orc_pbs_run_annot.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+    rc = L.orc_pbs_run_annot(vcf.encode(), pops.encode(), trios.encode(), size, step, fixed, run_name.encode(), out_dir.encode(),
+                             (annot or "").encode())
     if rc != 0:
         raise RuntimeError("orc_pbs_run failed: %d" % rc)
 

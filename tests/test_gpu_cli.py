@@ -320,7 +320,7 @@ def test_cli_allele_freq(tmp_path):
     assert sum(1 for _ in open(got)) > 30000
 
 
-def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25, quartets=False):
+def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25, quartets=False, annot_text=None):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=miss)
     pf, tf = str(tmp_path / "pops.txt"), str(tmp_path / "trios.txt")
@@ -339,15 +339,44 @@ def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samp
         open(tf, "w").write("popA\tpopB\tpopC\nsolo\tpopA\tpopB\npopA\tsolo\tduo\npopD\tduo\tsolo\npopC\tpopB\tpopA\nduo\tsolo\tduo\n")
     cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
     cli_dir.mkdir(); orc_dir.mkdir()
+    annot = None
+    if annot_text is not None:
+        annot = str(tmp_path / "genes.gffExtract")
+        open(annot, "w").write(annot_text)
+        args = args + ["--annot=" + annot]
     r = subprocess.run([EVO, "ABS" if quartets else "PBS", "-n", "p"] + args + [vcf, pf, tf], cwd=str(cli_dir), capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     if quartets:
         O.abs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step)
     else:
-        O.pbs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step, fixed=fixed)
+        O.pbs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step, fixed=fixed, annot=annot)
     _same_files(str(cli_dir), str(orc_dir))
     return cli_dir
+
+
+def _gene_annotation(scaffold_a, scaffold_b):
+    rows = []
+    for k in range(14):
+        a = 4000 + 5500 * k
+        ex = [(a, a + 300), (a + 900, a + 1300), (a + 2000, a + 2400)]
+        if k % 2:
+            ex.reverse()
+        name = ("5partial-" if k == 5 else "") + "tr%d" % k
+        rows += ["%s\t%d\t%d\t%s\t%s" % (scaffold_a, s, e, "-" if k % 2 else "+", name) for s, e in ex]
+    rows += ["%s\t1000\t30000\t+\tbig.1" % scaffold_b, "%s\t40000\t40100\t-\tsmall" % scaffold_b,
+             "%s\t45000\t45100\t-\tsmall" % scaffold_b, "chrZ\t1\t10\t+\tlast"]
+    return "\n".join(rows) + "\n"
+
+
+def test_cli_pbs_annot_gene_rows(tmp_path):
+    """PBS --annot (evo_PBS.cpp:282-286, 333-361): one row per gene and trio; ABS --annot loads the file and writes
+    nothing more (its gene rows are commented out in the reference)."""
+    d = _pbs_case(tmp_path, np.random.default_rng(45), [], 20, 10, annot_text=_gene_annotation("chr1", "chr2"))
+    genes = (d / "popA_popB_popC_PBSGenes_p_20_10.txt").read_text().splitlines()
+    assert len(genes) > 10 and len(os.listdir(d)) == 18
+    (tmp_path / "abs").mkdir()
+    _pbs_case(tmp_path / "abs", np.random.default_rng(46), ["-w", "9,4"], 9, 4, quartets=True, annot_text=_gene_annotation("chr1", "chr2"))
 
 
 def test_cli_pbs_default(tmp_path):
