@@ -18,6 +18,7 @@ ERR_ARG, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 REF, ALT, MISSING = 0, 1, 2
 SITE_SKIP = 1
 MODE_FST, MODE_GLOBAL = 0, 1
+MODE_GLOBAL_INDELS = 3      # MODE_GLOBAL with -i of evo PBS / DistOutgroups: only ALT == "*" is skipped
 
 _dp = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)

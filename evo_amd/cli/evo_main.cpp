@@ -245,7 +245,9 @@ struct Device {
         return pinned[turn];
     }
     // layoutToVcf[k] = genotype column of layout sample k (empty: identity)
-    void load(Batch &b, int mode, int nVcfSamples, const std::vector<int32_t> &layoutToVcf, long long firstLineNo) {
+    // allowIndels (-i of PBS and DistOutgroups, evo_PBS.cpp:248-256): only ALT == "*" is left out (EVOFST_MODE_GLOBAL_INDELS)
+    void load(Batch &b, int mode, int nVcfSamples, const std::vector<int32_t> &layoutToVcf, long long firstLineNo, bool allowIndels = false) {
+        if (allowIndels && mode == EVOFST_MODE_GLOBAL) mode = EVOFST_MODE_GLOBAL_INDELS;
         uint8_t *tiles = stage(std::max(evofst_tiles_bytes(ctx, (int64_t)b.n), evofst_tiles_bytes(ctx, (int64_t)kChunkSites)));
         b.flags.assign(b.n, 0);
         std::vector<const char *> ptr(b.n);
@@ -1286,6 +1288,7 @@ int AFmain(int argc, char **argv) {
 namespace bopt {
 string vcfFile, setsFile, tuplesFile, runName = "", annotFile;
 int fixedWindowSize = 10000, windowSize = 20, windowStep = 10;
+bool allowIndels = false;
 }
 
 const char *PBS_USAGE =
@@ -1296,7 +1299,8 @@ const char *PBS_USAGE =
     "       -f, --fixedW size                       fixed (physical) window size (default: 10000)\n"
     "       -w SIZE,STEP --window=SIZE,STEP         sliding window: SIZE SNPs, moving by STEP (default: 20,10)\n"
     "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n"
-    "       --annot=ANNOTATION.gffExtract           (optional) gene annotation: writes P1_P2_P3_PBSGenes_RUN_SIZE_STEP.txt, one row per gene\n\n";
+    "       --annot=ANNOTATION.gffExtract           (optional) gene annotation: writes P1_P2_P3_PBSGenes_RUN_SIZE_STEP.txt, one row per gene\n"
+    "       -i, --allow-indels-and-multiallelics    (optional) also use indels, and multiallelics with the second allele taken as REF\n\n";
 
 const char *ABS_USAGE =
     "Usage: evo ABS [OPTIONS] INPUT_FILE.vcf POPULATIONS.txt ABS_quartets.txt\n"
@@ -1318,7 +1322,7 @@ const uint8_t kPbsNanNegative[8] = {0, 4, 3, 0, 7, 4, 3, 0};
 const uint8_t kAbsNanNegative[64] = {0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 3, 2, 0, 0, 0, 0,
                                      3, 0, 3, 0, 1, 0, 0, 0, 3, 2, 3, 0, 1, 0, 1, 0, 3, 0, 3, 0, 1, 0, 1, 0, 0, 2, 3, 2, 1, 0, 1, 0};
 
-// evo PBS (PBSmain, evo_PBS.cpp:126-369, without --af and -i) and evo ABS (ABSmain, evo_ABS.cpp:109-293): the reference's two mains are one loop over a different per-site statistic.  Per-site values of
+// evo PBS (PBSmain, evo_PBS.cpp:126-369, without --af) and evo ABS (ABSmain, evo_ABS.cpp:109-293): the reference's two mains are one loop over a different per-site statistic.  Per-site values of
 // every trio / quartet come from the device; the sliding windows (and, for PBS, the fixed windows) are replayed on the
 // host in file order.  Line citations are PBSmain's unless marked.
 int branchMain(const int arity, int argc, char **argv) {
@@ -1343,7 +1347,7 @@ int branchMain(const int arity, int argc, char **argv) {
                 windowSize = atoi(ws[0].c_str()); windowStep = atoi(ws[1].c_str());
                 break;
             case 'n': arg >> runName; break;
-            case 'i': if (!pbsMode) { dieFlag = true; break; } die("-i (indels and multiallelics) is not carried by the GPU build");
+            case 'i': if (!pbsMode) { dieFlag = true; break; } allowIndels = true; break;
             case OPT_ANNOT: arg >> annotFile; break;
             case OPT_UNSUPPORTED: die("--af is not carried by the GPU build");
             case 'h': std::cout << usage; exit(EXIT_SUCCESS);
@@ -1432,7 +1436,7 @@ int branchMain(const int arity, int argc, char **argv) {
     auto flush = [&]() {
         if (batch.n == 0) return;
         const size_t n = batch.n;
-        dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
+        dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1, allowIndels);
         val.resize(T * nVal * n); used.resize(T * n);
         if (pbsMode) check(dev.ctx, evofst_get_pbs_site_stats(dev.ctx, 0, (int64_t)n, (int)T, tuples.data(), val.data(), used.data()), "pbs_site_stats");
         else check(dev.ctx, evofst_get_abs_site_stats(dev.ctx, 0, (int64_t)n, (int)T, tuples.data(), val.data(), used.data()), "abs_site_stats");
@@ -1576,6 +1580,7 @@ int branchMain(const int arity, int argc, char **argv) {
 namespace dopt {
 string vcfFile, setsFile, outgroupFile, ingroupFile, runName = "", accessibleBed = "";
 int fixedWindowSize = 10000;
+bool allowIndels = false;
 }
 
 const char *DISTOUT_USAGE =
@@ -1585,9 +1590,10 @@ const char *DISTOUT_USAGE =
     "       -h, --help                              display this help and exit\n"
     "       -f, --fixedW size                       fixed (physical) window size (default: 10000)\n"
     "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n"
-    "       --accessibleGenomeBED=BEDfile.bed           (optional) a bed file specifying the regions of the genome where we could call SNPs\n\n";
+    "       --accessibleGenomeBED=BEDfile.bed           (optional) a bed file specifying the regions of the genome where we could call SNPs\n"
+    "       -i, --allow-indels-and-multiallelics    (optional) also use indels, and multiallelics with the second allele taken as REF\n\n";
 
-// evo DistOutgroups (DistOutMain, evo_distanceToOutgroups.cpp:68-306) without -i.  The host
+// evo DistOutgroups (DistOutMain, evo_distanceToOutgroups.cpp:68-306).  The host
 // replays the fixed-window state machine on the coordinates alone to find where rows are emitted, the device adds up
 // the per-site dxy of every (outgroup, ingroup) pair between two emissions in site order, the host turns the sums
 // into rows.  A window left open at the end of a device batch is continued by the next batch (carry_first).
@@ -1604,7 +1610,7 @@ int DistOutMain(int argc, char **argv) {
             case '?': dieFlag = true; break;
             case 'f': arg >> fixedWindowSize; break;
             case 'n': arg >> runName; break;
-            case 'i': die("-i (indels and multiallelics) is not carried by the GPU build");
+            case 'i': allowIndels = true; break;
             case OPT_ACC_BED: arg >> accessibleBed; break;
             case 'h': std::cout << DISTOUT_USAGE; exit(EXIT_SUCCESS);
         }
@@ -1675,7 +1681,7 @@ int DistOutMain(int argc, char **argv) {
     auto flush = [&]() {
         if (batch.n == 0) return;
         const size_t n = batch.n;
-        dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
+        dev.load(batch, EVOFST_MODE_GLOBAL, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1, allowIndels);
         rows.clear();
         for (size_t s = 0; s < n; ++s) {                             // the state machine of :221-269 on coordinates alone
             if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :194-202

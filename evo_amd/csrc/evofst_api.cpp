@@ -747,6 +747,8 @@ int parse_vcf_line(const char *line, int mode, int n_samples, uint8_t *codes, ui
         // several ALT alleles is a missing allele; more than one real ALT allele makes the site multi-allelic
         const int miss_allele = stats_missing_allele(alt, alt_end, &fl);
         allele_as_missing = miss_allele;
+    } else if (mode == EVOFST_MODE_GLOBAL_INDELS) {
+        if (alt_len == 1 && alt[0] == '*') fl |= EVOFST_SITE_SKIP;        // evo_PBS.cpp:248-256 with -i
     } else {
         if (ref_len > 1 || alt_len > 1 || (alt_len == 1 && alt[0] == '*'))
             fl |= EVOFST_SITE_SKIP;                                       // FstAgainstAll.cpp:185
@@ -816,7 +818,7 @@ extern "C" int evofst_pack_vcf_lines(const evofst_ctx *c, int mode, int64_t n_li
                                      uint8_t *site_flags) try {
     if (!c || !lines || !tiles || !site_flags || n_lines < 0 || n_vcf_samples <= 0) return EVOFST_ERR_ARG;
     if (c->n_pops == 0) return EVOFST_ERR_STATE;
-    if (mode != EVOFST_MODE_FST && mode != EVOFST_MODE_GLOBAL && mode != EVOFST_MODE_STATS) return EVOFST_ERR_ARG;
+    if (mode != EVOFST_MODE_FST && mode != EVOFST_MODE_GLOBAL && mode != EVOFST_MODE_STATS && mode != EVOFST_MODE_GLOBAL_INDELS) return EVOFST_ERR_ARG;
     // haplotype of the packed layout -> index into a line's code row
     std::vector<int32_t> src((size_t)c->H);
     for (int h = 0; h < c->H; ++h) {

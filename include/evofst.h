@@ -56,6 +56,8 @@ extern "C" {
 #define EVOFST_MODE_STATS 2  /* `evo stats`       (getThisVariantCountsSimple, process_vcf_utils.cpp:358-408): an individual
                               * with a '.' or the missing allele in either position is missing as a whole (both haplotypes
                               * EVOFST_MISSING); ALT = the character '1'; no REF/ALT length filter */
+#define EVOFST_MODE_GLOBAL_INDELS 3 /* the rules of EVOFST_MODE_GLOBAL with -i / --allow-indels-and-multiallelics of `evo PBS` and
+                                     `evo DistOutgroups` (evo_PBS.cpp:248-256): only ALT == "*" is skipped; packer modes only */
 
 typedef struct evofst_ctx evofst_ctx;
 

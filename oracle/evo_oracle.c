@@ -1539,6 +1539,7 @@ void orc_abs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, 
  * The two mains are the same loop over a different statistic (arity 3 with fixed windows, arity 4 without); the
  * citations below are PBSmain's, ABSmain's lines are noted where the behaviour differs.  Output files go to out_dir. */
 static const char *g_pbs_annot_path = NULL;            /* set by orc_pbs_run_annot for the duration of one run */
+static int g_allow_indels = 0;                         /* -i of PBS / DistOutgroups (evo_PBS.cpp:250-252, evo_distanceToOutgroups.cpp:196-198), likewise */
 static int branch_run(int arity, const char *vcf_path, const char *pops_path, const char *trios_path,
                       int windowSize, int windowStep, int fixedWindowSize, const char *run_name, const char *out_dir) {
     const int nval = arity == 3 ? 3 : 2;                         /* values per site: PBS x3, or ABS and ABSalt */
@@ -1681,8 +1682,8 @@ static int branch_run(int arity, const char *vcf_path, const char *pops_path, co
             if (nf < 9) continue;
             const char *chr = fields[0]; const char *coord = fields[1];
             double coordDouble = strtod(coord, NULL);
-            /* :255-263 only biallelic SNPs (no -i) */
-            if (strcmp(fields[4], "*") == 0 || strlen(fields[3]) > 1 || strlen(fields[4]) > 1) continue;
+            /* :248-256 only biallelic SNPs, unless -i */
+            if (strcmp(fields[4], "*") == 0 || (!(arity == 3 && g_allow_indels) && (strlen(fields[3]) > 1 || strlen(fields[4]) > 1))) continue;
             orc_general_counts((const char *const *)(fields + 9), n_samples, sample_pop, n_pops, use_pop,
                                alt, alleles, aaf, allelesC, aafC);
             const char *snpGene = "", *snpCategory = "nonCoding";                                /* :282-286 */
@@ -1788,6 +1789,9 @@ int orc_pbs_run_annot(const char *vcf_path, const char *pops_path, const char *t
     g_pbs_annot_path = NULL;
     return rc;
 }
+/* -i / --allow-indels-and-multiallelics for the drivers that have it (PBS, DistOutgroups): only ALT == "*" is skipped;
+ * every other line is counted by the characters '0' and '1' of its genotypes (getBasicCounts) */
+void orc_set_allow_indels(int on) { g_allow_indels = on; }
 
 int orc_abs_run(const char *vcf_path, const char *pops_path, const char *quartets_path,
                 int windowSize, int windowStep, const char *run_name, const char *out_dir) {
@@ -2135,7 +2139,7 @@ int orc_distout_run_bed(const char *vcf_path, const char *pops_path, const char 
             if (nf < 9) continue;
             const char *chr = fields[0];
             double coordDouble = strtod(fields[1], NULL);
-            if (strcmp(fields[4], "*") == 0 || strlen(fields[3]) > 1 || strlen(fields[4]) > 1) continue;   /* :194-202 */
+            if (strcmp(fields[4], "*") == 0 || (!g_allow_indels && (strlen(fields[3]) > 1 || strlen(fields[4]) > 1))) continue;   /* :194-202 */
             orc_general_counts((const char *const *)(fields + 9), n_samples, sample_pop, n_pops, use_pop,
                                alt, alleles, aaf, allelesC, aafC);
             if (coordDouble > currentWindowEnd || coordDouble < currentWindowStart) {                    /* :221-269 */

@@ -543,12 +543,14 @@ def pbs_site_stats(alt, nm, trios, site_flags=None):
     return pbs, used
 
 
-def pbs_run(vcf, pops, trios, out_dir, run_name="", size=20, step=10, fixed=10000, annot=None):
+def pbs_run(vcf, pops, trios, out_dir, run_name="", size=20, step=10, fixed=10000, annot=None, allow_indels=False):
     L = lib()
+    L.orc_set_allow_indels(1 if allow_indels else 0)
     L.orc_pbs_run_annot.restype = C.c_int
     L.orc_pbs_run_annot.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
     rc = L.orc_pbs_run_annot(vcf.encode(), pops.encode(), trios.encode(), size, step, fixed, run_name.encode(), out_dir.encode(),
                              (annot or "").encode())
+    L.orc_set_allow_indels(0)
     if rc != 0:
         raise RuntimeError("orc_pbs_run failed: %d" % rc)
 
@@ -585,12 +587,14 @@ def dist_windows(alt, nm, win_off, out_idx, in_idx, site_flags=None, carry=None)
     return r
 
 
-def distout_run(vcf, pops, outgroups, ingroups, out_dir, run_name="", fixed=10000, bed=None):
+def distout_run(vcf, pops, outgroups, ingroups, out_dir, run_name="", fixed=10000, bed=None, allow_indels=False):
     L = lib()
+    L.orc_set_allow_indels(1 if allow_indels else 0)
     L.orc_distout_run_bed.restype = C.c_int
     L.orc_distout_run_bed.argtypes = [C.c_char_p] * 4 + [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
     rc = L.orc_distout_run_bed(vcf.encode(), pops.encode(), outgroups.encode(), ingroups.encode(), fixed, run_name.encode(),
                                out_dir.encode(), bed.encode() if bed else None)
+    L.orc_set_allow_indels(0)
     if rc != 0:
         raise RuntimeError("orc_distout_run failed: %d" % rc)
 

@@ -141,3 +141,6 @@ def test_vcf_line_codes_agree_with_oracle_allele_rules():
         assert fl == L.orc_general_site_flags(b"A", alt.encode())
         exp = [L.orc_general_allele_code(g[i].encode()) for g in gts for i in (0, 2)]
         assert list(c) == (exp if not fl else [2] * 12)
+        c, fl, _, _ = api.codes_from_vcf_line(line, api.MODE_GLOBAL_INDELS, 6)   # -i of PBS / DistOutgroups: only "*" is skipped
+        assert fl == (api.SITE_SKIP if alt == "*" else 0)
+        assert list(c) == (exp if not fl else [2] * 12)

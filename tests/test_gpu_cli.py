@@ -320,7 +320,7 @@ def test_cli_allele_freq(tmp_path):
     assert sum(1 for _ in open(got)) > 30000
 
 
-def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25, quartets=False, annot_text=None):
+def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25, quartets=False, annot_text=None, allow_indels=False):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=miss)
     pf, tf = str(tmp_path / "pops.txt"), str(tmp_path / "trios.txt")
@@ -350,7 +350,7 @@ def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samp
     if quartets:
         O.abs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step)
     else:
-        O.pbs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step, fixed=fixed, annot=annot)
+        O.pbs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step, fixed=fixed, annot=annot, allow_indels=allow_indels)
     _same_files(str(cli_dir), str(orc_dir))
     return cli_dir
 
@@ -377,6 +377,16 @@ def test_cli_pbs_annot_gene_rows(tmp_path):
     assert len(genes) > 10 and len(os.listdir(d)) == 18
     (tmp_path / "abs").mkdir()
     _pbs_case(tmp_path / "abs", np.random.default_rng(46), ["-w", "9,4"], 9, 4, quartets=True, annot_text=_gene_annotation("chr1", "chr2"))
+
+
+def test_cli_pbs_allow_indels(tmp_path):
+    """PBS -i (evo_PBS.cpp:248-256): indels and multi-allelic lines are used too, counted by their '0' and '1' characters;
+    more sites are used than without it."""
+    d = _pbs_case(tmp_path, np.random.default_rng(47), ["-i"], 20, 10, allow_indels=True)
+    with_i = len((d / "popA_popB_popC_PBS_p_20_10.txt").read_text().splitlines())
+    (tmp_path / "plain").mkdir()
+    d0 = _pbs_case(tmp_path / "plain", np.random.default_rng(47), [], 20, 10)
+    assert with_i > len((d0 / "popA_popB_popC_PBS_p_20_10.txt").read_text().splitlines())
 
 
 def test_cli_pbs_default(tmp_path):
@@ -412,7 +422,7 @@ def test_cli_abs_windows_crlf_batches(tmp_path):
     _pbs_case(tmp_path, np.random.default_rng(52), ["-w", "9,4"], 9, 4, crlf=True, miss=0.12, n_sites=40000, n_samples=14, quartets=True)
 
 
-def _dist_case(tmp_path, rng, args, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.3, bed_rows=None):
+def _dist_case(tmp_path, rng, args, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.3, bed_rows=None, allow_indels=False):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=miss)
     pf, of, inf = str(tmp_path / "pops.txt"), str(tmp_path / "outgroups.txt"), str(tmp_path / "ingroups.txt")
@@ -435,7 +445,7 @@ def _dist_case(tmp_path, rng, args, fixed=10000, n_sites=3000, n_samples=25, crl
     r = subprocess.run([EVO, "DistOutgroups", "-n", "d"] + args + [vcf, pf, of, inf], cwd=str(cli_dir), capture_output=True, text=True,
                        timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
-    O.distout_run(vcf, pf, of, inf, str(orc_dir), run_name="d", fixed=fixed, bed=bed)
+    O.distout_run(vcf, pf, of, inf, str(orc_dir), run_name="d", fixed=fixed, bed=bed, allow_indels=allow_indels)
     _same_files(str(cli_dir), str(orc_dir))
     return cli_dir
 
@@ -447,6 +457,11 @@ def test_cli_distoutgroups_default(tmp_path):
     assert len(os.listdir(d)) == 3
     rows = (d / "solo_DIST_d_FW10000.txt").read_text().splitlines()
     assert len(rows) > 30 and all(r.split("\t")[5] == "10000" for r in rows[1:])
+
+
+def test_cli_distoutgroups_allow_indels(tmp_path):
+    """DistOutgroups -i (evo_distanceToOutgroups.cpp:194-202): only ALT == "*" is left out."""
+    _dist_case(tmp_path, np.random.default_rng(64), ["-i", "-f", "5000"], fixed=5000, allow_indels=True)
 
 
 def test_cli_distoutgroups_small_windows_crlf_batches(tmp_path):
