@@ -203,7 +203,10 @@ int plan_chunks(evofst_ctx *c) {
     c->n_tiles = n_tiles_of(c->n_sites);
     int ct = 0;
     if (const char *e = getenv("EVOFST_CHUNK_TILES")) ct = atoi(e);
-    if (ct <= 0) ct = std::max(4, (c->n_tiles + 4095) / 4096);  // ~4096 chunks: 4 K2 waves per SIMD
+    // ~4096 chunks (4 waves of the walk per SIMD), and no fewer than 8 tiles a chunk: at 1 M sites chunks of 8 tiles cost
+    // K1 and the walk nothing against chunks of 4, halve the scan's and the stitch's work, and leave other streams'
+    // kernels more room (the 3-stream step of cfg2: 48.8 against 53.7 us; tools/gpu_ct.sh)
+    if (ct <= 0) ct = std::max(8, (c->n_tiles + 4095) / 4096);
     ct = std::min(ct, 256);   // K2's accumulators run from the start of a chunk: 16k sites keep their rounding
                               // error 1e-13 of a window's terms (and the 32-bit count prefixes far from wrapping)
     c->chunk_tiles = ct;
