@@ -239,11 +239,11 @@ def test_cli_fstglobal_several_device_batches(tmp_path):
     _global_case(tmp_path, np.random.default_rng(22), [], 20, 10, n_sites=70000, n_samples=8, pops=["popA", "popB", "popC"])
 
 
-def _all_pairs_case(tmp_path, rng, size, step, n_sites, n_samples, pops, scaffolds):
+def _all_pairs_case(tmp_path, rng, size, step, n_sites, n_samples, pops, scaffolds, miss=0.08):
     """evo fst --pops --pairs=all (one pass, window sums from the device's segment table) against P (P - 1) / 2 two-set runs
     of the oracle driver: each pair's file equals the _fst.txt of `evo fst --sets` on the two populations."""
     vcf = str(tmp_path / "in.vcf")
-    names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=scaffolds, miss=0.08)
+    names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=scaffolds, miss=miss)
     member = {}
     pf = str(tmp_path / "pops.txt")
     with open(pf, "w") as f:
@@ -296,6 +296,12 @@ def test_cli_fst_all_pairs_first_window_swallowed_and_overlap(tmp_path):
 
 def test_cli_fst_all_pairs_several_device_batches(tmp_path):
     _all_pairs_case(tmp_path, np.random.default_rng(34), 60, 20, 70000, 10, ["a", "b", "c"], ("scaffold_0", "chrB"))
+
+
+def test_cli_fst_all_pairs_clean_chunks_across_batches(tmp_path):
+    """No missing calls: most chunks are clean, K1 leaves them one byte per count and clean_walk_kernel takes them, with
+    windows that run across the device batches (the ALT = "*" / indel lines of the file still mark their own chunks)."""
+    _all_pairs_case(tmp_path, np.random.default_rng(35), 100, 50, 70000, 12, ["a", "b", "c", "d"], ("scaffold_0", "chrB"), miss=0.0)
 
 
 def test_cli_allele_freq(tmp_path):
