@@ -1069,6 +1069,57 @@ __global__ __launch_bounds__(256) void gram_popsums_kernel(GramParams p) {
     }
 }
 
+// The same sums for populations of at most 31 chromosomes (16-bit counts): one workgroup per window.  Eight lanes take
+// one population's 64 sites of a tile as eight 16-byte vectors (a tile's counts of all populations are one contiguous
+// run, so the wave's loads are 1 KiB each), t + h comes from a 1024-entry LDS table by packed count (built once per
+// workgroup: the two divisions per entry that the kernel above makes per site and population), and a group walks
+// populations g, g + 32, ... with the window's two or three tiles each.  12.5 M one-wave work items of a few
+// instructions each become 25 k workgroups of streaming loads.
+__global__ __launch_bounds__(256) void gram_popsums_tab_kernel(GramParams p) {
+    __shared__ double th[1024];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+        const int c = i & 31, nm = i >> 5;
+        double v = 0.0;
+        if (nm > 0 && c <= nm) {
+            const double pp = (double)c / (double)nm;
+            const double tt = pp * (1.0 - pp);
+            const double hh = nm > 1 ? tt / (double)(nm - 1) : 0.0;
+            v = tt + hh;
+        }
+        th[i] = v;
+    }
+    __syncthreads();
+    const int w = blockIdx.x;
+    const int64_t a = p.win_start[p.first_window + w], b = min(p.win_start[p.first_window + w + 1], p.n_sites);
+    const int group = threadIdx.x >> 3, j = threadIdx.x & 7;            // 32 groups of 8 lanes; lane j: sites 8 j .. 8 j + 7 of a tile
+    const int tw0 = (int)(a >> 6), tw1 = b > a ? (int)((b - 1) >> 6) : tw0 - 1;
+    const uint16_t *cb = reinterpret_cast<const uint16_t *>(p.counts);
+    for (int k = group; k < p.P; k += 32) {
+        double U = 0.0;
+        uint32_t C = 0;
+        for (int t = tw0; t <= tw1; ++t) {
+            uint64_t vm = ~p.skip_mask[t];                                // sites of the tile inside the window and not skipped
+            if (t == tw0) vm &= ~0ull << (a & 63);
+            if (t == tw1 && (b & 63)) vm &= ~0ull >> (64 - (b & 63));
+            const uint32_t bits = (uint32_t)(vm >> (8 * j)) & 0xffu;
+            if (__builtin_amdgcn_ballot_w64(bits != 0u) == 0) continue;
+            const uint4 v = *reinterpret_cast<const uint4 *>(cb + ((size_t)t * p.P + k) * kTileSites + 8 * j);
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t x = ((bits >> e) & 1u) ? (wv[e >> 1] >> (16 * (e & 1))) & 0xffffu : 0u;   // packed count, 0 outside
+                const uint32_t c = x & 0xffu, nm = x >> 8;
+                U += th[(nm << 5) | c];
+                C += c;
+            }
+        }
+        double Cd = (double)C;
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) { U += __shfl_xor(U, d); Cd += __shfl_xor(Cd, d); }
+        if (j == 0) { p.U[(size_t)w * p.P + k] = U; p.C[(size_t)w * p.P + k] = Cd; }
+    }
+}
+
 #ifndef EVOFST_GRAM_WPB
 #define EVOFST_GRAM_WPB 8
 #endif
@@ -1455,7 +1506,8 @@ hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, h
     if (p.n_windows <= 0 || p.P < 2) return hipSuccess;
     if (!(p.debug & 4)) {
         dim3 grid(p.n_windows, (p.P + 3) / 4), block(256);
-        if (count_bytes == 2) hipLaunchKernelGGL((gram_popsums_kernel<uint16_t>), grid, block, 0, st, p);
+        if (count_bytes == 2 && p.max_n <= 31) hipLaunchKernelGGL(gram_popsums_tab_kernel, dim3(p.n_windows), block, 0, st, p);
+        else if (count_bytes == 2) hipLaunchKernelGGL((gram_popsums_kernel<uint16_t>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gram_popsums_kernel<uint32_t>), grid, block, 0, st, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
