@@ -1371,6 +1371,10 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
                               (int64_t *)c->d_row_tot.p, c->n_chunks, 1, 1, nullptr, c->stream));
         record(c, 3, 1);
         GlobalParams p = make_global(c);
+        p.group = 0;   // the launcher cuts K1's chunks into groups that fill whole rounds of workgroups (launch_global)
+#ifdef EVOFST_EXPERIMENTS
+        if (const char *e = getenv("EVOFST_GLOBAL_GROUP_TILES")) p.group = std::max(1, atoi(e) / std::max(1, c->chunk_tiles));
+#endif
         record(c, 2, 0);
         HIPCHK(c, launch_global(p, c->count_bytes, lds, c->stream));
         record(c, 2, 1);

@@ -254,6 +254,7 @@ struct GlobalParams {
     int32_t *row_start, *row_end;  // [row_cap]
     double *row_num, *row_den;     // [row_cap][n_use]
     const int64_t *chunk_row_off;  // [n_chunks+1] first output row of the chunk
+    int32_t group;                 // global_window_kernel: K1 chunks a workgroup walks in a row (0: launch_global chooses)
     // per-site output (on demand)
     double *site_num, *site_den;   // [n_use][n_sites] or null
     uint8_t *site_kept;

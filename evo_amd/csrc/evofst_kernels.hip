@@ -2086,7 +2086,10 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     int32_t *ring_s = reinterpret_cast<int32_t *>(rcp_tab + (p.rcp_lo + 1 + p.rcp_hi + 1));  // [size]
     const GlobalRcp rcp{rcp_tab, p.rcp_lo, p.rcp_hi, p.tn_max};
 
-    const int c = blockIdx.x;
+    // a workgroup walks `group` consecutive chunks of K1's plan: the replay of the deque contents before its first site
+    // (up to a tile) and the tables below are paid once for all of them
+    const int group = max(1, p.group);
+    const int c = blockIdx.x * group;
     const int u = threadIdx.x;
     const bool active = u < p.n_use;
     const int k = active ? p.use_idx[u] : p.use_idx[0];
@@ -2096,7 +2099,7 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     for (int i = threadIdx.x; i <= p.rcp_lo; i += blockDim.x) rcp_tab[i] = 1.0 / (double)i;
     for (int i = threadIdx.x; i <= p.rcp_hi; i += blockDim.x) rcp_tab[p.rcp_lo + 1 + i] = 1.0 / (double)(p.tn_max - i);
 
-    const int t0 = c * p.chunk_tiles, t1 = min(t0 + p.chunk_tiles, p.n_tiles);
+    const int t0 = c * p.chunk_tiles, t1 = min(t0 + group * p.chunk_tiles, p.n_tiles);
     // ---- where the replay starts: walk back until SIZE kept sites of this shard are found
     int th = t0;
     int need = p.size;
@@ -2253,12 +2256,40 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
 }
 
 template <typename CT, bool RCP>
-static hipError_t launch_global_t(const GlobalParams &p, size_t lds_bytes, dim3 grid, dim3 block, hipStream_t st) {
+static hipError_t launch_global_t(const GlobalParams &p_, size_t lds_bytes, dim3 block, hipStream_t st) {
+    const void *fn = reinterpret_cast<const void *>(&global_window_kernel<CT, RCP>);
     if (lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&global_window_kernel<CT, RCP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
+    GlobalParams p = p_;
+    if (p.group <= 0) {
+        // K1 chunks per workgroup: the kernel's time follows the number of rounds its workgroups need on the device (on
+        // the cfg3 shard 8 / 16 / 24 / 32 / 48 tiles per workgroup take 1.07 / 1.12 / 1.31 / 0.89 / 1.33 ms: 977 workgroups are
+        // one round of the 1024 the device holds), so the groups are cut to fill whole rounds, the fewer the better
+        // (every workgroup first replays up to a tile before its own sites).
+        static thread_local struct { const void *fn; int threads; size_t lds; int dev; int cap; } memo = {nullptr, 0, 0, -1, 0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (memo.fn != fn || memo.threads != (int)block.x || memo.lds != lds_bytes || memo.dev != dev) {
+            int per_cu = 0, cus = 0;
+            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)block.x, lds_bytes)) != hipSuccess) return e;
+            if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+            memo = {fn, (int)block.x, lds_bytes, dev, std::max(1, per_cu) * std::max(1, cus)};
+        }
+        const int64_t cap = memo.cap;
+        double best = -1.0;
+        p.group = 1;
+        for (int r = 1; r <= 8; ++r) {
+            const int g = (int)std::max<int64_t>(1, (p.n_chunks + cap * r - 1) / (cap * r));
+            const int64_t blocks = (p.n_chunks + g - 1) / g, rounds = (blocks + cap - 1) / cap;
+            const double tiles = (double)g * p.chunk_tiles;
+            const double score = (double)blocks / (double)(rounds * cap) * tiles / (tiles + 1.0);
+            if (score > best + 1e-9) { best = score; p.group = g; }
+        }
+    }
+    dim3 grid((p.n_chunks + p.group - 1) / p.group);
     hipLaunchKernelGGL((global_window_kernel<CT, RCP>), grid, block, lds_bytes, st, p);
     return hipGetLastError();
 }
@@ -2266,12 +2297,12 @@ static hipError_t launch_global_t(const GlobalParams &p, size_t lds_bytes, dim3 
 hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_use <= 0) return hipSuccess;
     int threads = ((p.n_use + 63) / 64) * 64;
-    dim3 grid(p.n_chunks), block(threads);
+    dim3 block(threads);
     const bool rcp = true;   // the table is small whatever tn_max is
-    if (count_bytes == 2) return rcp ? launch_global_t<uint16_t, true>(p, lds_bytes, grid, block, st)
-                                     : launch_global_t<uint16_t, false>(p, lds_bytes, grid, block, st);
-    return rcp ? launch_global_t<uint32_t, true>(p, lds_bytes, grid, block, st)
-               : launch_global_t<uint32_t, false>(p, lds_bytes, grid, block, st);
+    if (count_bytes == 2) return rcp ? launch_global_t<uint16_t, true>(p, lds_bytes, block, st)
+                                     : launch_global_t<uint16_t, false>(p, lds_bytes, block, st);
+    return rcp ? launch_global_t<uint32_t, true>(p, lds_bytes, block, st)
+               : launch_global_t<uint32_t, false>(p, lds_bytes, block, st);
 }
 
 // per-site against-all values on demand: lane = site
