@@ -30,7 +30,8 @@ for cfg in sys.argv[1:]:
         out["walk"]["calls"] = parts[0]["calls"]
     traffic[cfg] = out
     stats = glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True)
-    if stats:
-        shutil.copy(stats[0], os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (RND, cfg)))
+    if stats:  # gpurun_out/ keeps the files of earlier calls: the newest one is this run's
+        stats.sort(key=os.path.getmtime)
+        shutil.copy(stats[-1], os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (RND, cfg)))
     print(cfg, {k: (round(v["avg_ns"] / 1e3, 1), round((v.get("hbm_read_bytes", 0) + v.get("hbm_write_bytes", 0)) / 1e6, 1)) for k, v in out.items()})
 json.dump(traffic, open(tp, "w"), indent=1)
