@@ -15,8 +15,8 @@
 // reference's load-bearing quirks -- are byte-identical.  Output goes
 // through iostreams with default formatting, exactly like the reference.
 // The optional host-side consumers of the per-site values are carried too: --annot (fst, FstGlobal), --ancSets,
-// --accessibleGenomeBED (fst, DistOutgroups), --regions-above.  Not carried over: the --ms* / --eigen modes of `evo fst`
-// (text post-processing of other programs' output, out of scope), PBS --annot / --af.
+// --accessibleGenomeBED (fst, DistOutgroups), --regions-above, PBS --annot / --af / -i.  Not carried over: the --ms* /
+// --eigen modes of `evo fst` (text post-processing of other programs' output, out of scope).
 #include <getopt.h>
 #include <zlib.h>
 
@@ -428,7 +428,7 @@ const char *FST_USAGE =
     "       --annot=ANNOTATION.gffExtract           (optional) gene annotation (scaffold, start, end, strand, transcript per line):\n"
     "                                               writes RUN_NAMESNPcategory_fst.txt with the category, Fst and dxy of every SNP\n\n";
 
-enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS, OPT_ACC_BED, OPT_ANNOT, OPT_ANC_SETS };
+enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS, OPT_ACC_BED, OPT_ANNOT, OPT_ANC_SETS, OPT_AF };
 
 void parseFstOptions(int argc, char **argv) {
     static const struct option longopts[] = {
@@ -1288,7 +1288,7 @@ int AFmain(int argc, char **argv) {
 namespace bopt {
 string vcfFile, setsFile, tuplesFile, runName = "", annotFile;
 int fixedWindowSize = 10000, windowSize = 20, windowStep = 10;
-bool allowIndels = false;
+bool allowIndels = false, af = false;
 }
 
 const char *PBS_USAGE =
@@ -1300,6 +1300,7 @@ const char *PBS_USAGE =
     "       -w SIZE,STEP --window=SIZE,STEP         sliding window: SIZE SNPs, moving by STEP (default: 20,10)\n"
     "       -n, --run-name=RUN_NAME                 run-name will be included in the output file names\n"
     "       --annot=ANNOTATION.gffExtract           (optional) gene annotation: writes P1_P2_P3_PBSGenes_RUN_SIZE_STEP.txt, one row per gene\n"
+    "       --af=ARG                                (optional) as in the reference: leaves POPULATIONS_AF.txt, empty (ARG is not read)\n"
     "       -i, --allow-indels-and-multiallelics    (optional) also use indels, and multiallelics with the second allele taken as REF\n\n";
 
 const char *ABS_USAGE =
@@ -1322,7 +1323,7 @@ const uint8_t kPbsNanNegative[8] = {0, 4, 3, 0, 7, 4, 3, 0};
 const uint8_t kAbsNanNegative[64] = {0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 3, 2, 0, 0, 0, 0,
                                      3, 0, 3, 0, 1, 0, 0, 0, 3, 2, 3, 0, 1, 0, 1, 0, 3, 0, 3, 0, 1, 0, 1, 0, 0, 2, 3, 2, 1, 0, 1, 0};
 
-// evo PBS (PBSmain, evo_PBS.cpp:126-369, without --af) and evo ABS (ABSmain, evo_ABS.cpp:109-293): the reference's two mains are one loop over a different per-site statistic.  Per-site values of
+// evo PBS (PBSmain, evo_PBS.cpp:126-369) and evo ABS (ABSmain, evo_ABS.cpp:109-293): the reference's two mains are one loop over a different per-site statistic.  Per-site values of
 // every trio / quartet come from the device; the sliding windows (and, for PBS, the fixed windows) are replayed on the
 // host in file order.  Line citations are PBSmain's unless marked.
 int branchMain(const int arity, int argc, char **argv) {
@@ -1331,7 +1332,7 @@ int branchMain(const int arity, int argc, char **argv) {
     const int nVal = pbsMode ? 3 : 2;
     const char *usage = pbsMode ? PBS_USAGE : ABS_USAGE;
     static const struct option longopts[] = {{"fixedW", required_argument, NULL, 'f'}, {"window", required_argument, NULL, 'w'},
-                                             {"annot", required_argument, NULL, OPT_ANNOT}, {"af", required_argument, NULL, OPT_UNSUPPORTED},
+                                             {"annot", required_argument, NULL, OPT_ANNOT}, {"af", required_argument, NULL, OPT_AF},
                                              {"allow-indels-and-multiallelics", no_argument, NULL, 'i'},
                                              {"help", no_argument, NULL, 'h'}, {"run-name", required_argument, NULL, 'n'}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
@@ -1349,7 +1350,7 @@ int branchMain(const int arity, int argc, char **argv) {
             case 'n': arg >> runName; break;
             case 'i': if (!pbsMode) { dieFlag = true; break; } allowIndels = true; break;
             case OPT_ANNOT: arg >> annotFile; break;
-            case OPT_UNSUPPORTED: die("--af is not carried by the GPU build");
+            case OPT_AF: if (!pbsMode) { dieFlag = true; break; } af = true; break;                           // :48, 393: the argument is not read
             case 'h': std::cout << usage; exit(EXIT_SUCCESS);
         }
     }
@@ -1431,7 +1432,7 @@ int branchMain(const int arity, int argc, char **argv) {
     std::vector<double> val;
     std::vector<uint8_t> used;
     std::vector<int32_t> altc, nmc;
-    bool haveHeader = false;
+    bool haveHeader = false, afMade = false;
 
     auto flush = [&]() {
         if (batch.n == 0) return;
@@ -1480,6 +1481,10 @@ int branchMain(const int arity, int argc, char **argv) {
             const string &chr = batch.chrom[s];
             const string &coord = batch.pos[s];
             double coordDouble; { std::stringstream ss(coord); ss >> coordDouble; }
+            // :264-271 --af: at every used line the reference opens stripExtension(setsFile) + "_AF.txt" anew, which
+            // empties it, on a stream that is never closed, flushed or deleted: the line it writes stays in a buffer
+            // that is lost at exit.  What a run leaves is the empty file; made once here, at the first used line.
+            if (pbsMode && af && !afMade) { std::ofstream((stripExtension(setsFile) + "_AF" + ".txt").c_str()); afMade = true; }
             int geneCategory = -1;                                   // :282-286
             if (pbsMode && haveAnnot) {
                 const string *gene;

@@ -1534,11 +1534,12 @@ void orc_abs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, 
         }
 }
 
-/* `evo PBS [-w SIZE,STEP] [-f FW] [-n RUN] VCF POPS TRIOS` (PBSmain, evo_PBS.cpp:125-363) without --annot,
- * --af and -i, and `evo ABS [-w SIZE,STEP] [-n RUN] VCF POPS QUARTETS` (ABSmain, evo_ABS.cpp:109-293) without --annot.
+/* `evo PBS [-w SIZE,STEP] [-f FW] [-n RUN] VCF POPS TRIOS` (PBSmain, evo_PBS.cpp:125-363) without --annot, --af
+ * and -i (those come in through orc_pbs_run_annot, orc_set_pbs_af and orc_set_allow_indels), and `evo ABS [-w SIZE,STEP] [-n RUN] VCF POPS QUARTETS` (ABSmain, evo_ABS.cpp:109-293) without --annot.
  * The two mains are the same loop over a different statistic (arity 3 with fixed windows, arity 4 without); the
  * citations below are PBSmain's, ABSmain's lines are noted where the behaviour differs.  Output files go to out_dir. */
 static const char *g_pbs_annot_path = NULL;            /* set by orc_pbs_run_annot for the duration of one run */
+static int g_pbs_af = 0;                               /* --af of PBS (evo_PBS.cpp:264-271), likewise */
 static int g_allow_indels = 0;                         /* -i of PBS / DistOutgroups (evo_PBS.cpp:250-252, evo_distanceToOutgroups.cpp:196-198), likewise */
 static int branch_run(int arity, const char *vcf_path, const char *pops_path, const char *trios_path,
                       int windowSize, int windowStep, int fixedWindowSize, const char *run_name, const char *out_dir) {
@@ -1686,6 +1687,20 @@ static int branch_run(int arity, const char *vcf_path, const char *pops_path, co
             if (strcmp(fields[4], "*") == 0 || (!(arity == 3 && g_allow_indels) && (strlen(fields[3]) > 1 || strlen(fields[4]) > 1))) continue;
             orc_general_counts((const char *const *)(fields + 9), n_samples, sample_pop, n_pops, use_pop,
                                alt, alleles, aaf, allelesC, aafC);
+            /* :264-271 --af: at every used line the reference opens stripExtension(setsFile) + "_AF.txt" anew (which
+             * empties it) on a stream it never closes, flushes or deletes, so the line written stays in a buffer that
+             * is lost at exit (a line of more than a stream buffer, 8 KiB in libstdc++, would reach the file in part;
+             * thousands of populations).  What a run leaves is the empty file, here made in out_dir. */
+            if (arity == 3 && g_pbs_af) {
+                const char *slash = strrchr(pops_path, '/');
+                char *base = strdup(slash ? slash + 1 : pops_path);
+                { char *dot = strrchr(base, '.'); if (dot) *dot = '\0'; }
+                char name[768];
+                snprintf(name, sizeof name, "%s_AF.txt", base);
+                free(base);
+                char *op = path_join(out_dir, name); FILE *af = fopen(op, "w"); free(op);
+                if (af) fclose(af);
+            }
             const char *snpGene = "", *snpCategory = "nonCoding";                                /* :282-286 */
             if (an) {
                 snpCategory = orc_annot_gene_details(an, chr, atoi(coord), &snpGene);
@@ -1792,6 +1807,8 @@ int orc_pbs_run_annot(const char *vcf_path, const char *pops_path, const char *t
 /* -i / --allow-indels-and-multiallelics for the drivers that have it (PBS, DistOutgroups): only ALT == "*" is skipped;
  * every other line is counted by the characters '0' and '1' of its genotypes (getBasicCounts) */
 void orc_set_allow_indels(int on) { g_allow_indels = on; }
+/* --af of PBS (takes an argument that is not read, evo_PBS.cpp:48, 393) */
+void orc_set_pbs_af(int on) { g_pbs_af = on; }
 
 int orc_abs_run(const char *vcf_path, const char *pops_path, const char *quartets_path,
                 int windowSize, int windowStep, const char *run_name, const char *out_dir) {

@@ -224,6 +224,7 @@ void orc_abs_site_stats(const int32_t *alt, const int32_t *nm, int64_t n_sites, 
 /* `evo PBS [-w] [-f] [-n] VCF POPS TRIOS` (PBSmain, evo_PBS.cpp:125-363) without --annot / --af / -i */
 int orc_pbs_run(const char *vcf_path, const char *pops_path, const char *trios_path,
                 int window_size, int window_step, int fixed_window_size, const char *run_name, const char *out_dir);
+void orc_set_pbs_af(int on);         /* --af of the PBS driver for the calls that follow: leaves <pops stem>_AF.txt, empty as the reference does */
 void orc_set_allow_indels(int on);   /* -i of the PBS and DistOutgroups drivers for the calls that follow (0 = off, the default) */
 /* with --annot (annot_path may be NULL or ""): a row per gene and trio, evo_PBS.cpp:176-181, 282-286, 333-361 */
 int orc_pbs_run_annot(const char *vcf_path, const char *pops_path, const char *trios_path, int window_size, int window_step,

@@ -543,14 +543,16 @@ def pbs_site_stats(alt, nm, trios, site_flags=None):
     return pbs, used
 
 
-def pbs_run(vcf, pops, trios, out_dir, run_name="", size=20, step=10, fixed=10000, annot=None, allow_indels=False):
+def pbs_run(vcf, pops, trios, out_dir, run_name="", size=20, step=10, fixed=10000, annot=None, allow_indels=False, af=False):
     L = lib()
     L.orc_set_allow_indels(1 if allow_indels else 0)
+    L.orc_set_pbs_af(1 if af else 0)
     L.orc_pbs_run_annot.restype = C.c_int
     L.orc_pbs_run_annot.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
     rc = L.orc_pbs_run_annot(vcf.encode(), pops.encode(), trios.encode(), size, step, fixed, run_name.encode(), out_dir.encode(),
                              (annot or "").encode())
     L.orc_set_allow_indels(0)
+    L.orc_set_pbs_af(0)
     if rc != 0:
         raise RuntimeError("orc_pbs_run failed: %d" % rc)
 

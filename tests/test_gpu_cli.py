@@ -326,7 +326,7 @@ def test_cli_allele_freq(tmp_path):
     assert sum(1 for _ in open(got)) > 30000
 
 
-def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25, quartets=False, annot_text=None, allow_indels=False):
+def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25, quartets=False, annot_text=None, allow_indels=False, af=False):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=miss)
     pf, tf = str(tmp_path / "pops.txt"), str(tmp_path / "trios.txt")
@@ -356,7 +356,9 @@ def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samp
     if quartets:
         O.abs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step)
     else:
-        O.pbs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step, fixed=fixed, annot=annot, allow_indels=allow_indels)
+        O.pbs_run(vcf, pf, tf, str(orc_dir), run_name="p", size=size, step=step, fixed=fixed, annot=annot, allow_indels=allow_indels, af=af)
+    if af:                                                           # written next to the populations file (evo_PBS.cpp:265)
+        os.rename(str(tmp_path / "pops_AF.txt"), str(cli_dir / "pops_AF.txt"))
     _same_files(str(cli_dir), str(orc_dir))
     return cli_dir
 
@@ -393,6 +395,15 @@ def test_cli_pbs_allow_indels(tmp_path):
     (tmp_path / "plain").mkdir()
     d0 = _pbs_case(tmp_path / "plain", np.random.default_rng(47), [], 20, 10)
     assert with_i > len((d0 / "popA_popB_popC_PBS_p_20_10.txt").read_text().splitlines())
+
+
+def test_cli_pbs_af_leaves_the_empty_file(tmp_path):
+    """PBS --af=ARG (evo_PBS.cpp:48, 264-271, 393): the reference reopens POPULATIONS_AF.txt at every used line on a stream it
+    never flushes or closes, so a run leaves the file empty; the other files are those of a run without it."""
+    d = _pbs_case(tmp_path, np.random.default_rng(48), ["--af=1"], 20, 10, af=True)
+    assert (d / "pops_AF.txt").stat().st_size == 0 and len(os.listdir(d)) == 13
+    r = subprocess.run([EVO, "ABS", "--af=1", "a", "b", "c"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0                                        # ABS has no such option (evo_ABS.cpp:39-45)
 
 
 def test_cli_pbs_default(tmp_path):
