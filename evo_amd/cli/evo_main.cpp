@@ -1779,8 +1779,8 @@ int DistOutMain(int argc, char **argv) {
 // ========================================================================================== stats
 
 namespace sopt {
-string vcfFile;
-int bootstrapBlockSize = 1000, numAccessibleBP = -1;
+string vcfFile, accessibleGenBedFile;
+int bootstrapBlockSize = 1000, numAccessibleBP = -1, accessibleGenBedWindow = 10000;
 bool bDiffs = false, bDoBootstrap = false;
 const int n_bootstrap_replicates = 100;
 }
@@ -1793,9 +1793,12 @@ const char *STATS_USAGE =
     "                                               FILE.hets_over_homs_matrix.txt and FILE.parwiseMissingness.txt\n"
     "       --block-bootstrap=BLOCKSIZE             also 100 bootstrap replicates of the diff_me matrix, resampling blocks of\n"
     "                                               BLOCKSIZE variants with replacement (written next to the VCF)\n"
-    "       --numAccessibleBP=NUM                   divide the diff_me matrix by the number of accessible base pairs\n\n";
+    "       --numAccessibleBP=NUM                   divide the diff_me matrix by the number of accessible base pairs\n"
+    "       --accessibleGenomeBED=BEDfile.bed       instead of a VCF the input is a file of scaffold names and lengths; prints the\n"
+    "                                               accessible bases of every window to stdout and does nothing else\n"
+    "       --accessibleGenBedWindow=NUMbp          the size of those windows (default 10000)\n\n";
 
-enum { OPT_DIFF_MATRIX = 64, OPT_BLOCK_BOOTSTRAP, OPT_NUM_ACCESSIBLE };
+enum { OPT_DIFF_MATRIX = 64, OPT_BLOCK_BOOTSTRAP, OPT_NUM_ACCESSIBLE, OPT_ACC_GEN_BED, OPT_ACC_GEN_BED_WINDOW };
 
 string stripPath(const string &filename) {                           // process_vcf_utils.cpp:153-160
     size_t slashPos = filename.find_last_of('/');
@@ -1815,8 +1818,8 @@ int statsMain(int argc, char **argv) {
         {"ind-file", required_argument, NULL, OPT_UNSUPPORTED}, {"pop-file", required_argument, NULL, OPT_UNSUPPORTED},
         {"hets-per-individual", no_argument, NULL, OPT_UNSUPPORTED}, {"doubleton-distribution", no_argument, NULL, OPT_UNSUPPORTED},
         {"diff-matrix-h1", no_argument, NULL, OPT_UNSUPPORTED}, {"diff-matrix-allH", no_argument, NULL, OPT_UNSUPPORTED},
-        {"private-variants", no_argument, NULL, OPT_UNSUPPORTED}, {"accessibleGenomeBED", required_argument, NULL, OPT_UNSUPPORTED},
-        {"accessibleGenBedWindow", required_argument, NULL, OPT_UNSUPPORTED}, {NULL, 0, NULL, 0}};
+        {"private-variants", no_argument, NULL, OPT_UNSUPPORTED}, {"accessibleGenomeBED", required_argument, NULL, OPT_ACC_GEN_BED},
+        {"accessibleGenBedWindow", required_argument, NULL, OPT_ACC_GEN_BED_WINDOW}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
     for (int c; (c = getopt_long(argc, argv, "h", longopts, NULL)) != -1;) {
         std::istringstream arg(optarg != NULL ? optarg : "");
@@ -1825,16 +1828,40 @@ int statsMain(int argc, char **argv) {
             case OPT_DIFF_MATRIX: bDiffs = true; break;
             case OPT_BLOCK_BOOTSTRAP: arg >> bootstrapBlockSize; bDoBootstrap = true; break;
             case OPT_NUM_ACCESSIBLE: arg >> numAccessibleBP; break;
-            case OPT_UNSUPPORTED: die("of `evo stats` the GPU build carries --diff-matrix, --block-bootstrap and --numAccessibleBP only");
+            case OPT_ACC_GEN_BED: arg >> accessibleGenBedFile; break;
+            case OPT_ACC_GEN_BED_WINDOW: arg >> accessibleGenBedWindow; break;
+            case OPT_UNSUPPORTED: die("of `evo stats` the GPU build carries --diff-matrix, --block-bootstrap, --numAccessibleBP and --accessibleGenomeBED only");
             case 'h': std::cout << STATS_USAGE; exit(EXIT_SUCCESS);
         }
     }
     if (argc - optind < 1) { std::cerr << "missing arguments\n"; dieFlag = true; }
     else if (argc - optind > 1) { std::cerr << "too many arguments\n"; dieFlag = true; }
-    if (!bDiffs) { std::cerr << "Which statistics should the program calculate?\n"; dieFlag = true; }
+    if (!bDiffs && accessibleGenBedFile.empty()) { std::cerr << "Which statistics should the program calculate?\n"; dieFlag = true; }   // :398
+    if (accessibleGenBedWindow <= 0) { std::cerr << "--accessibleGenBedWindow must be positive\n"; dieFlag = true; }
     if (bDoBootstrap && bootstrapBlockSize <= 0) { std::cerr << "the bootstrap BLOCKSIZE must be positive\n"; dieFlag = true; }
     if (dieFlag) { std::cout << "\n" << STATS_USAGE; exit(EXIT_FAILURE); }
     vcfFile = argv[optind++];
+
+    // --accessibleGenomeBED (:146-164): the input is a file of scaffold names and lengths, not a VCF; one row per window
+    // of --accessibleGenBedWindow bases with the accessible bases in [i, i + window] goes to stdout, and nothing else is
+    // done (host only: this is where --numAccessibleBP of the difference matrices comes from)
+    if (!accessibleGenBedFile.empty()) {
+        std::cerr << "Loading the accessible genome annotation" << std::endl;
+        AccessibleBed ag;
+        ag.load(accessibleGenBedFile);
+        std::cerr << "Done" << std::endl;
+        LineReader lengths(vcfFile);
+        string l;
+        while (lengths.getline(l)) {
+            std::vector<string> fields = split(l, '\t');
+            if (fields.size() < 2) die("the scaffold lengths file needs two tab-separated columns per line");
+            const string &sc = fields[0];
+            const int len = atoi(fields[1].c_str());
+            for (int i = 0; i < len; i = i + accessibleGenBedWindow)
+                std::cout << sc << "\t" << i << "\t" << i + accessibleGenBedWindow << "\t" << ag.basesIn(sc, i, i + accessibleGenBedWindow) << std::endl;
+        }
+        return 0;
+    }
 
     const string fileRoot = stripExtension(vcfFile);                 // :103
     std::cerr << "Calculating statistics from: " << vcfFile << std::endl;
