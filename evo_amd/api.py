@@ -87,6 +87,7 @@ SIGNATURES = {
     "evofst_stats_phase_draws": (C.c_int, [C.c_int64, C.POINTER(C.c_char_p), C.c_int, C.c_int, _i64p]),
     "evofst_set_multiallelic": (C.c_int, [_vp, C.c_int64, _i64p, _u8p]),
     "evofst_get_indiv_diffs": (C.c_int, [_vp, C.c_int, _i64p, _i32p, _i32p, _i32p, _i32p, _i32p]),
+    "evofst_get_indiv_hets": (C.c_int, [_vp, _i32p, _i32p]),
     "evofst_get_dist_windows": (C.c_int, [_vp, C.c_int, _i64p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _dp, _i32p, _i32p,
                                           _i32p, _i32p]),
     "evofst_get_pop_site_div": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp, _dp, _dp]),
@@ -427,6 +428,14 @@ class EvoFst:
         r = {k: np.zeros((B, n * (n + 1) // 2), np.int32) for k in ("hh", "hd", "oh", "ms", "d4")}
         self._chk(self.L.evofst_get_indiv_diffs(self.h, B, _ptr(bo, _i64p), *[_ptr(r[k], _i32p) for k in ("hh", "hd", "oh", "ms", "d4")]))
         return r
+
+    def indiv_hets(self):
+        """Per layout individual: heterozygous sites among the sites without a missing genotype, and those of them where
+        ALT was seen more than once -> (het, shared) int32 [n]."""
+        n = self.geometry().n_haplotypes // 2
+        het = np.zeros(n, np.int32); shared = np.zeros(n, np.int32)
+        self._chk(self.L.evofst_get_indiv_hets(self.h, _ptr(het, _i32p), _ptr(shared, _i32p)))
+        return het, shared
 
     def pop_site_div(self, first=0, n=None):
         n = self.n_sites - first if n is None else n

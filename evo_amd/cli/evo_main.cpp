@@ -1781,24 +1781,26 @@ int DistOutMain(int argc, char **argv) {
 namespace sopt {
 string vcfFile, accessibleGenBedFile;
 int bootstrapBlockSize = 1000, numAccessibleBP = -1, accessibleGenBedWindow = 10000;
-bool bDiffs = false, bDoBootstrap = false;
+bool bDiffs = false, bDoBootstrap = false, countHets = false;
 const int n_bootstrap_replicates = 100;
 }
 
 const char *STATS_USAGE =
     "Usage: evo stats [OPTIONS] INPUT_FILE.vcf\n"
-    "Pairwise difference statistics between the individuals of a VCF (GPU build: --diff-matrix only)\n"
+    "Pairwise difference statistics between the individuals of a VCF (GPU build: --diff-matrix, --hets-per-individual)\n"
     "       -h, --help                              display this help and exit\n"
     "       --diff-matrix                           writes FILE.diff_matrix.txt, FILE.diff_me_matrix.txt,\n"
     "                                               FILE.hets_over_homs_matrix.txt and FILE.parwiseMissingness.txt\n"
     "       --block-bootstrap=BLOCKSIZE             also 100 bootstrap replicates of the diff_me matrix, resampling blocks of\n"
     "                                               BLOCKSIZE variants with replacement (written next to the VCF)\n"
     "       --numAccessibleBP=NUM                   divide the diff_me matrix by the number of accessible base pairs\n"
+    "       --hets-per-individual                   writes FILE.hets.txt and FILE.sharedHets.txt (next to the VCF): heterozygous calls\n"
+    "                                               per individual at the sites without a missing genotype\n"
     "       --accessibleGenomeBED=BEDfile.bed       instead of a VCF the input is a file of scaffold names and lengths; prints the\n"
     "                                               accessible bases of every window to stdout and does nothing else\n"
     "       --accessibleGenBedWindow=NUMbp          the size of those windows (default 10000)\n\n";
 
-enum { OPT_DIFF_MATRIX = 64, OPT_BLOCK_BOOTSTRAP, OPT_NUM_ACCESSIBLE, OPT_ACC_GEN_BED, OPT_ACC_GEN_BED_WINDOW };
+enum { OPT_DIFF_MATRIX = 64, OPT_BLOCK_BOOTSTRAP, OPT_NUM_ACCESSIBLE, OPT_ACC_GEN_BED, OPT_ACC_GEN_BED_WINDOW, OPT_HETS };
 
 string stripPath(const string &filename) {                           // process_vcf_utils.cpp:153-160
     size_t slashPos = filename.find_last_of('/');
@@ -1816,7 +1818,7 @@ int statsMain(int argc, char **argv) {
         {"help", no_argument, NULL, 'h'}, {"diff-matrix", no_argument, NULL, OPT_DIFF_MATRIX},
         {"block-bootstrap", required_argument, NULL, OPT_BLOCK_BOOTSTRAP}, {"numAccessibleBP", required_argument, NULL, OPT_NUM_ACCESSIBLE},
         {"ind-file", required_argument, NULL, OPT_UNSUPPORTED}, {"pop-file", required_argument, NULL, OPT_UNSUPPORTED},
-        {"hets-per-individual", no_argument, NULL, OPT_UNSUPPORTED}, {"doubleton-distribution", no_argument, NULL, OPT_UNSUPPORTED},
+        {"hets-per-individual", no_argument, NULL, OPT_HETS}, {"doubleton-distribution", no_argument, NULL, OPT_UNSUPPORTED},
         {"diff-matrix-h1", no_argument, NULL, OPT_UNSUPPORTED}, {"diff-matrix-allH", no_argument, NULL, OPT_UNSUPPORTED},
         {"private-variants", no_argument, NULL, OPT_UNSUPPORTED}, {"accessibleGenomeBED", required_argument, NULL, OPT_ACC_GEN_BED},
         {"accessibleGenBedWindow", required_argument, NULL, OPT_ACC_GEN_BED_WINDOW}, {NULL, 0, NULL, 0}};
@@ -1828,15 +1830,17 @@ int statsMain(int argc, char **argv) {
             case OPT_DIFF_MATRIX: bDiffs = true; break;
             case OPT_BLOCK_BOOTSTRAP: arg >> bootstrapBlockSize; bDoBootstrap = true; break;
             case OPT_NUM_ACCESSIBLE: arg >> numAccessibleBP; break;
+            case OPT_HETS: countHets = true; break;
             case OPT_ACC_GEN_BED: arg >> accessibleGenBedFile; break;
             case OPT_ACC_GEN_BED_WINDOW: arg >> accessibleGenBedWindow; break;
-            case OPT_UNSUPPORTED: die("of `evo stats` the GPU build carries --diff-matrix, --block-bootstrap, --numAccessibleBP and --accessibleGenomeBED only");
+            case OPT_UNSUPPORTED: die("of `evo stats` the GPU build carries --diff-matrix, --block-bootstrap, --numAccessibleBP, --hets-per-individual and --accessibleGenomeBED only");
             case 'h': std::cout << STATS_USAGE; exit(EXIT_SUCCESS);
         }
     }
     if (argc - optind < 1) { std::cerr << "missing arguments\n"; dieFlag = true; }
     else if (argc - optind > 1) { std::cerr << "too many arguments\n"; dieFlag = true; }
-    if (!bDiffs && accessibleGenBedFile.empty()) { std::cerr << "Which statistics should the program calculate?\n"; dieFlag = true; }   // :398
+    if (bDoBootstrap && !bDiffs) { std::cerr << "--block-bootstrap needs --diff-matrix\n"; dieFlag = true; }
+    if (!bDiffs && !countHets && accessibleGenBedFile.empty()) { std::cerr << "Which statistics should the program calculate?\n"; dieFlag = true; }   // :398
     if (accessibleGenBedWindow <= 0) { std::cerr << "--accessibleGenBedWindow must be positive\n"; dieFlag = true; }
     if (bDoBootstrap && bootstrapBlockSize <= 0) { std::cerr << "the bootstrap BLOCKSIZE must be positive\n"; dieFlag = true; }
     if (dieFlag) { std::cout << "\n" << STATS_USAGE; exit(EXIT_FAILURE); }
@@ -1865,6 +1869,12 @@ int statsMain(int argc, char **argv) {
 
     const string fileRoot = stripExtension(vcfFile);                 // :103
     std::cerr << "Calculating statistics from: " << vcfFile << std::endl;
+    if (countHets) {                                                 // :167-170
+        std::cerr << "Het count per individual are going to be output to: " << fileRoot + ".hets.txt" << std::endl;
+        std::cerr << "Counts of hets (per individual) shared with others are going to be output to: " << fileRoot + ".sharedHets.txt" << std::endl;
+    }
+    std::vector<int> hetCounts, hetsSharedWithOthers;                // :138, :224
+    std::vector<int32_t> bhet, bshared;
     LineReader vcf(vcfFile);
     std::vector<string> sampleNames;
     int numSamples = 0, totalVariantNumber = 0;
@@ -1905,6 +1915,12 @@ int statsMain(int argc, char **argv) {
             if (evofst_stats_phase_draws((int64_t)n, ptr.data(), numSamples, threads, &draws) != EVOFST_OK) die("malformed VCF line");
             phaseDraws += draws;
         }
+        if (countHets) {                                             // :239-242 het_analysis at the sites without a missing genotype
+            bhet.resize(numSamples); bshared.resize(numSamples);
+            check(dev.ctx, evofst_get_indiv_hets(dev.ctx, bhet.data(), bshared.data()), "get_indiv_hets");
+            for (int i = 0; i < numSamples; ++i) { hetCounts[i] += bhet[i]; hetsSharedWithOthers[i] += bshared[i]; }
+        }
+        if (!bDiffs) { batch.clear(); return; }
         multiSite.clear(); multiAlleles.clear();
         for (size_t s = 0; s < n; ++s)
             if (batch.flags[s] & EVOFST_SITE_MULTI) {
@@ -1959,6 +1975,7 @@ int statsMain(int argc, char **argv) {
             isDiag.assign(T, 0);
             for (size_t i = 0; i < (size_t)numSamples; ++i) isDiag[i * (i + 1) / 2 + i] = 1;
             if (bDoBootstrap) { openMe4.assign(T, 0); openMs.assign(T, 0); }
+            hetCounts.assign(numSamples, 0); hetsSharedWithOthers.assign(numSamples, 0);
             std::vector<int32_t> sp(numSamples, 0);                  // one population: the layout keeps the VCF order
             dev.open();
             check(dev.ctx, evofst_set_layout(dev.ctx, numSamples, 1, sp.data()), "set_layout");
@@ -2008,6 +2025,20 @@ int statsMain(int argc, char **argv) {
             }
         }
     }
+
+    if (countHets) {                                                 // :336-337 print_het_counts (process_vcf_print_routines.cpp:29-56)
+        std::ofstream hetsOut((fileRoot + ".hets.txt").c_str()), sharedOut((fileRoot + ".sharedHets.txt").c_str());
+        hetsOut << "# Het counts" << std::endl;
+        hetsOut << "# Input file:" << fileRoot << ".vcf" << std::endl;
+        sharedOut << "# Shared het counts (line1) and proportions (line 2)" << std::endl;
+        sharedOut << "# Input file:" << fileRoot << ".vcf" << std::endl;
+        std::vector<double> sharedHetProportions;
+        for (size_t i = 0; i < N; i++) sharedHetProportions.push_back((double)hetsSharedWithOthers[i] / hetCounts[i]);   // 0 / 0: "-nan"
+        auto row = [&](std::ofstream &f, const auto &v) { for (size_t i = 0; i < N; i++) { f << v[i]; if (i == N - 1) f << std::endl; else f << "\t"; } };
+        row(hetsOut, sampleNames); row(hetsOut, hetCounts);
+        row(sharedOut, sampleNames); row(sharedOut, hetsSharedWithOthers); row(sharedOut, sharedHetProportions);
+    }
+    if (!bDiffs) { dev.close(); return 0; }
 
     // print_pairwise_diff_stats (process_vcf_print_routines.cpp:74-120) after finalize_diffs_Hets_vs_Homs_proportions
     const string fileNoPath = stripPath(fileRoot);                   // :328

@@ -1918,6 +1918,36 @@ extern "C" int evofst_get_indiv_diffs(evofst_ctx *c, int n_blocks, const int64_t
     return abi_exception(c);
 }
 
+extern "C" int evofst_get_indiv_hets(evofst_ctx *c, int32_t *het, int32_t *shared) try {
+    if (!c || !het || !shared) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->n_sites <= 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "get_indiv_hets: upload first");
+    HIPCHK(c, hipSetDevice(c->device));
+    IndivParams p{};
+    p.tiles = (const ulonglong2 *)c->tiles; p.site_flags = c->have_flags ? c->flags : nullptr;
+    p.n_sites = c->n_sites; p.W = c->W; p.n_tiles = n_tiles_of(c->n_sites); p.n_ind = c->H / 2;
+    if (p.n_ind <= 0) return fail(c, EVOFST_ERR_STATE, "get_indiv_hets: the layout has no individual");
+    int rc = ensure(c, c->d_planes, (size_t)p.n_tiles * p.n_ind * 32);
+    DevBuf b;
+    const size_t out_bytes = (size_t)p.n_ind * 4;
+    if (!rc) rc = ensure(c, b, 2 * out_bytes);
+    if (rc) { release(b); return rc; }
+    p.planes = (uint64_t *)c->d_planes.p;
+    p.het_cnt = (int32_t *)b.p; p.shared_cnt = p.het_cnt + p.n_ind;
+    hipError_t e = hipMemsetAsync(b.p, 0, 2 * out_bytes, c->stream);
+    if (e == hipSuccess) e = launch_indiv_planes(p, c->stream);
+    if (e == hipSuccess) e = launch_indiv_hets(p, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(het, p.het_cnt, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(shared, p.shared_cnt, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    else (void)hipStreamSynchronize(c->stream);
+    release(b);
+    if (e != hipSuccess) return hip_fail(c, e, "get_indiv_hets");
+    return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
+}
+
 extern "C" int evofst_get_pop_site_div(evofst_ctx *c, int64_t first_site, int64_t n_sites, double *het, double *het_nei,
                                        double *pi) try {
     if (!c) return EVOFST_ERR_ARG;

@@ -222,6 +222,7 @@ struct IndivParams {
     const int64_t *multi_site;       // [n_multi] site index of the multi-allelic sites, ascending
     const uint8_t *multi_alleles;    // [n_multi][n_ind][2], 255 = missing individual
     int64_t n_multi;
+    int32_t *het_cnt, *shared_cnt;   // [n_ind] each (indiv_hets_kernel; zeroed by the caller)
 };
 
 struct PopDivParams {
@@ -311,6 +312,7 @@ hipError_t launch_dist_windows(const DistParams &p, int count_bytes, hipStream_t
 hipError_t launch_indiv_planes(const IndivParams &p, hipStream_t st);
 hipError_t launch_indiv_pairs(const IndivParams &p, hipStream_t st);
 hipError_t launch_indiv_multi(const IndivParams &p, hipStream_t st);
+hipError_t launch_indiv_hets(const IndivParams &p, hipStream_t st);
 hipError_t launch_unpack_segments(const SegRow *rows, size_t n, double *num, double *den, double *k, int32_t *end, hipStream_t st);
 hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_unpack_counts(const void *counts, int count_bytes, int P, int64_t first_site, int64_t n_sites,

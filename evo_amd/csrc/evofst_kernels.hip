@@ -1882,6 +1882,50 @@ __global__ __launch_bounds__(256) void indiv_multi_kernel(IndivParams p) {
     if (ms) p.ms[o] += ms;
 }
 
+// het_analysis (process_vcf_stats_functions.cpp:19-28) at the sites where no genotype is missing
+// (process_vcf_stats.cpp:239-242): per individual its heterozygous sites, and those of them where the ALT allele was
+// seen more than once among all individuals (counts.overall > 1: some individual is hom-alt, or two are heterozygous).
+// One wave per tile; lanes take the individuals in turn.  "Seen in two individuals" is kept as a pair of masks
+// {one, two} that combines over disjoint groups: two = two_a | two_b | (one_a & one_b).  Multi-allelic and skipped
+// sites have empty planes (indiv_planes_kernel) and count nowhere, as in the reference (individualsWithVariant stays 0).
+__global__ __launch_bounds__(256) void indiv_hets_kernel(IndivParams p) {
+    const int lane = threadIdx.x & 63;
+    const int t = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (t >= p.n_tiles) return;                                  // wave-uniform
+    const uint64_t *pl = p.planes + (size_t)t * p.n_ind * 4;
+    uint64_t any_miss = 0, any_alt = 0, one = 0, two = 0;
+    for (int d = lane; d < p.n_ind; d += 64) {
+        const ulonglong2 ha = reinterpret_cast<const ulonglong2 *>(pl + (size_t)d * 4)[0];   // {het, hom-alt}
+        any_miss |= pl[(size_t)d * 4 + 3];
+        any_alt |= ha.y;
+        two |= one & ha.x;
+        one |= ha.x;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint64_t o1 = __shfl_xor(one, m), o2 = __shfl_xor(two, m);
+        two |= o2 | (one & o1);
+        one |= o1;
+        any_miss |= __shfl_xor(any_miss, m);
+        any_alt |= __shfl_xor(any_alt, m);
+    }
+    const uint64_t ok = ~any_miss, shared = any_alt | two;
+    for (int d = lane; d < p.n_ind; d += 64) {
+        const uint64_t h = pl[(size_t)d * 4] & ok;
+        if (h) {
+            atomicAdd(p.het_cnt + d, (int32_t)__popcll(h));
+            const int sh = (int)__popcll(h & shared);
+            if (sh) atomicAdd(p.shared_cnt + d, (int32_t)sh);
+        }
+    }
+}
+
+hipError_t launch_indiv_hets(const IndivParams &p, hipStream_t st) {
+    if (p.n_tiles <= 0 || p.n_ind <= 0) return hipSuccess;
+    hipLaunchKernelGGL(indiv_hets_kernel, dim3((unsigned)((p.n_tiles + 3) / 4)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_indiv_planes(const IndivParams &p, hipStream_t st) {
     const int64_t items = (int64_t)p.n_tiles * p.W;
     if (items <= 0) return hipSuccess;

@@ -312,6 +312,13 @@ int evofst_stats_phase_draws(int64_t n_lines, const char *const *lines, int n_sa
 int evofst_set_multiallelic(evofst_ctx *ctx, int64_t n_multi, const int64_t *site_index, const uint8_t *alleles);
 int evofst_get_indiv_diffs(evofst_ctx *ctx, int n_blocks, const int64_t *block_off, int32_t *hh, int32_t *hd, int32_t *oh,
                            int32_t *ms, int32_t *d4);
+/* Heterozygous calls per individual: het_analysis (process_vcf_stats_functions.cpp:19-28) as statsMain drives it
+ * (process_vcf_stats.cpp:239-242: only sites where no genotype is missing; multi-allelic sites count nowhere because
+ * getThisVariantCountsSimple leaves their individualsWithVariant at 0, process_vcf_utils.cpp:397-406) over the uploaded
+ * shard (tiles packed with EVOFST_MODE_STATS; individuals as for evofst_get_indiv_diffs): het[n_ind] = sites where the
+ * individual is heterozygous, shared[n_ind] = those of them where the ALT allele was seen more than once among all
+ * individuals (counts.overall > 1). */
+int evofst_get_indiv_hets(evofst_ctx *ctx, int32_t *het, int32_t *shared);
 /* Per-site per-population diversity (getSetHeterozygozities + calculatePiTwoSets,
  * process_vcf_fst.cpp:325-371): arrays [n_pops][n_sites]; any pointer may be NULL. */
 int evofst_get_pop_site_div(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *het,

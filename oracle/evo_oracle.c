@@ -2339,6 +2339,24 @@ void orc_indiv_diff_counts(int n, int64_t S, const int *ind_with_variant, const 
     }
 }
 
+/* het_analysis (stats_functions.cpp:19-28) as statsMain calls it (process_vcf_stats.cpp:239-242: only at sites where
+ * no genotype is missing), over S sites: counts.overall is the number of '1' characters of the line's genotypes
+ * (0 on multi-allelic lines, utils.cpp:397-406), i.e. the sum of ind_with_variant.  Counts are ADDED to. */
+void orc_indiv_hets(int n, int64_t S, const int *ind_with_variant, const uint8_t *missing, int32_t *het, int32_t *shared) {
+    for (int64_t s = 0; s < S; s++) {
+        const int *iv = ind_with_variant + s * n;
+        const uint8_t *ms = missing + s * n;
+        int anyMissing = 0, overall = 0;
+        for (int i = 0; i < n; i++) { anyMissing |= ms[i] != 0; overall += iv[i]; }
+        if (anyMissing) continue;
+        for (int i = 0; i < n; i++)
+            if (iv[i] == 1) {
+                het[i]++;
+                if (overall > 1) shared[i]++;
+            }
+    }
+}
+
 static void print_matrix_d(FILE *f, const double *m, int n, int precision) {      /* print_matrix, utils.h:326-335 */
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) fprintf(f, "%.*g%s", precision, m[(size_t)i * (size_t)n + (size_t)j], j == n - 1 ? "\n" : "\t");
@@ -2347,7 +2365,16 @@ static void print_matrix_d(FILE *f, const double *m, int n, int precision) {    
 /* `evo stats --diff-matrix [--block-bootstrap=B] [--numAccessibleBP=A] VCF` (statsMain, process_vcf_stats.cpp:98-355,
  * the bDiffs and bDoBootstrap parts; B = 0: no bootstrap, A < 0: no scaling).  The four matrix files go to out_dir
  * under the VCF's base name, the bootstrap replicates too (the reference writes those next to the VCF). */
+static int stats_run(const char *vcf_path, int doDiffs, int doHets, int bootstrapBlockSize, int numAccessibleBP, const char *out_dir);
 int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAccessibleBP, const char *out_dir) {
+    return stats_run(vcf_path, 1, 0, bootstrapBlockSize, numAccessibleBP, out_dir);
+}
+/* the same with --diff-matrix and / or --hets-per-individual (process_vcf_stats.cpp:240-242, 336-337; print_het_counts,
+ * process_vcf_print_routines.cpp:29-56: <VCF base>.hets.txt and <VCF base>.sharedHets.txt, here in out_dir) */
+int orc_stats_run(const char *vcf_path, int doDiffs, int doHets, int bootstrapBlockSize, int numAccessibleBP, const char *out_dir) {
+    return stats_run(vcf_path, doDiffs, doHets, bootstrapBlockSize, numAccessibleBP, out_dir);
+}
+static int stats_run(const char *vcf_path, int doDiffs, int doHets, int bootstrapBlockSize, int numAccessibleBP, const char *out_dir) {
     lreader vcf;
     if (lr_open(&vcf, vcf_path) != 0) { fprintf(stderr, "Error: could not open %s\n", vcf_path); return -1; }
     /* fileRoot = stripExtension(fileName), fileNoPath = stripPath(fileRoot) (:103, :328) */
@@ -2361,6 +2388,7 @@ int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAcc
     double *diffs = NULL, *diffs_me = NULL, *hvh = NULL, *boot = NULL, **bootBlocks = NULL;
     int *miss = NULL, *bootMiss = NULL, **bootMissBlocks = NULL;
     int *iv = NULL, *hp = NULL; uint8_t *ms = NULL;
+    int32_t *hetCounts = NULL, *hetsShared = NULL;
     char **fields = NULL; int fcap = 0;
     char *line;
     while ((line = lr_getline(&vcf)) != NULL) {
@@ -2376,6 +2404,7 @@ int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAcc
             miss = (int *)calloc(nn, sizeof(int)); bootMiss = (int *)calloc(nn, sizeof(int));
             iv = (int *)malloc(sizeof(int) * (size_t)(n + 1)); hp = (int *)malloc(sizeof(int) * (size_t)(2 * n + 2));
             ms = (uint8_t *)malloc((size_t)n + 1);
+            hetCounts = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t)); hetsShared = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
         } else {
             if (!names) { rc = -5; break; }
             totalVariantNumber++;
@@ -2386,7 +2415,8 @@ int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAcc
             if (n > 0 && fields[9][1] != '|')                       /* utils.cpp:384-387: randomisePhase draws from rand() */
                 for (int i = 0; i < n; i++) if (fields[9 + i][0] != fields[9 + i][2]) phaseDraws++;
             uint8_t m8 = (uint8_t)multi;
-            orc_indiv_diffs(n, 1, iv, hp, ms, &m8, diffs, diffs_me, boot, hvh, miss, bootMiss);
+            if (doHets) orc_indiv_hets(n, 1, iv, ms, hetCounts, hetsShared);                             /* :239-242 */
+            if (doDiffs) orc_indiv_diffs(n, 1, iv, hp, ms, &m8, diffs, diffs_me, boot, hvh, miss, bootMiss);   /* :257-263 */
             if (bootstrapBlockSize > 0 && totalVariantNumber % bootstrapBlockSize == 0) {              /* :265-275 */
                 size_t nn = (size_t)n * (size_t)n;
                 bootBlocks = (double **)realloc(bootBlocks, sizeof(double *) * (size_t)(bootstrapBlockNum + 1));
@@ -2432,6 +2462,29 @@ int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAcc
             }
             free(rep); free(repMiss);
         }
+        if (doHets) {                                        /* print_het_counts, print_routines.cpp:29-56; fileRoot keeps the path */
+            char name[1024];
+            snprintf(name, sizeof name, "%s.hets.txt", noPath);
+            char *pth = path_join(out_dir, name); FILE *fh = fopen(pth, "w"); free(pth);
+            snprintf(name, sizeof name, "%s.sharedHets.txt", noPath);
+            pth = path_join(out_dir, name); FILE *fs = fopen(pth, "w"); free(pth);
+            if (!fh || !fs) rc = -3;
+            else {
+                fprintf(fh, "# Het counts\n# Input file:%s.vcf\n", root);
+                fprintf(fs, "# Shared het counts (line1) and proportions (line 2)\n# Input file:%s.vcf\n", root);
+                for (int i = 0; i < n; i++) fprintf(fh, "%s%s", names[i], i == n - 1 ? "\n" : "\t");
+                for (int i = 0; i < n; i++) fprintf(fh, "%d%s", hetCounts[i], i == n - 1 ? "\n" : "\t");
+                for (int i = 0; i < n; i++) fprintf(fs, "%s%s", names[i], i == n - 1 ? "\n" : "\t");
+                for (int i = 0; i < n; i++) fprintf(fs, "%d%s", hetsShared[i], i == n - 1 ? "\n" : "\t");
+                for (int i = 0; i < n; i++) {                /* :45: 0 / 0 is the x86 default NaN, printed "-nan" */
+                    volatile double num = (double)hetsShared[i], den = (double)hetCounts[i];
+                    fprintf(fs, "%.6g%s", num / den, i == n - 1 ? "\n" : "\t");
+                }
+            }
+            if (fh) fclose(fh);
+            if (fs) fclose(fs);
+        }
+        if (doDiffs)
         for (int i = 0; i < n; i++)                          /* finalize_diffs_Hets_vs_Homs_proportions, utils.cpp:1148-1155 */
             for (int j = 0; j < i; j++) {
                 hvh[(size_t)i * (size_t)n + (size_t)j] = hvh[(size_t)i * (size_t)n + (size_t)j] / hvh[(size_t)j * (size_t)n + (size_t)i];
@@ -2440,13 +2493,13 @@ int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAcc
         /* print_pairwise_diff_stats, print_routines.cpp:74-120 */
         const char *suffix[4] = {".diff_matrix.txt", ".diff_me_matrix.txt", ".hets_over_homs_matrix.txt", ".parwiseMissingness.txt"};
         FILE *f[4] = {NULL, NULL, NULL, NULL};
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; doDiffs && k < 4; k++) {
             char name[1024];
             snprintf(name, sizeof name, "%s%s", noPath, suffix[k]);
             char *pth = path_join(out_dir, name); f[k] = fopen(pth, "w"); free(pth);
             if (!f[k]) rc = -3;
         }
-        if (!rc) {
+        if (!rc && doDiffs) {
             fprintf(f[0], "# Input file:%s.vcf\n# Total number of segragating variant sites in this sample:%d\n# Richard's scoring scheme\n", noPath, totalVariantNumber);
             fprintf(f[1], "# Input file:%s.vcf\n# Total number of segragating variant sites in this sample: %d\n# Homozygous difference = 1, one homozygous, another heterozygous = 0.5\n", noPath, totalVariantNumber);
             fprintf(f[2], "# Input file:%s.vcf\n# number of sites both individuals hets/number of sites individuals have a homozygous difference; i.e. num(1/0::1/0)/num(1/1::0/0)\n# For a free mixing population, we expect this number ~2; for fully separated species ~0\n", noPath);
@@ -2463,6 +2516,7 @@ int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAcc
     free(bootBlocks); free(bootMissBlocks);
     for (int i = 0; names && i < n; i++) free(names[i]);
     free(names); free(diffs); free(diffs_me); free(hvh); free(boot); free(miss); free(bootMiss); free(iv); free(hp); free(ms);
+    free(hetCounts); free(hetsShared);
     free(fields); free(root);
     lr_close(&vcf);
     return rc;

@@ -264,6 +264,10 @@ void orc_indiv_diffs(int n, int64_t S, const int *ind_with_variant, const int *h
 void orc_indiv_diff_counts(int n, int64_t S, const int *ind_with_variant, const int *haps, const uint8_t *missing, const uint8_t *multi,
                            int32_t *hh, int32_t *hd, int32_t *oh, int32_t *ms_out, int32_t *d4);
 int orc_stats_diffs_run(const char *vcf_path, int bootstrapBlockSize, int numAccessibleBP, const char *out_dir);
+/* het_analysis at the sites without a missing genotype (stats_functions.cpp:19-28, process_vcf_stats.cpp:239-242); ADDS */
+void orc_indiv_hets(int n, int64_t S, const int *ind_with_variant, const uint8_t *missing, int32_t *het, int32_t *shared);
+/* stats driver with --diff-matrix and / or --hets-per-individual (<VCF base>.hets.txt, <VCF base>.sharedHets.txt) */
+int orc_stats_run(const char *vcf_path, int doDiffs, int doHets, int bootstrapBlockSize, int numAccessibleBP, const char *out_dir);
 
 #ifdef __cplusplus
 }

@@ -356,6 +356,27 @@ def stats_variant_counts(alt_field, genotypes):
     return iv, hp, ms, multi.value
 
 
+def indiv_hets(iv, missing):
+    """het_analysis over the sites without a missing genotype -> (het, shared) int32 [n]."""
+    iv = np.ascontiguousarray(iv, np.intc); missing = np.ascontiguousarray(missing, np.uint8)
+    S, n = iv.shape
+    het = np.zeros(n, np.int32); shared = np.zeros(n, np.int32)
+    L = lib()
+    L.orc_indiv_hets.restype = None
+    L.orc_indiv_hets.argtypes = [C.c_int, C.c_int64, _ip, _u8p, _i32p, _i32p]
+    L.orc_indiv_hets(n, S, _p(iv, _ip), _p(missing, _u8p), _p(het, _i32p), _p(shared, _i32p))
+    return het, shared
+
+
+def stats_run(vcf, out_dir, diffs=True, hets=False, block=0, accessible=-1):
+    L = lib()
+    L.orc_stats_run.restype = C.c_int
+    L.orc_stats_run.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    rc = L.orc_stats_run(vcf.encode(), 1 if diffs else 0, 1 if hets else 0, block, accessible, out_dir.encode())
+    if rc != 0:
+        raise RuntimeError("orc_stats_run failed: %d" % rc)
+
+
 def stats_diffs_run(vcf, out_dir, block=0, accessible=-1):
     L = lib()
     L.orc_stats_diffs_run.restype = C.c_int

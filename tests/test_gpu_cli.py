@@ -497,19 +497,23 @@ def test_cli_distoutgroups_accessible_genome_bed(tmp_path):
     assert len(sizes) > 3 and "4000" in sizes and "0" in sizes
 
 
-def _stats_case(tmp_path, rng, args, block=0, accessible=-1, n_sites=3000, n_samples=19, crlf=False, miss=0.1):
+def _stats_case(tmp_path, rng, args, block=0, accessible=-1, n_sites=3000, n_samples=19, crlf=False, miss=0.1, diffs=True, hets=False):
     vdir = tmp_path / "data"
     vdir.mkdir()
     vcf = str(vdir / "cohort.v1.vcf")
     write_vcf(vcf, rng, n_sites, n_samples, crlf=crlf, miss=miss)
     cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
     cli_dir.mkdir(); orc_dir.mkdir()
-    r = subprocess.run([EVO, "stats", "--diff-matrix"] + args + [vcf], cwd=str(cli_dir), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EVO, "stats"] + (["--diff-matrix"] if diffs else []) + (["--hets-per-individual"] if hets else []) + args + [vcf],
+                       cwd=str(cli_dir), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    for f in os.listdir(vdir):                                        # the bootstrap replicates land next to the VCF
-        if "boot." in f:
+    for f in os.listdir(vdir):                                        # the bootstrap replicates and the het counts land next to the VCF
+        if "boot." in f or "ets.txt" in f:
             shutil.move(str(vdir / f), str(cli_dir / f))
-    O.stats_diffs_run(vcf, str(orc_dir), block=block, accessible=accessible)
+    if hets or not diffs:
+        O.stats_run(vcf, str(orc_dir), diffs=diffs, hets=hets, block=block, accessible=accessible)
+    else:
+        O.stats_diffs_run(vcf, str(orc_dir), block=block, accessible=accessible)
     _same_files(str(cli_dir), str(orc_dir))
     return cli_dir
 
@@ -522,6 +526,22 @@ def test_cli_stats_diff_matrix(tmp_path):
                                      "cohort.v1.hets_over_homs_matrix.txt", "cohort.v1.parwiseMissingness.txt"]
     rows = (d / "cohort.v1.diff_me_matrix.txt").read_text().splitlines()
     assert len(rows) == 3 + 1 + 19 and rows[-1].split("\t")[0] not in ("0", "")
+
+
+def test_cli_stats_hets_per_individual(tmp_path):
+    """evo stats --hets-per-individual (process_vcf_stats.cpp:239-242, 336-337; het_analysis, print_het_counts): heterozygous
+    calls per individual at the sites without a missing genotype, alone and next to --diff-matrix, over several device
+    batches; an individual without such a site prints the proportion 0 / 0 as the reference's build does ("-nan")."""
+    d = _stats_case(tmp_path, np.random.default_rng(74), [], n_sites=70000, n_samples=11, miss=0.004, diffs=False, hets=True)
+    assert sorted(os.listdir(d)) == ["cohort.v1.hets.txt", "cohort.v1.sharedHets.txt"]
+    counts = [int(x) for x in (d / "cohort.v1.hets.txt").read_text().splitlines()[3].split("\t")]
+    assert len(counts) == 11 and min(counts) > 1000
+    (tmp_path / "both").mkdir()
+    d = _stats_case(tmp_path / "both", np.random.default_rng(75), [], n_sites=900, n_samples=3, miss=0.3, hets=True)
+    assert len(os.listdir(d)) == 6
+    (tmp_path / "none").mkdir()
+    d = _stats_case(tmp_path / "none", np.random.default_rng(76), [], n_sites=40, n_samples=30, miss=0.3, diffs=False, hets=True)
+    assert "-nan" in (d / "cohort.v1.sharedHets.txt").read_text()
 
 
 def test_cli_stats_bootstrap_across_batches(tmp_path):

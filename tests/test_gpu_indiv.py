@@ -79,3 +79,23 @@ def test_indiv_diffs_no_multiallelic_and_new_upload_forgets_them(engine, tmp_pat
     for k in want:
         assert np.array_equal(got[k][0], want[k]), k
     assert got["d4"].sum() == 0
+
+
+@pytest.mark.parametrize("S,n,miss,seed", [(6000, 37, 0.004, 4), (2500, 150, 0.001, 5), (700, 16, 0.4, 6), (130, 70, 0.0, 7)])
+def test_indiv_hets(engine, tmp_path, S, n, miss, seed):
+    """evofst_get_indiv_hets vs het_analysis as statsMain drives it (process_vcf_stats_functions.cpp:19-28,
+    process_vcf_stats.cpp:239-242): integers, exact; more than 64 individuals take several per lane."""
+    rng = np.random.default_rng(seed)
+    vcf = str(tmp_path / "in.vcf")
+    write_vcf(vcf, rng, S, n, miss=miss)
+    lines = [l.rstrip("\n") for l in open(vcf) if not l.startswith("#")]
+    _load(engine, lines, n)
+    iv, hp, ms, mu = _oracle_inputs(lines, n)
+    het, shared = engine.indiv_hets()
+    want_het, want_shared = O.indiv_hets(iv, ms)
+    assert np.array_equal(het, want_het) and np.array_equal(shared, want_shared)
+    if miss < 0.1:
+        assert want_het.min() > 0 and want_shared.sum() > 0
+        assert n > 64 or (want_shared < want_het).any()                # among many individuals a heterozygote is hardly ever alone
+    het2, shared2 = engine.indiv_hets()                               # a second call starts from zero again
+    assert np.array_equal(het2, het) and np.array_equal(shared2, shared)
