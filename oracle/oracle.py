@@ -356,11 +356,18 @@ def stats_variant_counts(alt_field, genotypes):
     return iv, hp, ms, multi.value
 
 
-def indiv_hets(iv, missing):
-    """het_analysis over the sites without a missing genotype -> (het, shared) int32 [n]."""
+def indiv_hets(iv, missing, use_reference=False):
+    """het_analysis over the sites without a missing genotype -> (het, shared) int32 [n]; use_reference: the reference's
+    own function (oracle/_ref/libevo_refdiffs.so)."""
     iv = np.ascontiguousarray(iv, np.intc); missing = np.ascontiguousarray(missing, np.uint8)
     S, n = iv.shape
     het = np.zeros(n, np.int32); shared = np.zeros(n, np.int32)
+    if use_reference:
+        R = ref_diffs()
+        R.ref_het_analysis.restype = None
+        R.ref_het_analysis.argtypes = [C.c_int, C.c_long, _ip, _u8p, _ip, _ip]
+        R.ref_het_analysis(n, S, _p(iv, _ip), _p(missing, _u8p), _p(het, _ip), _p(shared, _ip))
+        return het, shared
     L = lib()
     L.orc_indiv_hets.restype = None
     L.orc_indiv_hets.argtypes = [C.c_int, C.c_int64, _ip, _u8p, _i32p, _i32p]

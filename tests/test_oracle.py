@@ -337,6 +337,23 @@ def test_indiv_diffs_bit_equal_to_reference():
         assert a["diffs"].sum() > 0 and a["hets_vs_homs"][np.triu_indices(n, 1)].sum() > 0 and a["miss"].sum() > 0
 
 
+@pytest.mark.skipif(O.ref_diffs() is None, reason="oracle/_ref not built (no /root/reference here)")
+def test_indiv_hets_equal_to_reference():
+    """orc_indiv_hets vs the reference's own het_analysis (process_vcf_stats_functions.cpp:19-28) compiled from
+    /root/reference, called under statsMain's condition (process_vcf_stats.cpp:239-242): exact."""
+    rng = np.random.default_rng(13)
+    for S, n, miss in ((2000, 9, 0.02), (500, 23, 0.01), (300, 5, 0.5), (50, 4, 0.0)):
+        iv, _, missing, mul = _random_diff_sites(rng, S, n, miss=miss)
+        iv[mul != 0] = 0                                             # multi-allelic lines leave individualsWithVariant at 0
+        iv[rng.random(S) < 0.3] = 0                                  # and many sites carry one or no ALT allele
+        for s in range(0, S, 3):
+            iv[s, rng.integers(0, n)] = 1
+        a = O.indiv_hets(iv, missing, use_reference=True)
+        b = O.indiv_hets(iv, missing)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert a[0].sum() > 0 and (miss > 0.4 or (a[1] < a[0]).any())
+
+
 def test_indiv_diff_counts_compose_the_matrices():
     """The five counts per pair give back the literal matrices: diffs_me, hets/homs and missingness exactly (all terms
     are multiples of 1/4), Richard's matrix to 1e-12 (its 2/3 weights are rounded site by site in the reference)."""
