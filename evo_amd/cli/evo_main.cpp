@@ -1779,9 +1779,9 @@ int DistOutMain(int argc, char **argv) {
 // ========================================================================================== stats
 
 namespace sopt {
-string vcfFile, accessibleGenBedFile;
+string vcfFile, accessibleGenBedFile, populationsFile, sampleNameFile;
 int bootstrapBlockSize = 1000, numAccessibleBP = -1, accessibleGenBedWindow = 10000;
-bool bDiffs = false, bDoBootstrap = false, countHets = false;
+bool bDiffs = false, bDoBootstrap = false, countHets = false, bDoubleton = false, countPrivateVars = false;
 const int n_bootstrap_replicates = 100;
 }
 
@@ -1796,11 +1796,16 @@ const char *STATS_USAGE =
     "       --numAccessibleBP=NUM                   divide the diff_me matrix by the number of accessible base pairs\n"
     "       --hets-per-individual                   writes FILE.hets.txt and FILE.sharedHets.txt (next to the VCF): heterozygous calls\n"
     "                                               per individual at the sites without a missing genotype\n"
+    "       --ind-file=NAMES                        sample names for the output headers, one per line, instead of the VCF's\n"
+    "       --pop-file=POPULATIONS                  sample<TAB>population lines; with --private-variants writes the reference's\n"
+    "                                               summary (FILE_POPULATIONS.privateFixedVars.txt; all 0: the counting is commented\n"
+    "                                               out there); --doubleton-distribution is accepted and writes nothing, as there\n"
     "       --accessibleGenomeBED=BEDfile.bed       instead of a VCF the input is a file of scaffold names and lengths; prints the\n"
     "                                               accessible bases of every window to stdout and does nothing else\n"
     "       --accessibleGenBedWindow=NUMbp          the size of those windows (default 10000)\n\n";
 
-enum { OPT_DIFF_MATRIX = 64, OPT_BLOCK_BOOTSTRAP, OPT_NUM_ACCESSIBLE, OPT_ACC_GEN_BED, OPT_ACC_GEN_BED_WINDOW, OPT_HETS };
+enum { OPT_DIFF_MATRIX = 64, OPT_BLOCK_BOOTSTRAP, OPT_NUM_ACCESSIBLE, OPT_ACC_GEN_BED, OPT_ACC_GEN_BED_WINDOW, OPT_HETS, OPT_INDIV, OPT_POP,
+       OPT_DOUBLETON, OPT_PRIVATE_VARS };
 
 string stripPath(const string &filename) {                           // process_vcf_utils.cpp:153-160
     size_t slashPos = filename.find_last_of('/');
@@ -1817,10 +1822,10 @@ int statsMain(int argc, char **argv) {
     static const struct option longopts[] = {
         {"help", no_argument, NULL, 'h'}, {"diff-matrix", no_argument, NULL, OPT_DIFF_MATRIX},
         {"block-bootstrap", required_argument, NULL, OPT_BLOCK_BOOTSTRAP}, {"numAccessibleBP", required_argument, NULL, OPT_NUM_ACCESSIBLE},
-        {"ind-file", required_argument, NULL, OPT_UNSUPPORTED}, {"pop-file", required_argument, NULL, OPT_UNSUPPORTED},
-        {"hets-per-individual", no_argument, NULL, OPT_HETS}, {"doubleton-distribution", no_argument, NULL, OPT_UNSUPPORTED},
+        {"ind-file", required_argument, NULL, OPT_INDIV}, {"pop-file", required_argument, NULL, OPT_POP},
+        {"hets-per-individual", no_argument, NULL, OPT_HETS}, {"doubleton-distribution", no_argument, NULL, OPT_DOUBLETON},
         {"diff-matrix-h1", no_argument, NULL, OPT_UNSUPPORTED}, {"diff-matrix-allH", no_argument, NULL, OPT_UNSUPPORTED},
-        {"private-variants", no_argument, NULL, OPT_UNSUPPORTED}, {"accessibleGenomeBED", required_argument, NULL, OPT_ACC_GEN_BED},
+        {"private-variants", no_argument, NULL, OPT_PRIVATE_VARS}, {"accessibleGenomeBED", required_argument, NULL, OPT_ACC_GEN_BED},
         {"accessibleGenBedWindow", required_argument, NULL, OPT_ACC_GEN_BED_WINDOW}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
     for (int c; (c = getopt_long(argc, argv, "h", longopts, NULL)) != -1;) {
@@ -1831,16 +1836,23 @@ int statsMain(int argc, char **argv) {
             case OPT_BLOCK_BOOTSTRAP: arg >> bootstrapBlockSize; bDoBootstrap = true; break;
             case OPT_NUM_ACCESSIBLE: arg >> numAccessibleBP; break;
             case OPT_HETS: countHets = true; break;
+            case OPT_POP: arg >> populationsFile; break;
+            case OPT_INDIV: arg >> sampleNameFile; break;
+            case OPT_DOUBLETON: bDoubleton = true; break;
+            case OPT_PRIVATE_VARS: countPrivateVars = true; break;
             case OPT_ACC_GEN_BED: arg >> accessibleGenBedFile; break;
             case OPT_ACC_GEN_BED_WINDOW: arg >> accessibleGenBedWindow; break;
-            case OPT_UNSUPPORTED: die("of `evo stats` the GPU build carries --diff-matrix, --block-bootstrap, --numAccessibleBP, --hets-per-individual and --accessibleGenomeBED only");
+            case OPT_UNSUPPORTED: die("`evo stats --diff-matrix-h1` and `--diff-matrix-allH` are not carried by the GPU build");
             case 'h': std::cout << STATS_USAGE; exit(EXIT_SUCCESS);
         }
     }
     if (argc - optind < 1) { std::cerr << "missing arguments\n"; dieFlag = true; }
     else if (argc - optind > 1) { std::cerr << "too many arguments\n"; dieFlag = true; }
     if (bDoBootstrap && !bDiffs) { std::cerr << "--block-bootstrap needs --diff-matrix\n"; dieFlag = true; }
-    if (!bDiffs && !countHets && accessibleGenBedFile.empty()) { std::cerr << "Which statistics should the program calculate?\n"; dieFlag = true; }   // :398
+    if (countPrivateVars && populationsFile.empty()) {               // :393-396
+        std::cerr << "You need to supply a file defining populations to count private fixed variants\n"; dieFlag = true;
+    }
+    if (!bDiffs && !bDoubleton && !countHets && !countPrivateVars && accessibleGenBedFile.empty()) { std::cerr << "Which statistics should the program calculate?\n"; dieFlag = true; }   // :398
     if (accessibleGenBedWindow <= 0) { std::cerr << "--accessibleGenBedWindow must be positive\n"; dieFlag = true; }
     if (bDoBootstrap && bootstrapBlockSize <= 0) { std::cerr << "the bootstrap BLOCKSIZE must be positive\n"; dieFlag = true; }
     if (dieFlag) { std::cout << "\n" << STATS_USAGE; exit(EXIT_FAILURE); }
@@ -1869,10 +1881,31 @@ int statsMain(int argc, char **argv) {
 
     const string fileRoot = stripExtension(vcfFile);                 // :103
     std::cerr << "Calculating statistics from: " << vcfFile << std::endl;
+    // --pop-file (:116-135): the populations are read and, at the header, looked for among the samples; the two
+    // analyses that would use them (--doubleton-distribution, --private-variants) are commented out in the reference
+    // (:243-249, :332-333), so the first writes nothing and the second a summary of zeros (:340-341)
+    std::map<string, std::vector<string>> popToIDsMap;
+    std::vector<string> populationsToUse;
+    if (!populationsFile.empty()) {
+        std::ifstream setsF(populationsFile.c_str());
+        if (!setsF.is_open()) die("could not open " + populationsFile);
+        string l;
+        while (getline(setsF, l)) {
+            std::vector<string> ID_Pop = split(l, '\t');
+            if (ID_Pop.size() < 2) die("the --pop-file needs two tab-separated columns per line");
+            popToIDsMap[ID_Pop[1]].push_back(ID_Pop[0]);
+        }
+        for (auto &kv : popToIDsMap) if (kv.first != "Outgroup" && kv.first != "xxx") populationsToUse.push_back(kv.first);
+        std::cerr << "There are " << popToIDsMap.size() << " populations " << std::endl;
+    }
     if (countHets) {                                                 // :167-170
         std::cerr << "Het count per individual are going to be output to: " << fileRoot + ".hets.txt" << std::endl;
         std::cerr << "Counts of hets (per individual) shared with others are going to be output to: " << fileRoot + ".sharedHets.txt" << std::endl;
     }
+    if (bDoubleton) std::cerr << "The distribution of doubletons is going to be output to: " << fileRoot + ".doubletons.txt" << std::endl;   // :171-174
+    if (countPrivateVars)                                            // :175-179
+        std::cerr << "The numbers of private variants fixed in groups defined in " << populationsFile << " are going to be output to: "
+                  << fileRoot + "_" + stripExtension(populationsFile) + ".privateFixedVars.txt" << std::endl;
     std::vector<int> hetCounts, hetsSharedWithOthers;                // :138, :224
     std::vector<int32_t> bhet, bshared;
     LineReader vcf(vcfFile);
@@ -1966,7 +1999,19 @@ int statsMain(int argc, char **argv) {
         if (line[0] == '#' && line[1] == '#') continue;
         if (line[0] == '#' && line[1] == 'C') {
             std::vector<string> fields = split(line, '\t');
-            for (size_t i = 9; i < fields.size(); i++) sampleNames.push_back(fields[i]);   // :196-199
+            if (sampleNameFile.empty()) {
+                for (size_t i = 9; i < fields.size(); i++) sampleNames.push_back(fields[i]);   // :191-194
+            } else {                                                 // :195-197 readSampleNamesFromTextFile: a name per line
+                std::ifstream namesF(sampleNameFile.c_str());
+                if (!namesF.is_open()) die("could not open " + sampleNameFile);
+                string l;
+                while (getline(namesF, l)) sampleNames.push_back(l);
+                // the reference sizes its matrices by this list and indexes the genotype columns with it; a list of
+                // another length reads past them there
+                if (sampleNames.size() + 9 != fields.size()) die("--ind-file must name every sample column of the VCF (" + numToString((int)fields.size() - 9) + ")");
+            }
+            for (auto &kv : popToIDsMap)                              // :206-216
+                if (locateSet(sampleNames, kv.second).empty()) { std::cerr << "Did not find any samples in the VCF for \"" << kv.first << "\"" << std::endl; exit(EXIT_FAILURE); }
             numSamples = (int)sampleNames.size();
             if (numSamples <= 0) die("VCF header has no sample columns");
             std::cerr << "Number of chromosomes: " << numSamples * 2 << std::endl;
@@ -2037,6 +2082,15 @@ int statsMain(int argc, char **argv) {
         auto row = [&](std::ofstream &f, const auto &v) { for (size_t i = 0; i < N; i++) { f << v[i]; if (i == N - 1) f << std::endl; else f << "\t"; } };
         row(hetsOut, sampleNames); row(hetsOut, hetCounts);
         row(sharedOut, sampleNames); row(sharedOut, hetsSharedWithOthers); row(sharedOut, sharedHetProportions);
+    }
+    if (countPrivateVars) {                                          // :340-341 print_privateFixedVarsSummary (print_routines.cpp:59-69)
+        std::ofstream pv((fileRoot + "_" + stripExtension(populationsFile) + ".privateFixedVars.txt").c_str());
+        pv << "# Counts of private fixed variants:" << std::endl;
+        pv << "# Input file:" << fileRoot << ".vcf" << std::endl;
+        pv << "# Groups defined in:" << populationsFile << std::endl;
+        const size_t np = populationsToUse.size();                   // the counts are never touched after :227: all 0
+        for (size_t i = 0; i < np; i++) { pv << populationsToUse[i]; if (i == np - 1) pv << std::endl; else pv << "\t"; }
+        for (size_t i = 0; i < np; i++) { pv << 0; if (i == np - 1) pv << std::endl; else pv << "\t"; }
     }
     if (!bDiffs) { dev.close(); return 0; }
 

@@ -544,6 +544,37 @@ def test_cli_stats_hets_per_individual(tmp_path):
     assert "-nan" in (d / "cohort.v1.sharedHets.txt").read_text()
 
 
+def test_cli_stats_names_file_and_population_options(tmp_path):
+    """--ind-file replaces the header names (process_vcf_stats.cpp:195-197); --pop-file / --private-variants write the
+    reference's summary of zeros (its counting is commented out, :243-246, print_routines.cpp:59-69) and
+    --doubleton-distribution writes nothing (:247-249, 332-333)."""
+    rng = np.random.default_rng(77)
+    vcf = str(tmp_path / "c.vcf")
+    names = write_vcf(vcf, rng, 600, 7, miss=0.05)
+    ind = tmp_path / "names.txt"
+    ind.write_text("".join("ind_%d\n" % i for i in range(7)))
+    pops = tmp_path / "pops.txt"
+    # the populations are looked for among the names of --ind-file, as in the reference (:201-216)
+    pops.write_text("".join("ind_%d\t%s\n" % (i, ["west", "Outgroup", "east", "xxx"][i % 4]) for i in range(7)))
+    cli_dir, orc_dir = tmp_path / "cli", tmp_path / "orc"
+    cli_dir.mkdir(); orc_dir.mkdir()
+    r = subprocess.run([EVO, "stats", "--diff-matrix", "--hets-per-individual", "--ind-file=" + str(ind), "--doubleton-distribution",
+                        "--private-variants", "--pop-file=pops.txt", vcf], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    O.stats_run(vcf, str(orc_dir), diffs=True, hets=True)
+    for f in os.listdir(orc_dir):                                     # the oracle driver has no --ind-file: put the names in
+        want = (orc_dir / f).read_text().replace("\t".join(names), "\t".join("ind_%d" % i for i in range(7)))
+        assert (tmp_path / f).read_text() == want, f
+    assert (tmp_path / "c_pops.privateFixedVars.txt").read_text() == (
+        "# Counts of private fixed variants:\n# Input file:%s.vcf\n# Groups defined in:pops.txt\neast\twest\n0\t0\n" % str(tmp_path / "c"))
+    assert not any("doubleton" in f for f in os.listdir(tmp_path))
+    r = subprocess.run([EVO, "stats", "--private-variants", vcf], cwd=str(cli_dir), capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "You need to supply a file defining populations" in r.stderr            # :393-396
+    (tmp_path / "short.txt").write_text("a\nb\n")
+    r = subprocess.run([EVO, "stats", "--diff-matrix", "--ind-file=" + str(tmp_path / "short.txt"), vcf], cwd=str(cli_dir), capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "--ind-file" in r.stderr
+
+
 def test_cli_stats_bootstrap_across_batches(tmp_path):
     """Blocks of 700 variants over 70 k lines (three device batches; blocks straddle the batch edges), 100 replicates
     drawn with the C library's unseeded rand() as the reference does, and --numAccessibleBP."""
