@@ -1170,19 +1170,21 @@ string stripExtension(const string &filename) {                      // process_
     return suffixPos == string::npos ? filename : filename.substr(0, suffixPos);
 }
 
-// evo alleleFreq (AFmain, evo_AlleleFeq.cpp:46-166) without --use-genotype-probabilities: the per-population
+// evo alleleFreq (AFmain, evo_AlleleFeq.cpp:46-166); --use-genotype-probabilities only on VCFs whose FORMAT is GT alone
+// (where the reference warns and falls back to the called genotypes): the per-population
 // counts come from K1, the frequency is alt / called alleles, or -1 for a population without a called allele.
 int AFmain(int argc, char **argv) {
     using namespace afopt;
     static const struct option longopts[] = {{"help", no_argument, NULL, 'h'}, {"run-name", required_argument, NULL, 'n'},
                                              {"use-genotype-probabilities", no_argument, NULL, 'g'}, {NULL, 0, NULL, 0}};
     bool dieFlag = false;
-    for (int c; (c = getopt_long(argc, argv, "hn:g", longopts, NULL)) != -1;) {
+    bool useGenotypeProbabilities = false;
+    for (int c; (c = getopt_long(argc, argv, "hn:", longopts, NULL)) != -1;) {   // :28: no 'g' among the short options
         std::istringstream arg(optarg != NULL ? optarg : "");
         switch (c) {
             case '?': dieFlag = true; break;
             case 'n': arg >> runName; break;
-            case 'g': die("--use-genotype-probabilities is not carried by the GPU build");
+            case 'g': useGenotypeProbabilities = true; break;
             case 'h': std::cout << AF_USAGE; exit(EXIT_SUCCESS);
         }
     }
@@ -1226,6 +1228,25 @@ int AFmain(int argc, char **argv) {
         for (size_t s = 0; s < n; ++s) {
             if (batch.flags[s] & EVOFST_SITE_SKIP) continue;         // :124-127
             out << batch.chrom[s] << "\t" << batch.pos[s] << "\t" << refs[s] << "\t" << alts[s];
+            if (useGenotypeProbabilities) {
+                // :141-150 with a FORMAT column of GT alone (checkForGenotypeLikelihoodsOrProbabilities, utils.cpp:1122-1124):
+                // the warning, the option is dropped for the rest of the run, and this one line still prints the
+                // likelihood-based frequencies, which nothing has set: -1 for every population (utils.h:76).  Lines that
+                // do carry GP / GL / PL take a per-sample floating-point path that is another input format than genotype
+                // bit planes: not carried.
+                const string &l = batch.lines[s];
+                size_t a = 0;
+                for (int f = 0; f < 8 && a != string::npos; ++f) { a = l.find('\t', a); if (a != string::npos) ++a; }
+                const size_t b = a == string::npos ? string::npos : l.find('\t', a);
+                if (b == string::npos) die("malformed VCF line");
+                if (l.find(':', a) < b) die("--use-genotype-probabilities on a VCF with more FORMAT tags than GT is not carried by the GPU build");
+                std::cerr << "WARNING: Could not fing genotype likelihoods/probabilities (GP, PL, or GL fields) for variant at " << batch.chrom[s] << " " << batch.pos[s] << std::endl;
+                std::cerr << "WARNING: Did you really mean to use the -g option? Reverting to using called genotypes." << std::endl;
+                useGenotypeProbabilities = false;
+                for (size_t k = 0; k < P; ++k) out << "\t" << -1.0;
+                out << "\n";
+                continue;
+            }
             for (size_t k = 0; k < P; ++k) {                          // utils.cpp:56-58, setAAFs init -1.0 (utils.h:75)
                 double aaf = -1.0;
                 if (nmc[s * P + k] > 0) aaf = (double)altc[s * P + k] / nmc[s * P + k];

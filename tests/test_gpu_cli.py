@@ -326,6 +326,36 @@ def test_cli_allele_freq(tmp_path):
     assert sum(1 for _ in open(got)) > 30000
 
 
+def test_cli_allele_freq_genotype_probabilities_fall_back(tmp_path):
+    """--use-genotype-probabilities on a VCF whose FORMAT is GT alone (evo_AlleleFeq.cpp:141-150,
+    process_vcf_utils.cpp:1122-1124): the reference warns, drops the option, and the first used line still prints the
+    likelihood-based frequencies nothing has set (-1 for every population); `-g` itself is no short option there (:28).
+    A VCF with other FORMAT tags would take the per-sample likelihood path (not carried: the binary says so)."""
+    rng = np.random.default_rng(32)
+    full = str(tmp_path / "full.vcf")
+    names = write_vcf(full, rng, 500, 8)
+    vcf = str(tmp_path / "gt.vcf")
+    with open(vcf, "w") as f:
+        for ln in open(full):
+            if ln.startswith("#"):
+                f.write(ln); continue
+            c = ln.rstrip("\n").split("\t")
+            f.write("\t".join(c[:8] + ["GT"] + [g.split(":")[0] for g in c[9:]]) + "\n")
+    pf = str(tmp_path / "pops.txt")
+    open(pf, "w").write("".join("%s\t%s\n" % (n, "AB"[i % 2]) for i, n in enumerate(names)))
+    orc_dir = tmp_path / "orc"; orc_dir.mkdir()
+    r = subprocess.run([EVO, "alleleFreq", "--use-genotype-probabilities", vcf, pf], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stderr.count("Reverting to using called genotypes") == 1, r.stderr[-2000:]
+    O.af_run(vcf, pf, str(orc_dir))
+    want = (orc_dir / "pops_out_AF.txt").read_text().splitlines()
+    want[1] = "\t".join(want[1].split("\t")[:4] + ["-1", "-1"])
+    assert (tmp_path / "pops_out_AF.txt").read_text().splitlines() == want
+    r = subprocess.run([EVO, "alleleFreq", "--use-genotype-probabilities", full, pf], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "not carried" in r.stderr
+    r = subprocess.run([EVO, "alleleFreq", "-g", vcf, pf], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+
+
 def _pbs_case(tmp_path, rng, args, size, step, fixed=10000, n_sites=3000, n_samples=25, crlf=False, miss=0.25, quartets=False, annot_text=None, allow_indels=False, af=False):
     vcf = str(tmp_path / "in.vcf")
     names = write_vcf(vcf, rng, n_sites, n_samples, scaffolds=("chr1", "chr2"), crlf=crlf, miss=miss)
