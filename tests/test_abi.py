@@ -40,7 +40,8 @@ def test_no_cpu_fallback():
         api.EvoFst(0)
     e = api.EvoFst(-1)
     e.set_layout(round_robin_pops(8, 2), 2)
-    for call in (e.run_counts, e.run_stats, e.run, e.sync, lambda: e.reserve(10), lambda: e.set_pairs()):
+    for call in (e.run_counts, e.run_stats, e.run, e.sync, lambda: e.reserve(10), lambda: e.set_pairs(), e.indiv_hets,
+                 lambda: e.indiv_diffs([0, 1])):
         with pytest.raises(api.EvoFstError) as ex:
             call()
         assert ex.value.code == api.ERR_STATE
