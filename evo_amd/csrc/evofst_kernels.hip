@@ -86,11 +86,13 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     // "everything outstanding".
     const bool have_flags = p.site_flags != nullptr;
     const ulonglong2 *dummy = p.tiles + (size_t)t0 * p.W * kTileSites;   // the wave's own first line: no address shared by all waves
-    auto load_item = [&](Batch &b, int item) {
-        const bool past = item >= n_items;
-        const int it = past ? 0 : item;
-        const int ti = it / nb, bi = it - ti * nb;
-        const int t = t0 + ti, wb = bi * NB;
+    // items (tile, batch) are requested and counted in order: two cursors instead of a division by nb per item
+    const int n_own = t1 - t0;
+    int l_ti = 0, l_bi = 0, c_ti = 0, c_bi = 0;
+    auto load_item = [&](Batch &b) {
+        const bool past = l_ti >= n_own;
+        const int t = t0 + (past ? 0 : l_ti), wb = (past ? 0 : l_bi) * NB;
+        if (++l_bi == nb) { l_bi = 0; ++l_ti; }
         const ulonglong2 *tp = p.tiles + (size_t)t * p.W * kTileSites + lane;
 #pragma unroll
         for (int u = 0; u < NB; ++u)
@@ -99,9 +101,9 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
         const uint8_t *fp = (have_flags && !past && site < p.n_sites) ? p.site_flags + site : reinterpret_cast<const uint8_t *>(dummy);
         b.flag = *fp;
     };
-    load_item(b0, 0);                                   // the first batches go out before the pair list is staged
-    load_item(b1, 1);
-    load_item(b2, 2);
+    load_item(b0);                                      // the first batches go out before the pair list is staged
+    load_item(b1);
+    load_item(b2);
     if (MODE == MODE_PAIRS) {
         if ((int)threadIdx.x < npq) lpairs[threadIdx.x] = p.pairs[threadIdx.x];       // one round trip for up to 256 pairs
         for (int i = threadIdx.x + kK1Threads; i < npq; i += kK1Threads) lpairs[i] = p.pairs[i];
@@ -246,21 +248,22 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     // Past the chunk's end (the last round of four) a step still requests and takes its batch: with `break`s between
     // the steps the loop header is reached with the buffers requested in different orders, and the compiler's wait there
     // becomes "everything outstanding" (two of the three batches in flight drained at every fourth batch).
-    auto step = [&](Batch &cur, Batch &spare, int item) {
-        const bool live = item < n_items;
-        const int ti = item / nb, bi = item - ti * nb;
+    auto step = [&](Batch &cur, Batch &spare) {
+        const int ti = c_ti, bi = c_bi;
+        if (++c_bi == nb) { c_bi = 0; ++c_ti; }
+        const bool live = ti < n_own;
         const int t = t0 + ti, wb = bi * NB;
         if (bi == 0 && live) {
 #ifdef EVOFST_EXPERIMENTS
             if (!(p.debug & 2))
 #endif
-            if (item > 0) epilogue(t - 1);
+            if (ti > 0) epilogue(t - 1);
             skip = (int64_t)t * kTileSites + lane >= p.n_sites || (have_flags && (cur.flag & 1u) != 0);
             skipmask = __ballot(skip);
             c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false; anymiss = false; poison = false; nanany = false;
             sidx = 0; d = segs[0]; dn = segs[1];
         }
-        load_item(spare, item + 3);
+        load_item(spare);
         // the flag byte is the last load of its batch: taking it here marks the whole batch as arrived, including rows
         // past W that nothing reads (their registers would otherwise count as outstanding when they are reused)
         asm volatile("" :: "v"(cur.flag));
@@ -318,10 +321,10 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
         }
     };
     for (int item = 0; item < n_items; item += 4) {
-        step(b0, b3, item);
-        step(b1, b0, item + 1);
-        step(b2, b1, item + 2);
-        step(b3, b2, item + 3);
+        step(b0, b3);
+        step(b1, b0);
+        step(b2, b1);
+        step(b3, b2);
     }
     if (n_items > 0) epilogue(t1 - 1);
     if (have) {

@@ -1,6 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 CFG=${CFG:-cfg4s}
-CTRS=${CTRS:-GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD}
+# one pass holds at most 8 SQ_ counters
+CTRS=${CTRS:-GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD}
 OUT=gpurun_out/${TAG:-pmc}
 rm -rf $OUT
 timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -- python3 bench.py --config $CFG --steps 3 --warmup 1 --cpu-sites 0 --no-hbm-leg --streams 1 > $OUT.log 2>&1 || { tail -5 $OUT.log; exit 1; }
