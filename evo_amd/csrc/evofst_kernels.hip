@@ -115,11 +115,14 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     // per-tile state
     uint32_t c = 0, mc = 0;
     uint32_t Tc = 0, Tn = 0, c0 = 0, nm0 = 0;
-    bool irregular = false, skip = false, anymiss = false;
+    // per-lane flags as 0 / 1 words: as bools they live in scalar register pairs, merged with exec at every join of
+    // the segment loop (a dozen scalar instructions per segment word, in a kernel that is short of scalar registers)
+    uint32_t irregular = 0, anymiss = 0;
+    bool skip = false;
     uint64_t skipmask = 0;
     bool dirty = false;                                 // wave-uniform: the chunk has a site clean_walk_kernel cannot take
     int n_compact = 0;                                  // wave-uniform: the chunk's tiles so far, all written one byte per count
-    bool nanany = false;                                // this lane's site: some population has fewer than two called alleles
+    uint32_t nanany = 0;                                // this lane's site: some population has fewer than two called alleles (0 / 1)
     bool poison = false;                                // wave-uniform, Gram mode: the tile has a site where a population has < 2 called alleles
     int zlo = 0, zhi = 0, flo = 0, fhi = 0, ylo1 = 0, yhi1 = 0, ylo0 = 0, yhi0 = 0;   // ballots by population, lane = pop & 63
     auto wave_lds_sync = [&]() {
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
         uint64_t pim = 0, pmm = 0, pnn = 0;                 // pairs mode: the tile's irregular / missing / NaN sites
         bool compact_tile = false;
         if (MODE == MODE_PAIRS) {
-            pim = __ballot(irregular && !skip); pmm = __ballot(anymiss); pnn = __ballot(nanany && !skip);
+            pim = __ballot(irregular != 0 && !skip); pmm = __ballot(anymiss != 0); pnn = __ballot(nanany != 0 && !skip);
             const bool was_dirty = dirty;
             dirty = dirty || (pim | pmm | skipmask) != 0;
             if (ST && sizeof(CT) == 2 && p.compact) {
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             }
         }
         if (MODE == MODE_GRAM) {
-            const uint64_t im = __ballot(irregular && !skip);
+            const uint64_t im = __ballot(irregular != 0 && !skip);
             if (lane == 0) { p.irr_mask[t] = im; p.skip_mask[t] = skipmask; p.tile_poison[t] = poison ? 1u : 0u; }
             if (ST) {
 #pragma unroll
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
             if (ti > 0) epilogue(t - 1);
             skip = (int64_t)t * kTileSites + lane >= p.n_sites || (have_flags && (cur.flag & 1u) != 0);
             skipmask = __ballot(skip);
-            c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = false; anymiss = false; poison = false; nanany = false;
+            c = 0; mc = 0; Tc = 0; Tn = 0; c0 = 0; nm0 = 0; irregular = 0; anymiss = 0; poison = false; nanany = 0;
             sidx = 0; d = segs[0]; dn = segs[1];
         }
         load_item(spare);
@@ -303,9 +306,10 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                             // site with a dxy term (fixed with missing alleles).  Both need a missing allele unless n_full < 2.
                             const bool anym = mc != 0;
                             if (__any(anym) || nfull < 2u) {
-                                irregular = irregular || nm < 2 || (c == nm && nm < nfull);
-                                nanany = nanany || nm < 2;
-                                anymiss = anymiss || anym;
+                                const uint32_t few = nm < 2u ? 1u : 0u;
+                                irregular |= few | ((c == nm && nm < nfull) ? 1u : 0u);
+                                nanany |= few;
+                                anymiss |= anym ? 1u : 0u;
                             }
                         }
                         if (MODE == MODE_GLOBAL) {
