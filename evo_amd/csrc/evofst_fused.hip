@@ -153,7 +153,8 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 #endif
     if (n_items > 0) EVOFST_FUSED_LOAD(cur, 0);
     uint32_t c = 0, mc = 0;
-    bool irregular = false, skip = false, anymiss = false, nanany = false;
+    uint32_t irregular = 0, anymiss = 0, nanany = 0;   // per-lane 0 / 1 words, not lane masks merged at every join (see K1)
+    bool skip = false;
     uint64_t skipmask = 0;
     int sidx = 0;                          // next descriptor of the stream
     uint4 d = lsegs[0];                    // {mask lo, mask hi, pop, flags | n_full << 8}
@@ -166,7 +167,7 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
             skip = site >= p.n_sites;
             if (!skip && p.site_flags) skip = (p.site_flags[site] & 1u) != 0;
             skipmask = __ballot(skip);
-            c = 0; mc = 0; irregular = false; anymiss = false; nanany = false;
+            c = 0; mc = 0; irregular = 0; anymiss = 0; nanany = 0;
             sidx = 0; d = lsegs[0];
         }
         CT *cp = lcnt + (size_t)slot * P * kTileSites + lane;
@@ -194,9 +195,10 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
                         if (lane == 0) { zp[d.z] = z; zp[P + d.z] = f; }
                         // sites phase B must take through its general loop: a NaN in the reference (nm < 2) or an
                         // excluded site with a dxy term (fixed with missing alleles)
-                        irregular = irregular || nm < 2 || (c == nm && nm < nfull);
-                        nanany = nanany || nm < 2;
-                        anymiss = anymiss || mc != 0;
+                        const uint32_t few = nm < 2u ? 1u : 0u;
+                        irregular |= few | ((c == nm && nm < nfull) ? 1u : 0u);
+                        nanany |= few;
+                        anymiss |= mc != 0 ? 1u : 0u;
                         c = 0; mc = 0;
                     }
                     more = (fl & kSegWordEnd) == 0u;
@@ -205,7 +207,7 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
             }
         }
         if (bi == nb - 1) {
-            const uint64_t im = __ballot(irregular && !skip), mm = __ballot(anymiss), nn = __ballot(nanany && !skip);
+            const uint64_t im = __ballot(irregular != 0 && !skip), mm = __ballot(anymiss != 0), nn = __ballot(nanany != 0 && !skip);
             if (lane == 0) { lirr[slot] = im; lskip[slot] = skipmask; lmiss[slot] = mm; lnan[slot] = nn; }
         }
         if (item + 1 < n_items) {
