@@ -188,6 +188,11 @@ def main():
                          "independent batches overlap, as a run that keeps several batches in flight would)")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the short cfg4-shard run behind roofline_hbm")
     ap.add_argument("--sites", type=int, default=0, help="experiments only: another number of sites per GPU (the label says so)")
+    ap.add_argument("--pairs-pass", type=int, default=0, choices=(0, 1, 2, 3),
+                    help="evofst_set_option pairs_pass: 0 the library's choice (the stream pass), 1 counts + scan + walk as "
+                         "separate kernels, 2 stream pass, 3 the lock-step one-kernel pass")
+    ap.add_argument("--chunk-tiles", type=int, default=0, help="evofst_set_option chunk_tiles (0: the library's choice)")
+    ap.add_argument("--stream-blocks", type=int, default=0, help="evofst_set_option stream_blocks (0: what the device holds)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.sites > 0:
@@ -241,7 +246,13 @@ def main():
             os.close(saved_fd)
 
     from evo_amd import EvoFst
-    e = EvoFst(local_rank)
+    def tune(x):
+        x.set_option("pairs_pass", args.pairs_pass)
+        x.set_option("chunk_tiles", args.chunk_tiles)
+        x.set_option("stream_blocks", args.stream_blocks)
+        return x
+
+    e = tune(EvoFst(local_rank))
     S, N, P = cfg["sites"], cfg["samples"], cfg["pops"]
     sp = (np.arange(N) % P).astype(np.int32)
     e.set_layout(sp, P)
@@ -279,7 +290,7 @@ def main():
         shared = streams[0]
         e.set_stream(shared.cuda_stream)
         for b in range(1, n_batches):
-            eb = EvoFst(local_rank)
+            eb = tune(EvoFst(local_rank))
             eb.set_layout(sp, P)
             if cfg["mode"] == "pairs":
                 eb.set_pairs()

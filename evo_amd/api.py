@@ -76,6 +76,7 @@ SIGNATURES = {
     "evofst_run_stats": (C.c_int, [_vp]),
     "evofst_run": (C.c_int, [_vp]),
     "evofst_sync": (C.c_int, [_vp]),
+    "evofst_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "evofst_set_profiling": (C.c_int, [_vp, C.c_int]),
     "evofst_get_kernel_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
     "evofst_get_counts": (C.c_int, [_vp, C.c_int64, C.c_int64, _i32p, _i32p]),
@@ -352,6 +353,10 @@ class EvoFst:
 
     def sync(self):
         self._chk(self.L.evofst_sync(self.h))
+
+    def set_option(self, name, value):
+        """Tuning / test switches of this context (include/evofst.h: evofst_set_option)."""
+        self._chk(self.L.evofst_set_option(self.h, name.encode(), int(value)))
 
     def set_profiling(self, on=True):
         self._chk(self.L.evofst_set_profiling(self.h, 1 if on else 0))

@@ -101,12 +101,24 @@ struct evofst_ctx {
     // fused pairs pass (evofst_fused.hip): look-back granules, ticket + error words, launch epoch
     DevBuf d_agg0, d_agg1, d_agg2, d_fsync, d_miss, d_dirty, d_poison, d_nan;
     uint32_t epoch = 0;
-    bool fused_check = false;         // a fused launch has not had its error word looked at yet
     bool plain_counts = false;        // d_counts holds the packed counts of the loaded data, every tile (from any K1 launch)
     bool compact_counts = false;      // d_counts comes from a pairs-mode K1 that left one byte per count in its clean chunks
     bool prefer_plain = false;        // a getter has asked for per-site values on this context: K1 keeps to packed counts
     bool counts_done = false, stats_done = false;
     bool profiling = false;
+
+    // options (evofst_set_option): read when a pass is planned, never from the process environment
+    int opt_pairs_pass = 0;           // 0 auto, 1 K1 + scan + walk, 2 the producer / consumer stream pass, 3 the lock-step one-kernel pass
+    int opt_chunk_tiles = 0;          // tiles per chunk (0: the library chooses)
+    int opt_walk = 0;                 // K1 + scan + walk: 0 auto, 1 general walk on every chunk, 2 k2_window_kernel
+    int opt_stream_blocks = 0;        // workgroups of the stream pass (0: as many as the device holds)
+    // stream pairs pass (evofst_stream.hip): granule tables (two copies), ticket / error / launch words
+    DevBuf d_sagg, d_ssync;
+    int64_t sagg_rows = -1, sagg_pairs = -1;   // shape of the tables at the last launch (another shape: zero them)
+    // a one-kernel pass has not had its error word looked at yet: where the word is, and what to zero when it is set
+    const uint32_t *check_word = nullptr;
+    void *check_zero[2] = {nullptr, nullptr};
+    size_t check_zero_bytes[2] = {0, 0};
     hipEvent_t ev[kNumKernels][2] = {};
     bool ev_valid[kNumKernels] = {};
 };
@@ -201,8 +213,7 @@ void record(evofst_ctx *c, int which, int end) {
 
 int plan_chunks(evofst_ctx *c) {
     c->n_tiles = n_tiles_of(c->n_sites);
-    int ct = 0;
-    if (const char *e = getenv("EVOFST_CHUNK_TILES")) ct = atoi(e);
+    int ct = c->opt_chunk_tiles;
     // ~4096 chunks (4 waves of the walk per SIMD), and no fewer than 8 tiles a chunk: at 1 M sites chunks of 8 tiles cost
     // K1 and the walk nothing against chunks of 4, halve the scan's and the stitch's work, and leave other streams'
     // kernels more room (the 3-stream step of cfg2: 48.8 against 53.7 us; tools/gpu_ct.sh)
@@ -328,9 +339,9 @@ constexpr int kFusedFan = 32, kFusedMaxChunks = 32 * 32 * 64;
 // Tiles per chunk of the fused pairs pass and sites per table fill, or 0 when this shape goes through K1 + scan + K2.
 int fused_plan(evofst_ctx *c, int64_t n_sites, bool always, int *sub_out) {
     if (c->mode != MODE_PAIRS || c->pairs.size() > (size_t)kK2Threads || c->gathered) return 0;
-    // Opt-in for now: on cfg2 the one-kernel pass equals K1 + scan + K2 in time and on many-pair shapes it is slower (its
-    // workgroups move through their phases in lockstep), so the default stays the three-kernel pass.
-    if (!always && !getenv("EVOFST_FUSE")) return 0;
+    // Opt-in (evofst_set_option "pairs_pass" 3) and the pass behind evofst_run_pairs_noalloc: its workgroups move through
+    // their phases in lock-step; evofst_run takes the stream pass of evofst_stream.hip instead.
+    if (!always && c->opt_pairs_pass != 3) return 0;
     const int n_tiles = n_tiles_of(n_sites);
     const int np = (int)c->pairs.size();
     const int max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
@@ -340,8 +351,7 @@ int fused_plan(evofst_ctx *c, int64_t n_sites, bool always, int *sub_out) {
     if (const char *e = getenv("EVOFST_FUSED_SUB")) sub = atoi(e) == 16 ? 16 : 32;
 #endif
     auto lds = [&](int ct) { return fused_lds_bytes(c->n_pops, (int)c->segs.size(), max_n, np, ct, c->count_bytes, sub); };
-    int ct = 0;
-    if (const char *e = getenv("EVOFST_CHUNK_TILES")) ct = atoi(e);
+    int ct = c->opt_chunk_tiles;
     if (ct <= 0) ct = 4 * unit;
     ct = std::max(ct, (n_tiles + kFusedMaxChunks - 1) / kFusedMaxChunks);
     ct = (ct + unit - 1) / unit * unit;
@@ -401,24 +411,29 @@ int run_fused(evofst_ctx *c, int ct, int sub) {
     record(c, 3, 0);
     HIPCHK(c, launch_stitch(k2, c->stream));
     record(c, 3, 1);
-    c->fused_check = true;
+    c->check_word = (const uint32_t *)c->d_fsync.p + 32;
+    c->check_zero[0] = c->d_fsync.p; c->check_zero_bytes[0] = 256;
+    c->check_zero[1] = nullptr; c->check_zero_bytes[1] = 0;
     c->offsets_dirty = false;
     c->counts_done = false;          // K1's census / masks are not there (plain_counts says whether its counts are)
     c->stats_done = true;
     return EVOFST_OK;
 }
 
-// After the stream has been waited for: did a wait inside the last fused launch give up?
+// After the stream has been waited for: did a wait inside the last one-kernel pass give up?  (Bounded spins raise an
+// error word instead of hanging; the pass then leaves rows and tails unwritten.)
 int fused_verdict(evofst_ctx *c) {
-    if (!c->fused_check) return EVOFST_OK;
+    if (!c->check_word) return EVOFST_OK;
     uint32_t err = 0;
-    HIPCHK(c, hipMemcpyAsync(&err, (const uint32_t *)c->d_fsync.p + 32, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&err, c->check_word, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->fused_check = false;
+    c->check_word = nullptr;
     if (err) {
-        HIPCHK(c, hipMemsetAsync(c->d_fsync.p, 0, 256, c->stream));
+        for (int i = 0; i < 2; ++i)
+            if (c->check_zero[i]) HIPCHK(c, hipMemsetAsync(c->check_zero[i], 0, c->check_zero_bytes[i], c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         c->stats_done = false;
-        return fail(c, EVOFST_ERR_HIP, "fused pairs pass: a look-back wait gave up (results discarded)");
+        return fail(c, EVOFST_ERR_HIP, "one-kernel pairs pass: a look-back wait gave up (results discarded)");
     }
     return EVOFST_OK;
 }
@@ -437,11 +452,149 @@ int need_counts(evofst_ctx *c, const char *who) {
 bool clean_walk_applies(const evofst_ctx *c) {
     const size_t np = c->pairs.size();
     if (c->mode != MODE_PAIRS || c->count_bytes != 2 || np == 0 || np > (size_t)kK2Threads) return false;
-    if (getenv("EVOFST_OLD_K2") || getenv("EVOFST_NO_CLEAN_WALK")) return false;
+    if (c->opt_walk != 0) return false;
     const int piece_tiles = std::max(1, std::min(2, c->chunk_tiles));
     const int max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
     if (fused_lds_bytes(c->n_pops, 0, max_n, (int)np, 2 * piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, 32) > 100 * 1024) return false;
     return clean_walk_lds_bytes(c->n_pops, (int)np, piece_tiles, false) <= 64 * 1024;
+}
+
+
+// The statistics walk over counts, ballots and offsets that lie in HBM (K1 + scan, or the chunks the stream pass left to
+// it).  Up to 256 pairs: the walk of evofst_fused.hip (regions in LDS, exact integer sums where no allele is missing);
+// more pairs, or layouts its LDS regions cannot hold: k2_window_kernel.  marked_only: chunk_dirty says which chunks the
+// general walk takes; with_clean: clean_walk_kernel takes the others (else somebody else has).
+bool lds_walk_fits(const evofst_ctx *c, int chunk_tiles) {
+    const size_t np = c->pairs.size();
+    if (np == 0 || np > (size_t)kK2Threads || c->opt_walk == 2) return false;
+    const int max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
+    const int piece_tiles = std::max(1, std::min(2, chunk_tiles));
+    return fused_lds_bytes(c->n_pops, 0, max_n, (int)np, 2 * piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, 32) <= 100 * 1024;
+}
+int launch_walks(evofst_ctx *c, const K2Params &p, bool with_clean, bool compact, bool marked_only = false) {
+    const size_t np = c->pairs.size();
+    if (lds_walk_fits(c, c->chunk_tiles)) {
+        FusedParams f{};
+        f.site_flags = p.site_flags; f.n_sites = c->n_sites; f.n_tiles = c->n_tiles; f.W = c->W; f.P = c->n_pops;
+        f.n_segs = 0; f.n_full = p.n_full; f.max_n = p.max_n; f.pairs = p.pairs; f.n_pairs = p.n_pairs;
+        f.chunk_tiles = c->chunk_tiles; f.n_chunks = c->n_chunks; f.g = c->g;
+        f.base = (const int64_t *)c->d_base.p;
+        f.first_segment = (int64_t *)c->d_first_seg.p; f.incl_totals = (int64_t *)c->d_incl_totals.p;
+        f.seg_cap = c->seg_cap; f.seg_rows = p.seg_rows; f.tail = p.tail; f.tail_n = p.tail_n;
+        f.counts = p.counts; f.zf_masks = p.zf_masks; f.irr_mask = p.irr_mask; f.skip_mask = p.skip_mask; f.miss_mask = p.miss_mask;
+        f.chunk_offsets = p.chunk_offsets;
+        f.nan_mask = (const uint64_t *)c->d_nan.p;
+        f.piece_tiles = std::max(1, std::min(2, c->chunk_tiles));     // two buffers of two tiles per region
+        int wsub = 32;
+#ifdef EVOFST_EXPERIMENTS
+        if (const char *e = getenv("EVOFST_WALK_SUB")) wsub = atoi(e) == 16 ? 16 : 32;
+        if (const char *e = getenv("EVOFST_DEBUG_WALK")) f.debug = atoi(e);
+#endif
+        // chunks without a skipped, irregular or missing-allele site (K1 marks the others) go through the lean
+        // integer walk, the rest through the general one; each kernel leaves the other's chunks alone
+        if (with_clean || marked_only) f.chunk_dirty = (const uint32_t *)c->d_dirty.p;
+        if (with_clean) {
+            f.compact = compact ? 1 : 0;
+            HIPCHK(c, launch_clean_walk(f, c->stream));
+        }
+        HIPCHK(c, launch_fused(f, c->count_bytes, wsub, 0, c->stream));
+        return EVOFST_OK;
+    }
+    if (marked_only) return fail(c, EVOFST_ERR_STATE, "internal: the stream pass was planned for a layout the LDS walk cannot take");
+    (void)np;
+    HIPCHK(c, launch_k2(p, c->count_bytes, c->stream));
+    return EVOFST_OK;
+}
+
+
+// ---- the stream pairs pass (evofst_stream.hip): tiles -> segment rows in one launch of producer / consumer workgroups
+constexpr int kStreamMaxChunks = 1 << 17;
+
+// Tiles a producer wave counts per chunk, or 0 when this shape goes through K1 + scan + walk.
+int stream_plan(const evofst_ctx *c, int64_t n_sites) {
+    if (c->mode != MODE_PAIRS || c->count_bytes != 2 || c->n_pops > 64 || c->pairs.empty() || c->pairs.size() > (size_t)kStreamMaxPairs ||
+        c->gathered) return 0;
+    if (c->opt_pairs_pass != 0 && c->opt_pairs_pass != 2) return 0;
+    const int n_tiles = n_tiles_of(n_sites);
+    const int np = (int)c->pairs.size();
+    int tr = c->opt_chunk_tiles > 0 ? std::max(1, c->opt_chunk_tiles / kStreamProd) : 2;
+    while ((n_tiles + tr * kStreamProd - 1) / (tr * kStreamProd) > kStreamMaxChunks && tr < 16) ++tr;
+    // two workgroups per CU at the very least, three where the layout allows
+    while (tr > 1 && stream_lds_bytes(c->n_pops, np, tr * kStreamProd) > 52 * 1024) --tr;
+    if (tr * kStreamProd > 64 || stream_lds_bytes(c->n_pops, np, tr * kStreamProd) > 76 * 1024) return 0;
+    if ((n_tiles + tr * kStreamProd - 1) / (tr * kStreamProd) > kStreamMaxChunks) return 0;
+    // the chunks the integer walk cannot take go to the walk of evofst_fused.hip over counts in HBM
+    if (c->opt_walk == 2 || !lds_walk_fits(c, tr * kStreamProd)) return 0;
+    return tr;
+}
+
+int run_stream(evofst_ctx *c, int tr) {
+    const size_t np = c->pairs.size();
+    c->n_tiles = n_tiles_of(c->n_sites);
+    c->chunk_tiles = tr * kStreamProd;
+    c->n_chunks = (c->n_tiles + c->chunk_tiles - 1) / c->chunk_tiles;
+    c->seg_cap = c->n_sites / c->g + 2;
+    int rc;
+    if ((rc = ensure(c, c->d_incl_totals, np * 8)) || (rc = ensure(c, c->d_first_seg, np * 8))) return rc;
+    if ((rc = ensure(c, c->d_seg_rows, (size_t)c->seg_cap * np * sizeof(SegRow)))) return rc;
+    const size_t cq = (size_t)c->n_chunks * np;
+    if ((rc = ensure(c, c->d_tail, cq * 3 * 8)) || (rc = ensure(c, c->d_tail_n, cq * 16))) return rc;
+    // what a chunk with a skipped site or a missing allele leaves for the general walk
+    if ((rc = ensure(c, c->d_counts, (size_t)c->n_tiles * c->n_pops * kTileSites * c->count_bytes))) return rc;
+    if ((rc = ensure(c, c->d_zf, (size_t)c->n_tiles * c->n_pops * 16))) return rc;
+    if ((rc = ensure(c, c->d_irr, (size_t)c->n_tiles * 8)) || (rc = ensure(c, c->d_skip, (size_t)c->n_tiles * 8)) ||
+        (rc = ensure(c, c->d_miss, (size_t)c->n_tiles * 8)) || (rc = ensure(c, c->d_nan, (size_t)c->n_tiles * 8))) return rc;
+    if ((rc = ensure(c, c->d_dirty, (size_t)c->n_chunks * 4)) || (rc = ensure(c, c->d_offsets, cq * 8))) return rc;
+    // granule tables: rows of level 0, 1, 2 one after the other, two copies
+    const int64_t n1 = (c->n_chunks + kStreamFan - 1) / kStreamFan, n2 = (n1 + kStreamFan - 1) / kStreamFan;
+    const int64_t rows = (int64_t)c->n_chunks + n1 + n2;
+    const size_t copy_bytes = ((size_t)rows * np * 4 + 255) & ~(size_t)255;
+    if ((rc = ensure_zeroed(c, c->d_ssync, 256))) return rc;
+    const bool fresh = c->d_sagg.bytes < 2 * copy_bytes;
+    if ((rc = ensure(c, c->d_sagg, 2 * copy_bytes))) return rc;
+    if (fresh || c->sagg_rows != rows || c->sagg_pairs != (int64_t)np) {
+        // another shape than the last launch zeroed the tables for (or none yet): zero both copies
+        HIPCHK(c, hipMemsetAsync(c->d_sagg.p, 0, c->d_sagg.bytes, c->stream));
+        c->sagg_rows = rows; c->sagg_pairs = (int64_t)np;
+    }
+    StreamParams p{};
+    p.tiles = (const ulonglong2 *)c->tiles;
+    p.site_flags = c->have_flags ? c->flags : nullptr;
+    p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.W = c->W; p.P = c->n_pops;
+    p.segs = (const SegDesc *)c->d_segs.p;
+    p.n_full = (const int32_t *)c->d_nfull.p;
+    p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)np;
+    p.tr = tr; p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
+    p.g = c->g;
+    p.base = (const int64_t *)c->d_base.p;
+    p.first_segment = (int64_t *)c->d_first_seg.p; p.incl_totals = (int64_t *)c->d_incl_totals.p;
+    p.seg_rows = (SegRow *)c->d_seg_rows.p;
+    p.tail = (double *)c->d_tail.p; p.tail_n = (int4 *)c->d_tail_n.p;
+    p.agg[0] = (uint32_t *)c->d_sagg.p; p.agg[1] = (uint32_t *)((unsigned char *)c->d_sagg.p + copy_bytes);
+    p.l1_row = c->n_chunks; p.l2_row = c->n_chunks + (int)n1;
+    p.ticket = (uint32_t *)c->d_ssync.p; p.err = (uint32_t *)c->d_ssync.p + 32; p.launches = (uint32_t *)c->d_ssync.p + 48;
+    p.counts = c->d_counts.p;
+    p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
+    p.miss_mask = (uint64_t *)c->d_miss.p; p.nan_mask = (uint64_t *)c->d_nan.p;
+    p.chunk_offsets = (int64_t *)c->d_offsets.p; p.chunk_dirty = (uint32_t *)c->d_dirty.p;
+    record(c, 4, 0);
+    HIPCHK(c, launch_stream(p, c->opt_stream_blocks, c->stream));
+    record(c, 4, 1);
+    K2Params k2 = make_k2(c);
+    record(c, 2, 0);
+    if ((rc = launch_walks(c, k2, false, false, true))) return rc;   // the chunks the stream pass marked, if any
+    record(c, 2, 1);
+    record(c, 3, 0);
+    HIPCHK(c, launch_stitch(k2, c->stream));
+    record(c, 3, 1);
+    c->check_word = (const uint32_t *)c->d_ssync.p + 32;
+    c->check_zero[0] = c->d_ssync.p; c->check_zero_bytes[0] = 128;           // ticket and error words; the launch counter stays
+    c->check_zero[1] = c->d_sagg.p; c->check_zero_bytes[1] = c->d_sagg.bytes;
+    c->offsets_dirty = false;
+    c->counts_done = false;          // K1's census is not there, and its counts only for the marked chunks
+    c->plain_counts = false; c->compact_counts = false;
+    c->stats_done = true;
+    return EVOFST_OK;
 }
 
 }  // namespace
@@ -498,7 +651,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles, &c->d_agg0, &c->d_agg1,
-                      &c->d_agg2, &c->d_fsync, &c->d_miss, &c->d_dirty, &c->d_poison, &c->d_nan};
+                      &c->d_agg2, &c->d_fsync, &c->d_miss, &c->d_dirty, &c->d_poison, &c->d_nan, &c->d_sagg, &c->d_ssync};
     for (DevBuf *b : bufs) release(*b);
     for (auto &pair : c->ev)
         for (auto &e : pair)
@@ -1305,42 +1458,7 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
         if (k2_lds_bytes(c->n_pops, *std::max_element(c->n_full.begin(), c->n_full.end())) > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: too many populations for the LDS table");
         K2Params p = make_k2(c);
         record(c, 2, 0);
-        // up to 256 pairs: the walk of evofst_fused.hip over K1's counts (regions in LDS, exact integer sums where no allele
-        // is missing); more pairs, or layouts its LDS regions cannot hold: k2_window_kernel
-        bool lds_walk = false;
-        if (np <= (size_t)kK2Threads && !getenv("EVOFST_OLD_K2")) {
-            FusedParams f{};
-            f.site_flags = p.site_flags; f.n_sites = c->n_sites; f.n_tiles = c->n_tiles; f.W = c->W; f.P = c->n_pops;
-            f.n_segs = 0; f.n_full = p.n_full; f.max_n = p.max_n; f.pairs = p.pairs; f.n_pairs = p.n_pairs;
-            f.chunk_tiles = c->chunk_tiles; f.n_chunks = c->n_chunks; f.g = c->g;
-            f.base = (const int64_t *)c->d_base.p;
-            f.first_segment = (int64_t *)c->d_first_seg.p; f.incl_totals = (int64_t *)c->d_incl_totals.p;
-            f.seg_cap = c->seg_cap; f.seg_rows = p.seg_rows; f.tail = p.tail; f.tail_n = p.tail_n;
-            f.counts = p.counts; f.zf_masks = p.zf_masks; f.irr_mask = p.irr_mask; f.skip_mask = p.skip_mask; f.miss_mask = p.miss_mask;
-            f.chunk_offsets = p.chunk_offsets;
-            f.nan_mask = (const uint64_t *)c->d_nan.p;
-            f.piece_tiles = std::max(1, std::min(2, c->chunk_tiles));     // two buffers of two tiles per region
-            int wsub = 32;
-#ifdef EVOFST_EXPERIMENTS
-            if (const char *e = getenv("EVOFST_WALK_SUB")) wsub = atoi(e) == 16 ? 16 : 32;
-#endif
-            const size_t lds = fused_lds_bytes(c->n_pops, 0, p.max_n, (int)np, 2 * f.piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, wsub);
-#ifdef EVOFST_EXPERIMENTS
-            if (const char *e = getenv("EVOFST_DEBUG_WALK")) f.debug = atoi(e);
-#endif
-            if (lds <= 100 * 1024) {
-                // chunks without a skipped, irregular or missing-allele site (K1 marks the others) go through the lean
-                // integer walk, the rest through the general one; each kernel leaves the other's chunks alone
-                if (clean_walk_applies(c)) {
-                    f.chunk_dirty = (const uint32_t *)c->d_dirty.p;
-                    f.compact = c->compact_counts ? 1 : 0;
-                    HIPCHK(c, launch_clean_walk(f, c->stream));
-                }
-                HIPCHK(c, launch_fused(f, c->count_bytes, wsub, 0, c->stream));
-                lds_walk = true;
-            }
-        }
-        if (!lds_walk) HIPCHK(c, launch_k2(p, c->count_bytes, c->stream));
+        if ((rc = launch_walks(c, p, clean_walk_applies(c), c->compact_counts))) return rc;
         record(c, 2, 1);
         record(c, 3, 0);
         HIPCHK(c, launch_stitch(p, c->stream));
@@ -1459,6 +1577,8 @@ extern "C" int evofst_run(evofst_ctx *c) try {
         // pairs mode: one streaming kernel from the tiles to the segment rows (no counts kept in HBM; the getters
         // that want them run K1 on demand)
         HIPCHK(c, hipSetDevice(c->device));
+        const int tr = stream_plan(c, c->n_sites);
+        if (tr > 0) return run_stream(c, tr);
         int sub = 32;
         const int ct = fused_plan(c, c->n_sites, false, &sub);
         if (ct > 0) return run_fused(c, ct, sub);
@@ -1532,6 +1652,10 @@ extern "C" int evofst_run_pairs_noalloc(evofst_ctx *c, int64_t n_sites, const vo
     k2.seg_rows = (SegRow *)d_seg_rows; k2.tail = p.tail; k2.tail_n = p.tail_n;
     HIPCHK(c, launch_stitch(k2, c->stream));
     HIPCHK(c, launch_totals(k2, (const int64_t *)c->d_base.p, d_incl_totals, nullptr, d_carry, c->stream));
+    // evofst_sync looks at the pass's error word (a look-back wait that gave up leaves rows, tails and totals unwritten)
+    c->check_word = (const uint32_t *)sp + 32;
+    c->check_zero[0] = sp; c->check_zero_bytes[0] = 256;
+    c->check_zero[1] = nullptr; c->check_zero_bytes[1] = 0;
     return EVOFST_OK;
 } catch (...) {
     return abi_exception(c);
@@ -1545,6 +1669,30 @@ extern "C" int evofst_sync(evofst_ctx *c) try {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return fused_verdict(c);
+} catch (...) {
+    return abi_exception(c);
+}
+
+extern "C" int evofst_set_option(evofst_ctx *c, const char *name, int64_t value) try {
+    if (!c || !name) return EVOFST_ERR_ARG;
+    const std::string n(name);
+    if (n == "pairs_pass") {
+        if (value < 0 || value > 3) return fail(c, EVOFST_ERR_ARG, "set_option: pairs_pass is 0 (auto), 1 (counts + scan + walk), 2 (stream pass) or 3 (lock-step one-kernel pass)");
+        c->opt_pairs_pass = (int)value;
+    } else if (n == "chunk_tiles") {
+        if (value < 0 || value > 256) return fail(c, EVOFST_ERR_ARG, "set_option: chunk_tiles is 0 (auto) .. 256");
+        c->opt_chunk_tiles = (int)value;
+    } else if (n == "walk") {
+        if (value < 0 || value > 2) return fail(c, EVOFST_ERR_ARG, "set_option: walk is 0 (auto), 1 (general walk only) or 2 (k2_window_kernel)");
+        c->opt_walk = (int)value;
+    } else if (n == "stream_blocks") {
+        if (value < 0 || value > (1 << 20)) return fail(c, EVOFST_ERR_ARG, "set_option: stream_blocks is 0 (auto) or a number of workgroups");
+        c->opt_stream_blocks = (int)value;
+    } else {
+        return fail(c, EVOFST_ERR_ARG, "set_option: unknown option '" + n + "'");
+    }
+    c->stats_done = false;
+    return EVOFST_OK;
 } catch (...) {
     return abi_exception(c);
 }

@@ -173,6 +173,49 @@ struct FusedParams {
     int32_t debug;                  // -DEVOFST_EXPERIMENTS builds only (tools/): 1 no look-back waits, 2 no phase B, 4 no tile loads
 };
 
+// pairs mode as one streaming kernel with producer and consumer waves (evofst_stream.hip)
+constexpr int kStreamProd = 4;                         // producer waves per workgroup (+ one consumer wave)
+constexpr int kStreamThreads = 64 * (kStreamProd + 1);
+constexpr int kStreamFan = 32;                         // look-back fan-out per level
+constexpr int kStreamRow = 72;                         // u16 per (tile, population) row of counts in LDS: 64 + 8 of padding
+constexpr int kStreamMaxPairs = 256;
+#ifndef EVOFST_STREAM_WPS
+#define EVOFST_STREAM_WPS 4                            // waves per SIMD the register allocation aims at
+#endif
+struct StreamParams {
+    const ulonglong2 *tiles;
+    const uint8_t *site_flags;      // may be null
+    int64_t n_sites;
+    int32_t n_tiles, W, P;
+    const SegDesc *segs;            // [n_segs + 2] descriptor stream, two spare entries behind it (upload_layout)
+    const int32_t *n_full;          // [P]
+    const uint32_t *pairs;          // i | j << 16
+    int32_t n_pairs;
+    int32_t tr;                     // tiles a producer wave counts per chunk
+    int32_t chunk_tiles, n_chunks;  // chunk_tiles = kStreamProd * tr
+    int32_t g;
+    const int64_t *base;            // [n_pairs] included sites of the pair before this shard
+    int64_t *first_segment;         // [n_pairs] out: base / g
+    int64_t *incl_totals;           // [n_pairs] out: included sites of the shard
+    SegRow *seg_rows;               // [seg_cap][n_pairs]
+    double *tail;                   // [3][n_chunks][n_pairs]
+    int4 *tail_n;                   // [n_chunks][n_pairs]
+    // look-back granules, value + 1 (0: not there yet): one table of rows of n_pairs 32-bit words -- rows [0, n_chunks)
+    // the included sites of a chunk, rows l1_row + [0, ceil(n_chunks / 32)) those of a group of 32 chunks, rows l2_row +
+    // [0, ceil(n_chunks / 1024)) those of a group of 32 groups.  Two copies: a launch uses copy (launch counter & 1) and
+    // zeroes the rows of the other one
+    uint32_t *agg[2];
+    int32_t l1_row, l2_row;
+    uint32_t *ticket;               // chunk tickets; back to 0 when the launch ends
+    uint32_t *err;                  // set when a wait gave up
+    uint32_t *launches;             // launch counter, bumped by the launch's last ticket draw
+    // what a chunk the integer walk cannot take leaves for the general walk (K1's and the scan's outputs)
+    void *counts;                   // u16 [n_tiles][P][64]
+    uint64_t *zf_masks, *irr_mask, *skip_mask, *miss_mask, *nan_mask;
+    int64_t *chunk_offsets;         // [n_pairs][n_chunks]
+    uint32_t *chunk_dirty;          // [n_chunks]
+};
+
 struct SiteStatParams {
     const void *counts;
     const uint8_t *site_flags;
@@ -334,6 +377,10 @@ int fused_tail_chunks(int n_pairs, int n_chunks);   // entries per pair of the t
 // sub: sites per table fill (16 or 32); max_blocks <= 0: as many workgroups as the device holds at once (occupancy query)
 hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_blocks, hipStream_t st);
 size_t clean_walk_lds_bytes(int P, int n_pairs, int piece_tiles, bool compact);
+size_t stream_buffer_bytes(int P, int chunk_tiles);
+size_t stream_lds_bytes(int P, int n_pairs, int chunk_tiles);
+// max_blocks <= 0: as many workgroups as the device holds at once (occupancy query); any number is safe
+hipError_t launch_stream(const StreamParams &p, int max_blocks, hipStream_t st);
 hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st);
 size_t global_lds_bytes(int tn_max, int max_n, int n_use, int size);
 void global_rcp_split(int tn_max, int max_n, int *lo, int *hi);

@@ -241,6 +241,19 @@ int evofst_run_pairs_noalloc(evofst_ctx *ctx, int64_t n_sites, const void *d_til
                              double *d_carry);
 int64_t evofst_noalloc_scratch_bytes(void);
 
+/* Tuning and test switches of one context (no counterpart in the reference; nothing here changes a result beyond the
+ * summation order inside a window).  The library reads no environment variable for them.
+ *   "pairs_pass"    how evofst_run takes pairs mode: 0 = the library chooses (default), 1 = counts + scan + walk as separate
+ *                   kernels (what evofst_run_counts + evofst_run_stats do), 2 = the stream pass (one launch of producer /
+ *                   consumer workgroups, evo_amd/csrc/evofst_stream.hip; shapes it does not take fall back to 1),
+ *                   3 = the lock-step one-kernel pass of evofst_fused.hip (the pass behind evofst_run_pairs_noalloc)
+ *   "chunk_tiles"   tiles of 64 sites per chunk, 0 = chosen by the library
+ *   "walk"          statistics walk of pairs_pass 1: 0 = chosen by the library, 1 = general walk on every chunk,
+ *                   2 = k2_window_kernel
+ *   "stream_blocks" workgroups of the stream pass, 0 = as many as the device holds (any number is safe)
+ * Unknown names and values out of range return EVOFST_ERR_ARG. */
+int evofst_set_option(evofst_ctx *ctx, const char *name, int64_t value);
+
 /* When enabled, evofst_run_* bracket every kernel with HIP events on the context's stream. */
 int evofst_set_profiling(evofst_ctx *ctx, int enabled);
 /* Milliseconds of the last run of kernel `which` (0 = counts, 1 = offsets scan, 2 = pair/global

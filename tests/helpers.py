@@ -30,6 +30,28 @@ def random_codes(rng, n_sites, sample_pop, n_pops, miss=0.05, edge=True):
     return codes
 
 
+class options:
+    """with options(engine, chunk_tiles=1, pairs_pass=1): ... -- evofst_set_option for the block, back to 0 (the library's
+    own choice) afterwards; the GPU tests share one context."""
+
+    def __init__(self, engine, **kw):
+        self.engine, self.kw = engine, kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.engine.set_option(k, v)
+        return self.engine
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            self.engine.set_option(k, 0)
+        return False
+
+
+# how evofst_run takes pairs mode (evofst_set_option "pairs_pass"): tag suffix of the parity log -> value
+PAIRS_PASSES = (("", 1), ("_fused", 3), ("_stream", 2))
+
+
 def round_robin_pops(n_samples, n_pops):
     return (np.arange(n_samples) % n_pops).astype(np.int32)
 

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import round_robin_pops, n_full_of, assert_same_bits
+from tests.helpers import round_robin_pops, n_full_of, assert_same_bits, options
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -20,20 +20,10 @@ pytestmark = pytest.mark.gpu
 S, N, P, SIZE, STEP = 1_000_000, 200, 10, 100, 100
 
 
-def _run(engine, chunk_tiles, fuse=False):
-    old = os.environ.get("EVOFST_CHUNK_TILES")
-    os.environ["EVOFST_CHUNK_TILES"] = str(chunk_tiles)
-    if fuse:
-        os.environ["EVOFST_FUSE"] = "1"
-    try:
+def _run(engine, chunk_tiles, pairs_pass=0):
+    with options(engine, chunk_tiles=chunk_tiles, pairs_pass=pairs_pass):
         engine.run()
         return engine.segments(), engine.totals(), engine.boundary()
-    finally:
-        os.environ.pop("EVOFST_FUSE", None)
-        if old is None:
-            os.environ.pop("EVOFST_CHUNK_TILES", None)
-        else:
-            os.environ["EVOFST_CHUNK_TILES"] = old
 
 
 def test_cfg2_properties(engine):
@@ -54,12 +44,13 @@ def _pairs_properties(engine, S, N, P, slices, miss):
     engine.set_windows(SIZE, STEP)
     engine.reserve(S)
     engine.synth(S, seed=20261110, missing_rate=miss)
-    seg_a, tot_a, car_a = _run(engine, 0)      # the library's own choice
-    seg_b, tot_b, car_b = _run(engine, 7, fuse=True)      # the one-kernel pass, chunk edges inside other windows
+    seg_a, tot_a, car_a = _run(engine, 0)      # the library's own choice: the stream pass
     nq = engine.n_pairs
-    assert np.array_equal(seg_a["n_segments"], seg_b["n_segments"])
-    assert np.array_equal(tot_a[:, 3], tot_b[:, 3])
-    for q in range(nq):
+    # the separate kernels with chunk edges inside other windows, and the lock-step one-kernel pass
+    for seg_b, tot_b, car_b in (_run(engine, 7, pairs_pass=1), _run(engine, 12, pairs_pass=3)):
+      assert np.array_equal(seg_a["n_segments"], seg_b["n_segments"])
+      assert np.array_equal(tot_a[:, 3], tot_b[:, 3])
+      for q in range(nq):
         n = int(seg_a["n_segments"][q])
         assert n > 1000
         assert np.array_equal(seg_a["end_site"][:n, q], seg_b["end_site"][:n, q])
@@ -72,6 +63,8 @@ def _pairs_properties(engine, S, N, P, slices, miss):
             err = np.abs(a - b)
             parity_log.record("fullsize_%dx%d/chunking_invariance/%s" % (S, N, name), err, 2e-12 * scale)
             assert np.all(err <= 2e-12 * scale)
+    for q in range(nq):
+        n = int(seg_a["n_segments"][q])
         # additivity: segments + carry = totals
         for col, name in ((0, "sum_num"), (1, "sum_den"), (2, "sum_dxy_k")):
             s = seg_a[name][:n, q].sum() + car_a[q, col]
@@ -114,16 +107,9 @@ def _pairs_properties(engine, S, N, P, slices, miss):
                     assert np.all(err <= bar)
 
 
-def _with_chunk_tiles(ct, fn):
-    old = os.environ.get("EVOFST_CHUNK_TILES")
-    os.environ["EVOFST_CHUNK_TILES"] = str(ct)
-    try:
+def _with_chunk_tiles(engine, ct, fn):
+    with options(engine, chunk_tiles=ct):
         return fn()
-    finally:
-        if old is None:
-            os.environ.pop("EVOFST_CHUNK_TILES", None)
-        else:
-            os.environ["EVOFST_CHUNK_TILES"] = old
 
 
 def test_cfg3_full_size_properties(engine):
@@ -143,8 +129,8 @@ def test_cfg3_full_size_properties(engine):
     def run():
         engine.run()
         return engine.global_windows(), engine.included_totals().copy()
-    ga, ta = _with_chunk_tiles(0, run)      # the library's own choice
-    gb, tb = _with_chunk_tiles(9, run)
+    ga, ta = _with_chunk_tiles(engine, 0, run)      # the library's own choice
+    gb, tb = _with_chunk_tiles(engine, 9, run)
     assert np.array_equal(ta, tb)
     assert len(ga["end_site"]) == len(gb["end_site"]) > 800_000
     for k in ("start_site", "end_site"):

@@ -70,7 +70,8 @@ def test_global_subset_and_threshold(engine):
     _run(engine, rng, 2500, 60, P, 0.15, 20, 10, use=use, set_sizes=sizes)
 
 
-def test_global_small_chunks(engine, monkeypatch):
-    monkeypatch.setenv("EVOFST_CHUNK_TILES", "1")
-    _run(engine, np.random.default_rng(5), 3000, 40, 4, 0.2, 50, 25, flags=True)
-    _run(engine, np.random.default_rng(6), 1000, 40, 4, 0.9, 20, 10)   # few kept sites: long replays
+def test_global_small_chunks(engine):
+    from tests.helpers import options
+    with options(engine, chunk_tiles=1):
+        _run(engine, np.random.default_rng(5), 3000, 40, 4, 0.2, 50, 25, flags=True)
+        _run(engine, np.random.default_rng(6), 1000, 40, 4, 0.9, 20, 10)   # few kept sites: long replays

@@ -9,7 +9,7 @@ import math
 import numpy as np
 import pytest
 
-from tests.helpers import random_codes, round_robin_pops, n_full_of, assert_same_bits
+from tests.helpers import random_codes, round_robin_pops, n_full_of, assert_same_bits, options, PAIRS_PASSES
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -90,16 +90,12 @@ def _window_abs_sums(terms, first_var, size):
 
 
 def _check_windows(engine, sp, codes, fl, P, size, step, pairs=None, tag="snp_windows"):
-    """Both forms of the pairs pass against the oracle: K1 + scan + K2 + stitch (the default) and the one-kernel pass
-    (EVOFST_FUSE=1; it takes up to 256 pairs, more fall back to the default)."""
-    import os
-    for fuse in (False, True):
-        if fuse:
-            os.environ["EVOFST_FUSE"] = "1"
-        try:
-            _check_windows_once(engine, sp, codes, fl, P, size, step, pairs, tag + ("_fused" if fuse else ""))
-        finally:
-            os.environ.pop("EVOFST_FUSE", None)
+    """Every form of the pairs pass against the oracle: counts + scan + walk + stitch as separate kernels, the lock-step
+    one-kernel pass and the stream pass (evofst_run's choice where the shape allows; shapes a one-kernel pass does not
+    take fall back to the separate kernels)."""
+    for suffix, pass_ in PAIRS_PASSES:
+        with options(engine, pairs_pass=pass_):
+            _check_windows_once(engine, sp, codes, fl, P, size, step, pairs, tag + suffix)
 
 
 def _check_windows_once(engine, sp, codes, fl, P, size, step, pairs, tag):
@@ -195,11 +191,10 @@ def test_snp_windows_without_missing_alleles(engine, S, N, P, size, step, dirty)
 
 
 @pytest.mark.parametrize("S,N,P,dirty", [(200_000, 40, 4, 900), (100_000, 48, 12, 500)])
-def test_snp_windows_clean_and_dirty_chunks(engine, monkeypatch, S, N, P, dirty):
+def test_snp_windows_clean_and_dirty_chunks(engine, S, N, P, dirty):
     """One-tile chunks, a few hundred of them with a missing allele: clean_walk_kernel takes the chunks K1 left unmarked,
     the general walk strides over the marked ones with a grid smaller than the number of regions, and every window
     straddles chunks of both kinds (6 pairs: a wave per chunk; 66 pairs: a workgroup per chunk)."""
-    monkeypatch.setenv("EVOFST_CHUNK_TILES", "1")
     rng = np.random.default_rng(S + dirty)
     sp = round_robin_pops(N, P)
     codes = random_codes(rng, S, sp, P, miss=0.0, edge=False)
@@ -208,18 +203,18 @@ def test_snp_windows_clean_and_dirty_chunks(engine, monkeypatch, S, N, P, dirty)
     engine.set_layout(sp, P)
     engine.upload(engine.pack_codes(codes), S)
     engine.set_pairs()
-    _check_windows(engine, sp, codes, None, P, 100, 50, tag="snp_windows_clean_and_dirty_chunks")
+    with options(engine, chunk_tiles=1):
+        _check_windows(engine, sp, codes, None, P, 100, 50, tag="snp_windows_clean_and_dirty_chunks")
 
 
 @pytest.mark.parametrize("chunk_tiles", [4, 16])
-def test_one_byte_counts_of_clean_chunks(monkeypatch, chunk_tiles):
+def test_one_byte_counts_of_clean_chunks(chunk_tiles):
     """K1 leaves one byte per count in chunks without a skipped, irregular or missing-allele site (pairs mode, 16-bit
     counts).  Same data through a context that walks them (run, segments) and one that was asked for per-site values
     first (which keeps K1 to packed counts): segments, totals and boundary bit-identical; the per-site getters after the
     walk (K1 runs again behind them) equal the other context's.  Chunks that turn dirty at their first, a middle and
     their last tile cover the return of already written one-byte tiles to packed counts."""
     from evo_amd import EvoFst
-    monkeypatch.setenv("EVOFST_CHUNK_TILES", str(chunk_tiles))
     rng = np.random.default_rng(1000 + chunk_tiles)
     S, N, P = 64 * chunk_tiles * 9 + 37, 60, 6
     sp = round_robin_pops(N, P)
@@ -232,6 +227,8 @@ def test_one_byte_counts_of_clean_chunks(monkeypatch, chunk_tiles):
     for ask_first in (False, True):
         e = EvoFst(0)
         try:
+            e.set_option("chunk_tiles", chunk_tiles)
+            e.set_option("pairs_pass", 1)                           # counts, scan and walk as separate kernels
             e.set_layout(sp, P)
             e.upload(e.pack_codes(codes), S, site_flags=fl)
             e.set_pairs()
@@ -293,25 +290,25 @@ def test_snp_windows_lds_near_the_limit(engine):
     _check_windows(engine, sp, codes, fl, P, 20, 20, pairs=(pi, pj))
 
 
-def test_snp_windows_small_chunks(engine, monkeypatch):
+def test_snp_windows_small_chunks(engine):
     """Chunks of one tile: every window straddles chunk boundaries (stitch path)."""
-    monkeypatch.setenv("EVOFST_CHUNK_TILES", "1")
     rng = np.random.default_rng(99)
     sp, codes, fl = _setup(engine, rng, 3000, 40, 4, 0.3, flags=True)
     engine.set_pairs()
-    _check_windows(engine, sp, codes, fl, 4, 150, 150)
-    _check_windows(engine, sp, codes, fl, 4, 64, 32)
+    with options(engine, chunk_tiles=1):
+        _check_windows(engine, sp, codes, fl, 4, 150, 150)
+        _check_windows(engine, sp, codes, fl, 4, 64, 32)
 
 
-def test_snp_windows_longest_chunks(engine, monkeypatch):
+def test_snp_windows_longest_chunks(engine):
     """Chunks of 256 tiles (16 k sites, the library's maximum) with short overlapping windows: the error of a window's
     sums must not grow with the position of the window in its chunk."""
-    monkeypatch.setenv("EVOFST_CHUNK_TILES", "256")
     rng = np.random.default_rng(256)
     sp, codes, fl = _setup(engine, rng, 40000, 40, 4, 0.05, flags=True)
     engine.set_pairs()
-    _check_windows(engine, sp, codes, fl, 4, 20, 10, tag="snp_windows_256_tile_chunks")
-    _check_windows(engine, sp, codes, fl, 4, 100, 100, tag="snp_windows_256_tile_chunks")
+    with options(engine, chunk_tiles=256):
+        _check_windows(engine, sp, codes, fl, 4, 20, 10, tag="snp_windows_256_tile_chunks")
+        _check_windows(engine, sp, codes, fl, 4, 100, 100, tag="snp_windows_256_tile_chunks")
 
 
 def test_base_offsets_shift_windows(engine):

@@ -66,12 +66,12 @@ def _one_call(engine, hip, rng, S, N, P, size, step, miss):
     engine.upload(tiles, S, site_flags=fl)
     engine.run()
     ref = dict(seg=engine.segments(), tot=engine.included_totals().copy(), carry=engine.boundary().copy())
-    os.environ["EVOFST_FUSE"] = "1"
+    engine.set_option("pairs_pass", 3)               # the lock-step one-kernel pass: what the entry point below runs
     try:
         engine.run()
         one = dict(seg=engine.segments(), tot=engine.included_totals().copy(), carry=engine.boundary().copy())
     finally:
-        os.environ.pop("EVOFST_FUSE", None)
+        engine.set_option("pairs_pass", 0)
     # the entry point that allocates nothing, on buffers of the caller
     g = int(np.gcd(size, step))
     cap = S // g + 2
