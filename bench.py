@@ -193,6 +193,7 @@ def main():
                          "separate kernels, 2 stream pass, 3 the lock-step one-kernel pass")
     ap.add_argument("--chunk-tiles", type=int, default=0, help="evofst_set_option chunk_tiles (0: the library's choice)")
     ap.add_argument("--stream-blocks", type=int, default=0, help="evofst_set_option stream_blocks (0: what the device holds)")
+    ap.add_argument("--stream-waves", default="0,0", help="evofst_set_option stream_producers,stream_consumers (0: the library's choice)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.sites > 0:
@@ -250,6 +251,8 @@ def main():
         x.set_option("pairs_pass", args.pairs_pass)
         x.set_option("chunk_tiles", args.chunk_tiles)
         x.set_option("stream_blocks", args.stream_blocks)
+        x.set_option("stream_producers", int(args.stream_waves.split(",")[0]))
+        x.set_option("stream_consumers", int(args.stream_waves.split(",")[1]))
         return x
 
     e = tune(EvoFst(local_rank))

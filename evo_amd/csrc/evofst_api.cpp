@@ -112,13 +112,14 @@ struct evofst_ctx {
     int opt_chunk_tiles = 0;          // tiles per chunk (0: the library chooses)
     int opt_walk = 0;                 // K1 + scan + walk: 0 auto, 1 general walk on every chunk, 2 k2_window_kernel
     int opt_stream_blocks = 0;        // workgroups of the stream pass (0: as many as the device holds)
-    // stream pairs pass (evofst_stream.hip): granule tables (two copies), ticket / error / launch words
-    DevBuf d_sagg, d_ssync;
+    int opt_stream_prod = 0, opt_stream_cons = 0;   // its producer / consumer waves per workgroup (0: the library chooses)
+    // stream pairs pass (evofst_stream.hip): granule rows and their flags (two copies each), ticket / error / launch words
+    DevBuf d_sagg, d_sflag, d_ssync;
     int64_t sagg_rows = -1, sagg_pairs = -1;   // shape of the tables at the last launch (another shape: zero them)
     // a one-kernel pass has not had its error word looked at yet: where the word is, and what to zero when it is set
     const uint32_t *check_word = nullptr;
-    void *check_zero[2] = {nullptr, nullptr};
-    size_t check_zero_bytes[2] = {0, 0};
+    void *check_zero[3] = {nullptr, nullptr, nullptr};
+    size_t check_zero_bytes[3] = {0, 0, 0};
     hipEvent_t ev[kNumKernels][2] = {};
     bool ev_valid[kNumKernels] = {};
 };
@@ -413,7 +414,7 @@ int run_fused(evofst_ctx *c, int ct, int sub) {
     record(c, 3, 1);
     c->check_word = (const uint32_t *)c->d_fsync.p + 32;
     c->check_zero[0] = c->d_fsync.p; c->check_zero_bytes[0] = 256;
-    c->check_zero[1] = nullptr; c->check_zero_bytes[1] = 0;
+    c->check_zero[1] = c->check_zero[2] = nullptr; c->check_zero_bytes[1] = c->check_zero_bytes[2] = 0;
     c->offsets_dirty = false;
     c->counts_done = false;          // K1's census / masks are not there (plain_counts says whether its counts are)
     c->stats_done = true;
@@ -429,7 +430,7 @@ int fused_verdict(evofst_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->check_word = nullptr;
     if (err) {
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 3; ++i)
             if (c->check_zero[i]) HIPCHK(c, hipMemsetAsync(c->check_zero[i], 0, c->check_zero_bytes[i], c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->stats_done = false;
@@ -510,28 +511,39 @@ int launch_walks(evofst_ctx *c, const K2Params &p, bool with_clean, bool compact
 // ---- the stream pairs pass (evofst_stream.hip): tiles -> segment rows in one launch of producer / consumer workgroups
 constexpr int kStreamMaxChunks = 1 << 17;
 
-// Tiles a producer wave counts per chunk, or 0 when this shape goes through K1 + scan + walk.
-int stream_plan(const evofst_ctx *c, int64_t n_sites) {
+// Shape of the stream pass's workgroups: producer waves, consumer waves, tiles a producer counts per chunk.
+struct StreamPlan { int n_prod = 0, n_cons = 0, tr = 0; };
+// tr == 0 when this shape goes through K1 + scan + walk.
+StreamPlan stream_plan(const evofst_ctx *c, int64_t n_sites) {
+    StreamPlan pl;
     if (c->mode != MODE_PAIRS || c->count_bytes != 2 || c->n_pops > 64 || c->pairs.empty() || c->pairs.size() > (size_t)kStreamMaxPairs ||
-        c->gathered) return 0;
-    if (c->opt_pairs_pass != 0 && c->opt_pairs_pass != 2) return 0;
+        c->gathered) return pl;
+    if (c->opt_pairs_pass != 0 && c->opt_pairs_pass != 2) return pl;
     const int n_tiles = n_tiles_of(n_sites);
     const int np = (int)c->pairs.size();
-    int tr = c->opt_chunk_tiles > 0 ? std::max(1, c->opt_chunk_tiles / kStreamProd) : 2;
-    while ((n_tiles + tr * kStreamProd - 1) / (tr * kStreamProd) > kStreamMaxChunks && tr < 16) ++tr;
-    // two workgroups per CU at the very least, three where the layout allows
-    while (tr > 1 && stream_lds_bytes(c->n_pops, np, tr * kStreamProd) > 52 * 1024) --tr;
-    if (tr * kStreamProd > 64 || stream_lds_bytes(c->n_pops, np, tr * kStreamProd) > 76 * 1024) return 0;
-    if ((n_tiles + tr * kStreamProd - 1) / (tr * kStreamProd) > kStreamMaxChunks) return 0;
+    // a consumer wave per 64 pairs; producers: four, or what the options say
+    pl.n_cons = c->opt_stream_cons > 0 ? std::min(c->opt_stream_cons, (np + 63) / 64) : (np + 63) / 64;
+    pl.n_prod = c->opt_stream_prod > 0 ? c->opt_stream_prod : 4;
+    if (pl.n_prod + pl.n_cons > kStreamMaxWaves) return StreamPlan();
+    int tr = c->opt_chunk_tiles > 0 ? std::max(1, c->opt_chunk_tiles / pl.n_prod) : 2;
+    while ((n_tiles + tr * pl.n_prod - 1) / (tr * pl.n_prod) > kStreamMaxChunks && tr < 16) ++tr;
+    // as many workgroups per CU as 16 waves allow (two at the very least); LDS must not be what cuts that number
+    const int wgs = std::max(2, 16 / (pl.n_prod + pl.n_cons));
+    const size_t lds_cap = (size_t)(156 * 1024) / wgs;
+    while (tr > 1 && stream_lds_bytes(c->n_pops, np, tr * pl.n_prod) > lds_cap) --tr;
+    if (tr * pl.n_prod > 64 || stream_lds_bytes(c->n_pops, np, tr * pl.n_prod) > lds_cap) return StreamPlan();
+    if ((n_tiles + tr * pl.n_prod - 1) / (tr * pl.n_prod) > kStreamMaxChunks) return StreamPlan();
     // the chunks the integer walk cannot take go to the walk of evofst_fused.hip over counts in HBM
-    if (c->opt_walk == 2 || !lds_walk_fits(c, tr * kStreamProd)) return 0;
-    return tr;
+    if (c->opt_walk == 2 || !lds_walk_fits(c, tr * pl.n_prod)) return StreamPlan();
+    pl.tr = tr;
+    return pl;
 }
 
-int run_stream(evofst_ctx *c, int tr) {
+int run_stream(evofst_ctx *c, const StreamPlan &pl) {
+    const int tr = pl.tr;
     const size_t np = c->pairs.size();
     c->n_tiles = n_tiles_of(c->n_sites);
-    c->chunk_tiles = tr * kStreamProd;
+    c->chunk_tiles = tr * pl.n_prod;
     c->n_chunks = (c->n_tiles + c->chunk_tiles - 1) / c->chunk_tiles;
     c->seg_cap = c->n_sites / c->g + 2;
     int rc;
@@ -548,13 +560,16 @@ int run_stream(evofst_ctx *c, int tr) {
     // granule tables: rows of level 0, 1, 2 one after the other, two copies
     const int64_t n1 = (c->n_chunks + kStreamFan - 1) / kStreamFan, n2 = (n1 + kStreamFan - 1) / kStreamFan;
     const int64_t rows = (int64_t)c->n_chunks + n1 + n2;
-    const size_t copy_bytes = ((size_t)rows * np * 4 + 255) & ~(size_t)255;
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b0 = a256((size_t)c->n_chunks * np * 4), b1 = a256((size_t)n1 * np * 8), b2 = a256((size_t)n2 * np * 8);
+    const size_t copy_bytes = b0 + b1 + b2, flag_bytes = a256((size_t)rows * 4);
     if ((rc = ensure_zeroed(c, c->d_ssync, 256))) return rc;
-    const bool fresh = c->d_sagg.bytes < 2 * copy_bytes;
-    if ((rc = ensure(c, c->d_sagg, 2 * copy_bytes))) return rc;
+    const bool fresh = c->d_sflag.bytes < 2 * flag_bytes || c->d_sagg.bytes < 2 * copy_bytes;
+    if ((rc = ensure(c, c->d_sagg, 2 * copy_bytes)) || (rc = ensure(c, c->d_sflag, 2 * flag_bytes))) return rc;
     if (fresh || c->sagg_rows != rows || c->sagg_pairs != (int64_t)np) {
-        // another shape than the last launch zeroed the tables for (or none yet): zero both copies
+        // another shape than the last launch zeroed the rows and flags for (or none yet): zero both copies
         HIPCHK(c, hipMemsetAsync(c->d_sagg.p, 0, c->d_sagg.bytes, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_sflag.p, 0, c->d_sflag.bytes, c->stream));
         c->sagg_rows = rows; c->sagg_pairs = (int64_t)np;
     }
     StreamParams p{};
@@ -564,23 +579,57 @@ int run_stream(evofst_ctx *c, int tr) {
     p.segs = (const SegDesc *)c->d_segs.p;
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)np;
+    p.n_prod = pl.n_prod; p.n_cons = pl.n_cons;
+    p.ahead = 1;
+#ifdef EVOFST_EXPERIMENTS
+    if (const char *e = getenv("EVOFST_STREAM_AHEAD")) p.ahead = atoi(e) == 2 ? 2 : 1;
+#endif
     p.tr = tr; p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
     p.g = c->g;
     p.base = (const int64_t *)c->d_base.p;
     p.first_segment = (int64_t *)c->d_first_seg.p; p.incl_totals = (int64_t *)c->d_incl_totals.p;
     p.seg_rows = (SegRow *)c->d_seg_rows.p;
     p.tail = (double *)c->d_tail.p; p.tail_n = (int4 *)c->d_tail_n.p;
-    p.agg[0] = (uint32_t *)c->d_sagg.p; p.agg[1] = (uint32_t *)((unsigned char *)c->d_sagg.p + copy_bytes);
+    for (int k = 0; k < 2; ++k) {
+        unsigned char *base = (unsigned char *)c->d_sagg.p + (size_t)k * copy_bytes;
+        p.agg0[k] = (uint32_t *)base; p.agg1[k] = (uint64_t *)(base + b0); p.agg2[k] = (uint64_t *)(base + b0 + b1);
+    }
+    p.flags[0] = (uint32_t *)c->d_sflag.p; p.flags[1] = (uint32_t *)((unsigned char *)c->d_sflag.p + flag_bytes);
     p.l1_row = c->n_chunks; p.l2_row = c->n_chunks + (int)n1;
     p.ticket = (uint32_t *)c->d_ssync.p; p.err = (uint32_t *)c->d_ssync.p + 32; p.launches = (uint32_t *)c->d_ssync.p + 48;
     p.counts = c->d_counts.p;
     p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
     p.miss_mask = (uint64_t *)c->d_miss.p; p.nan_mask = (uint64_t *)c->d_nan.p;
     p.chunk_offsets = (int64_t *)c->d_offsets.p; p.chunk_dirty = (uint32_t *)c->d_dirty.p;
+#ifdef EVOFST_EXPERIMENTS
+    if (const char *e = getenv("EVOFST_DEBUG_STREAM")) p.debug = atoi(e);
+    // in-kernel time stamps of one launch (the EVOFST_STREAM_STAMPS_AT-th of this context), written to the file named
+    static thread_local int stamp_launch = 0;
+    const char *stamp_file = getenv("EVOFST_STREAM_STAMPS");
+    const int stamp_at = getenv("EVOFST_STREAM_STAMPS_AT") ? atoi(getenv("EVOFST_STREAM_STAMPS_AT")) : 5;
+    const size_t stamp_bytes = (size_t)4096 * kStreamStampIters * 16 * 8;
+    const bool stamping = stamp_file && stamp_launch++ == stamp_at;
+    if (stamping) {
+        if ((rc = ensure(c, c->d_gnum, stamp_bytes))) return rc;     // a buffer of the Gram getters, idle in pairs mode
+        HIPCHK(c, hipMemsetAsync(c->d_gnum.p, 0, stamp_bytes, c->stream));
+        p.stamps = (unsigned long long *)c->d_gnum.p;
+    }
+#endif
     record(c, 4, 0);
     HIPCHK(c, launch_stream(p, c->opt_stream_blocks, c->stream));
     record(c, 4, 1);
+#ifdef EVOFST_EXPERIMENTS
+    if (stamping) {
+        std::vector<unsigned long long> h(stamp_bytes / 8);
+        HIPCHK(c, hipMemcpyAsync(h.data(), c->d_gnum.p, stamp_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (FILE *fp = fopen(stamp_file, "wb")) { fwrite(h.data(), 1, stamp_bytes, fp); fclose(fp); }
+    }
+#endif
     K2Params k2 = make_k2(c);
+#ifdef EVOFST_EXPERIMENTS
+    if (p.debug) return EVOFST_OK;   // timing switches: rows, tails and marks are not all there, nothing may read them
+#endif
     record(c, 2, 0);
     if ((rc = launch_walks(c, k2, false, false, true))) return rc;   // the chunks the stream pass marked, if any
     record(c, 2, 1);
@@ -589,7 +638,8 @@ int run_stream(evofst_ctx *c, int tr) {
     record(c, 3, 1);
     c->check_word = (const uint32_t *)c->d_ssync.p + 32;
     c->check_zero[0] = c->d_ssync.p; c->check_zero_bytes[0] = 128;           // ticket and error words; the launch counter stays
-    c->check_zero[1] = c->d_sagg.p; c->check_zero_bytes[1] = c->d_sagg.bytes;
+    c->check_zero[1] = c->d_sflag.p; c->check_zero_bytes[1] = c->d_sflag.bytes;
+    c->check_zero[2] = c->d_sagg.p; c->check_zero_bytes[2] = c->d_sagg.bytes;
     c->offsets_dirty = false;
     c->counts_done = false;          // K1's census is not there, and its counts only for the marked chunks
     c->plain_counts = false; c->compact_counts = false;
@@ -651,7 +701,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles, &c->d_agg0, &c->d_agg1,
-                      &c->d_agg2, &c->d_fsync, &c->d_miss, &c->d_dirty, &c->d_poison, &c->d_nan, &c->d_sagg, &c->d_ssync};
+                      &c->d_agg2, &c->d_fsync, &c->d_miss, &c->d_dirty, &c->d_poison, &c->d_nan, &c->d_sagg, &c->d_sflag, &c->d_ssync};
     for (DevBuf *b : bufs) release(*b);
     for (auto &pair : c->ev)
         for (auto &e : pair)
@@ -1577,8 +1627,8 @@ extern "C" int evofst_run(evofst_ctx *c) try {
         // pairs mode: one streaming kernel from the tiles to the segment rows (no counts kept in HBM; the getters
         // that want them run K1 on demand)
         HIPCHK(c, hipSetDevice(c->device));
-        const int tr = stream_plan(c, c->n_sites);
-        if (tr > 0) return run_stream(c, tr);
+        const StreamPlan pl = stream_plan(c, c->n_sites);
+        if (pl.tr > 0) return run_stream(c, pl);
         int sub = 32;
         const int ct = fused_plan(c, c->n_sites, false, &sub);
         if (ct > 0) return run_fused(c, ct, sub);
@@ -1655,7 +1705,7 @@ extern "C" int evofst_run_pairs_noalloc(evofst_ctx *c, int64_t n_sites, const vo
     // evofst_sync looks at the pass's error word (a look-back wait that gave up leaves rows, tails and totals unwritten)
     c->check_word = (const uint32_t *)sp + 32;
     c->check_zero[0] = sp; c->check_zero_bytes[0] = 256;
-    c->check_zero[1] = nullptr; c->check_zero_bytes[1] = 0;
+    c->check_zero[1] = c->check_zero[2] = nullptr; c->check_zero_bytes[1] = c->check_zero_bytes[2] = 0;
     return EVOFST_OK;
 } catch (...) {
     return abi_exception(c);
@@ -1688,6 +1738,9 @@ extern "C" int evofst_set_option(evofst_ctx *c, const char *name, int64_t value)
     } else if (n == "stream_blocks") {
         if (value < 0 || value > (1 << 20)) return fail(c, EVOFST_ERR_ARG, "set_option: stream_blocks is 0 (auto) or a number of workgroups");
         c->opt_stream_blocks = (int)value;
+    } else if (n == "stream_producers" || n == "stream_consumers") {
+        if (value < 0 || value >= kStreamMaxWaves) return fail(c, EVOFST_ERR_ARG, "set_option: " + n + " is 0 (auto) .. 11");
+        (n == "stream_producers" ? c->opt_stream_prod : c->opt_stream_cons) = (int)value;
     } else {
         return fail(c, EVOFST_ERR_ARG, "set_option: unknown option '" + n + "'");
     }

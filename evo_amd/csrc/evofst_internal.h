@@ -174,10 +174,10 @@ struct FusedParams {
 };
 
 // pairs mode as one streaming kernel with producer and consumer waves (evofst_stream.hip)
-constexpr int kStreamProd = 4;                         // producer waves per workgroup (+ one consumer wave)
-constexpr int kStreamThreads = 64 * (kStreamProd + 1);
+constexpr int kStreamMaxWaves = 12;                    // producer + consumer waves of a workgroup
+constexpr int kStreamMaxThreads = 64 * kStreamMaxWaves;
 constexpr int kStreamFan = 32;                         // look-back fan-out per level
-constexpr int kStreamRow = 72;                         // u16 per (tile, population) row of counts in LDS: 64 + 8 of padding
+constexpr int kStreamRow = 80;                         // bytes per (tile, population) row of alt counts in LDS: 64 sites + 16 of padding
 constexpr int kStreamMaxPairs = 256;
 #ifndef EVOFST_STREAM_WPS
 #define EVOFST_STREAM_WPS 4                            // waves per SIMD the register allocation aims at
@@ -191,8 +191,10 @@ struct StreamParams {
     const int32_t *n_full;          // [P]
     const uint32_t *pairs;          // i | j << 16
     int32_t n_pairs;
+    int32_t n_prod, n_cons;         // producer and consumer waves of a workgroup
+    int32_t ahead;                  // iterations a chunk's ticket is drawn before the chunk is counted (1 or 2)
     int32_t tr;                     // tiles a producer wave counts per chunk
-    int32_t chunk_tiles, n_chunks;  // chunk_tiles = kStreamProd * tr
+    int32_t chunk_tiles, n_chunks;  // chunk_tiles = n_prod * tr
     int32_t g;
     const int64_t *base;            // [n_pairs] included sites of the pair before this shard
     int64_t *first_segment;         // [n_pairs] out: base / g
@@ -200,11 +202,13 @@ struct StreamParams {
     SegRow *seg_rows;               // [seg_cap][n_pairs]
     double *tail;                   // [3][n_chunks][n_pairs]
     int4 *tail_n;                   // [n_chunks][n_pairs]
-    // look-back granules, value + 1 (0: not there yet): one table of rows of n_pairs 32-bit words -- rows [0, n_chunks)
-    // the included sites of a chunk, rows l1_row + [0, ceil(n_chunks / 32)) those of a group of 32 chunks, rows l2_row +
-    // [0, ceil(n_chunks / 1024)) those of a group of 32 groups.  Two copies: a launch uses copy (launch counter & 1) and
-    // zeroes the rows of the other one
-    uint32_t *agg[2];
+    // look-back (evofst_stream.hip, "Look-back"): included sites per pair of a chunk (+ 1), of a group of 32 chunks and of a
+    // group of 32 groups ({contributions, sum} in 64 bits), and one flag word per row (rows 0.., l1_row.., l2_row..) that
+    // counts the row's contributions.  Two copies: a launch uses copy (launch counter & 1) and zeroes the other one
+    uint32_t *agg0[2];              // [n_chunks][n_pairs]
+    uint64_t *agg1[2];              // [ceil(n_chunks / 32)][n_pairs]
+    uint64_t *agg2[2];              // [ceil(n_chunks / 1024)][n_pairs]
+    uint32_t *flags[2];             // [n_chunks + ceil(n_chunks / 32) + ceil(n_chunks / 1024)]
     int32_t l1_row, l2_row;
     uint32_t *ticket;               // chunk tickets; back to 0 when the launch ends
     uint32_t *err;                  // set when a wait gave up
@@ -214,7 +218,10 @@ struct StreamParams {
     uint64_t *zf_masks, *irr_mask, *skip_mask, *miss_mask, *nan_mask;
     int64_t *chunk_offsets;         // [n_pairs][n_chunks]
     uint32_t *chunk_dirty;          // [n_chunks]
+    int32_t debug;                  // -DEVOFST_EXPERIMENTS builds only (tools/): 1 no walk, 2 no look-back, 4 no counting, 8 no consumer work
+    unsigned long long *stamps;     // -DEVOFST_EXPERIMENTS: [workgroups][kStreamStampIters][16] s_memrealtime stamps, or null
 };
+constexpr int kStreamStampIters = 48;
 
 struct SiteStatParams {
     const void *counts;

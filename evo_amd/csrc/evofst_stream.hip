@@ -4,15 +4,15 @@
 // (process_vcf_fst.cpp:243-280), the site filter (:543-544), calculateFstNumerator / Denominator
 // (process_vcf_fst.h:19-30), calculateDxy (process_vcf_fst.cpp:297-323) and the SNP windows (:638-650).
 //
-// A workgroup is four PRODUCER waves and one CONSUMER wave and works through chunks of a few tiles in ticket order
-// (one atomic per chunk).  In iteration i
+// A workgroup is a few PRODUCER waves and one or more CONSUMER waves (one per 64 pairs at most) and works through
+// chunks of a few tiles in ticket order (one atomic per chunk, drawn two iterations ahead).  In iteration i
 //   the producers  count chunk c_i: lane = site, 16-byte coalesced loads of the tile rows (three batches of four
 //                  rows requested ahead of the one being counted), popcounts under the wave-uniform masks of the
 //                  layout's descriptor stream (scalar cache), packed {alt, non-missing} counts and the zero / fixed
 //                  ballots of every population INTO LDS buffer i & 1 -- nothing but the tiles is read from HBM and no
-//                  count is written to it;
-//   the consumer   takes chunk c_(i-1) from LDS buffer (i-1) & 1: census of included sites per pair (filter :543-544,
-//                  lane = pair), published as one 4-byte granule per pair; look-back over the chunks before it (three
+//                  count is written to it; then the census of included sites per pair (filter :543-544, lane = pair),
+//                  which the producer that finishes last publishes as one row of 4-byte words;
+//   the consumers  take chunk c_(i-1) from LDS buffer (i-1) & 1: look-back over the rows of the chunks before it (three
 //                  levels of fan-out 32: chunks of its group, groups of its super-group, super-groups); then the
 //                  statistics walk over the chunk's counts in LDS (exact integer sums, four sites per
 //                  v_dot4_u32_u8, segment rows at the window boundaries) -- the arithmetic of clean_walk_kernel.
@@ -26,9 +26,10 @@
 // and its pairs' offsets in HBM, exactly as K1 + scan would have, and is walked by fused_pairs_kernel's HBM mode in a
 // second launch that finds nothing to do on clean data.  stitch_kernel completes the segments that straddle chunks.
 //
-// Granules carry no launch tag: a granule is value + 1, and 0 means "not there yet".  The granule arrays exist
-// twice; launch L uses copy L & 1 and zeroes, chunk by chunk, the rows of the other copy for launch L + 1.  The launch
-// counter is a device word that the launch's last ticket draw bumps, so a replayed launch (HIP graph) alternates too.
+// The look-back state carries no launch tag: a row of the granule table is complete when its flag word has counted all
+// groups of pairs.  The flag words exist twice; launch L uses copy L & 1 (of flags and rows) and zeroes, chunk by chunk,
+// the flags of the other copy for launch L + 1.  The launch counter is a device word that the launch's last ticket draw
+// bumps, so a replayed launch (HIP graph) alternates too.
 #include "evofst_internal.h"
 
 #include <algorithm>
@@ -40,24 +41,47 @@ typedef const __attribute__((address_space(4))) SegWords *SegStream;
 extern "C" __device__ int evofst_write_lane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
 typedef __attribute__((address_space(1))) uint32_t gu32;
+typedef __attribute__((address_space(1))) uint64_t gu64;
 
+#ifdef EVOFST_EXPERIMENTS
+// slot k of (workgroup, iteration): the 100 MHz real-time counter, written by one lane
+#define STREAM_STAMP(p, it, k) do { if ((p).stamps && (it) < kStreamStampIters && (threadIdx.x & 63) == 0) \
+    (p).stamps[((size_t)blockIdx.x * kStreamStampIters + (it)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STREAM_STAMP(p, it, k) do {} while (0)
+#endif
 constexpr uint32_t kStreamSpinLimit = 1u << 20;   // polls (with a sleep each) before a wait gives up: seconds
 
 static __host__ __device__ constexpr size_t s16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-size_t stream_buffer_bytes(int P, int chunk_tiles) {
-    return s16((size_t)chunk_tiles * P * kStreamRow * 2) + s16((size_t)chunk_tiles * 2 * P * 8) + s16((size_t)chunk_tiles * 4 * 8);
+// One LDS buffer = one counted chunk: alt counts, one byte each, rows of kStreamRow bytes per (tile, population) (64 sites
+// + padding: rows of different populations start in different banks); non-missing counts, one byte each (only a chunk
+// the integer walk cannot take needs them); zero / fixed ballots [tile][z|f][P]; the four site masks of every tile.
+struct StreamBuf { unsigned char *c, *m; uint64_t *zf, *flg; };
+static __host__ __device__ size_t stream_c_bytes(int P, int chunk_tiles) { return s16((size_t)chunk_tiles * P * kStreamRow); }
+static __host__ __device__ size_t stream_m_bytes(int P, int chunk_tiles) { return s16((size_t)chunk_tiles * P * kTileSites); }
+static __host__ __device__ size_t stream_buf_bytes(int P, int chunk_tiles) {
+    return stream_c_bytes(P, chunk_tiles) + stream_m_bytes(P, chunk_tiles) + s16((size_t)chunk_tiles * 2 * P * 8) + s16((size_t)chunk_tiles * 4 * 8);
 }
+size_t stream_buffer_bytes(int P, int chunk_tiles) { return stream_buf_bytes(P, chunk_tiles); }
+static __device__ __forceinline__ StreamBuf stream_buf(unsigned char *base, int P, int chunk_tiles) {
+    StreamBuf b;
+    b.c = base; b.m = base + stream_c_bytes(P, chunk_tiles);
+    b.zf = reinterpret_cast<uint64_t *>(b.m + stream_m_bytes(P, chunk_tiles));
+    b.flg = b.zf + (size_t)chunk_tiles * 2 * P;
+    return b;
+}
+// + the table of byte masks, the workgroup's words, three per-pair arrays, the quarter table of the chunk being walked
 size_t stream_lds_bytes(int P, int n_pairs, int chunk_tiles) {
-    return 1024 + 64 + 2 * s16((size_t)n_pairs * 4) + 2 * stream_buffer_bytes(P, chunk_tiles);
+    return 1024 + 64 + 3 * s16((size_t)n_pairs * 4) + s16((size_t)chunk_tiles * P * 32) + 2 * stream_buffer_bytes(P, chunk_tiles);
 }
 
 // ------------------------------------------------------------------------------------------------ producer
 // Counts tiles [t0, t0 + n_own) of the shard into slots slot0, slot0 + 1, ... of an LDS buffer.  All arguments but
 // `lane` are wave-uniform.  The batch pipeline is K1's (evofst_kernels.hip): every request is unconditional, so the
 // wait for a batch is a count of younger loads, never "everything outstanding".
-__device__ __forceinline__ void stream_count_piece(const StreamParams &p, int lane, int t0, int n_own, int slot0, uint16_t *cnt,
-                                                   uint64_t *zf, uint64_t *flg, SegStream segs) {
+__device__ __forceinline__ void stream_count_piece(const StreamParams &p, int lane, int t0, int n_own, int slot0, const StreamBuf &buf, SegStream segs) {
+    uint64_t *zf = buf.zf, *flg = buf.flg;
     constexpr int NB = 4;                                // rows per batch
     const int P = p.P;
     const int nb = (p.W + NB - 1) / NB;                  // batches per tile
@@ -114,7 +138,11 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
         load_item(spare);
         asm volatile("" :: "v"(cur.flag));               // the flag byte is the last load of its batch: the batch has arrived
         if (!live) return;
-        uint16_t *cp = cnt + (size_t)(slot0 + ti) * P * kStreamRow + lane;
+        unsigned char *cp = buf.c + (size_t)(slot0 + ti) * P * kStreamRow + lane;
+        unsigned char *mp = buf.m + (size_t)(slot0 + ti) * P * kTileSites + lane;
+#ifdef EVOFST_EXPERIMENTS
+        if (p.debug & 4) { c += (uint32_t)cur.r[0].x ^ (uint32_t)cur.r[1].y ^ (uint32_t)cur.r[2].x ^ (uint32_t)cur.r[3].y; if (c == 0x12345u) { cp[0] = 1; mp[0] = 1; } return; }
+#endif
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             if (wb + u < p.W) {
@@ -129,7 +157,8 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
                     if (fl & kSegLast) {
                         const uint32_t nfull = fl >> kSegNFullShift;
                         const uint32_t nm = nfull - mc;
-                        cp[pop * kStreamRow] = (uint16_t)(c | (nm << 8));
+                        cp[pop * kStreamRow] = (unsigned char)c;
+                        mp[pop * kTileSites] = (unsigned char)nm;
                         const uint64_t z = __ballot(c == 0) | skipmask;
                         const uint64_t f = __ballot(c == nm) | skipmask;
                         const int pl = (int)pop;
@@ -162,58 +191,148 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
 }
 
 // ------------------------------------------------------------------------------------------------ consumer
-// Sums of the granules before `chunk` for column q, as one list of rows: chunks [grp0 * 32, chunk) of level 0, groups
-// [grp1 * 32, grp0) of level 1, super-groups [0, grp1) of level 2; s[level] get the sums.  Sixteen rows are requested at
-// a time (one round trip when they are there); a batch with a row that is not there yet is asked for again after a
-// sleep.  False when the wait gave up (error word set, by this wave or by another).
-__device__ __forceinline__ bool stream_lookback(const StreamParams &p, int par, int chunk, int q, uint32_t (&s)[3]) {
-    constexpr int F = kStreamFan, B = 16;
-    const int grp0 = chunk / F, grp1 = grp0 / F;
-    const int n0 = chunk - grp0 * F, n1 = grp0 - grp1 * F, n2 = grp1;
-    const int total = n0 + n1 + n2;
-    const uint32_t np = (uint32_t)p.n_pairs;
-    const uint32_t *agg = p.agg[par];
-    s[0] = s[1] = s[2] = 0u;
+// Look-back.  Three tables, all written by the producer that publishes a chunk (stream_publish) and read by the
+// consumers of later chunks:
+//   level 0  agg0[chunk][pair]  32-bit words, included sites of the chunk + 1 (0: not there yet);
+//   level 1  agg1[group of 32 chunks][pair]: 64-bit words that every chunk of the group adds {1, its included sites} to
+//            (one atomic add): the sum is complete when the high half says 32 -- no chunk waits for another to form the
+//            aggregate, and it is there as soon as the group's last chunk has been counted;
+//   level 2  agg2[group of 32 groups][pair]: the same with a group's total as the contribution, added by a consumer of
+//            the first chunk of the next group (stream_consume) -- 32 adds per word over a long time, where 1024 chunks
+//            adding straight into one row queue up at the memory side.
+// The rows before a chunk: chunks [grp0 * 32, chunk) of level 0, groups [grp1 * 32, grp0) of level 1, super-groups
+// [0, grp1) of level 2 (all of them full groups).  Flag word r counts the chunks that have published into row r of
+// {level 0 | level 1 | level 2} (rows 0.., l1_row.., l2_row..): a consumer polls those -- one or two 4-byte loads per
+// lane and poll -- and reads the rows when the flags say they are worth reading.  The flags are raised without waiting
+// for the row's stores or adds, so a row can lag its flag: every word read is checked and read again if need be.
+struct StreamRows {
+    int grp0, grp1, n0, n1, n2;
+    __device__ __forceinline__ StreamRows(int chunk) {
+        grp0 = chunk / kStreamFan; grp1 = grp0 / kStreamFan;
+        n0 = chunk - grp0 * kStreamFan; n1 = grp0 - grp1 * kStreamFan; n2 = grp1;
+    }
+};
+// Polls the flags until every row before the chunk has all its contributions; false when the wait gave up (error word
+// set, here or elsewhere).
+__device__ __forceinline__ bool stream_wait_flags(const StreamParams &p, const StreamRows &r, int lane, int par, uint32_t &polls) {
+    constexpr int F = kStreamFan;
+    const uint32_t *flags = p.flags[par];
+    const int idx = lane < F ? (lane < r.n0 ? r.grp0 * F + lane : -1) : (lane - F < r.n1 ? p.l1_row + r.grp1 * F + lane - F : -1);
+    const uint32_t want = lane < F ? 1u : (uint32_t)F;
     uint32_t spins = 0;
-    for (int r0 = 0; r0 < total; r0 += B) {
-        uint32_t off[B];
-        int lev[B];
+    for (;;) {
+        bool ok = true;
+        if (idx >= 0) ok = __hip_atomic_load((gu32 *)(flags + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+        for (int r0 = 0; r0 < r.n2; r0 += 64)
+            if (r0 + lane < r.n2) ok = ok && __hip_atomic_load((gu32 *)(flags + p.l2_row + r0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)F;
+        if (__all(ok)) { polls = spins; return true; }
+        if (++spins > kStreamSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        if ((spins & 63u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        // polls are uncached loads of lines many waves want: a few per microsecond and CU slow the tile stream of every CU
+        // down.  The consumer has most of an iteration to spare, so it asks again only every few microseconds.
+#ifdef EVOFST_EXPERIMENTS
+        if (p.debug & 512) { __builtin_amdgcn_s_sleep(8); continue; }
+#endif
+        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+    }
+}
+// Included sites of column q in the rows before the chunk.  False when a row stayed incomplete and the wait gave up.
+__device__ __forceinline__ bool stream_sum_rows(const StreamParams &p, const StreamRows &r, int par, int q, uint64_t &before, uint32_t &retries) {
+    constexpr int F = kStreamFan, B = 32;
+    const uint32_t np = (uint32_t)p.n_pairs;
+    uint32_t spins = 0;
+    uint64_t sum = 0;
+    {   // level 0: at most 31 rows
+        const uint32_t *a0 = p.agg0[par];                 // uniform base + 32-bit offsets: one address register per load
+        const uint32_t o0 = (uint32_t)(r.grp0 * F) * np + (uint32_t)q;
+        uint32_t x[B - 1];
+        while (r.n0 > 0) {
 #pragma unroll
-        for (int u = 0; u < B; ++u) {
-            const int r = min(r0 + u, total - 1);
-            lev[u] = r < n0 ? 0 : (r < n0 + n1 ? 1 : 2);
-            const int row = lev[u] == 0 ? grp0 * F + r : (lev[u] == 1 ? p.l1_row + grp1 * F + r - n0 : p.l2_row + r - n0 - n1);
-            off[u] = (uint32_t)row * np + (uint32_t)q;
+            for (int u = 0; u < B - 1; ++u) x[u] = __hip_atomic_load((gu32 *)(a0 + (o0 + (uint32_t)min(u, r.n0 - 1) * np)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < B - 1; ++u) ok = ok && x[u] != 0u;
+            if (__all(ok)) break;
+            if (++spins > kStreamSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+            if ((spins & 63u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (p.debug & 512) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(96);
         }
-        uint32_t x[B];
+        if (r.n0 > 0) {
+#pragma unroll
+            for (int u = 0; u < B - 1; ++u) sum += u < r.n0 ? x[u] - 1u : 0u;
+        }
+    }
+    // levels 1 and 2 as one list of 64-bit words, 16 in flight (the two tables lie one behind the other: one base)
+    constexpr int B2 = 16;
+    const int total = r.n1 + r.n2;
+    const uint64_t *a1 = p.agg1[par];
+    const uint32_t o1 = (uint32_t)(r.grp1 * F) * np + (uint32_t)q, o2 = (uint32_t)(p.agg2[par] - p.agg1[par]) + (uint32_t)q;
+    for (int r0 = 0; r0 < total; r0 += B2) {
+        uint64_t x[B2];
         for (;;) {
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < B; ++u) x[u] = __hip_atomic_load((gu32 *)(agg + off[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int u = 0; u < B; ++u) ok = ok && x[u] != 0u;
-            if (ok) break;
+            for (int u = 0; u < B2; ++u) {
+                const int i = min(r0 + u, total - 1);
+                const uint32_t off = i < r.n1 ? o1 + (uint32_t)i * np : o2 + (uint32_t)(i - r.n1) * np;
+                x[u] = __hip_atomic_load((gu64 *)(a1 + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (uint32_t)(x[u] >> 32) == (uint32_t)F;
+            }
+            if (__all(ok)) break;
             if (++spins > kStreamSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
             if ((spins & 63u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            __builtin_amdgcn_s_sleep(16);
+            if (p.debug & 512) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(96);
         }
 #pragma unroll
-        for (int u = 0; u < B; ++u) {
-            const uint32_t v = r0 + u < total ? x[u] - 1u : 0u;
-            s[0] += lev[u] == 0 ? v : 0u; s[1] += lev[u] == 1 ? v : 0u; s[2] += lev[u] == 2 ? v : 0u;
-        }
+        for (int u = 0; u < B2; ++u) sum += r0 + u < total ? (x[u] & 0xffffffffull) : 0ull;
     }
+    before = sum;
+    retries = spins;
     return true;
 }
 
-// The statistics walk of one pair (this lane) over the nt tiles of a chunk whose packed counts and ballots lie in LDS:
-// clean_walk_kernel's arithmetic (evofst_fused.hip).  No site of the chunk is skipped and no allele is missing, so
-// p = c / n with the population's full n, and the window sums of d^2, p(1-p) and sumKij follow exactly from integer
-// sums of c_i c_j, c and c^2 (a chunk has at most 2^10 sites and c <= 255: every sum stays below 2^31 and every
-// product below 2^53).
-__device__ __forceinline__ void stream_walk_pair(const StreamParams &p, const uint16_t *cnt, const uint64_t *zf, const uint32_t *pmask, int nt,
-                                                 int gtile0, int chunk, int q, uint32_t pi, uint32_t pj, int64_t b0, int64_t g0) {
-    constexpr int SUB = 32, NW4 = SUB / 4;
+// position of the n-th (1-based) set bit of the 64-bit mask {hi, lo}; needs 1 <= n <= popc
+__device__ __forceinline__ int nth_set_bit64(uint32_t lo, uint32_t hi, int n) {
+    const int cl = __popc(lo);
+    const bool up = n > cl;
+    return nth_set_bit(up ? hi : lo, up ? n - cl : n) + (up ? 32 : 0);
+}
+
+// Per (tile, population) of a counted chunk: the sums of c and of c^2 over the tile's first 16, 32, 48 and 64 sites
+// ([4] x {C, Q}).  Every consumer wave fills the whole table itself before it reads it (the waves write the same words).
+__device__ __forceinline__ void stream_quarter_table(int lane, int nt, int P, const unsigned char *cpl, uint32_t *qtab) {
+    constexpr uint32_t kOnes = 0x01010101u;
+    for (int item = lane; item < nt * P; item += 64) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(cpl + (size_t)item * kStreamRow);
+        uint32_t C = 0, Q = 0;
+        uint32_t out[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 x = row[k];
+            C = __builtin_amdgcn_udot4(x.x, kOnes, C, false); C = __builtin_amdgcn_udot4(x.y, kOnes, C, false);
+            C = __builtin_amdgcn_udot4(x.z, kOnes, C, false); C = __builtin_amdgcn_udot4(x.w, kOnes, C, false);
+            Q = __builtin_amdgcn_udot4(x.x, x.x, Q, false); Q = __builtin_amdgcn_udot4(x.y, x.y, Q, false);
+            Q = __builtin_amdgcn_udot4(x.z, x.z, Q, false); Q = __builtin_amdgcn_udot4(x.w, x.w, Q, false);
+            out[2 * k] = C; out[2 * k + 1] = Q;
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(qtab + (size_t)item * 8);
+        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    }
+}
+
+// The statistics walk of one pair (this lane) over the nt tiles of a chunk whose alt counts and ballots lie in LDS:
+// clean_walk_kernel's arithmetic (evofst_fused.hip), a tile of 64 sites per step.  No site of the chunk is skipped and
+// no allele is missing, so p = c / n with the population's full n, and the window sums of d^2, p(1-p) and sumKij follow
+// exactly from integer sums of c_i c_j, c and c^2 (a chunk has at most 2^12 sites and c <= 255: every sum stays below
+// 2^32 and every product below 2^53).  Per tile a lane forms the sum of c_i c_j (sixteen v_dot4_u32_u8, kept per
+// quarter of 16 sites) and takes the sums of c and c^2 from the quarter table; at a window boundary the sums up to the
+// boundary site are the quarter-table entry before its quarter plus masked dot products over that quarter alone.
+__device__ __forceinline__ void stream_walk_pair(const StreamParams &p, const unsigned char *cpl, const uint64_t *zf, const uint32_t *qtab,
+                                                 const uint32_t *pmask, int nt, int gtile0, int chunk, int q, uint32_t pi, uint32_t pj,
+                                                 int64_t b0, int64_t g0) {
+    constexpr int SUB = kTileSites;
+    constexpr uint32_t kOnes = 0x01010101u;
     const int P = p.P;
     const uint32_t ni = (uint32_t)p.n_full[pi], nj = (uint32_t)p.n_full[pj];
     const int64_t first_seg = b0 / p.g;
@@ -238,51 +357,57 @@ __device__ __forceinline__ void stream_walk_pair(const StreamParams &p, const ui
         den = dE + dTi * rTi + dTj * rTj;
         k = fma(dnj, Ci, fma(dni, Cj, -2.0 * CC));                        // sumKij (fst.cpp:299-321)
     };
-    for (int st = 0; st < 2 * nt; ++st) {
-        const int ti = st >> 1, sh = (st & 1) * SUB;
+    for (int ti = 0; ti < nt; ++ti) {
         const uint64_t *zp = zf + (size_t)ti * 2 * P;
-        const uint32_t incl = ~(uint32_t)(((zp[pi] & zp[pj]) | (zp[P + pi] & zp[P + pj])) >> sh);   // fst.cpp:543-544
-        int b = SUB;                                       // site of this lane's next boundary in the fill (SUB: none)
+        const uint64_t incl = ~((zp[pi] & zp[pj]) | (zp[P + pi] & zp[P + pj]));   // fst.cpp:543-544
+        int b = SUB;                                       // site of this lane's next boundary in the tile (SUB: none)
         {
-            const int n = __popc(incl);
-            if (left <= n) b = nth_set_bit(incl, left);
+            const int n = __popcll(incl);
+            if (left <= n) b = nth_set_bit64((uint32_t)incl, (uint32_t)(incl >> 32), left);
             else left -= n;
         }
-        constexpr uint32_t kOnes = 0x01010101u;
-        uint32_t wi[NW4], wj[NW4];
-        {
-            const uint4 *ri = reinterpret_cast<const uint4 *>(cnt + ((size_t)ti * P + pi) * kStreamRow + sh);
-            const uint4 *rj = reinterpret_cast<const uint4 *>(cnt + ((size_t)ti * P + pj) * kStreamRow + sh);
+        const unsigned char *ri = cpl + ((size_t)ti * P + pi) * kStreamRow, *rj = cpl + ((size_t)ti * P + pj) * kStreamRow;
+        uint32_t cq[4];                                    // sum of c_i c_j over the tile's quarters
 #pragma unroll
-            for (int v = 0; v < SUB / 8; ++v) {            // 8 packed {c, nm} pairs -> two words of 4 c bytes
-                const uint4 x = ri[v], y = rj[v];
-                wi[2 * v] = __builtin_amdgcn_perm(x.y, x.x, 0x06040200u); wi[2 * v + 1] = __builtin_amdgcn_perm(x.w, x.z, 0x06040200u);
-                wj[2 * v] = __builtin_amdgcn_perm(y.y, y.x, 0x06040200u); wj[2 * v + 1] = __builtin_amdgcn_perm(y.w, y.z, 0x06040200u);
-            }
+        for (int k = 0; k < 4; ++k) {
+#ifdef EVOFST_EXPERIMENTS
+            const uint4 x = (p.debug & 32) ? make_uint4(pi, pj, ti, k) : reinterpret_cast<const uint4 *>(ri)[k];
+            const uint4 y = (p.debug & 32) ? make_uint4(pj, pi, k, ti) : reinterpret_cast<const uint4 *>(rj)[k];
+#else
+            const uint4 x = reinterpret_cast<const uint4 *>(ri)[k], y = reinterpret_cast<const uint4 *>(rj)[k];
+#endif
+            uint32_t v = __builtin_amdgcn_udot4(x.x, y.x, 0u, false);
+            v = __builtin_amdgcn_udot4(x.y, y.y, v, false); v = __builtin_amdgcn_udot4(x.z, y.z, v, false);
+            cq[k] = __builtin_amdgcn_udot4(x.w, y.w, v, false);
         }
-        uint32_t tCC = 0, tCi = 0, tCj = 0, tQi = 0, tQj = 0;     // over the whole fill
-#pragma unroll
-        for (int m_ = 0; m_ < NW4; ++m_) {
-            tCC = __builtin_amdgcn_udot4(wi[m_], wj[m_], tCC, false);
-            tCi = __builtin_amdgcn_udot4(wi[m_], kOnes, tCi, false); tCj = __builtin_amdgcn_udot4(wj[m_], kOnes, tCj, false);
-            tQi = __builtin_amdgcn_udot4(wi[m_], wi[m_], tQi, false); tQj = __builtin_amdgcn_udot4(wj[m_], wj[m_], tQj, false);
-        }
-        uint32_t dCC = 0, dCi = 0, dCj = 0, dQi = 0, dQj = 0;     // of them, up to the last boundary
+        const uint2 *qi = reinterpret_cast<const uint2 *>(qtab + ((size_t)ti * P + pi) * 8), *qj = reinterpret_cast<const uint2 *>(qtab + ((size_t)ti * P + pj) * 8);
+        const uint2 Ti = qi[3], Tj = qj[3];                // {sum c, sum c^2} over the tile
+        const uint32_t tCC = (cq[0] + cq[1]) + (cq[2] + cq[3]);
+        uint32_t dCC = 0, dCi = 0, dCj = 0, dQi = 0, dQj = 0;     // of the tile's sums, the part up to the last boundary
         while (b < SUB) {
-            uint32_t pCC = 0, pCi = 0, pCj = 0, pQi = 0, pQj = 0;  // sites 0 .. b
-            const uint4 *mk4 = reinterpret_cast<const uint4 *>(pmask + b * NW4);
-            const uint4 mka = mk4[0], mkb = mk4[1];
-            const uint32_t mk[NW4] = {mka.x, mka.y, mka.z, mka.w, mkb.x, mkb.y, mkb.z, mkb.w};
-#pragma unroll
-            for (int m_ = 0; m_ < NW4; ++m_) {
-                const uint32_t x = wi[m_] & mk[m_], y = wj[m_] & mk[m_];
-                pCC = __builtin_amdgcn_udot4(x, y, pCC, false);
-                pCi = __builtin_amdgcn_udot4(x, kOnes, pCi, false); pCj = __builtin_amdgcn_udot4(y, kOnes, pCj, false);
-                pQi = __builtin_amdgcn_udot4(x, x, pQi, false); pQj = __builtin_amdgcn_udot4(y, y, pQj, false);
-            }
+            const int qb = b >> 4;                         // the boundary's quarter: the quarters before it come whole
+            const uint2 Bi = qi[max(qb - 1, 0)], Bj = qj[max(qb - 1, 0)];
+            uint32_t pCi = qb ? Bi.x : 0u, pQi = qb ? Bi.y : 0u, pCj = qb ? Bj.x : 0u, pQj = qb ? Bj.y : 0u;
+            uint32_t pCC = qb == 0 ? 0u : (qb == 1 ? cq[0] : (qb == 2 ? cq[0] + cq[1] : cq[0] + cq[1] + cq[2]));
+            const uint4 mk = reinterpret_cast<const uint4 *>(pmask)[b & 15];     // bytes of sites 0 .. b & 15 of a quarter
+            uint4 x = reinterpret_cast<const uint4 *>(ri)[qb], y = reinterpret_cast<const uint4 *>(rj)[qb];
+            x.x &= mk.x; x.y &= mk.y; x.z &= mk.z; x.w &= mk.w; y.x &= mk.x; y.y &= mk.y; y.z &= mk.z; y.w &= mk.w;
+            pCC = __builtin_amdgcn_udot4(x.x, y.x, pCC, false); pCC = __builtin_amdgcn_udot4(x.y, y.y, pCC, false);
+            pCC = __builtin_amdgcn_udot4(x.z, y.z, pCC, false); pCC = __builtin_amdgcn_udot4(x.w, y.w, pCC, false);
+            pCi = __builtin_amdgcn_udot4(x.x, kOnes, pCi, false); pCi = __builtin_amdgcn_udot4(x.y, kOnes, pCi, false);
+            pCi = __builtin_amdgcn_udot4(x.z, kOnes, pCi, false); pCi = __builtin_amdgcn_udot4(x.w, kOnes, pCi, false);
+            pCj = __builtin_amdgcn_udot4(y.x, kOnes, pCj, false); pCj = __builtin_amdgcn_udot4(y.y, kOnes, pCj, false);
+            pCj = __builtin_amdgcn_udot4(y.z, kOnes, pCj, false); pCj = __builtin_amdgcn_udot4(y.w, kOnes, pCj, false);
+            pQi = __builtin_amdgcn_udot4(x.x, x.x, pQi, false); pQi = __builtin_amdgcn_udot4(x.y, x.y, pQi, false);
+            pQi = __builtin_amdgcn_udot4(x.z, x.z, pQi, false); pQi = __builtin_amdgcn_udot4(x.w, x.w, pQi, false);
+            pQj = __builtin_amdgcn_udot4(y.x, y.x, pQj, false); pQj = __builtin_amdgcn_udot4(y.y, y.y, pQj, false);
+            pQj = __builtin_amdgcn_udot4(y.z, y.z, pQj, false); pQj = __builtin_amdgcn_udot4(y.w, y.w, pQj, false);
             SegRow row;
             parts(aCC + (pCC - dCC), aCi + (pCi - dCi), aCj + (pCj - dCj), aQi + (pQi - dQi), aQj + (pQj - dQj), row.num, row.den, row.k);
-            row.end = (gtile0 + ti) * kTileSites + sh + b; row.pad = 0;
+            row.end = (gtile0 + ti) * kTileSites + b; row.pad = 0;
+#ifdef EVOFST_EXPERIMENTS
+            if (!(p.debug & 16) || row.end == -12345)
+#endif
             {   // two 16-byte stores into one 32-byte sector
                 uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
                 const uint4 *src = reinterpret_cast<const uint4 *>(&row);
@@ -292,100 +417,197 @@ __device__ __forceinline__ void stream_walk_pair(const StreamParams &p, const ui
             dCC = pCC; dCi = pCi; dCj = pCj; dQi = pQi; dQj = pQj;
             ++nflush;
             orow += p.n_pairs;
-            const uint32_t rem = b >= SUB - 1 ? 0u : incl & ~((2u << b) - 1u);
-            const int c2 = __popc(rem);
-            if (p.g <= c2) b = nth_set_bit(rem, p.g);
+            const uint64_t rem = b >= SUB - 1 ? 0ull : incl & ~((2ull << b) - 1ull);
+            const int c2 = __popcll(rem);
+            if (p.g <= c2) b = nth_set_bit64((uint32_t)rem, (uint32_t)(rem >> 32), p.g);
             else { left = p.g - c2; b = SUB; }
         }
-        aCC += tCC - dCC; aCi += tCi - dCi; aCj += tCj - dCj; aQi += tQi - dQi; aQj += tQj - dQj;
+        aCC += tCC - dCC; aCi += Ti.x - dCi; aCj += Tj.x - dCj; aQi += Ti.y - dQi; aQj += Tj.y - dQj;
     }
     // what the chunk holds behind its last boundary
-    const size_t cq = (size_t)chunk * p.n_pairs + q;
+    const size_t cq_ = (size_t)chunk * p.n_pairs + q;
     const size_t plane = (size_t)p.n_pairs * p.n_chunks;
     double num, den, k;
     parts(aCC, aCi, aCj, aQi, aQj, num, den, k);
-    p.tail[cq] = num; p.tail[plane + cq] = den; p.tail[2 * plane + cq] = k;
-    p.tail_n[cq] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);   // {sites summed in the tail, segments completed, row of the first}
+    p.tail[cq_] = num; p.tail[plane + cq_] = den; p.tail[2 * plane + cq_] = k;
+    p.tail_n[cq_] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);   // {sites summed in the tail, segments completed, row of the first}
 }
 
-// Everything the consumer wave does with a counted chunk.  Returns false when a look-back wait gave up.
-__device__ __forceinline__ bool stream_consume(const StreamParams &p, int lane, int par, int chunk, const uint16_t *cnt, const uint64_t *zf,
-                                               const uint64_t *flg, const uint32_t *lpairs, uint32_t *lcen, const uint32_t *pmask) {
+// What a producer wave does once its tiles of chunk `chunk` are counted: the census of its tiles (included sites per
+// pair, filter fst.cpp:543-544, lane = pair) goes into the workgroup's census of the chunk in LDS, and the producer
+// that arrives last publishes the chunk's row -- straight after the counting, whatever the consumers are busy with.
+// The flag is raised without waiting for the row's stores: it only tells pollers when reading the row is worth it.
+__device__ __forceinline__ void stream_publish(const StreamParams &p, int lane, int par, int chunk, int n_prod, int slot0, int n_own, const uint64_t *zf,
+                                               const uint32_t *lpairs, uint32_t *cen, uint32_t *done) {
     constexpr int F = kStreamFan;
+    const int P = p.P;
     const int NG = (p.n_pairs + 63) >> 6;
+    if (n_own > 0)
+        for (int g = 0; g < NG; ++g) {
+            const int q = g * 64 + lane;
+            if (q < p.n_pairs) {
+                const uint32_t ij = lpairs[q];
+                const uint32_t pi = ij & 0xffffu, pj = ij >> 16;
+                uint32_t n = 0;
+                for (int ti = 0; ti < n_own; ++ti) {
+                    const uint64_t *zp = zf + (size_t)(slot0 + ti) * 2 * P;
+                    const uint64_t ex = (zp[pi] & zp[pj]) | (zp[P + pi] & zp[P + pj]);
+                    n += 64u - (uint32_t)__popcll(ex);
+                }
+                __hip_atomic_fetch_add(cen + q, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    int last = 0;
+    if (lane == 0) last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)n_prod - 1u ? 1 : 0;
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
+#ifdef EVOFST_EXPERIMENTS
+    if (p.debug & 256) return;                             // nothing published at all (timing only, with bit 2)
+#endif
+    const size_t np = (size_t)p.n_pairs;
+    const int grp0 = chunk / F, grp1 = grp0 / F;
+    uint32_t *row0 = p.agg0[par] + (size_t)chunk * np;
+    uint64_t *row1 = p.agg1[par] + (size_t)grp0 * np;
+    for (int g = 0; g < NG; ++g) {
+        const int q = g * 64 + lane;
+        if (q < p.n_pairs) {
+            const uint32_t n = cen[q];
+            __hip_atomic_store((gu32 *)(row0 + q), n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t one = (1ull << 32) | n;             // {one more chunk, its included sites}
+#ifdef EVOFST_EXPERIMENTS
+            if (!(p.debug & 128))
+#endif
+            __hip_atomic_fetch_add((gu64 *)(row1 + q), one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the other copy's rows, for the next launch
+            p.agg0[par ^ 1][(size_t)chunk * np + q] = 0u;
+            if (chunk % F == 0) p.agg1[par ^ 1][(size_t)grp0 * np + q] = 0ull;
+            if (chunk % (F * F) == 0) p.agg2[par ^ 1][(size_t)grp1 * np + q] = 0ull;
+        }
+    }
+    if (lane == 0) {
+        uint32_t *flags = p.flags[par], *oflags = p.flags[par ^ 1];
+        __hip_atomic_fetch_add((gu32 *)(flags + chunk), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add((gu32 *)(flags + p.l1_row + grp0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        oflags[chunk] = 0u;
+        if (chunk % F == 0) oflags[p.l1_row + grp0] = 0u;
+        if (chunk % (F * F) == 0) oflags[p.l2_row + grp1] = 0u;
+    }
+}
+
+// Everything a consumer wave does with a counted chunk.  Returns false when a look-back wait gave up.
+// Consumer wave `cw` of `ncw` takes the groups of 64 pairs cw, cw + ncw, ...; the first one also hands a chunk the integer
+// walk cannot take to the general walk.
+__device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, int lane, int cw, int ncw, int par, int chunk, const StreamBuf &buf,
+                                               const uint32_t *lpairs, uint32_t *lcen, uint32_t *ldone, int32_t *lready, uint32_t *qtab, const uint32_t *pmask) {
+    const uint64_t *zf = buf.zf, *flg = buf.flg;
+    const int NG = (p.n_pairs + 63) >> 6;
+    const int my_groups = cw < NG ? (NG - cw + ncw - 1) / ncw : 0;
     const int P = p.P;
     const int gtile0 = chunk * p.chunk_tiles;
     const int nt = min(p.chunk_tiles, p.n_tiles - gtile0);
-    const size_t np = (size_t)p.n_pairs;
     // a site skipped, an allele missing, a population with fewer than two chromosomes: the general walk's chunk
     uint64_t fw = 0;
     if (lane < nt) fw = flg[lane * 4 + 0] | flg[lane * 4 + 1] | flg[lane * 4 + 2];
     const bool dirty = __any(fw != 0);
-    const int grp0 = chunk / F, grp1 = grp0 / F;
-
-    // ---- census of every pair, published before anything is waited for
+    if (my_groups == 0) return true;
+    // ---- the rows before this chunk: wait until their flags say they are complete, read them once per group of 64 pairs;
+    // then the walk (or the chunk's offsets for the general walk)
+    const StreamRows rows(chunk);
+    uint32_t polls = 0, retries = 0;
+    // The first chunk of a group of 32 hands the total of the group before it to level 2 -- before it waits for level 2
+    // itself, which its own hand-over may complete (one add per group and row: no contention there).
+#ifdef EVOFST_EXPERIMENTS
+    if (!(p.debug & 2))
+#endif
+    if (chunk % kStreamFan == 0 && chunk > 0) {
+        const int gprev = rows.grp0 - 1;
+        const uint32_t np = (uint32_t)p.n_pairs;
+        uint32_t spins = 0;
 #pragma unroll 1
-    for (int g = 0; g < NG; ++g) {
+        for (int g = cw; g < NG; g += ncw) {
+            const int q = g * 64 + lane;
+            const uint64_t *src = p.agg1[par] + ((uint32_t)gprev * np + (uint32_t)(q < p.n_pairs ? q : 0));
+            uint64_t v;
+            for (;;) {
+                v = __hip_atomic_load((gu64 *)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((uint32_t)(v >> 32) == (uint32_t)kStreamFan)) break;
+                if (++spins > kStreamSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+                if ((spins & 63u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (q < p.n_pairs)
+                __hip_atomic_fetch_add((gu64 *)(p.agg2[par] + ((uint32_t)(gprev / kStreamFan) * np + (uint32_t)q)), (1ull << 32) | (v & 0xffffffffull),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (cw == 0 && lane == 0) __hip_atomic_fetch_add((gu32 *)(p.flags[par] + p.l2_row + gprev / kStreamFan), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#ifdef EVOFST_EXPERIMENTS
+    if (!(p.debug & 2))
+#endif
+    {   // one consumer wave of the workgroup polls the flags; the others wait for its word in LDS
+        if (cw == 0) {
+            const bool ok = stream_wait_flags(p, rows, lane, par, polls);
+            if (lane == 0) __hip_atomic_store(lready, ok ? chunk : -1 - chunk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!ok) return false;
+        } else {
+            uint32_t spins = 0;
+            for (;;) {
+                const int32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(lready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (v == chunk) break;
+                if (v == -1 - chunk || ++spins > (kStreamSpinLimit << 4)) return false;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
+    if (cw == 0) STREAM_STAMP(p, it, 5);                  // flags complete
+    if (!dirty) {
+        stream_quarter_table(lane, nt, P, buf.c, qtab);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll 1
+    for (int g = cw; g < NG; g += ncw) {
         const int q = g * 64 + lane;
+        uint64_t before = 0;
+#ifdef EVOFST_EXPERIMENTS
+        if (!(p.debug & 2))
+#endif
+        if (!stream_sum_rows(p, rows, par, q < p.n_pairs ? q : 0, before, retries)) return false;
+        if (cw == 0 && g == 0) {
+            STREAM_STAMP(p, it, 6);     // first sums there
+#ifdef EVOFST_EXPERIMENTS
+            if (p.stamps != nullptr && it < kStreamStampIters && lane == 0) p.stamps[((size_t)blockIdx.x * kStreamStampIters + it) * 16 + 10] = ((unsigned long long)polls << 32) | retries;
+#endif
+        }
         if (q < p.n_pairs) {
             const uint32_t ij = lpairs[q];
             const uint32_t pi = ij & 0xffffu, pj = ij >> 16;
-            uint32_t n = 0;
-            for (int ti = 0; ti < nt; ++ti) {
-                const uint64_t *zp = zf + (size_t)ti * 2 * P;
-                const uint64_t ex = (zp[pi] & zp[pj]) | (zp[P + pi] & zp[P + pj]);     // fst.cpp:543-544
-                n += 64u - (uint32_t)__popcll(ex);
-            }
-            lcen[q] = n;                                   // this lane reads it back below
-            __hip_atomic_store((gu32 *)(p.agg[par] + (size_t)chunk * np + q), n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // the other copy's rows, for the next launch
-            uint32_t *other = p.agg[par ^ 1];
-            other[(size_t)chunk * np + q] = 0u;
-            if (chunk % F == 0) other[(size_t)(p.l1_row + grp0) * np + q] = 0u;
-            if (chunk % (F * F) == 0) other[(size_t)(p.l2_row + grp1) * np + q] = 0u;
-        }
-    }
-    // ---- per group of 64 pairs: look back, then walk (or leave the chunk to the general walk)
-    bool all_ok = true;
-#pragma unroll 1
-    for (int g = 0; g < NG; ++g) {
-        const int q = g * 64 + lane;
-        const bool active = q < p.n_pairs;
-        uint32_t s[3];
-#ifndef STREAM_NO_LB
-        const bool ok = stream_lookback(p, par, chunk, active ? q : 0, s);
-#else
-        const bool ok = true; s[0] = s[1] = s[2] = chunk;
-#endif
-        if (__any(!ok)) { all_ok = false; break; }
-        if (active) {
-            const uint32_t ij = lpairs[q];
-            const uint32_t pi = ij & 0xffffu, pj = ij >> 16;
             const uint32_t cen = lcen[q];
-            if (chunk % F == F - 1) {
-                __hip_atomic_store((gu32 *)(p.agg[par] + (size_t)(p.l1_row + grp0) * np + q), s[0] + cen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (grp0 % F == F - 1)
-                    __hip_atomic_store((gu32 *)(p.agg[par] + (size_t)(p.l2_row + grp1) * np + q), s[1] + s[0] + cen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            lcen[q] = 0u;                                  // for the chunk that takes this buffer next
             const int64_t b0 = p.base[q];
-            const int64_t before = (int64_t)s[2] + (int64_t)s[1] + (int64_t)s[0];
-            if (chunk == p.n_chunks - 1) p.incl_totals[q] = before + (int64_t)cen;
+            if (chunk == p.n_chunks - 1) p.incl_totals[q] = (int64_t)before + (int64_t)cen;
             if (chunk == 0) p.first_segment[q] = b0 / p.g;
-            const int64_t g0 = b0 + before;
+            const int64_t g0 = b0 + (int64_t)before;
             if (dirty) p.chunk_offsets[(size_t)q * p.n_chunks + chunk] = g0;
-#ifndef STREAM_NO_WALK
-            else stream_walk_pair(p, cnt, zf, pmask, nt, gtile0, chunk, q, pi, pj, b0, g0);
+#ifdef EVOFST_EXPERIMENTS
+            else if (p.debug & 1) {}
 #endif
+            else stream_walk_pair(p, buf.c, zf, qtab, pmask, nt, gtile0, chunk, q, pi, pj, b0, g0);
         }
     }
-    if (!all_ok) return false;
+    if (cw == 0) STREAM_STAMP(p, it, 8);                  // walked
+    if (cw != 0) return true;
+    if (lane == 0) *ldone = 0u;                            // for the chunk that takes this buffer next
     if (dirty) {
         // K1's outputs for this chunk: packed counts [tile][P][64], ballots [tile][z|f][P], the four site masks
-        const int nv = nt * P * 8;                         // 16-byte vectors of the counts
+        const int nv = nt * P * 4;                         // groups of 16 sites: 16 alt bytes + 16 non-missing bytes -> 16 packed counts
         uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.counts) + (size_t)gtile0 * P * kTileSites);
         for (int v = lane; v < nv; v += 64) {
-            const int row = v >> 3, part = v & 7;          // row = slot * P + population
-            dst[v] = *reinterpret_cast<const uint4 *>(cnt + (size_t)row * kStreamRow + part * 8);
+            const int row = v >> 2, part = v & 3;          // row = slot * P + population
+            const uint4 c16 = *reinterpret_cast<const uint4 *>(buf.c + (size_t)row * kStreamRow + part * 16);
+            const uint4 n16 = *reinterpret_cast<const uint4 *>(buf.m + (size_t)row * kTileSites + part * 16);
+            dst[2 * v] = make_uint4(__builtin_amdgcn_perm(n16.x, c16.x, 0x05010400u), __builtin_amdgcn_perm(n16.x, c16.x, 0x07030602u),
+                                    __builtin_amdgcn_perm(n16.y, c16.y, 0x05010400u), __builtin_amdgcn_perm(n16.y, c16.y, 0x07030602u));
+            dst[2 * v + 1] = make_uint4(__builtin_amdgcn_perm(n16.z, c16.z, 0x05010400u), __builtin_amdgcn_perm(n16.z, c16.z, 0x07030602u),
+                                        __builtin_amdgcn_perm(n16.w, c16.w, 0x05010400u), __builtin_amdgcn_perm(n16.w, c16.w, 0x07030602u));
         }
         for (int i = lane; i < nt * 2 * P; i += 64) p.zf_masks[(size_t)gtile0 * 2 * P + i] = zf[i];
         if (lane < nt) {
@@ -397,18 +619,22 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int lane, 
     return true;
 }
 
-__global__ __launch_bounds__(kStreamThreads, EVOFST_STREAM_WPS) void stream_pairs_kernel(StreamParams p) {
+__global__ __launch_bounds__(kStreamMaxThreads, EVOFST_STREAM_WPS) void stream_pairs_kernel(StreamParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool consumer = wave == kStreamProd;
-    uint32_t *pmask = reinterpret_cast<uint32_t *>(smem);                      // [32][8] byte masks of sites 0 .. b of a fill
-    volatile int32_t *lmisc = reinterpret_cast<volatile int32_t *>(smem + 1024); // [0], [1]: chunk of iteration i & 1; [2]: a wait gave up; [3]: granule copy of this launch
+    const int NP = p.n_prod, NC = p.n_cons;                                    // waves 0 .. NP-1 count, NP .. NP+NC-1 consume
+    const bool consumer = wave >= NP;
+    const int nthreads = 64 * (NP + NC);
+    uint32_t *pmask = reinterpret_cast<uint32_t *>(smem);                      // [16][4] byte masks of sites 0 .. r of a quarter of 16 sites
+    int32_t *lmisc = reinterpret_cast<int32_t *>(smem + 1024);                 // [i & 3]: chunk of iteration i; [4]: a wait gave up; [5]: granule copy of this launch; [6], [7]: ldone; [8]: lready
     uint32_t *lpairs = reinterpret_cast<uint32_t *>(smem + 1024 + 64);
-    uint32_t *lcen = reinterpret_cast<uint32_t *>(smem + 1024 + 64 + s16((size_t)p.n_pairs * 4));   // the consumer's: census of the chunk it holds
-    unsigned char *bufs = smem + 1024 + 64 + 2 * s16((size_t)p.n_pairs * 4);
-    const size_t cnt_bytes = s16((size_t)p.chunk_tiles * p.P * kStreamRow * 2), zf_bytes = s16((size_t)p.chunk_tiles * 2 * p.P * 8);
-    const size_t buf_bytes = cnt_bytes + zf_bytes + s16((size_t)p.chunk_tiles * 4 * 8);
+    const size_t pw = s16((size_t)p.n_pairs * 4) / 4;                          // words of one per-pair array
+    uint32_t *lcen = lpairs + pw;                                              // [2][pw] census of the chunk in buffer 0 / 1 (the producers add, the consumers read and clear)
+    uint32_t *ldone = reinterpret_cast<uint32_t *>(lmisc + 6);                 // [2] producers that have added their census to buffer 0 / 1
+    uint32_t *qtab = reinterpret_cast<uint32_t *>(smem + 1024 + 64 + 3 * s16((size_t)p.n_pairs * 4));   // [chunk_tiles][P][4] x {C, Q}: stream_quarter_table
+    unsigned char *bufs = reinterpret_cast<unsigned char *>(qtab) + s16((size_t)p.chunk_tiles * p.P * 32);
+    const size_t buf_bytes = stream_buf_bytes(p.P, p.chunk_tiles);
     const SegStream segs = (SegStream)(uintptr_t)p.segs;
     const int n_chunks = p.n_chunks;
     const uint32_t last_draw = (uint32_t)n_chunks + gridDim.x - 1u;            // every workgroup draws until its ticket is past the end
@@ -422,48 +648,76 @@ __global__ __launch_bounds__(kStreamThreads, EVOFST_STREAM_WPS) void stream_pair
     };
     // which copy of the granule arrays this launch uses: the launch counter changes only with the launch's last draw,
     // which comes after every workgroup's first, and a workgroup reads the counter before its first draw
-    if (tid == 0) lmisc[3] = (int32_t)(__hip_atomic_load((gu32 *)p.launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
-    for (int i = tid; i < 32 * 8; i += kStreamThreads) {
-        const int b = i >> 3, m = i & 7, nbv = b + 1 - 4 * m;
+    if (tid == 0) lmisc[5] = (int32_t)(__hip_atomic_load((gu32 *)p.launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
+    for (int i = tid; i < 16 * 4; i += nthreads) {
+        const int b = i >> 2, m = i & 3, nbv = b + 1 - 4 * m;
         pmask[i] = nbv >= 4 ? 0xffffffffu : (nbv <= 0 ? 0u : ((1u << (8 * nbv)) - 1u));
     }
-    for (int i = tid; i < p.n_pairs; i += kStreamThreads) lpairs[i] = p.pairs[i];
-    if (tid == 0) { lmisc[0] = draw(); lmisc[2] = 0; }   // after the launch counter has been read (same thread, above)
+    for (int i = tid; i < p.n_pairs; i += nthreads) lpairs[i] = p.pairs[i];
+    for (int i = tid; i < 2 * (int)pw; i += nthreads) lcen[i] = 0u;
+    if (tid == 0) {   // after the launch counter has been read (same thread, above)
+        ldone[0] = ldone[1] = 0u;
+        lmisc[8] = INT32_MIN;                              // the chunk whose look-back flags consumer 0 has seen complete (-1 - chunk: it gave up)
+        const int32_t c0 = draw();
+        lmisc[0] = c0;
+        if (p.ahead > 1) lmisc[1] = c0 < n_chunks ? draw() : n_chunks;
+        lmisc[4] = 0;
+    }
     __syncthreads();
-    const int par = lmisc[3];
+    const int par = __builtin_amdgcn_readfirstlane(lmisc[5]);   // (what comes out of LDS is wave-uniform here; the compiler is told so)
+    // The consumers are the youngest waves of their workgroup and would get the issue slots the producers leave; the
+    // producers mostly wait for memory, so the consumers go first.
+#ifdef EVOFST_EXPERIMENTS
+    if (consumer && !(p.debug & 64)) __builtin_amdgcn_s_setprio(3);
+#else
+    if (consumer) __builtin_amdgcn_s_setprio(3);
+#endif
 
+    // Iteration i: the producers count chunk c_i into buffer i & 1, the consumers take chunk c_(i-1) from the other one,
+    // and one lane draws the ticket of iteration i + 2 (so nobody ever waits for the counter's round trip).
     bool dead = false;
     int32_t prev = n_chunks;
     for (int i = 0;; ++i) {
-        const int32_t ci = lmisc[i & 1];
+        const int32_t ci = __builtin_amdgcn_readfirstlane(lmisc[i & 3]);
+        const int32_t cn = p.ahead > 1 ? __builtin_amdgcn_readfirstlane(lmisc[(i + 1) & 3]) : 0;
         const bool have = ci < n_chunks;
-        unsigned char *bi_ = bufs + (size_t)(i & 1) * buf_bytes, *bp_ = bufs + (size_t)((i & 1) ^ 1) * buf_bytes;
+        const StreamBuf bi_ = stream_buf(bufs + (size_t)(i & 1) * buf_bytes, p.P, p.chunk_tiles), bp_ = stream_buf(bufs + (size_t)((i & 1) ^ 1) * buf_bytes, p.P, p.chunk_tiles);
+        if (wave == 0) STREAM_STAMP(p, i, 0);             // iteration begins (producer 0)
+        if (wave == NP) { STREAM_STAMP(p, i, 3); if (lane == 0 && p.stamps != nullptr && i < kStreamStampIters) p.stamps[((size_t)blockIdx.x * kStreamStampIters + i) * 16 + 15] = (unsigned long long)(uint32_t)ci | ((unsigned long long)(uint32_t)prev << 32); }
         if (!consumer) {
-#ifndef STREAM_NO_COUNT
             if (have && !dead) {
-                const int t0 = ci * p.chunk_tiles + wave * p.tr;
-                const int n_own = min(p.tr, p.n_tiles - t0);
+                const int t0 = __builtin_amdgcn_readfirstlane(ci * p.chunk_tiles + wave * p.tr);
+                const int n_own = __builtin_amdgcn_readfirstlane(min(p.tr, p.n_tiles - t0));
                 if (n_own > 0)
-                stream_count_piece(p, lane, t0, n_own, wave * p.tr, reinterpret_cast<uint16_t *>(bi_),
-                                   reinterpret_cast<uint64_t *>(bi_ + cnt_bytes), reinterpret_cast<uint64_t *>(bi_ + cnt_bytes + zf_bytes), segs);
-            }
+                stream_count_piece(p, lane, t0, n_own, wave * p.tr, bi_, segs);
+#ifdef EVOFST_EXPERIMENTS
+                if (!(p.debug & 8))
 #endif
+                stream_publish(p, lane, par, ci, NP, wave * p.tr, n_own, bi_.zf, lpairs,
+                               lcen + (size_t)(i & 1) * pw, ldone + (i & 1));
+            }
         } else {
-            if (lane == 0) {
-                lmisc[(i + 1) & 1] = have ? draw() : n_chunks;
-                if (__hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) lmisc[2] = 1;
+            if (wave == NP && lane == 0) {
+                if (p.ahead > 1) lmisc[(i + 2) & 3] = cn < n_chunks ? draw() : n_chunks;
+                else lmisc[(i + 1) & 3] = have ? draw() : n_chunks;
             }
-#ifndef STREAM_NO_CONSUME
-            if (prev < n_chunks && !dead) {
-                const bool ok = stream_consume(p, lane, par, prev, reinterpret_cast<const uint16_t *>(bp_),
-                                               reinterpret_cast<const uint64_t *>(bp_ + cnt_bytes),
-                                               reinterpret_cast<const uint64_t *>(bp_ + cnt_bytes + zf_bytes), lpairs, lcen, pmask);
-                if (!ok && lane == 0) lmisc[2] = 1;
-            }
+#ifdef EVOFST_EXPERIMENTS
+            if (p.debug & 8) {} else
 #endif
+            if (prev < n_chunks && !dead) {
+                const bool ok = stream_consume(p, i, lane, wave - NP, NC, par, prev, bp_, lpairs,
+                                               lcen + (size_t)((i & 1) ^ 1) * pw, ldone + ((i & 1) ^ 1), lmisc + 8, qtab, pmask);
+                if (!ok && lane == 0) {                    // whatever made this wave give up: every workgroup stops, the host is told
+                    lmisc[4] = 1;
+                    __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
+        if (wave == 0) STREAM_STAMP(p, i, 1);             // counted (producer 0)
+        if (wave == NP) STREAM_STAMP(p, i, 9);            // consumer 0 at the barrier
         __syncthreads();
-        dead = dead || lmisc[2] != 0;
+        if (wave == 0) STREAM_STAMP(p, i, 2);             // past the barrier
+        dead = dead || __builtin_amdgcn_readfirstlane(lmisc[4]) != 0;
         if (!have) break;
         prev = ci;
     }
@@ -471,7 +725,9 @@ __global__ __launch_bounds__(kStreamThreads, EVOFST_STREAM_WPS) void stream_pair
 
 hipError_t launch_stream(const StreamParams &p, int max_blocks, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
-    if (p.n_pairs > kStreamMaxPairs || p.P > 64 || p.tr <= 0 || p.chunk_tiles != p.tr * kStreamProd || p.chunk_tiles > 64) return hipErrorInvalidValue;
+    if (p.n_pairs > kStreamMaxPairs || p.P > 64 || p.tr <= 0 || p.n_prod < 1 || p.n_cons < 1 || p.n_prod + p.n_cons > kStreamMaxWaves ||
+        p.chunk_tiles != p.tr * p.n_prod || p.chunk_tiles > 64) return hipErrorInvalidValue;
+    const int threads = 64 * (p.n_prod + p.n_cons);
     const void *fn = reinterpret_cast<const void *>(&stream_pairs_kernel);
     const size_t lds = stream_lds_bytes(p.P, p.n_pairs, p.chunk_tiles);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -483,20 +739,20 @@ hipError_t launch_stream(const StreamParams &p, int max_blocks, hipStream_t st) 
     if (grid <= 0) {
         // workgroups the device holds at once; asked once per shape (the query costs more than a launch).  Any grid is
         // safe -- chunks go by ticket -- this one just leaves no workgroup waiting for a slot.
-        static thread_local struct { size_t lds; int dev; int grid; } memo = {0, -1, 0};
+        static thread_local struct { size_t lds; int threads; int dev; int grid; } memo = {0, 0, -1, 0};
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        if (memo.lds != lds || memo.dev != dev) {
+        if (memo.lds != lds || memo.threads != threads || memo.dev != dev) {
             int per_cu = 0, cus = 0;
-            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kStreamThreads, lds)) != hipSuccess) return e;
+            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds)) != hipSuccess) return e;
             if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-            memo = {lds, dev, std::max(1, per_cu) * std::max(1, cus)};
+            memo = {lds, threads, dev, std::max(1, per_cu) * std::max(1, cus)};
         }
         grid = memo.grid;
     }
     grid = std::max(1, std::min(grid, p.n_chunks));
-    hipLaunchKernelGGL(stream_pairs_kernel, dim3(grid), dim3(kStreamThreads), lds, st, p);
+    hipLaunchKernelGGL(stream_pairs_kernel, dim3(grid), dim3(threads), lds, st, p);
     return hipGetLastError();
 }
 

@@ -251,6 +251,7 @@ int64_t evofst_noalloc_scratch_bytes(void);
  *   "walk"          statistics walk of pairs_pass 1: 0 = chosen by the library, 1 = general walk on every chunk,
  *                   2 = k2_window_kernel
  *   "stream_blocks" workgroups of the stream pass, 0 = as many as the device holds (any number is safe)
+ *   "stream_producers", "stream_consumers"  its producer / consumer waves per workgroup, 0 = chosen by the library
  * Unknown names and values out of range return EVOFST_ERR_ARG. */
 int evofst_set_option(evofst_ctx *ctx, const char *name, int64_t value);
 
