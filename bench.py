@@ -193,6 +193,8 @@ def main():
                          "separate kernels, 2 stream pass, 3 the lock-step one-kernel pass")
     ap.add_argument("--chunk-tiles", type=int, default=0, help="evofst_set_option chunk_tiles (0: the library's choice)")
     ap.add_argument("--stream-blocks", type=int, default=0, help="evofst_set_option stream_blocks (0: what the device holds)")
+    ap.add_argument("--stream-sets", type=int, default=0, help="evofst_set_option stream_sets (0: the library's choice)")
+    ap.add_argument("--stream-buffers", type=int, default=0, help="evofst_set_option stream_buffers (0: the library's choice)")
     ap.add_argument("--stream-waves", default="0,0", help="evofst_set_option stream_producers,stream_consumers (0: the library's choice)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -251,6 +253,8 @@ def main():
         x.set_option("pairs_pass", args.pairs_pass)
         x.set_option("chunk_tiles", args.chunk_tiles)
         x.set_option("stream_blocks", args.stream_blocks)
+        x.set_option("stream_buffers", args.stream_buffers)
+        x.set_option("stream_sets", args.stream_sets)
         x.set_option("stream_producers", int(args.stream_waves.split(",")[0]))
         x.set_option("stream_consumers", int(args.stream_waves.split(",")[1]))
         return x

@@ -112,6 +112,8 @@ struct evofst_ctx {
     int opt_chunk_tiles = 0;          // tiles per chunk (0: the library chooses)
     int opt_walk = 0;                 // K1 + scan + walk: 0 auto, 1 general walk on every chunk, 2 k2_window_kernel
     int opt_stream_blocks = 0;        // workgroups of the stream pass (0: as many as the device holds)
+    int opt_stream_sets = 0;                        // its sets of consumer waves (0: the library chooses)
+    int opt_stream_bufs = 0;                        // its LDS buffers per workgroup (0: the library chooses)
     int opt_stream_prod = 0, opt_stream_cons = 0;   // its producer / consumer waves per workgroup (0: the library chooses)
     // stream pairs pass (evofst_stream.hip): granule rows and their flags (two copies each), ticket / error / launch words
     DevBuf d_sagg, d_sflag, d_ssync;
@@ -512,7 +514,7 @@ int launch_walks(evofst_ctx *c, const K2Params &p, bool with_clean, bool compact
 constexpr int kStreamMaxChunks = 1 << 17;
 
 // Shape of the stream pass's workgroups: producer waves, consumer waves, tiles a producer counts per chunk.
-struct StreamPlan { int n_prod = 0, n_cons = 0, tr = 0; };
+struct StreamPlan { int n_prod = 0, n_cons = 0, tr = 0, n_buf = 2, n_sets = 1; };
 // tr == 0 when this shape goes through K1 + scan + walk.
 StreamPlan stream_plan(const evofst_ctx *c, int64_t n_sites) {
     StreamPlan pl;
@@ -524,14 +526,18 @@ StreamPlan stream_plan(const evofst_ctx *c, int64_t n_sites) {
     // a consumer wave per 64 pairs; producers: four, or what the options say
     pl.n_cons = c->opt_stream_cons > 0 ? std::min(c->opt_stream_cons, (np + 63) / 64) : (np + 63) / 64;
     pl.n_prod = c->opt_stream_prod > 0 ? c->opt_stream_prod : 4;
+    pl.n_sets = c->opt_stream_sets > 0 ? c->opt_stream_sets : 1;
+    pl.n_cons *= pl.n_sets;
     if (pl.n_prod + pl.n_cons > kStreamMaxWaves) return StreamPlan();
+    pl.n_buf = c->opt_stream_bufs > 0 ? c->opt_stream_bufs : 2;
     int tr = c->opt_chunk_tiles > 0 ? std::max(1, c->opt_chunk_tiles / pl.n_prod) : 2;
     while ((n_tiles + tr * pl.n_prod - 1) / (tr * pl.n_prod) > kStreamMaxChunks && tr < 16) ++tr;
     // as many workgroups per CU as 16 waves allow (two at the very least); LDS must not be what cuts that number
-    const int wgs = std::max(2, 16 / (pl.n_prod + pl.n_cons));
+    // (a chunk size the options ask for may take the whole CU's LDS for one workgroup)
+    const int wgs = c->opt_chunk_tiles > 0 ? 1 : std::max(pl.n_prod + pl.n_cons > 8 ? 1 : 2, 16 / (pl.n_prod + pl.n_cons));
     const size_t lds_cap = (size_t)(156 * 1024) / wgs;
-    while (tr > 1 && stream_lds_bytes(c->n_pops, np, tr * pl.n_prod) > lds_cap) --tr;
-    if (tr * pl.n_prod > 64 || stream_lds_bytes(c->n_pops, np, tr * pl.n_prod) > lds_cap) return StreamPlan();
+    while (tr > 1 && stream_lds_bytes(c->n_pops, np, tr * pl.n_prod, pl.n_buf) > lds_cap) --tr;
+    if (tr * pl.n_prod > 64 || stream_lds_bytes(c->n_pops, np, tr * pl.n_prod, pl.n_buf) > lds_cap) return StreamPlan();
     if ((n_tiles + tr * pl.n_prod - 1) / (tr * pl.n_prod) > kStreamMaxChunks) return StreamPlan();
     // the chunks the integer walk cannot take go to the walk of evofst_fused.hip over counts in HBM
     if (c->opt_walk == 2 || !lds_walk_fits(c, tr * pl.n_prod)) return StreamPlan();
@@ -580,14 +586,15 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.pairs = (const uint32_t *)c->d_pairs.p; p.n_pairs = (int)np;
     p.n_prod = pl.n_prod; p.n_cons = pl.n_cons;
-    p.ahead = 1;
+    p.poll = 8; p.n_buf = pl.n_buf; p.n_sets = pl.n_sets;
 #ifdef EVOFST_EXPERIMENTS
-    if (const char *e = getenv("EVOFST_STREAM_AHEAD")) p.ahead = atoi(e) == 2 ? 2 : 1;
+    if (const char *e = getenv("EVOFST_STREAM_POLL")) p.poll = std::max(0, atoi(e));
 #endif
     p.tr = tr; p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
     p.g = c->g;
     p.base = (const int64_t *)c->d_base.p;
     p.first_segment = (int64_t *)c->d_first_seg.p; p.incl_totals = (int64_t *)c->d_incl_totals.p;
+    p.seg_cap = c->seg_cap;
     p.seg_rows = (SegRow *)c->d_seg_rows.p;
     p.tail = (double *)c->d_tail.p; p.tail_n = (int4 *)c->d_tail_n.p;
     for (int k = 0; k < 2; ++k) {
@@ -1738,6 +1745,12 @@ extern "C" int evofst_set_option(evofst_ctx *c, const char *name, int64_t value)
     } else if (n == "stream_blocks") {
         if (value < 0 || value > (1 << 20)) return fail(c, EVOFST_ERR_ARG, "set_option: stream_blocks is 0 (auto) or a number of workgroups");
         c->opt_stream_blocks = (int)value;
+    } else if (n == "stream_sets") {
+        if (value < 0 || value > 2) return fail(c, EVOFST_ERR_ARG, "set_option: stream_sets is 0 (auto), 1 or 2");
+        c->opt_stream_sets = (int)value;
+    } else if (n == "stream_buffers") {
+        if (value != 0 && (value < 2 || value > kStreamMaxBufs)) return fail(c, EVOFST_ERR_ARG, "set_option: stream_buffers is 0 (auto) or 2 .. 4");
+        c->opt_stream_bufs = (int)value;
     } else if (n == "stream_producers" || n == "stream_consumers") {
         if (value < 0 || value >= kStreamMaxWaves) return fail(c, EVOFST_ERR_ARG, "set_option: " + n + " is 0 (auto) .. 11");
         (n == "stream_producers" ? c->opt_stream_prod : c->opt_stream_cons) = (int)value;

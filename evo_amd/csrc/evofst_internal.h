@@ -192,13 +192,16 @@ struct StreamParams {
     const uint32_t *pairs;          // i | j << 16
     int32_t n_pairs;
     int32_t n_prod, n_cons;         // producer and consumer waves of a workgroup
-    int32_t ahead;                  // iterations a chunk's ticket is drawn before the chunk is counted (1 or 2)
+    int32_t poll;                   // s_sleep(16)s between two polls of the look-back flags
+    int32_t n_sets;                 // sets of consumer waves (1 or 2) that take the workgroup's chunks in turn; n_cons = all of them
+    int32_t n_buf;                  // LDS buffers (chunks of a workgroup in flight): 2 .. kStreamMaxBufs
     int32_t tr;                     // tiles a producer wave counts per chunk
     int32_t chunk_tiles, n_chunks;  // chunk_tiles = n_prod * tr
     int32_t g;
     const int64_t *base;            // [n_pairs] included sites of the pair before this shard
     int64_t *first_segment;         // [n_pairs] out: base / g
     int64_t *incl_totals;           // [n_pairs] out: included sites of the shard
+    int64_t seg_cap;
     SegRow *seg_rows;               // [seg_cap][n_pairs]
     double *tail;                   // [3][n_chunks][n_pairs]
     int4 *tail_n;                   // [n_chunks][n_pairs]
@@ -222,6 +225,7 @@ struct StreamParams {
     unsigned long long *stamps;     // -DEVOFST_EXPERIMENTS: [workgroups][kStreamStampIters][16] s_memrealtime stamps, or null
 };
 constexpr int kStreamStampIters = 48;
+constexpr int kStreamMaxBufs = 4;                      // LDS buffers of a workgroup (chunks in flight)
 
 struct SiteStatParams {
     const void *counts;
@@ -385,7 +389,7 @@ int fused_tail_chunks(int n_pairs, int n_chunks);   // entries per pair of the t
 hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_blocks, hipStream_t st);
 size_t clean_walk_lds_bytes(int P, int n_pairs, int piece_tiles, bool compact);
 size_t stream_buffer_bytes(int P, int chunk_tiles);
-size_t stream_lds_bytes(int P, int n_pairs, int chunk_tiles);
+size_t stream_lds_bytes(int P, int n_pairs, int chunk_tiles, int n_buf);
 // max_blocks <= 0: as many workgroups as the device holds at once (occupancy query); any number is safe
 hipError_t launch_stream(const StreamParams &p, int max_blocks, hipStream_t st);
 hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st);

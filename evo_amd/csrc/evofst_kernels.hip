@@ -942,6 +942,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(K2Params p) {
     const int4 pv = p.tail_n[op];
     const double pn = p.tail[op], pd = p.tail[plane + op], pk = p.tail[2 * plane + op];
     if (me.y == 0) return;                                  // this chunk completed no segment
+    if ((uint64_t)(int64_t)me.z >= (uint64_t)p.seg_cap) return;      // (never from a healthy walk: no store outside the table whatever the words say)
     const size_t o = (size_t)me.z * p.n_pairs + q;
     SegRow &row = p.seg_rows[o];
     const double rn = row.num, rd = row.den, rk = row.k;

@@ -56,12 +56,14 @@ static __host__ __device__ constexpr size_t s16(size_t x) { return (x + 15) & ~(
 
 // One LDS buffer = one counted chunk: alt counts, one byte each, rows of kStreamRow bytes per (tile, population) (64 sites
 // + padding: rows of different populations start in different banks); non-missing counts, one byte each (only a chunk
-// the integer walk cannot take needs them); zero / fixed ballots [tile][z|f][P]; the four site masks of every tile.
-struct StreamBuf { unsigned char *c, *m; uint64_t *zf, *flg; };
+// the integer walk cannot take needs them); zero / fixed ballots [tile][z|f][P]; the four site masks of every tile; the quarter
+// table of the integer walk (stream_quarter_table), which the consumers fill in.
+struct StreamBuf { unsigned char *c, *m; uint64_t *zf, *flg; uint32_t *qt; };
 static __host__ __device__ size_t stream_c_bytes(int P, int chunk_tiles) { return s16((size_t)chunk_tiles * P * kStreamRow); }
 static __host__ __device__ size_t stream_m_bytes(int P, int chunk_tiles) { return s16((size_t)chunk_tiles * P * kTileSites); }
 static __host__ __device__ size_t stream_buf_bytes(int P, int chunk_tiles) {
-    return stream_c_bytes(P, chunk_tiles) + stream_m_bytes(P, chunk_tiles) + s16((size_t)chunk_tiles * 2 * P * 8) + s16((size_t)chunk_tiles * 4 * 8);
+    return stream_c_bytes(P, chunk_tiles) + stream_m_bytes(P, chunk_tiles) + s16((size_t)chunk_tiles * 2 * P * 8) + s16((size_t)chunk_tiles * 4 * 8) +
+           s16((size_t)chunk_tiles * P * 32);
 }
 size_t stream_buffer_bytes(int P, int chunk_tiles) { return stream_buf_bytes(P, chunk_tiles); }
 static __device__ __forceinline__ StreamBuf stream_buf(unsigned char *base, int P, int chunk_tiles) {
@@ -69,11 +71,12 @@ static __device__ __forceinline__ StreamBuf stream_buf(unsigned char *base, int 
     b.c = base; b.m = base + stream_c_bytes(P, chunk_tiles);
     b.zf = reinterpret_cast<uint64_t *>(b.m + stream_m_bytes(P, chunk_tiles));
     b.flg = b.zf + (size_t)chunk_tiles * 2 * P;
+    b.qt = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(b.flg) + s16((size_t)chunk_tiles * 4 * 8));
     return b;
 }
-// + the table of byte masks, the workgroup's words, three per-pair arrays, the quarter table of the chunk being walked
-size_t stream_lds_bytes(int P, int n_pairs, int chunk_tiles) {
-    return 1024 + 64 + 3 * s16((size_t)n_pairs * 4) + s16((size_t)chunk_tiles * P * 32) + 2 * stream_buffer_bytes(P, chunk_tiles);
+// + the table of byte masks, the workgroup's words, three per-pair arrays
+size_t stream_lds_bytes(int P, int n_pairs, int chunk_tiles, int n_buf) {
+    return 1024 + 128 + (size_t)(1 + n_buf) * s16((size_t)n_pairs * 4) + (size_t)n_buf * stream_buffer_bytes(P, chunk_tiles);
 }
 
 // ------------------------------------------------------------------------------------------------ producer
@@ -230,10 +233,7 @@ __device__ __forceinline__ bool stream_wait_flags(const StreamParams &p, const S
         if ((spins & 63u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
         // polls are uncached loads of lines many waves want: a few per microsecond and CU slow the tile stream of every CU
         // down.  The consumer has most of an iteration to spare, so it asks again only every few microseconds.
-#ifdef EVOFST_EXPERIMENTS
-        if (p.debug & 512) { __builtin_amdgcn_s_sleep(8); continue; }
-#endif
-        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+        for (int z = 0; z < p.poll; ++z) __builtin_amdgcn_s_sleep(16);
     }
 }
 // Included sites of column q in the rows before the chunk.  False when a row stayed incomplete and the wait gave up.
@@ -346,6 +346,7 @@ __device__ __forceinline__ void stream_walk_pair(const StreamParams &p, const un
     const int32_t left0 = left;
     const int32_t row0 = (int32_t)(m - first_seg);
     size_t orow = (size_t)row0 * p.n_pairs + q;
+    const size_t orow_end = (size_t)p.seg_cap * p.n_pairs;
     int32_t nflush = 0;
     uint32_t aCC = 0, aCi = 0, aCj = 0, aQi = 0, aQj = 0;                 // integer sums since the last boundary
     auto parts = [&](uint32_t iCC, uint32_t iCi, uint32_t iCj, uint32_t iQi, uint32_t iQj, double &num, double &den, double &k) {
@@ -406,9 +407,11 @@ __device__ __forceinline__ void stream_walk_pair(const StreamParams &p, const un
             parts(aCC + (pCC - dCC), aCi + (pCi - dCi), aCj + (pCj - dCj), aQi + (pQi - dQi), aQj + (pQj - dQj), row.num, row.den, row.k);
             row.end = (gtile0 + ti) * kTileSites + b; row.pad = 0;
 #ifdef EVOFST_EXPERIMENTS
-            if (!(p.debug & 16) || row.end == -12345)
+            if ((p.debug & 16) && row.end != -12345) {} else
 #endif
-            {   // two 16-byte stores into one 32-byte sector
+            if (orow >= orow_end) {   // never with a sound prefix; no store outside the table whatever the look-back handed over
+                __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {   // two 16-byte stores into one 32-byte sector
                 uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
                 const uint4 *src = reinterpret_cast<const uint4 *>(&row);
                 dst[0] = src[0]; dst[1] = src[1];
@@ -433,13 +436,9 @@ __device__ __forceinline__ void stream_walk_pair(const StreamParams &p, const un
     p.tail_n[cq_] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);   // {sites summed in the tail, segments completed, row of the first}
 }
 
-// What a producer wave does once its tiles of chunk `chunk` are counted: the census of its tiles (included sites per
-// pair, filter fst.cpp:543-544, lane = pair) goes into the workgroup's census of the chunk in LDS, and the producer
-// that arrives last publishes the chunk's row -- straight after the counting, whatever the consumers are busy with.
-// The flag is raised without waiting for the row's stores: it only tells pollers when reading the row is worth it.
-__device__ __forceinline__ void stream_publish(const StreamParams &p, int lane, int par, int chunk, int n_prod, int slot0, int n_own, const uint64_t *zf,
-                                               const uint32_t *lpairs, uint32_t *cen, uint32_t *done) {
-    constexpr int F = kStreamFan;
+// The census of a producer's tiles (included sites per pair, filter fst.cpp:543-544, lane = pair), added to the
+// workgroup's census of the chunk in LDS.
+__device__ __forceinline__ void stream_census(const StreamParams &p, int lane, int slot0, int n_own, const uint64_t *zf, const uint32_t *lpairs, uint32_t *cen) {
     const int P = p.P;
     const int NG = (p.n_pairs + 63) >> 6;
     if (n_own > 0)
@@ -457,11 +456,20 @@ __device__ __forceinline__ void stream_publish(const StreamParams &p, int lane, 
                 __hip_atomic_fetch_add(cen + q, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-    int last = 0;
-    if (lane == 0) last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)n_prod - 1u ? 1 : 0;
-    if (!__builtin_amdgcn_readfirstlane(last)) return;
+}
+
+// The producer that arrives last at a chunk publishes the chunk's row -- straight after the counting, whatever the
+// consumers are busy with.  The flag is raised without waiting for the row's stores: it only tells pollers when reading
+// the row is worth it.  `pub` = uses of the buffer whose census has been read for publishing: what the consumers wait
+// for, since they clear the census.
+__device__ __forceinline__ void stream_publish(const StreamParams &p, int lane, int par, int chunk, const uint32_t *cen, uint32_t *pub, int use) {
+    constexpr int F = kStreamFan;
+    const int NG = (p.n_pairs + 63) >> 6;
 #ifdef EVOFST_EXPERIMENTS
-    if (p.debug & 256) return;                             // nothing published at all (timing only, with bit 2)
+    if (p.debug & 256) {                                   // nothing published at all (timing only, with bit 2)
+        if (lane == 0) __hip_atomic_store(pub, (uint32_t)use + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
 #endif
     const size_t np = (size_t)p.n_pairs;
     const int grp0 = chunk / F, grp1 = grp0 / F;
@@ -483,6 +491,8 @@ __device__ __forceinline__ void stream_publish(const StreamParams &p, int lane, 
             if (chunk % (F * F) == 0) p.agg2[par ^ 1][(size_t)grp1 * np + q] = 0ull;
         }
     }
+    // (the release makes this wave's reads of the census complete before the consumers may clear it)
+    if (lane == 0) __hip_atomic_store(pub, (uint32_t)use + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (lane == 0) {
         uint32_t *flags = p.flags[par], *oflags = p.flags[par ^ 1];
         __hip_atomic_fetch_add((gu32 *)(flags + chunk), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -496,8 +506,10 @@ __device__ __forceinline__ void stream_publish(const StreamParams &p, int lane, 
 // Everything a consumer wave does with a counted chunk.  Returns false when a look-back wait gave up.
 // Consumer wave `cw` of `ncw` takes the groups of 64 pairs cw, cw + ncw, ...; the first one also hands a chunk the integer
 // walk cannot take to the general walk.
+// `lready` = chunks of this workgroup whose look-back flags consumer 0 has seen complete; `dead` != 0: some wave gave up.
 __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, int lane, int cw, int ncw, int par, int chunk, const StreamBuf &buf,
-                                               const uint32_t *lpairs, uint32_t *lcen, uint32_t *ldone, int32_t *lready, uint32_t *qtab, const uint32_t *pmask) {
+                                               const uint32_t *lpairs, uint32_t *lcen, int32_t *lready, const int32_t *dead, const uint32_t *pmask) {
+    uint32_t *qtab = buf.qt;
     const uint64_t *zf = buf.zf, *flg = buf.flg;
     const int NG = (p.n_pairs + 63) >> 6;
     const int my_groups = cw < NG ? (NG - cw + ncw - 1) / ncw : 0;
@@ -513,6 +525,10 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
     // then the walk (or the chunk's offsets for the general walk)
     const StreamRows rows(chunk);
     uint32_t polls = 0, retries = 0;
+    if (!dirty) {   // (needs nothing from other chunks: done before the wait)
+        stream_quarter_table(lane, nt, P, buf.c, qtab);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     // The first chunk of a group of 32 hands the total of the group before it to level 2 -- before it waits for level 2
     // itself, which its own hand-over may complete (one add per group and row: no contention there).
 #ifdef EVOFST_EXPERIMENTS
@@ -545,24 +561,20 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
 #endif
     {   // one consumer wave of the workgroup polls the flags; the others wait for its word in LDS
         if (cw == 0) {
-            const bool ok = stream_wait_flags(p, rows, lane, par, polls);
-            if (lane == 0) __hip_atomic_store(lready, ok ? chunk : -1 - chunk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!ok) return false;
+            if (!stream_wait_flags(p, rows, lane, par, polls)) return false;       // (the caller raises `dead`)
+            if (lane == 0) __hip_atomic_store(lready, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             uint32_t spins = 0;
             for (;;) {
                 const int32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(lready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (v == chunk) break;
-                if (v == -1 - chunk || ++spins > (kStreamSpinLimit << 4)) return false;
+                if (v > it) break;
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0 ||
+                    ++spins > (kStreamSpinLimit << 4)) return false;
                 __builtin_amdgcn_s_sleep(8);
             }
         }
     }
     if (cw == 0) STREAM_STAMP(p, it, 5);                  // flags complete
-    if (!dirty) {
-        stream_quarter_table(lane, nt, P, buf.c, qtab);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
 #pragma unroll 1
     for (int g = cw; g < NG; g += ncw) {
         const int q = g * 64 + lane;
@@ -595,7 +607,6 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
     }
     if (cw == 0) STREAM_STAMP(p, it, 8);                  // walked
     if (cw != 0) return true;
-    if (lane == 0) *ldone = 0u;                            // for the chunk that takes this buffer next
     if (dirty) {
         // K1's outputs for this chunk: packed counts [tile][P][64], ballots [tile][z|f][P], the four site masks
         const int nv = nt * P * 4;                         // groups of 16 sites: 16 alt bytes + 16 non-missing bytes -> 16 packed counts
@@ -627,13 +638,18 @@ __global__ __launch_bounds__(kStreamMaxThreads, EVOFST_STREAM_WPS) void stream_p
     const bool consumer = wave >= NP;
     const int nthreads = 64 * (NP + NC);
     uint32_t *pmask = reinterpret_cast<uint32_t *>(smem);                      // [16][4] byte masks of sites 0 .. r of a quarter of 16 sites
-    int32_t *lmisc = reinterpret_cast<int32_t *>(smem + 1024);                 // [i & 3]: chunk of iteration i; [4]: a wait gave up; [5]: granule copy of this launch; [6], [7]: ldone; [8]: lready
-    uint32_t *lpairs = reinterpret_cast<uint32_t *>(smem + 1024 + 64);
+    // the workgroup's words: [k & 7] ticket of its chunk k; [8] a wait gave up; [9] granule copy of this launch; [10], [11] lready
+    // of consumer set 0 / 1; [24] chunks drawn; [12 + b] producers arrived at buffer b; [16 + b] uses of buffer b published; [20 + b] consumers
+    // done with buffer b (all counters run on through the launch)
+    int32_t *lmisc = reinterpret_cast<int32_t *>(smem + 1024);
+    uint32_t *lpairs = reinterpret_cast<uint32_t *>(smem + 1024 + 128);
+    const int NB = p.n_buf;
     const size_t pw = s16((size_t)p.n_pairs * 4) / 4;                          // words of one per-pair array
-    uint32_t *lcen = lpairs + pw;                                              // [2][pw] census of the chunk in buffer 0 / 1 (the producers add, the consumers read and clear)
-    uint32_t *ldone = reinterpret_cast<uint32_t *>(lmisc + 6);                 // [2] producers that have added their census to buffer 0 / 1
-    uint32_t *qtab = reinterpret_cast<uint32_t *>(smem + 1024 + 64 + 3 * s16((size_t)p.n_pairs * 4));   // [chunk_tiles][P][4] x {C, Q}: stream_quarter_table
-    unsigned char *bufs = reinterpret_cast<unsigned char *>(qtab) + s16((size_t)p.chunk_tiles * p.P * 32);
+    uint32_t *lcen = lpairs + pw;                                              // [NB][pw] census of the chunk in buffer b (the producers add, the consumers read and clear)
+    int32_t *ldead = lmisc + 8, *lready = lmisc + 10;
+    uint32_t *ldrawn = reinterpret_cast<uint32_t *>(lmisc + 24), *ldone = reinterpret_cast<uint32_t *>(lmisc + 12),
+             *lpub = reinterpret_cast<uint32_t *>(lmisc + 16), *lfree = reinterpret_cast<uint32_t *>(lmisc + 20);
+    unsigned char *bufs = reinterpret_cast<unsigned char *>(lpairs) + (size_t)(1 + NB) * s16((size_t)p.n_pairs * 4);
     const size_t buf_bytes = stream_buf_bytes(p.P, p.chunk_tiles);
     const SegStream segs = (SegStream)(uintptr_t)p.segs;
     const int n_chunks = p.n_chunks;
@@ -648,88 +664,127 @@ __global__ __launch_bounds__(kStreamMaxThreads, EVOFST_STREAM_WPS) void stream_p
     };
     // which copy of the granule arrays this launch uses: the launch counter changes only with the launch's last draw,
     // which comes after every workgroup's first, and a workgroup reads the counter before its first draw
-    if (tid == 0) lmisc[5] = (int32_t)(__hip_atomic_load((gu32 *)p.launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
+    if (tid == 0) lmisc[9] = (int32_t)(__hip_atomic_load((gu32 *)p.launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
     for (int i = tid; i < 16 * 4; i += nthreads) {
         const int b = i >> 2, m = i & 3, nbv = b + 1 - 4 * m;
         pmask[i] = nbv >= 4 ? 0xffffffffu : (nbv <= 0 ? 0u : ((1u << (8 * nbv)) - 1u));
     }
     for (int i = tid; i < p.n_pairs; i += nthreads) lpairs[i] = p.pairs[i];
-    for (int i = tid; i < 2 * (int)pw; i += nthreads) lcen[i] = 0u;
+    for (int i = tid; i < NB * (int)pw; i += nthreads) lcen[i] = 0u;
     if (tid == 0) {   // after the launch counter has been read (same thread, above)
-        ldone[0] = ldone[1] = 0u;
-        lmisc[8] = INT32_MIN;                              // the chunk whose look-back flags consumer 0 has seen complete (-1 - chunk: it gave up)
-        const int32_t c0 = draw();
-        lmisc[0] = c0;
-        if (p.ahead > 1) lmisc[1] = c0 < n_chunks ? draw() : n_chunks;
-        lmisc[4] = 0;
+        for (int i = 10; i < 25; ++i) lmisc[i] = 0;
+        const int32_t t = draw();
+        lmisc[0] = lmisc[1] = lmisc[2] = lmisc[3] = t;
+        *ldrawn = t >= n_chunks ? 4u : 1u;
+        *ldead = 0;
     }
     __syncthreads();
-    const int par = __builtin_amdgcn_readfirstlane(lmisc[5]);   // (what comes out of LDS is wave-uniform here; the compiler is told so)
-    // The consumers are the youngest waves of their workgroup and would get the issue slots the producers leave; the
-    // producers mostly wait for memory, so the consumers go first.
-#ifdef EVOFST_EXPERIMENTS
-    if (consumer && !(p.debug & 64)) __builtin_amdgcn_s_setprio(3);
-#else
-    if (consumer) __builtin_amdgcn_s_setprio(3);
-#endif
-
-    // Iteration i: the producers count chunk c_i into buffer i & 1, the consumers take chunk c_(i-1) from the other one,
-    // and one lane draws the ticket of iteration i + 2 (so nobody ever waits for the counter's round trip).
-    bool dead = false;
-    int32_t prev = n_chunks;
-    for (int i = 0;; ++i) {
-        const int32_t ci = __builtin_amdgcn_readfirstlane(lmisc[i & 3]);
-        const int32_t cn = p.ahead > 1 ? __builtin_amdgcn_readfirstlane(lmisc[(i + 1) & 3]) : 0;
-        const bool have = ci < n_chunks;
-        const StreamBuf bi_ = stream_buf(bufs + (size_t)(i & 1) * buf_bytes, p.P, p.chunk_tiles), bp_ = stream_buf(bufs + (size_t)((i & 1) ^ 1) * buf_bytes, p.P, p.chunk_tiles);
-        if (wave == 0) STREAM_STAMP(p, i, 0);             // iteration begins (producer 0)
-        if (wave == NP) { STREAM_STAMP(p, i, 3); if (lane == 0 && p.stamps != nullptr && i < kStreamStampIters) p.stamps[((size_t)blockIdx.x * kStreamStampIters + i) * 16 + 15] = (unsigned long long)(uint32_t)ci | ((unsigned long long)(uint32_t)prev << 32); }
-        if (!consumer) {
-            if (have && !dead) {
-                const int t0 = __builtin_amdgcn_readfirstlane(ci * p.chunk_tiles + wave * p.tr);
-                const int n_own = __builtin_amdgcn_readfirstlane(min(p.tr, p.n_tiles - t0));
-                if (n_own > 0)
-                stream_count_piece(p, lane, t0, n_own, wave * p.tr, bi_, segs);
-#ifdef EVOFST_EXPERIMENTS
-                if (!(p.debug & 8))
-#endif
-                stream_publish(p, lane, par, ci, NP, wave * p.tr, n_own, bi_.zf, lpairs,
-                               lcen + (size_t)(i & 1) * pw, ldone + (i & 1));
-            }
-        } else {
-            if (wave == NP && lane == 0) {
-                if (p.ahead > 1) lmisc[(i + 2) & 3] = cn < n_chunks ? draw() : n_chunks;
-                else lmisc[(i + 1) & 3] = have ? draw() : n_chunks;
-            }
-#ifdef EVOFST_EXPERIMENTS
-            if (p.debug & 8) {} else
-#endif
-            if (prev < n_chunks && !dead) {
-                const bool ok = stream_consume(p, i, lane, wave - NP, NC, par, prev, bp_, lpairs,
-                                               lcen + (size_t)((i & 1) ^ 1) * pw, ldone + ((i & 1) ^ 1), lmisc + 8, qtab, pmask);
-                if (!ok && lane == 0) {                    // whatever made this wave give up: every workgroup stops, the host is told
-                    lmisc[4] = 1;
+    const int par = __builtin_amdgcn_readfirstlane(lmisc[9]);   // (what comes out of LDS is wave-uniform here; the compiler is told so)
+    auto is_dead = [&]() -> bool { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(ldead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0; };
+    // waits until an LDS counter has reached `want`; false when some wave of the workgroup has given up
+    auto wait_word = [&](const uint32_t *w, uint32_t want) -> bool {
+        for (uint32_t spins = 0;; ++spins) {
+            const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (v >= want) return true;
+            if (is_dead()) return false;
+            if (spins > (kStreamSpinLimit << 5)) {             // seconds: never on a healthy launch
+                if (lane == 0) {
+                    __hip_atomic_store(ldead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                return false;
             }
+            __builtin_amdgcn_s_sleep(4);
         }
-        if (wave == 0) STREAM_STAMP(p, i, 1);             // counted (producer 0)
-        if (wave == NP) STREAM_STAMP(p, i, 9);            // consumer 0 at the barrier
-        __syncthreads();
-        if (wave == 0) STREAM_STAMP(p, i, 2);             // past the barrier
-        dead = dead || __builtin_amdgcn_readfirstlane(lmisc[4]) != 0;
-        if (!have) break;
-        prev = ci;
+    };
+
+    // No barrier from here on.  Chunk k of this workgroup (ticket c_k) lives in buffer k mod NB:
+    //   a producer  counts its tiles of c_k as soon as every consumer is done with c_(k-NB), whatever the other
+    //               producers are doing; the producer that finishes c_k first draws the ticket of c_(k+1);
+    //   a consumer  takes c_k once the producer that finished last has published its row.
+    // So a wave only ever waits for a wave that is ahead of it in this order, and the ticket ring of eight cannot be
+    // overrun: slot (k + 1) & 7 is written when every wave is past c_(k-NB), NB <= 4.
+    if (!consumer) {
+        for (int k = 0, kb = 0, use = 0;; ++k, kb = kb + 1 == NB ? 0 : kb + 1, use += kb == 0 ? 1 : 0) {
+            if (wave == 0) STREAM_STAMP(p, k, 0);             // iteration begins (producer 0)
+            if (!wait_word(ldrawn, (uint32_t)k + 1u)) break;
+            const int32_t ci = __builtin_amdgcn_readfirstlane(lmisc[k & 7]);
+            if (ci >= n_chunks) break;
+            const StreamBuf bk = stream_buf(bufs + (size_t)kb * buf_bytes, p.P, p.chunk_tiles);
+            if (use > 0 && !wait_word(lfree + kb, (uint32_t)(NC / p.n_sets * use))) break;
+            if (wave == 0) STREAM_STAMP(p, k, 1);             // buffer free
+            const int t0 = __builtin_amdgcn_readfirstlane(ci * p.chunk_tiles + wave * p.tr);
+            const int n_own = __builtin_amdgcn_readfirstlane(min(p.tr, p.n_tiles - t0));
+            if (n_own > 0) stream_count_piece(p, lane, t0, n_own, wave * p.tr, bk, segs);
+            if (wave == 0) STREAM_STAMP(p, k, 2);             // counted
+            stream_census(p, lane, wave * p.tr, n_own, bk.zf, lpairs, lcen + (size_t)kb * pw);
+            // arrival: the first producer there draws the next ticket (the others are still counting, nobody waits for
+            // the round trip, and a chunk is counted straight after its ticket is drawn: chunks with smaller tickets
+            // are never far behind); the last one publishes
+            uint32_t old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(ldone + kb, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old) - (uint32_t)(NP * use);
+            if (old == 0u && lane == 0) {
+                const int32_t t = draw();
+                lmisc[(k + 1) & 7] = t;
+                if (t >= n_chunks) lmisc[(k + 2) & 7] = lmisc[(k + 3) & 7] = lmisc[(k + 4) & 7] = t;   // the end, for every set of consumers
+                __hip_atomic_store(ldrawn, (uint32_t)k + (t >= n_chunks ? 5u : 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#ifdef EVOFST_EXPERIMENTS
+            if (p.debug & 8) continue;
+#endif
+            if (old == (uint32_t)NP - 1u) stream_publish(p, lane, par, ci, lcen + (size_t)kb * pw, lpub + kb, use);
+        }
+    } else {
+        // The consumers are the youngest waves of their workgroup and would get the issue slots the producers leave;
+        // the producers mostly wait for memory, so the consumers go first.
+#ifdef EVOFST_EXPERIMENTS
+        if (!(p.debug & 64)) __builtin_amdgcn_s_setprio(3);
+#else
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        // NS sets of consumer waves take the workgroup's chunks in turn: a set has NS chunk times for the wait on its chunk's
+        // predecessors plus the walk
+        const int NS = p.n_sets, ncw = NC / NS;
+        const int set = (wave - NP) / ncw, cw = (wave - NP) - set * ncw;
+        for (int k = set;; k += NS) {
+            const int use = k / NB, kb = k - use * NB;
+            if (!wait_word(ldrawn, (uint32_t)k + 1u)) break;
+            const int32_t ck = __builtin_amdgcn_readfirstlane(lmisc[k & 7]);
+            if (ck >= n_chunks) break;
+            const StreamBuf bk = stream_buf(bufs + (size_t)kb * buf_bytes, p.P, p.chunk_tiles);
+            if (wave == NP) STREAM_STAMP(p, k, 3);            // consumer 0 begins
+#ifdef EVOFST_EXPERIMENTS
+            if (p.debug & 8) {                                // no consumer work: the buffer is free as soon as it is counted
+                if (!wait_word(ldone + kb, (uint32_t)(NP * (use + 1)))) break;
+                if (lane == 0) __hip_atomic_fetch_add(lfree + kb, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+            }
+#endif
+            if (!wait_word(lpub + kb, (uint32_t)use + 1u)) break;
+            if (wave == NP) STREAM_STAMP(p, k, 4);            // chunk counted and published
+            const bool ok = stream_consume(p, k, lane, cw, ncw, par, ck, bk, lpairs, lcen + (size_t)kb * pw, lready + set, ldead, pmask);
+            if (!ok) {                                        // whatever made this wave give up: every workgroup stops, the host is told
+                if (lane == 0) {
+                    __hip_atomic_store(ldead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            if (lane == 0) __hip_atomic_fetch_add(lfree + kb, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wave == NP) STREAM_STAMP(p, k, 9);            // consumer 0 done with the chunk
+        }
     }
 }
 
 hipError_t launch_stream(const StreamParams &p, int max_blocks, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
     if (p.n_pairs > kStreamMaxPairs || p.P > 64 || p.tr <= 0 || p.n_prod < 1 || p.n_cons < 1 || p.n_prod + p.n_cons > kStreamMaxWaves ||
-        p.chunk_tiles != p.tr * p.n_prod || p.chunk_tiles > 64) return hipErrorInvalidValue;
+        p.chunk_tiles != p.tr * p.n_prod || p.chunk_tiles > 64 || p.n_buf < 2 || p.n_buf > kStreamMaxBufs ||
+        p.n_sets < 1 || p.n_sets > 2 || p.n_cons % p.n_sets != 0) return hipErrorInvalidValue;
     const int threads = 64 * (p.n_prod + p.n_cons);
     const void *fn = reinterpret_cast<const void *>(&stream_pairs_kernel);
-    const size_t lds = stream_lds_bytes(p.P, p.n_pairs, p.chunk_tiles);
+    const size_t lds = stream_lds_bytes(p.P, p.n_pairs, p.chunk_tiles, p.n_buf);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

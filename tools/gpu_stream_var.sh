@@ -1,4 +1,4 @@
-# stream pass variants (exp build): EVOFST_STREAM_AHEAD, producers/consumers, chunk tiles, blocks
+# stream pass variants (exp build): producers/consumers, chunk tiles
 set -e
 mkdir -p gpurun_out
 export EVOFST_LIB=$PWD/evo_amd/libevofst_exp.so
@@ -10,13 +10,10 @@ import json
 d = json.load(open('gpurun_out/var.json'))
 print('$cfg', '$label', 'ms/step %.4f' % d['ms_per_step'], {k.split('(')[0]: round(v, 4) for k, v in d['roofline']['kernels_ms'].items()})"
 }
-for a in 1 2; do
-  BARGS="" run cfg2 200 "ahead=$a" EVOFST_STREAM_AHEAD=$a
-  BARGS="" run cfg4s 20 "ahead=$a" EVOFST_STREAM_AHEAD=$a
+# VARS: producers,consumers per set:chunk tiles:buffers:consumer sets
+for v in ${VARS:-4,3:8:2 8,3:16:2 6,3:12:3}; do
+  IFS=: read w ct nb ns <<< "$v"
+  for poll in ${POLLS:-8}; do
+    BARGS="--stream-waves $w --chunk-tiles $ct --stream-buffers $nb --stream-sets ${ns:-1}" run ${CFG:-cfg4s} ${STEPS:-20} "waves $w chunk $ct buffers $nb sets ${ns:-1} poll $poll" EVOFST_STREAM_POLL=$poll
+  done
 done
-BARGS="--stream-waves 4,1" run cfg4s 20 "waves 4,1" EVOFST_STREAM_AHEAD=1
-BARGS="--stream-waves 2,1" run cfg2 200 "waves 2,1" EVOFST_STREAM_AHEAD=1
-BARGS="--stream-waves 3,1" run cfg2 200 "waves 3,1" EVOFST_STREAM_AHEAD=1
-BARGS="--chunk-tiles 4" run cfg2 200 "chunk 4" EVOFST_STREAM_AHEAD=1
-BARGS="--chunk-tiles 16" run cfg2 200 "chunk 16" EVOFST_STREAM_AHEAD=1
-BARGS="--chunk-tiles 4" run cfg4s 20 "chunk 4" EVOFST_STREAM_AHEAD=1

@@ -11,9 +11,8 @@ wg = np.where(a[:, 0, 0] != 0)[0]
 a = a[wg].astype(np.int64)
 t0 = a[:, 0, 0].min()
 print("workgroups", len(wg), "launch span %.1f us" % ((a[:, :, :10].max() - t0) / 100.0))
-names = ["count (P0: begin->counted)", "P0 waits at barrier", "C: begin->census out", "C: wait level-0 flags", "C: first sums",
-         "C: upper levels", "C: walk", "C: walk end->barrier"]
-pairs = [(0, 1), (1, 2), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9)]
+names = ["P0 waits for buffer", "count", "C: waits for chunk", "C: flags seen", "C: first sums", "C: sums->walked", "C: begin->done"]
+pairs = [(0, 1), (1, 2), (3, 4), (4, 5), (5, 6), (6, 8), (3, 9)]
 for it in range(IT):
     live = a[:, it, 0] != 0
     if not live.any():
