@@ -34,6 +34,8 @@ CONFIGS = {
                   label="synthetic 2M-site shard x 1000 samples, 100 pops, Fst-against-all, windows 20,10"),
     "cfg4s": dict(sites=6_250_000, samples=2000, pops=20, mode="pairs", size=100, step=100, miss=0.0,
                   label="synthetic 6.25M-site shard (1/8 of 50M) x 2000 samples, 20 pops (190 pairs), windows 100,100"),
+    "cfg4m": dict(sites=6_250_000, samples=2000, pops=20, mode="pairs", size=100, step=100, miss=0.02,
+                  label="cfg4s with 2% missing calls (diagnostic: every chunk takes the general walk)"),
     "cfg5s": dict(sites=2_500_000, samples=5000, pops=500, mode="gram", size=100, step=100, miss=0.15,
                   label="synthetic 2.5M-site shard (1/8 of 20M) x 5000 samples, 500 pops (124,750 pairs), 15% missing, "
                         "Gram path (FP64 MFMA) over fixed 100-site windows"),

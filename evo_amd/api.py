@@ -77,6 +77,7 @@ SIGNATURES = {
     "evofst_run": (C.c_int, [_vp]),
     "evofst_sync": (C.c_int, [_vp]),
     "evofst_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "evofst_last_pairs_pass": (C.c_int, [_vp]),
     "evofst_set_profiling": (C.c_int, [_vp, C.c_int]),
     "evofst_get_kernel_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
     "evofst_get_counts": (C.c_int, [_vp, C.c_int64, C.c_int64, _i32p, _i32p]),
@@ -357,6 +358,10 @@ class EvoFst:
     def set_option(self, name, value):
         """Tuning / test switches of this context (include/evofst.h: evofst_set_option)."""
         self._chk(self.L.evofst_set_option(self.h, name.encode(), int(value)))
+
+    def last_pairs_pass(self):
+        """1 = separate kernels, 2 = stream pass, 3 = lock-step one-kernel pass (the last run's; 0: none)."""
+        return int(self.L.evofst_last_pairs_pass(self.h))
 
     def set_profiling(self, on=True):
         self._chk(self.L.evofst_set_profiling(self.h, 1 if on else 0))

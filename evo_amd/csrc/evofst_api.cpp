@@ -112,6 +112,7 @@ struct evofst_ctx {
     int opt_chunk_tiles = 0;          // tiles per chunk (0: the library chooses)
     int opt_walk = 0;                 // K1 + scan + walk: 0 auto, 1 general walk on every chunk, 2 k2_window_kernel
     int opt_stream_blocks = 0;        // workgroups of the stream pass (0: as many as the device holds)
+    int last_pairs_pass = 0;                        // evofst_last_pairs_pass
     int opt_stream_sets = 0;                        // its sets of consumer waves (0: the library chooses)
     int opt_stream_bufs = 0;                        // its LDS buffers per workgroup (0: the library chooses)
     int opt_stream_prod = 0, opt_stream_cons = 0;   // its producer / consumer waves per workgroup (0: the library chooses)
@@ -523,9 +524,14 @@ StreamPlan stream_plan(const evofst_ctx *c, int64_t n_sites) {
     if (c->opt_pairs_pass != 0 && c->opt_pairs_pass != 2) return pl;
     const int n_tiles = n_tiles_of(n_sites);
     const int np = (int)c->pairs.size();
-    // a consumer wave per 64 pairs; producers: four, or what the options say
+    // Left to itself the library takes this pass where a tile row is long and the shard large: there K1's store stream and
+    // the walk's re-read cost more than the look-back does (cfg4 shard: 1.57 against 1.74 ms); on short rows (cfg2:
+    // 7 words) the three small kernels of the split pass are the faster ones (0.07 against 0.11 ms).
+    const bool wide = c->W >= 32;
+    if (c->opt_pairs_pass == 0 && (!wide || n_tiles < 16 * 1024)) return pl;
+    // a consumer wave per 64 pairs; producers: two per SIMD on long rows, else four, or what the options say
     pl.n_cons = c->opt_stream_cons > 0 ? std::min(c->opt_stream_cons, (np + 63) / 64) : (np + 63) / 64;
-    pl.n_prod = c->opt_stream_prod > 0 ? c->opt_stream_prod : 4;
+    pl.n_prod = c->opt_stream_prod > 0 ? c->opt_stream_prod : (wide && pl.n_cons <= 4 ? 8 : 4);
     pl.n_sets = c->opt_stream_sets > 0 ? c->opt_stream_sets : 1;
     pl.n_cons *= pl.n_sets;
     if (pl.n_prod + pl.n_cons > kStreamMaxWaves) return StreamPlan();
@@ -1635,11 +1641,12 @@ extern "C" int evofst_run(evofst_ctx *c) try {
         // that want them run K1 on demand)
         HIPCHK(c, hipSetDevice(c->device));
         const StreamPlan pl = stream_plan(c, c->n_sites);
-        if (pl.tr > 0) return run_stream(c, pl);
+        if (pl.tr > 0) { c->last_pairs_pass = 2; return run_stream(c, pl); }
         int sub = 32;
         const int ct = fused_plan(c, c->n_sites, false, &sub);
-        if (ct > 0) return run_fused(c, ct, sub);
+        if (ct > 0) { c->last_pairs_pass = 3; return run_fused(c, ct, sub); }
     }
+    c->last_pairs_pass = c->mode == MODE_PAIRS ? 1 : 0;
     int rc = evofst_run_counts(c);
     if (rc) return rc;
     return evofst_run_stats(c);
@@ -1761,6 +1768,10 @@ extern "C" int evofst_set_option(evofst_ctx *c, const char *name, int64_t value)
     return EVOFST_OK;
 } catch (...) {
     return abi_exception(c);
+}
+
+extern "C" int evofst_last_pairs_pass(const evofst_ctx *c) {
+    return c ? c->last_pairs_pass : 0;
 }
 
 extern "C" int evofst_set_profiling(evofst_ctx *c, int enabled) try {

@@ -580,7 +580,7 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
         const int q = g * 64 + lane;
         uint64_t before = 0;
 #ifdef EVOFST_EXPERIMENTS
-        if (!(p.debug & 2))
+        if (!(p.debug & (2 | 2048)))                       // (2048: flags waited for, rows not read -- prefix 0, rows stay inside the table)
 #endif
         if (!stream_sum_rows(p, rows, par, q < p.n_pairs ? q : 0, before, retries)) return false;
         if (cw == 0 && g == 0) {
@@ -715,25 +715,40 @@ __global__ __launch_bounds__(kStreamMaxThreads, EVOFST_STREAM_WPS) void stream_p
             if (wave == 0) STREAM_STAMP(p, k, 1);             // buffer free
             const int t0 = __builtin_amdgcn_readfirstlane(ci * p.chunk_tiles + wave * p.tr);
             const int n_own = __builtin_amdgcn_readfirstlane(min(p.tr, p.n_tiles - t0));
+#ifdef EVOFST_EXPERIMENTS
+            const unsigned long long tc0 = __builtin_amdgcn_s_memrealtime();
+#endif
             if (n_own > 0) stream_count_piece(p, lane, t0, n_own, wave * p.tr, bk, segs);
             if (wave == 0) STREAM_STAMP(p, k, 2);             // counted
+#ifdef EVOFST_EXPERIMENTS
+            if (p.stamps && k < kStreamStampIters && lane == 0 && wave < 8)   // every producer's counting time, 10 ns units, 16 bits each
+                reinterpret_cast<unsigned short *>(p.stamps + ((size_t)blockIdx.x * kStreamStampIters + k) * 16 + 14)[wave] =
+                    (unsigned short)min(__builtin_amdgcn_s_memrealtime() - tc0, 65535ull);
+#endif
             stream_census(p, lane, wave * p.tr, n_own, bk.zf, lpairs, lcen + (size_t)kb * pw);
             // arrival: the first producer there draws the next ticket (the others are still counting, nobody waits for
             // the round trip, and a chunk is counted straight after its ticket is drawn: chunks with smaller tickets
-            // are never far behind); the last one publishes
+            // are never far behind); the last one publishes -- unless it is also the first, then it publishes first
             uint32_t old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(ldone + kb, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             old = __builtin_amdgcn_readfirstlane(old) - (uint32_t)(NP * use);
-            if (old == 0u && lane == 0) {
-                const int32_t t = draw();
+#ifdef EVOFST_EXPERIMENTS
+            if (!(p.debug & 8))
+#endif
+            if (old == (uint32_t)NP - 1u) { STREAM_STAMP(p, k, 11); stream_publish(p, lane, par, ci, lcen + (size_t)kb * pw, lpub + kb, use); STREAM_STAMP(p, k, 13); }
+            if (old == 0u) STREAM_STAMP(p, k, 12);
+            if (old == 0u) {
+                // ... once the next chunk's buffer is free: a ticket held through a wait would be a chunk that every
+                // later chunk of the shard waits for
+                const int kb1 = kb + 1 == NB ? 0 : kb + 1, use1 = use + (kb1 == 0 ? 1 : 0);
+                const bool live = use1 == 0 || wait_word(lfree + kb1, (uint32_t)(NC / p.n_sets * use1));
+                if (lane == 0) {
+                const int32_t t = live ? draw() : n_chunks;
                 lmisc[(k + 1) & 7] = t;
                 if (t >= n_chunks) lmisc[(k + 2) & 7] = lmisc[(k + 3) & 7] = lmisc[(k + 4) & 7] = t;   // the end, for every set of consumers
                 __hip_atomic_store(ldrawn, (uint32_t)k + (t >= n_chunks ? 5u : 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
-#ifdef EVOFST_EXPERIMENTS
-            if (p.debug & 8) continue;
-#endif
-            if (old == (uint32_t)NP - 1u) stream_publish(p, lane, par, ci, lcen + (size_t)kb * pw, lpub + kb, use);
         }
     } else {
         // The consumers are the youngest waves of their workgroup and would get the issue slots the producers leave;

@@ -251,9 +251,16 @@ int64_t evofst_noalloc_scratch_bytes(void);
  *   "walk"          statistics walk of pairs_pass 1: 0 = chosen by the library, 1 = general walk on every chunk,
  *                   2 = k2_window_kernel
  *   "stream_blocks" workgroups of the stream pass, 0 = as many as the device holds (any number is safe)
- *   "stream_producers", "stream_consumers"  its producer / consumer waves per workgroup, 0 = chosen by the library
- * Unknown names and values out of range return EVOFST_ERR_ARG. */
+ *   "stream_producers", "stream_consumers"  its producer / consumer waves per workgroup (consumers: per set),
+ *                   0 = chosen by the library
+ *   "stream_buffers" chunks of a workgroup in flight (LDS buffers), 2 .. 4, 0 = chosen by the library
+ *   "stream_sets"   sets of consumer waves that take a workgroup's chunks in turn, 1 or 2, 0 = chosen by the library
+ * Unknown names and values out of range return EVOFST_ERR_ARG.  A shape an option does not fit (LDS, waves) takes
+ * the next pass in the order stream, lock-step, separate kernels. */
 int evofst_set_option(evofst_ctx *ctx, const char *name, int64_t value);
+/* Which form of the pairs pass the last evofst_run took: 1 = separate kernels, 2 = stream pass, 3 = lock-step
+ * one-kernel pass; 0 = none yet, or not pairs mode.  (No counterpart in the reference.) */
+int evofst_last_pairs_pass(const evofst_ctx *ctx);
 
 /* When enabled, evofst_run_* bracket every kernel with HIP events on the context's stream. */
 int evofst_set_profiling(evofst_ctx *ctx, int enabled);

@@ -207,6 +207,27 @@ def test_snp_windows_clean_and_dirty_chunks(engine, S, N, P, dirty):
         _check_windows(engine, sp, codes, None, P, 100, 50, tag="snp_windows_clean_and_dirty_chunks")
 
 
+@pytest.mark.parametrize("prod,cons,chunk_tiles,bufs,sets", [(8, 0, 16, 2, 1), (6, 0, 12, 3, 1), (6, 0, 12, 3, 2), (3, 1, 3, 4, 2),
+                                                             (1, 0, 2, 2, 1), (8, 0, 8, 4, 1)])
+def test_stream_pass_shapes(engine, prod, cons, chunk_tiles, bufs, sets):
+    """The stream pass (evofst_stream.hip) with every knob of evofst_set_option turned: producer and consumer waves per
+    workgroup, tiles per chunk, LDS buffers (chunks of a workgroup in flight) and consumer sets; 78 pairs (two groups of
+    lanes), clean chunks and chunks with a missing allele, windows that straddle both, more chunks than workgroups."""
+    S, N, P, dirty = 150_000, 52, 13, 300
+    rng = np.random.default_rng(prod * 100 + chunk_tiles + bufs)
+    sp = round_robin_pops(N, P)
+    codes = random_codes(rng, S, sp, P, miss=0.0, edge=False)
+    for s_ in rng.choice(S, dirty, replace=False):
+        codes[s_, rng.choice(2 * N, 2, replace=False)] = 2
+    engine.set_layout(sp, P)
+    engine.upload(engine.pack_codes(codes), S)
+    engine.set_pairs()
+    with options(engine, pairs_pass=2, stream_producers=prod, stream_consumers=cons, chunk_tiles=chunk_tiles, stream_buffers=bufs,
+                 stream_sets=sets, stream_blocks=16 if prod == 1 else 0):
+        _check_windows_once(engine, sp, codes, None, P, 100, 50, None, "snp_windows_stream_shapes")
+        assert engine.last_pairs_pass() == 2
+
+
 @pytest.mark.parametrize("chunk_tiles", [4, 16])
 def test_one_byte_counts_of_clean_chunks(chunk_tiles):
     """K1 leaves one byte per count in chunks without a skipped, irregular or missing-allele site (pairs mode, 16-bit
