@@ -111,29 +111,54 @@ def cpu_baseline(e, cfg, sample_sites):
     return evals / dtn, cores, dtn, evals / dt1, dt1
 
 
-def hbm_leg(device, steps=10):
+def timed_reps(run_steps, first=None, min_total=0.05, agree=None):
+    """Repeats a timed region (run_steps() -> seconds of exactly --steps steps, fenced on both sides) until at least
+    min_total seconds have been timed and at least three times (once if one region alone takes a second); `agree` makes
+    the ranks of a multi-GPU run take the same number.  Returns the list of durations."""
+    dts = [run_steps() if first is None else first]
+    n = 1 if dts[0] >= 1.0 else max(3, int(np.ceil(min_total / max(dts[0], 1e-9))))
+    n = min(n, 400)
+    if agree is not None:
+        n = agree(n)
+    while len(dts) < n:
+        dts.append(run_steps())
+    return dts
+
+
+PASS_NAMES = {1: "k1_count_kernel + scan_kernel + walk + stitch_kernel (separate kernels)", 2: "stream_pairs_kernel + stitch_kernel",
+              3: "fused_pairs_kernel (lock-step) + stitch_kernel"}
+
+
+def hbm_leg(device, steps=10, tune=None):
     """The pairs pass on one GPU's share of BASELINE configs[3] (6.25 M sites x 2000 samples, 190 pairs): 6.25 GB of tiles
     per step, far beyond every cache.  Returns the roofline object of its dominant kernel (command: bench.py --config cfg4s)."""
     from evo_amd import EvoFst
     cfg = CONFIGS["cfg4s"]
     S, N, P = cfg["sites"], cfg["samples"], cfg["pops"]
     e = EvoFst(device)
+    if tune:
+        tune(e)
     e.set_layout((np.arange(N) % P).astype(np.int32), P)
     e.set_pairs()
     e.set_windows(cfg["size"], cfg["step"])
     e.reserve(S)
     e.synth(S, seed=20261110, missing_rate=cfg["miss"])
-    for _ in range(2):
+    for _ in range(3):
         e.run()
     e.sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        e.run()
-    e.sync()
-    dt = (time.perf_counter() - t0) / steps
+
+    def run_steps():
+        e.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.run()
+        e.sync()
+        return time.perf_counter() - t0
+    dts = np.array(timed_reps(run_steps)) / steps
+    dt = float(np.median(dts))
     e.set_profiling(True)
-    km = np.zeros((3, 5))
-    for i in range(3):
+    km = np.zeros((5, 5))
+    for i in range(len(km)):
         e.run(); e.sync()
         for k in range(5):
             try:
@@ -141,17 +166,99 @@ def hbm_leg(device, steps=10):
             except Exception:
                 km[i, k] = 0.0
     k = km.mean(axis=0)
+    which = e.last_pairs_pass()
     cb = e.geometry().count_bytes
     g = np.gcd(cfg["size"], cfg["step"])
-    cbw = 1 if cb == 2 and not cfg.get("miss") else cb     # clean chunks leave one byte per count (K1Params::compact)
-    k1_bytes = S * (N / 2.0) + S * P * cbw + S / 64.0 * (2 * P + 3) * 8.0
+    rows_bytes = (S / g) * 190 * 28.0
+    if which == 1:
+        cbw = 1 if cb == 2 and not cfg.get("miss") else cb     # clean chunks leave one byte per count (K1Params::compact)
+        dom, kernel = 0, "k1_count_kernel"
+        dom_bytes = S * (N / 2.0) + S * P * cbw + S / 64.0 * (2 * P + 3) * 8.0
+        kernels = {"k1_count_kernel": float(k[0]), "scan_kernel": float(k[1]),
+                   "walk(clean_walk_kernel + fused_pairs_kernel on K1 counts)": float(k[2]), "stitch_kernel": float(k[3])}
+    else:
+        # one kernel from the tiles to the segment rows: 2 bits per haplotype read, one 28-byte row per segment and pair written
+        dom, kernel = 4, "stream_pairs_kernel" if which == 2 else "fused_pairs_kernel"
+        dom_bytes = S * (N / 2.0) + rows_bytes
+        kernels = {kernel: float(k[4]), "stitch_kernel": float(k[3])}
+        if k[2] > 0:
+            kernels["walk of the chunks the stream pass marked"] = float(k[2])
     e.close()
-    return {"workload": cfg["label"], "ms_per_step": dt * 1e3, "site_pairs_per_s": S * 190 / dt, "bound": "hbm",
-            "kernel": "k1_count_kernel", "algorithmic_bytes": k1_bytes, "achieved": k1_bytes / (k[0] * 1e-3) / 1e9 if k[0] > 0 else 0.0,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_bytes / (k[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if k[0] > 0 else 0.0,
+    ach = dom_bytes / (k[dom] * 1e-3) / 1e9 if k[dom] > 0 else 0.0
+    return {"workload": cfg["label"], "pairs_pass": PASS_NAMES.get(which, "?"), "ms_per_step": dt * 1e3,
+            "ms_per_step_min": float(dts.min()) * 1e3, "ms_per_step_max": float(dts.max()) * 1e3, "timed_reps": len(dts), "steps": steps,
+            "site_pairs_per_s": S * 190 / dt, "bound": "hbm",
+            "kernel": kernel, "algorithmic_bytes": dom_bytes, "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "pipeline_GBps": S * (N / 2.0 + 4.0) / dt / 1e9, "pipeline_frac": S * (N / 2.0 + 4.0) / dt / 1e9 / HBM_PEAK_GBS,
-            "kernels_ms": {"k1_count_kernel": float(k[0]), "scan_kernel": float(k[1]), "walk(clean_walk_kernel + fused_pairs_kernel on K1 counts)": float(k[2]), "stitch_kernel": float(k[3])},
+            "kernels_ms": kernels,
             "command": "python bench.py --config cfg4s"}
+
+
+def scale_hbm_leg(local_rank, rank, world, tune, steps=10):
+    """N > 1: the multi-rank pairs pass (counts -> included-site totals over RCCL -> base offsets -> walk -> carries) on
+    BASELINE configs[3]'s per-GPU share, 6.25 M sites per rank -- north_star's 8-GPU pairs configuration.  Every rank
+    calls this; returns the object for the JSON line (the slowest rank's time per repetition, median over repetitions)."""
+    import torch
+    import torch.distributed as dist
+    from evo_amd import EvoFst, shard
+    cfg = CONFIGS["cfg4s"]
+    S, N, P = cfg["sites"], cfg["samples"], cfg["pops"]
+    e = tune(EvoFst(local_rank))
+    e.set_layout((np.arange(N) % P).astype(np.int32), P)
+    e.set_pairs()
+    e.set_windows(cfg["size"], cfg["step"])
+    st = torch.cuda.Stream()
+    e.set_stream(st.cuda_stream)
+    e.reserve(S)
+    e.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=rank * S)
+    e.sync()
+    msg = shard.PairsPassMessage(e.n_pairs, world, rank, "cuda")
+    st.wait_stream(torch.cuda.current_stream())
+
+    def one_pass():
+        with torch.cuda.stream(st):
+            e.run_counts()
+            e.copy_included_totals(msg.totals_ptr())
+            msg.gather(dist)
+            e.set_base_offsets_gathered(msg.recv_ptr(), msg.row, rank)
+            e.run_stats()
+            e.copy_boundary(msg.carry_ptr())
+
+    def fence():
+        e.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_steps():
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_pass()
+        with torch.cuda.stream(st):
+            msg.gather(dist)                       # the carries of the last pass
+        fence()
+        return time.perf_counter() - t0
+
+    def agree(n):
+        t = torch.tensor([n], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+    for _ in range(2):
+        one_pass()
+    dts = timed_reps(run_steps, agree=agree)
+    t = torch.tensor(dts, dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dts = np.array([float(x) for x in t.cpu()]) / steps
+    dt = float(np.median(dts))
+    e.close()
+    return {"workload": cfg["label"] + " per rank", "rccl_ranks": dist.get_world_size(), "scaling": "weak", "sites_per_gpu": S,
+            "pairs_pass": "k1_count_kernel -> all-gather of included-site totals (RCCL) -> scan_kernel + walk + stitch_kernel",
+            "ms_per_step": dt * 1e3, "ms_per_step_min": float(dts.min()) * 1e3, "ms_per_step_max": float(dts.max()) * 1e3,
+            "timed_reps": len(dts), "steps": steps, "value": S * 190.0 * world / dt, "unit": "site*pair/s",
+            "pipeline_GBps": S * (N / 2.0 + 4.0) * world / dt / 1e9,
+            "pipeline_frac_of_n_gpus": S * (N / 2.0 + 4.0) / dt / 1e9 / HBM_PEAK_GBS}
 
 
 def spawn_ranks(n):
@@ -390,12 +497,26 @@ def main():
         step()
     fence()
     kms = np.zeros((args.steps, 5))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-    flush()
-    fence()
-    dt = time.perf_counter() - t0
+
+    def run_steps():
+        # EXACTLY --steps steps between two fences (barrier + synchronize)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step()
+        flush()
+        fence()
+        return time.perf_counter() - t0
+
+    def agree(n):
+        if not multi:
+            return n
+        t = torch.tensor([n], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+    # A region of 20 cfg2 steps is 1.5 ms long, too short to be stable: the region is repeated until 50 ms have been
+    # timed, every repetition is --steps steps, and the line carries the median (min and max beside it).
+    dts = timed_reps(run_steps, agree=agree)
     # per-kernel durations from HIP events on the library's stream (last step; then a few more
     # profiled steps outside the timed region to average)
     reps = min(args.steps, 20) if cfg["mode"] != "gram" else 1
@@ -416,9 +537,10 @@ def main():
     flush()          # every rank: the carries of the last profiled pass, for the exchange check below
     fence()
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor(dts, dtype=torch.float64, device="cuda")     # per repetition: the slowest rank's time
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dts = [float(x) for x in t.cpu()]
+    dt = float(np.median(dts))
     ms_per_step = dt / args.steps * 1e3
     evals = float(S) * units_per_site * world
     value = evals / (dt / args.steps)
@@ -443,9 +565,13 @@ def main():
         kavg[2] = float(np.sum(gram_ms))          # popsums + gram launches of every batch of one step
     fused = cfg["mode"] == "pairs" and not multi and kavg[4] > 0
     if fused:
+        names[4] = "stream_pairs_kernel" if e.last_pairs_pass() == 2 else "fused_pairs_kernel"
+        walk_ms = kavg[2] if e.last_pairs_pass() == 2 else 0.0       # the general walk over the chunks the stream pass marked
+        names[2] = "walk of the chunks the stream pass marked (fused_pairs_kernel on spilled counts)"
         # one kernel from the tiles to the segment rows: 2 bits per haplotype read, one 28-byte row per segment and pair written
         dom = 4
-        kavg[0] = kavg[1] = kavg[2] = 0.0         # stale events of a K1 launch behind a getter, if any
+        kavg[0] = kavg[1] = 0.0                   # stale events of a K1 launch behind a getter, if any
+        kavg[2] = walk_ms
         dom_bytes = S * (N / 2.0) + (S / g) * e.n_pairs * 28.0
     else:
         dom = 0 if kavg[0] >= kavg[2] else 2
@@ -455,7 +581,7 @@ def main():
     # WRITE_SIZE; profiles/README.md says how they were collected) -- null for a configuration not profiled
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
             tr = json.load(f).get(args.config, {}).get(names[dom].split("(")[0])
         if tr:
             traffic = tr["hbm_read_bytes"] + tr["hbm_write_bytes"]
@@ -497,7 +623,8 @@ def main():
     out = {
         "metric": "site x pop-pair Fst+dxy evaluations/sec",
         "value": value, "unit": "site*pair/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "timed_reps": len(dts), "ms_per_step_min": min(dts) / args.steps * 1e3,
+        "ms_per_step_max": max(dts) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["label"], "sites_per_gpu": S, "samples": N, "pops": P,
                    "units_per_site": units_per_site, "sharding": "contiguous site shards, one per GPU",
@@ -532,7 +659,15 @@ def main():
         for x in es[1:]:
             x.close()
         del es[1:]
-        out["roofline_hbm"] = hbm_leg(local_rank)
+        out["roofline_hbm"] = hbm_leg(local_rank, tune=tune)
+    if multi and not args.no_hbm_leg and args.config == "cfg2" and args.sites == 0:
+        # the same multi-rank pass on north_star's 8-GPU pairs configuration (6.25 M sites per rank): the curve that matters
+        for x in es[1:]:
+            x.close()
+        del es[1:]
+        sh = scale_hbm_leg(local_rank, rank, world, tune)
+        if rank == 0:
+            out["scale_hbm"] = sh
     if rank == 0:
         print(json.dumps(out))
     for x in es[1:]:

@@ -112,6 +112,8 @@ struct evofst_ctx {
     int opt_chunk_tiles = 0;          // tiles per chunk (0: the library chooses)
     int opt_walk = 0;                 // K1 + scan + walk: 0 auto, 1 general walk on every chunk, 2 k2_window_kernel
     int opt_stream_blocks = 0;        // workgroups of the stream pass (0: as many as the device holds)
+    bool check_dirty = false;                       // the check word is the stream pass's: its count of marked chunks lies behind it
+    uint32_t stream_dirty_cum = 0, stream_dirty_last = 0; bool stream_dirty_known = false;   // (what the last synchronised passes marked)
     int last_pairs_pass = 0;                        // evofst_last_pairs_pass
     int opt_stream_sets = 0;                        // its sets of consumer waves (0: the library chooses)
     int opt_stream_bufs = 0;                        // its LDS buffers per workgroup (0: the library chooses)
@@ -415,7 +417,7 @@ int run_fused(evofst_ctx *c, int ct, int sub) {
     record(c, 3, 0);
     HIPCHK(c, launch_stitch(k2, c->stream));
     record(c, 3, 1);
-    c->check_word = (const uint32_t *)c->d_fsync.p + 32;
+    c->check_word = (const uint32_t *)c->d_fsync.p + 32; c->check_dirty = false;
     c->check_zero[0] = c->d_fsync.p; c->check_zero_bytes[0] = 256;
     c->check_zero[1] = c->check_zero[2] = nullptr; c->check_zero_bytes[1] = c->check_zero_bytes[2] = 0;
     c->offsets_dirty = false;
@@ -428,11 +430,16 @@ int run_fused(evofst_ctx *c, int ct, int sub) {
 // error word instead of hanging; the pass then leaves rows and tails unwritten.)
 int fused_verdict(evofst_ctx *c) {
     if (!c->check_word) return EVOFST_OK;
-    uint32_t err = 0;
-    HIPCHK(c, hipMemcpyAsync(&err, c->check_word, 4, hipMemcpyDeviceToHost, c->stream));
+    uint32_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // [0] error word; [8] (stream pass) chunks left to the general walk, all launches so far
+    HIPCHK(c, hipMemcpyAsync(w, c->check_word, c->check_dirty ? sizeof(w) : 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->check_word = nullptr;
+    const uint32_t err = w[0];
+    if (c->check_dirty && !err) {
+        c->stream_dirty_last = w[8] - c->stream_dirty_cum; c->stream_dirty_cum = w[8]; c->stream_dirty_known = true;
+    }
     if (err) {
+        c->stream_dirty_cum = 0; c->stream_dirty_known = false;
         for (int i = 0; i < 3; ++i)
             if (c->check_zero[i]) HIPCHK(c, hipMemsetAsync(c->check_zero[i], 0, c->check_zero_bytes[i], c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -475,7 +482,7 @@ bool lds_walk_fits(const evofst_ctx *c, int chunk_tiles) {
     const int piece_tiles = std::max(1, std::min(2, chunk_tiles));
     return fused_lds_bytes(c->n_pops, 0, max_n, (int)np, 2 * piece_tiles * (np <= 64 ? 4 : 1), c->count_bytes, 32) <= 100 * 1024;
 }
-int launch_walks(evofst_ctx *c, const K2Params &p, bool with_clean, bool compact, bool marked_only = false) {
+int launch_walks(evofst_ctx *c, const K2Params &p, bool with_clean, bool compact, bool marked_only = false, int max_blocks = 0) {
     const size_t np = c->pairs.size();
     if (lds_walk_fits(c, c->chunk_tiles)) {
         FusedParams f{};
@@ -501,7 +508,7 @@ int launch_walks(evofst_ctx *c, const K2Params &p, bool with_clean, bool compact
             f.compact = compact ? 1 : 0;
             HIPCHK(c, launch_clean_walk(f, c->stream));
         }
-        HIPCHK(c, launch_fused(f, c->count_bytes, wsub, 0, c->stream));
+        HIPCHK(c, launch_fused(f, c->count_bytes, wsub, max_blocks, c->stream));
         return EVOFST_OK;
     }
     if (marked_only) return fail(c, EVOFST_ERR_STATE, "internal: the stream pass was planned for a layout the LDS walk cannot take");
@@ -609,7 +616,7 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
     }
     p.flags[0] = (uint32_t *)c->d_sflag.p; p.flags[1] = (uint32_t *)((unsigned char *)c->d_sflag.p + flag_bytes);
     p.l1_row = c->n_chunks; p.l2_row = c->n_chunks + (int)n1;
-    p.ticket = (uint32_t *)c->d_ssync.p; p.err = (uint32_t *)c->d_ssync.p + 32; p.launches = (uint32_t *)c->d_ssync.p + 48;
+    p.ticket = (uint32_t *)c->d_ssync.p; p.err = (uint32_t *)c->d_ssync.p + 32; p.n_dirty = (uint32_t *)c->d_ssync.p + 40; p.launches = (uint32_t *)c->d_ssync.p + 48;
     p.counts = c->d_counts.p;
     p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
     p.miss_mask = (uint64_t *)c->d_miss.p; p.nan_mask = (uint64_t *)c->d_nan.p;
@@ -644,13 +651,15 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
     if (p.debug) return EVOFST_OK;   // timing switches: rows, tails and marks are not all there, nothing may read them
 #endif
     record(c, 2, 0);
-    if ((rc = launch_walks(c, k2, false, false, true))) return rc;   // the chunks the stream pass marked, if any
+    // the chunks the stream pass marked, if any: a launch that finds none costs 40 us with a grid that fills the device and
+    // a few with a small one, so the grid follows what the passes before this one marked (known at evofst_sync)
+    if ((rc = launch_walks(c, k2, false, false, true, c->stream_dirty_known && c->stream_dirty_last == 0 ? 8 : 0))) return rc;
     record(c, 2, 1);
     record(c, 3, 0);
     HIPCHK(c, launch_stitch(k2, c->stream));
     record(c, 3, 1);
-    c->check_word = (const uint32_t *)c->d_ssync.p + 32;
-    c->check_zero[0] = c->d_ssync.p; c->check_zero_bytes[0] = 128;           // ticket and error words; the launch counter stays
+    c->check_word = (const uint32_t *)c->d_ssync.p + 32; c->check_dirty = true;
+    c->check_zero[0] = c->d_ssync.p; c->check_zero_bytes[0] = 192;           // ticket, error and marked-chunk words; the launch counter stays
     c->check_zero[1] = c->d_sflag.p; c->check_zero_bytes[1] = c->d_sflag.bytes;
     c->check_zero[2] = c->d_sagg.p; c->check_zero_bytes[2] = c->d_sagg.bytes;
     c->offsets_dirty = false;
@@ -1138,6 +1147,7 @@ static int begin_data(evofst_ctx *c, int64_t n_sites) {
     c->plain_counts = false; c->compact_counts = false;
     c->offsets_dirty = true;
     c->n_multi = 0;
+    c->stream_dirty_known = false;       // new data: what the passes before marked says nothing about it
     return EVOFST_OK;
 }
 
@@ -1717,7 +1727,7 @@ extern "C" int evofst_run_pairs_noalloc(evofst_ctx *c, int64_t n_sites, const vo
     HIPCHK(c, launch_stitch(k2, c->stream));
     HIPCHK(c, launch_totals(k2, (const int64_t *)c->d_base.p, d_incl_totals, nullptr, d_carry, c->stream));
     // evofst_sync looks at the pass's error word (a look-back wait that gave up leaves rows, tails and totals unwritten)
-    c->check_word = (const uint32_t *)sp + 32;
+    c->check_word = (const uint32_t *)sp + 32; c->check_dirty = false;
     c->check_zero[0] = sp; c->check_zero_bytes[0] = 256;
     c->check_zero[1] = c->check_zero[2] = nullptr; c->check_zero_bytes[1] = c->check_zero_bytes[2] = 0;
     return EVOFST_OK;

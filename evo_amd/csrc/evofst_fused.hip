@@ -228,11 +228,12 @@ template <typename CT, bool use_rcp, bool WP, int SUB, bool HBM>
 __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WPS) void fused_pairs_kernel(FusedParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (HBM && p.chunk_dirty != nullptr) {        // before anything is set up: does this workgroup's stride hold a marked chunk at all?
+        // (one thread per stride of the grid, all loads at once: a launch that finds nothing costs one memory round trip)
         const int per = WP ? (int)(blockDim.x >> 6) : 1;
-        bool any = false;
-        for (int kc_ = (int)blockIdx.x * per; kc_ < p.n_chunks && !any; kc_ += (int)gridDim.x * per)
-            for (int w = 0; w < per; ++w) any = any || (kc_ + w < p.n_chunks && p.chunk_dirty[kc_ + w] != 0u);
-        if (!any) return;
+        int any = 0;
+        for (int64_t kc_ = ((int64_t)blockIdx.x + (int64_t)threadIdx.x * gridDim.x) * per; kc_ < p.n_chunks; kc_ += (int64_t)blockDim.x * gridDim.x * per)
+            for (int w = 0; w < per; ++w) any |= (kc_ + w < p.n_chunks && p.chunk_dirty[kc_ + w] != 0u) ? 1 : 0;
+        if (!__syncthreads_or(any)) return;
     }
     constexpr int SUBP = SUB + 1;                 // row stride in entries: pop-indexed reads stay conflict-free
     constexpr int SPT = kTileSites / SUB;         // table fills per tile

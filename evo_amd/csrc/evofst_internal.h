@@ -216,6 +216,7 @@ struct StreamParams {
     uint32_t *ticket;               // chunk tickets; back to 0 when the launch ends
     uint32_t *err;                  // set when a wait gave up
     uint32_t *launches;             // launch counter, bumped by the launch's last ticket draw
+    uint32_t *n_dirty;              // chunks left to the general walk, counted on through the launches (the host takes differences)
     // what a chunk the integer walk cannot take leaves for the general walk (K1's and the scan's outputs)
     void *counts;                   // u16 [n_tiles][P][64]
     uint64_t *zf_masks, *irr_mask, *skip_mask, *miss_mask, *nan_mask;

@@ -627,6 +627,7 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
         }
     }
     if (lane == 0) p.chunk_dirty[chunk] = dirty ? 1u : 0u;
+    if (lane == 0 && dirty) __hip_atomic_fetch_add((gu32 *)p.n_dirty, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 
