@@ -13,6 +13,7 @@
 #include <new>
 #include <numeric>
 #include <stdexcept>
+#include <mutex>
 #include <string>
 #include <atomic>
 #include <thread>
@@ -31,6 +32,7 @@ namespace {
 constexpr int kMaxDevices = 64;
 void *g_scratch_ptr[kMaxDevices] = {};        // per device, set by evofst_create
 uint32_t g_scratch_epoch[kMaxDevices] = {};   // per device: launch epochs of the granules in that GPU's scratch
+std::mutex g_scratch_mu[kMaxDevices];         // per device: one host thread at a time carves the scratch, takes an epoch and launches
 
 thread_local std::string g_create_error;
 
@@ -691,14 +693,17 @@ extern "C" evofst_ctx *evofst_create(int device_id) {
         g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
         return nullptr;
     }
-    if (device_id < kMaxDevices && !g_scratch_ptr[device_id]) {
-        // this GPU's copy of the no-allocation scratch array (evofst_run_pairs_noalloc)
-        void *sp = nullptr;
+    if (device_id < kMaxDevices) {
+        // this GPU's copy of the no-allocation scratch array (evofst_run_pairs_noalloc); two threads may create contexts at once
+        std::lock_guard<std::mutex> scratch_lock(g_scratch_mu[device_id]);
+        void *sp = g_scratch_ptr[device_id];
+        if (!sp) {
         if ((e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch))) != hipSuccess) {
             g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
             return nullptr;
         }
         g_scratch_ptr[device_id] = sp;
+        }
     }
     evofst_ctx *c = new (std::nothrow) evofst_ctx();
     if (!c) { g_create_error = "out of host memory"; return nullptr; }
@@ -1696,6 +1701,7 @@ extern "C" int evofst_run_pairs_noalloc(evofst_ctx *c, int64_t n_sites, const vo
     if (need > kNoAllocScratchBytes)
         return fail(c, EVOFST_ERR_UNSUPPORTED, "run_pairs_noalloc: " + std::to_string(need) + " bytes of scratch needed for this many sites x pairs, the static array holds " +
                                                    std::to_string(kNoAllocScratchBytes) + " (use evofst_run)");
+    std::lock_guard<std::mutex> scratch_lock(g_scratch_mu[c->device]);
     unsigned char *sp = (unsigned char *)g_scratch_ptr[c->device];     // the address, never the array's name
     uint32_t &epoch = g_scratch_epoch[c->device];
     if (epoch == 0xffffffffu) {            // the epoch counter wraps: forget every tag

@@ -219,8 +219,11 @@ int evofst_run_stats(evofst_ctx *ctx);
 int evofst_run(evofst_ctx *ctx);
 int evofst_sync(evofst_ctx *ctx);
 
-/* evofst_run for callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc.  It has NO counterpart in the reference (which has no device at all); it is a form of evofst_run in
+/* evofst_run for callers that cannot allocate device memory -- tight serving loops, harnesses that forbid hipMalloc, code
+ * that runs between the launches of a captured graph and must not disturb the allocator.  The call itself is issued from the
+ * host every time and is NOT meant to be recorded into a HIP graph: each call hands the kernels a new launch epoch (a host
+ * counter per GPU that tells this call's look-back granules from the last call's), which a replayed graph would not renew.
+ * It has NO counterpart in the reference (which has no device at all); it is a form of evofst_run in
  * pairs mode that calls no hipMalloc / hipFree: the one-kernel pairs pass (evo_amd/csrc/evofst_fused.hip) keeps its look-back
  * granules, ticket / error words and tail table in a static device array of evofst_noalloc_scratch_bytes() = 16 MiB that every
  * GPU the library runs on holds until the process ends.  Shapes whose scratch would be larger (about n_sites / 16 x n_pairs
@@ -234,8 +237,12 @@ int evofst_sync(evofst_ctx *ctx);
  *   d_first_segment  [n_pairs] index of the first segment that ends in this shard,
  *   d_incl_totals    [n_pairs] included sites of the shard (n_segments = (base + total) / g - base / g),
  *   d_carry          [n_pairs][4] {sum_num, sum_den, sum_dxy_k, n_sites} behind the last complete segment (evofst_get_boundary).
- * Asynchronous on the context's stream.  All calls on one GPU share that GPU's scratch array: calls that overlap on one GPU
- * (two contexts or streams at once) race; one at a time per GPU. */
+ * Asynchronous on the context's stream.  All calls on one GPU share that GPU's scratch array and its epoch counter (process
+ * globals, the one exception to "no global state" behind this ABI): host threads may call concurrently (the library takes a
+ * lock per GPU while it carves the scratch and launches), but the GPU work of two calls on one GPU must not overlap (two
+ * contexts or streams at once race on the array): one at a time per GPU.  The pass sizes its grid for a device it has to
+ * itself; when other streams hold compute units a look-back wait can run out of polls, and then evofst_sync (or the next
+ * getter) returns EVOFST_ERR_HIP and the outputs must be discarded -- never silently wrong rows. */
 int evofst_run_pairs_noalloc(evofst_ctx *ctx, int64_t n_sites, const void *d_tiles, const uint8_t *d_site_flags,
                              void *d_seg_rows, int64_t seg_rows_capacity, int64_t *d_first_segment, int64_t *d_incl_totals,
                              double *d_carry);

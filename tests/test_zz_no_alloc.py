@@ -25,7 +25,14 @@ class Hip:
         self.L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.L.hipFree.argtypes = [C.c_void_p]
+        self.L.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         self.bufs = []
+
+    def free_bytes(self):
+        """Free device memory as the runtime reports it: any hipMalloc / hipFree between two readings shows."""
+        fr, tot = C.c_size_t(), C.c_size_t()
+        assert self.L.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0
+        return fr.value
 
     def alloc(self, nbytes):
         p = C.c_void_p()
@@ -80,6 +87,13 @@ def _one_call(engine, hip, rng, S, N, P, size, step, miss):
     rc = engine.L.evofst_run_pairs_noalloc(engine.h, S, d_tiles, d_fl, d_rows, cap, d_first, d_tot, d_carry)
     assert rc == 0, engine.L.evofst_last_error(engine.h)
     engine.sync()
+    # the property the entry point exists for: once more on the same buffers (code objects are loaded now), and the
+    # runtime's free memory is the same before and after -- nothing was allocated, nothing freed
+    free_before = hip.free_bytes()
+    rc = engine.L.evofst_run_pairs_noalloc(engine.h, S, d_tiles, d_fl, d_rows, cap, d_first, d_tot, d_carry)
+    assert rc == 0, engine.L.evofst_last_error(engine.h)
+    engine.sync()
+    assert hip.free_bytes() == free_before
     rows = hip.down(d_rows, (cap, nq), ROW)
     first = hip.down(d_first, nq, np.int64); tot = hip.down(d_tot, nq, np.int64); carry = hip.down(d_carry, (nq, 4), np.float64)
     hip.free_all()
@@ -114,6 +128,13 @@ def test_no_alloc_entry_point_twice(engine):
     assert engine.L.evofst_noalloc_scratch_bytes() == 16 << 20
     _one_call(engine, hip, rng, 30000, 40, 4, 100, 100, 0.05)
     _one_call(engine, hip, rng, 2500, 60, 5, 20, 10, 0.0)       # a smaller input on the same scratch, other shapes
+
+
+def test_no_alloc_entry_point_more_than_64_pairs(engine):
+    """78 pairs: the workgroup-per-chunk shape of the one-kernel pass (two groups of lanes share a chunk's region)."""
+    hip = Hip()
+    rng = np.random.default_rng(78)
+    _one_call(engine, hip, rng, 20000, 52, 13, 50, 25, 0.02)
 
 
 def test_no_alloc_entry_point_refuses_what_does_not_fit(engine):
