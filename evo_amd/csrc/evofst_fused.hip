@@ -430,11 +430,14 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
         const int32_t left0 = left;
         const int32_t row0 = (int32_t)(m - first_seg);
         size_t orow = (size_t)row0 * p.n_pairs + q;
-        double D = 0.0;                       // sum d^2 (masked by the site filter in general fills)
+        double D = 0.0;                       // sum d^2 over the sites of the current fill (masked by the site filter in general fills)
         uint64_t cc = 0;                      // sum c_i c_j
         uint32_t exi = 0, exj = 0;            // sum of c_i / c_j over excluded sites (general fills only)
         uint32_t bn = 0, bd = 0;              // included sites whose numerator / denominator is NaN in the reference
-        double prevN = 0.0, prevD = 0.0;      // their values at the last boundary
+        // Numerator / denominator sums since the last boundary, complete fills only.  Every floating-point sum here starts at a
+        // fill (D, the per-population tables PH / PT) or at a boundary (segN, segD), never at the chunk: a segment's error
+        // scales with the segment's own sums, whatever the chunk length (256-tile chunks and 20-site windows included).
+        double segN = 0.0, segD = 0.0;
         uint32_t prevCi = 0, prevCj = 0, prevBn = 0, prevBd = 0;
         uint64_t prevCC = 0;
         uint64_t kx = 0, prevKx = 0;          // sumKij terms of excluded sites the regular loop's sums include (fixed in both, alleles missing)
@@ -515,9 +518,9 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
                 const uint32_t yc = __shfl_up(ec, d, VPR);
                 if (r >= d) { eh += yh; et += yt; ec += yc; }
             }
-            const double ch = carH[k], ct = carT[k];
+            const double ch = 0.0, ct = 0.0;                          // the h / t tables start at the fill (see segN below)
             const uint32_t ccar = carC[k];
-            if (r == VPR - 1) { carH[k] = ch + eh; carT[k] = ct + et; carC[k] = ccar + ec; }
+            if (r == VPR - 1) carC[k] = ccar + ec;
             double ah = ch + (eh - rh), at = ct + (et - rt);       // sums before this vector
             uint32_t ac = ccar + (ec - rc);
 #pragma unroll
@@ -607,8 +610,8 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
                     double numI = 0.0, denI = 0.0;
                     if (kInt) int_parts(iCC, iCi, iCj, iQi, iQj, numI, denI, kk);
                     SegRow row;
-                    row.num = cbn != prevBn ? kNaN : (cumN - prevN) + numI;
-                    row.den = cbd != prevBd ? kNaN : (cumD - prevD) + denI;
+                    row.num = cbn != prevBn ? kNaN : (segN + cumN) + numI;      // cumN, cumD: this fill's sums up to b
+                    row.den = cbd != prevBd ? kNaN : (segD + cumD) + denI;
                     row.k = (double)kk;
                     row.end = (gtile0 + ti) * kTileSites + sh + b; row.pad = 0;
                     {   // two 16-byte stores into one 32-byte sector
@@ -616,7 +619,8 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
                         const uint4 *src = reinterpret_cast<const uint4 *>(&row);
                         dst[0] = src[0]; dst[1] = src[1];
                     }
-                    prevN = cumN; prevD = cumD; prevCi = Ci; prevCj = Cj; prevCC = ccc; prevKx = ckx; prevBn = cbn; prevBd = cbd;
+                    segN = -cumN; segD = -cumD;                     // the rest of the fill comes in with the fill's totals
+                    prevCi = Ci; prevCj = Cj; prevCC = ccc; prevKx = ckx; prevBn = cbn; prevBd = cbd;
                     ++nflush;
                     orow += p.n_pairs;
                     const uint32_t rem = b >= SUB - 1 ? 0u : incl & ~((2u << b) - 1u);
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
                             pCi = __builtin_amdgcn_udot4(x, kOnes, pCi, false); pCj = __builtin_amdgcn_udot4(y, kOnes, pCj, false);
                             pQi = __builtin_amdgcn_udot4(x, x, pQi, false); pQj = __builtin_amdgcn_udot4(y, y, pQj, false);
                         }
-                        emit(D, cc, kx, exi, exj, bn, bd, carH[pi] + carH[pj], carT[pi] + carT[pj], carC[pi], carC[pj],
+                        emit(0.0, cc, kx, exi, exj, bn, bd, 0.0, 0.0, carC[pi], carC[pj],
                              aCC + (pCC - dCC), aCi + (pCi - dCi), aCj + (pCj - dCj), aQi + (pQi - dQi), aQj + (pQj - dQj));
                         aCC = aCi = aCj = aQi = aQj = 0;
                         dCC = pCC; dCi = pCi; dCj = pCj; dQi = pQi; dQj = pQj;
@@ -684,6 +688,7 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
                     return sum;
                 };
                 const int bgrp = b & ~(kGrp - 1);
+                D = 0.0;
                 double sD = D;                                 // snapshots at the end of the boundary's group
                 uint64_t scc = cc;
                 uint32_t sexi = exi, sexj = exj, sbn = bn, sbd = bd;   // (the regular loop leaves these four alone)
@@ -791,6 +796,9 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
                     }
                 }
                 if (E) kx = kx0 + kx_sum(E);                   // the whole fill
+                // the fill's totals join the segment's sums (PH / PT at the last site = the populations' totals over the fill)
+                segN += D - (PH[io + SUB - 1] + PH[jo + SUB - 1]);
+                segD += D + (PT[io + SUB - 1] + PT[jo + SUB - 1]);
                 }   // general fill
             }
             region_sync();
@@ -802,13 +810,12 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
             const int sub = HBM ? kc : (WP ? chunk * NWV + wave : chunk);
             const size_t cq = (size_t)sub * p.n_pairs + q;
             const size_t plane = (size_t)p.n_pairs * n_sub;
-            const double H = carH[pi] + carH[pj], T = carT[pi] + carT[pj];
             const uint32_t Ci = carC[pi] - exi, Cj = carC[pj] - exj;
             uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (cc - prevCC) - (kx - prevKx);
             double numI = 0.0, denI = 0.0;
             if (kInt) int_parts(aCC, aCi, aCj, aQi, aQj, numI, denI, kk);
-            p.tail[cq] = bn != prevBn ? kNaN : ((D - H) - prevN) + numI;
-            p.tail[plane + cq] = bd != prevBd ? kNaN : ((D + T) - prevD) + denI;
+            p.tail[cq] = bn != prevBn ? kNaN : segN + numI;
+            p.tail[plane + cq] = bd != prevBd ? kNaN : segD + denI;
             p.tail[2 * plane + cq] = (double)kk;
             p.tail_n[cq] = make_int4((nflush ? p.g : left0) - left, nflush, row0, 0);   // {sites summed in the tail, segments completed, row of the first}
         }
