@@ -78,6 +78,7 @@ SIGNATURES = {
     "evofst_sync": (C.c_int, [_vp]),
     "evofst_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "evofst_last_pairs_pass": (C.c_int, [_vp]),
+    "evofst_get_pair_range_sums": (C.c_int, [_vp, C.c_int, C.c_int64, _i64p, _i64p, _dp, _dp]),
     "evofst_set_profiling": (C.c_int, [_vp, C.c_int]),
     "evofst_get_kernel_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
     "evofst_get_counts": (C.c_int, [_vp, C.c_int64, C.c_int64, _i32p, _i32p]),
@@ -453,6 +454,17 @@ class EvoFst:
         het = np.empty((P, n)); hn = np.empty((P, n)); pi = np.empty((P, n))
         self._chk(self.L.evofst_get_pop_site_div(self.h, first, n, _ptr(het, _dp), _ptr(hn, _dp), _ptr(pi, _dp)))
         return het, hn, pi
+
+    def pair_range_sums(self, pair, lo, hi, init=None):
+        """Sums of one pair's per-site values over site ranges [lo, hi), added in site order from `init` (include/evofst.h:
+        evofst_get_pair_range_sums).  Returns [n_ranges][12]."""
+        lo = np.ascontiguousarray(lo, np.int64); hi = np.ascontiguousarray(hi, np.int64)
+        out = np.empty((len(lo), 12))
+        if init is not None:
+            init = np.ascontiguousarray(init, np.float64)
+            assert init.shape == out.shape
+        self._chk(self.L.evofst_get_pair_range_sums(self.h, int(pair), len(lo), _ptr(lo, _i64p), _ptr(hi, _i64p), _ptr(init, _dp), _ptr(out, _dp)))
+        return out
 
     def segments(self):
         cap = self.L.evofst_max_segments(self.h)

@@ -2222,6 +2222,65 @@ extern "C" int evofst_get_pop_site_div(evofst_ctx *c, int64_t first_site, int64_
     return abi_exception(c);
 }
 
+extern "C" int evofst_get_pair_range_sums(evofst_ctx *c, int pair, int64_t n_ranges, const int64_t *lo, const int64_t *hi,
+                                          const double *init, double *out) try {
+    if (!c || !lo || !hi || !out || n_ranges < 0) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    if (c->mode != MODE_PAIRS) return fail(c, EVOFST_ERR_STATE, "get_pair_range_sums: pairs mode first");
+    if (pair < 0 || (size_t)pair >= c->pairs.size()) return fail(c, EVOFST_ERR_ARG, "get_pair_range_sums: no such pair");
+    if (n_ranges == 0) return EVOFST_OK;
+    if (c->n_sites <= 0 || !c->tiles) return fail(c, EVOFST_ERR_STATE, "get_pair_range_sums: no data");
+    for (int64_t r = 0; r < n_ranges; ++r)
+        if (lo[r] < 0 || hi[r] > c->n_sites || lo[r] > hi[r]) return fail(c, EVOFST_ERR_ARG, "get_pair_range_sums: range outside the shard");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = need_counts(c, "get_pair_range_sums");
+    if (rc) return rc;
+    const size_t n = (size_t)c->n_sites, P = (size_t)c->n_pops;
+    const uint32_t ij = c->pairs[(size_t)pair];
+    const size_t pi = ij & 0xffffu, pj = ij >> 16;
+    DevBuf b[11];
+    rc = EVOFST_OK;
+    const size_t sizes[11] = {n * 8, n * 8, n * 8, n, P * n * 8, P * n * 8, P * n * 8, (size_t)n_ranges * 8, (size_t)n_ranges * 8,
+                              (size_t)n_ranges * kRangeSumCols * 8, (size_t)n_ranges * kRangeSumCols * 8};
+    for (int i = 0; i < 11 && !rc; ++i) rc = ensure(c, b[i], sizes[i]);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        // the pair's per-site values (site_stats_kernel on a one-pair list: the pair's entry of the context's list) and the
+        // per-population diversities, left on the device
+        SiteStatParams sp{};
+        sp.counts = c->d_counts.p; sp.site_flags = c->have_flags ? c->flags : nullptr;
+        sp.n_sites_total = c->n_sites; sp.first_site = 0; sp.n_sites = c->n_sites;
+        sp.P = c->n_pops; sp.n_full = (const int32_t *)c->d_nfull.p;
+        sp.pairs = (const uint32_t *)c->d_pairs.p + pair; sp.n_pairs = 1;
+        sp.num = (double *)b[0].p; sp.den = (double *)b[1].p; sp.dxy = (double *)b[2].p; sp.include = (uint8_t *)b[3].p;
+        e = launch_site_stats(sp, c->count_bytes, c->stream);
+        PopDivParams dp{};
+        dp.counts = c->d_counts.p; dp.first_site = 0; dp.n_sites = c->n_sites; dp.P = c->n_pops;
+        dp.n_full = (const int32_t *)c->d_nfull.p;
+        dp.het = (double *)b[4].p; dp.het_nei = (double *)b[5].p; dp.pi = (double *)b[6].p;
+        if (e == hipSuccess) e = launch_pop_div(dp, c->count_bytes, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(b[7].p, lo, (size_t)n_ranges * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(b[8].p, hi, (size_t)n_ranges * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && init) e = hipMemcpyAsync(b[9].p, init, sizes[9], hipMemcpyHostToDevice, c->stream);
+        RangeSumParams rp{};
+        rp.num = sp.num; rp.den = sp.den; rp.dxy = sp.dxy; rp.include = sp.include;
+        rp.het_i = dp.het + pi * n; rp.het_j = dp.het + pj * n; rp.nei_i = dp.het_nei + pi * n; rp.nei_j = dp.het_nei + pj * n;
+        rp.pi_i = dp.pi + pi * n; rp.pi_j = dp.pi + pj * n;
+        rp.n_sites = c->n_sites; rp.n_ranges = n_ranges;
+        rp.lo = (const int64_t *)b[7].p; rp.hi = (const int64_t *)b[8].p; rp.init = init ? (const double *)b[9].p : nullptr;
+        rp.out = (double *)b[10].p;
+        if (e == hipSuccess) e = launch_pair_range_sums(rp, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out, b[10].p, sizes[10], hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    for (auto &x : b) release(x);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(c, e, "get_pair_range_sums");
+    return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
+}
+
 extern "C" int64_t evofst_max_segments(evofst_ctx *c) {
     if (!c || !c->stats_done || c->mode != MODE_PAIRS) return 0;
     return c->seg_cap;

@@ -288,6 +288,18 @@ struct PopDivParams {
     double *het, *het_nei, *pi;  // [P][n_sites]
 };
 
+// evofst_get_pair_range_sums: per-site arrays of ONE pair ([n_sites] each) and the caller's ranges
+constexpr int kRangeSumCols = 12;
+struct RangeSumParams {
+    const double *num, *den, *dxy, *het_i, *het_j, *nei_i, *nei_j, *pi_i, *pi_j;
+    const uint8_t *include;
+    int64_t n_sites, n_ranges;
+    const int64_t *lo, *hi;      // [n_ranges] sites [lo, hi)
+    const double *init;          // [n_ranges][kRangeSumCols] or null
+    double *out;                 // [n_ranges][kRangeSumCols]
+};
+hipError_t launch_pair_range_sums(const RangeSumParams &p, hipStream_t st);
+
 struct GlobalParams {
     const void *counts;
     const uint2 *totals;

@@ -1990,6 +1990,36 @@ hipError_t launch_pop_div(const PopDivParams &p, int count_bytes, hipStream_t st
     return hipGetLastError();
 }
 
+// Sums of one pair's per-site values over ranges of sites, one thread per range, the sites in order: exactly the order in
+// which vector_average / vector_average_withRegion add a window's values (process_vcf_utils.h:369-385), so a window that
+// continues a partial sum of an earlier batch (init) comes out as the reference's one loop over it would.  The ranges are
+// the caller's: SNP windows, physical windows, the whole shard (process_vcf_fst.cpp:589-692, 701-709).
+__global__ __launch_bounds__(64) void pair_range_sums_kernel(RangeSumParams p) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n_ranges) return;
+    double a[kRangeSumCols];
+#pragma unroll
+    for (int k = 0; k < kRangeSumCols; ++k) a[k] = p.init ? p.init[r * kRangeSumCols + k] : 0.0;
+    const int64_t lo = max((int64_t)0, p.lo[r]), hi = min(p.n_sites, p.hi[r]);
+    for (int64_t s = lo; s < hi; ++s) {
+        if (!p.include[s]) continue;                         // filter, fst.cpp:543-544
+        a[0] += p.num[s]; a[1] += p.den[s]; a[2] += p.dxy[s];
+        const double pi_i = p.pi_i[s], pi_j = p.pi_j[s];
+        a[3] += p.het_i[s]; a[4] += p.het_j[s]; a[5] += p.nei_i[s]; a[6] += p.nei_j[s];
+        a[7] += pi_i; a[8] += pi_j;
+        a[9] += 1.0;
+        a[10] += pi_i != 0.0 ? 1.0 : 0.0; a[11] += pi_j != 0.0 ? 1.0 : 0.0;   // (std::count(.., 0) of fst.cpp:609-610, complemented)
+    }
+#pragma unroll
+    for (int k = 0; k < kRangeSumCols; ++k) p.out[r * kRangeSumCols + k] = a[k];
+}
+
+hipError_t launch_pair_range_sums(const RangeSumParams &p, hipStream_t st) {
+    if (p.n_ranges <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pair_range_sums_kernel, dim3((unsigned)((p.n_ranges + 63) / 64)), dim3(64), 0, st, p);
+    return hipGetLastError();
+}
+
 template <typename CT>
 __global__ __launch_bounds__(256) void unpack_counts_kernel(const void *counts, int P, int64_t first_site,
                                                             int64_t n_sites, int32_t *alt, int32_t *nm) {

@@ -351,6 +351,16 @@ int evofst_get_indiv_hets(evofst_ctx *ctx, int32_t *het, int32_t *shared);
  * process_vcf_fst.cpp:325-371): arrays [n_pops][n_sites]; any pointer may be NULL. */
 int evofst_get_pop_site_div(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *het,
                             double *het_nei, double *pi);
+/* Sums of ONE pair's per-site values over ranges of sites of the uploaded shard: the window sums of the two-set `evo fst`
+ * (SNP windows process_vcf_fst.cpp:638-692, physical windows :589-629, the genome-wide averages :701-709), which the
+ * reference forms by adding per-site values in site order (vector_average / vector_average_withRegion,
+ * process_vcf_utils.h:369-385).  Range r = sites [lo[r], hi[r]); only the sites the pair includes (filter :543-544) count.
+ * out[r][12] = sums of {Fst numerator, Fst denominator, dxy, heterozygosity of population i, of j, Nei's of i, of j,
+ * pi of i, of j}, then {included sites, included sites with pi(i) != 0, with pi(j) != 0}; every sum starts from init[r][..]
+ * (NULL: zero) and adds the sites in order, one after the other, so a window cut in two by a batch boundary comes out as
+ * one loop over it would.  The caller owns the coordinates (which sites a window holds); the device owns every sum. */
+int evofst_get_pair_range_sums(evofst_ctx *ctx, int pair, int64_t n_ranges, const int64_t *lo, const int64_t *hi,
+                               const double *init, double *out);
 /* Segment sums.  A segment is g = gcd(SIZE, STEP) consecutive included sites of a pair (in
  * against-all mode: see evofst_get_global_windows instead).  Segment m of pair q covers the
  * pair's included sites with 1-based global rank (m*g, (m+1)*g]; window "ending at rank e" is

@@ -207,6 +207,42 @@ def test_snp_windows_clean_and_dirty_chunks(engine, S, N, P, dirty):
         _check_windows(engine, sp, codes, None, P, 100, 50, tag="snp_windows_clean_and_dirty_chunks")
 
 
+def test_pair_range_sums_in_site_order(engine):
+    """evofst_get_pair_range_sums: the sums of a pair's per-site values over caller-cut ranges, added in site order from a
+    carried-in start value -- bit for bit what one loop over the oracle's per-site values gives (the per-site values are
+    bit-exact, test_site_stats_bit_exact, and the order of the additions is the reference's, process_vcf_utils.h:369-385)."""
+    S, N, P = 3000, 46, 3
+    rng = np.random.default_rng(4242)
+    sp, codes, fl = _setup(engine, rng, S, N, P, 0.15, flags=True)
+    engine.set_pairs()
+    pi, pj = engine.all_pairs()
+    nf = n_full_of(sp, P)
+    oalt, onm = O.counts_from_codes(codes, sp, P)
+    onum, oden, odxy, oinc = O.pair_site_stats(oalt, onm, nf, pi, pj, fl)
+    ohet, ohn, opi = O.pop_site_div(oalt, onm, nf)
+    lo = np.concatenate(([0, 0, S, 17], rng.integers(0, S - 200, 40)))
+    hi = np.concatenate(([S, 0, S, 18], lo[4:] + rng.integers(0, 200, 40)))
+    init = rng.normal(0, 3, (len(lo), 12)); init[::3] = 0.0
+    for q in (0, len(pi) - 1):
+        for start in (None, init):
+            got = engine.pair_range_sums(q, lo, hi, start)
+            for r in range(len(lo)):
+                a = np.zeros(12) if start is None else start[r].copy()
+                with np.errstate(all="ignore"):
+                    for s_ in range(lo[r], hi[r]):
+                        if not oinc[s_, q]:
+                            continue
+                        vals = (onum[s_, q], oden[s_, q], odxy[s_, q], ohet[s_, pi[q]], ohet[s_, pj[q]], ohn[s_, pi[q]], ohn[s_, pj[q]],
+                                opi[s_, pi[q]], opi[s_, pj[q]], 1.0, float(opi[s_, pi[q]] != 0), float(opi[s_, pj[q]] != 0))
+                        for k, v in enumerate(vals):
+                            a[k] = a[k] + v
+                assert_same_bits(got[r], a)
+    with pytest.raises(Exception):
+        engine.pair_range_sums(0, [0], [S + 1])
+    with pytest.raises(Exception):
+        engine.pair_range_sums(len(pi), [0], [1])
+
+
 @pytest.mark.parametrize("prod,cons,chunk_tiles,bufs,sets", [(8, 0, 16, 2, 1), (6, 0, 12, 3, 1), (6, 0, 12, 3, 2), (3, 1, 3, 4, 2),
                                                              (1, 0, 2, 2, 1), (8, 0, 8, 4, 1)])
 def test_stream_pass_shapes(engine, prod, cons, chunk_tiles, bufs, sets):
