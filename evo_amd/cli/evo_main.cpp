@@ -160,16 +160,6 @@ double vector_average(const std::vector<double> &v) {   // process_vcf_utils.h:3
     for (size_t i = 0; i < v.size(); i++) sum += v[i];
     return (double)sum / (double)v.size();
 }
-double vector_average_tail(const std::vector<double> &v, size_t n) {
-    double sum = 0;
-    for (size_t i = v.size() - n; i < v.size(); i++) sum += v[i];
-    return (double)sum / (double)n;
-}
-double vector_tail_with_region(const std::vector<double> &v, size_t n, int region) {  // utils.h:378-385
-    double sum = 0;
-    for (size_t i = v.size() - n; i < v.size(); i++) sum += v[i];
-    return (double)sum / (double)region;
-}
 double calculateFst(double numAvg, double denAvg) {      // process_vcf_fst.cpp:354-360
     double Fst = numAvg / denAvg;
     if (Fst < 0) Fst = 0;
@@ -700,22 +690,45 @@ int fstMain(int argc, char **argv) {
     std::vector<string> set1 = split(set1String, ','), set2 = split(set2String, ',');
     std::sort(set1.begin(), set1.end()); std::sort(set2.begin(), set2.end());
 
-    // reference state (process_vcf_fst.cpp:448-472)
+    // What the host keeps is coordinates and counters (process_vcf_fst.cpp:448-472): which included site a window starts and
+    // ends at, scaffold and position strings, the accessible bases.  Every sum -- SNP windows (:638-692), physical windows
+    // (:589-629), the genome-wide averages (:701-709) -- is formed on the device over site ranges this bookkeeping cuts
+    // (evofst_get_pair_range_sums: the sites of a range added one after the other, as vector_average does), and a window a
+    // batch boundary cuts in two goes on from the sums of its first part.
     int totalVariantNumber = 0, countedVariantNumber = 0;
     string windowMiddleVariant = "first\tWindow", windowStartEnd = "scaffold_0\t0";
     int windowStart = 0, windowEnd = 0, fixedWindowStart = 0;
-    std::vector<double> fwDxy, fwNum, fwDen, fwPi1, fwPi2;
-    std::vector<double> fstNumerators, fstDenominators, DxyVector, het1S, het2S, het1N, het2N, pi1V, pi2V;
     std::vector<size_t> set1Loci, set2Loci;
+    typedef std::array<double, 12> Sums;   // {num, den, dxy, het1, het2, hetNei1, hetNei2, pi1, pi2, sites, sites pi1 != 0, sites pi2 != 0}
+    enum RequestKind { SNP_WINDOW, FIXED_WINDOW, OPEN_SNP_WINDOW, OPEN_FIXED_WINDOW, WHOLE_BATCH };
+    struct Request {
+        RequestKind kind;
+        int64_t lo = 0, hi = 0;            // sites of this batch
+        bool carried = false; Sums init{}; // goes on from an earlier batch's part
+        long long endCount = 0;            // SNP windows: countedVariantNumber at the last site
+        bool equalStep = false, sameScaffold = false;
+        string where, scaffold, regionStart, after;   // coordinates of the row; rows without sums that follow it
+        int region = 0, acc = 0, fwStart = 0;
+    };
+    std::vector<Request> req;
+    std::map<long long, Sums> openSnp;     // SNP windows begun in an earlier batch: end count -> sums so far
+    Sums fwCarry{}; bool fwCarried = false;   // the physical window begun in an earlier batch
+    Sums total{};                          // all included sites so far
 
     Device dev;
     Batch batch;
     int nSamples = 0, nVirtual = 0;
     std::vector<size_t> virt;          // virtual sample -> VCF column (set 1 entries, then set 2 entries)
     std::vector<int32_t> virt32;
-    std::vector<double> num, den, dxy, het, hetNei, pi;
+    std::vector<double> num, den, dxy;   // per-site values: only for the outputs that are per site (-w 1,1, --annot, --ancSets)
     std::vector<uint8_t> inc;
+    std::vector<int64_t> incSites, rlo, rhi;
+    std::vector<double> rinit, rout;
     bool haveHeader = false;
+    const bool perSite = windowSize == 1 || haveAnc || haveAnnot;
+    const size_t W = (size_t)std::max(windowSize, 0);
+
+    auto negNaN = [](Sums &a) { for (int k = 0; k < 9; ++k) if (a[k] != a[k]) a[k] = -__builtin_fabs(a[k]); };   // the sign of x86's default NaN ("-nan")
 
     auto flush = [&]() {
         if (batch.n == 0) return;
@@ -723,26 +736,28 @@ int fstMain(int argc, char **argv) {
         const auto tFlush = std::chrono::steady_clock::now();
         struct Acc { std::chrono::steady_clock::time_point t; ~Acc() { g_timing.batches += Timing::since(t); } } acc{tFlush};
         dev.load(batch, EVOFST_MODE_FST, nSamples, virt32, totalVariantNumber - (long long)n + 1);
-        num.resize(n); den.resize(n); dxy.resize(n); inc.resize(n);
-        het.resize(2 * n); hetNei.resize(2 * n); pi.resize(2 * n);
-        check(dev.ctx, evofst_get_site_stats(dev.ctx, 0, (int64_t)n, num.data(), den.data(), dxy.data(), inc.data()), "site_stats");
-        check(dev.ctx, evofst_get_pop_site_div(dev.ctx, 0, (int64_t)n, het.data(), hetNei.data(), pi.data()), "pop_site_div");
-        x86_nan_sign(num); x86_nan_sign(den); x86_nan_sign(dxy); x86_nan_sign(het); x86_nan_sign(hetNei); x86_nan_sign(pi);
+        inc.resize(n);
+        if (perSite) { num.resize(n); den.resize(n); dxy.resize(n); }
+        check(dev.ctx, evofst_get_site_stats(dev.ctx, 0, (int64_t)n, perSite ? num.data() : nullptr, perSite ? den.data() : nullptr,
+                                             perSite ? dxy.data() : nullptr, inc.data()), "site_stats");
+        if (perSite) { x86_nan_sign(num); x86_nan_sign(den); x86_nan_sign(dxy); }
+        incSites.clear();
+        for (size_t s = 0; s < n; ++s) if (inc[s]) incSites.push_back((int64_t)s);
+        const long long counted0 = countedVariantNumber;
+        // first site of a window that ends at count `endCount`, or -1 when it began in an earlier batch
+        auto firstSiteOf = [&](long long endCount) -> int64_t {
+            const long long first = endCount - (long long)W + 1;
+            return first > counted0 ? incSites[(size_t)(first - counted0 - 1)] : -1;
+        };
+        req.clear();
+        int64_t fwLo = 0;
         for (size_t s = 0; s < n; ++s) {
             if (!inc[s]) continue;                                  // filter, fst.cpp:543-544
             const string &scaffold = batch.chrom[s];
             const string &loc = batch.pos[s];
             countedVariantNumber++;
-            const double FstNumerator = num[s], FstDenominator = den[s], thisSNPDxy = dxy[s];
-            fstNumerators.push_back(FstNumerator); fwNum.push_back(FstNumerator);
-            fstDenominators.push_back(FstDenominator); fwDen.push_back(FstDenominator);
-            DxyVector.push_back(thisSNPDxy); fwDxy.push_back(thisSNPDxy);
-            fwPi1.push_back(pi[s]); fwPi2.push_back(pi[n + s]);
-            pi1V.push_back(pi[s]); pi2V.push_back(pi[n + s]);
-            het1S.push_back(het[s]); het2S.push_back(het[n + s]);
-            het1N.push_back(hetNei[s]); het2N.push_back(hetNei[n + s]);
             if (haveAnc) {                                          // fst.cpp:563-588
-                double thisSNPFst = FstNumerator / FstDenominator;
+                double thisSNPFst = num[s] / den[s];
                 if (thisSNPFst < 0) thisSNPFst = 0;
                 const std::vector<string> fields = split(batch.lines[s], '\t');
                 const std::vector<string> info = split(fields[7], ';');
@@ -767,80 +782,124 @@ int fstMain(int argc, char **argv) {
                 ancSetsOutFile << (((f3 > 0) & (f3 < 1)) ? "1" : "0") << "\t" << (((f4 > 0) & (f4 < 1)) ? "1" : "0") << std::endl;
             }
             if (haveAnnot)                                          // fst.cpp:558-562
-                snpCategoryFstFile << annotation.category(scaffold, loc) << "\t" << FstNumerator / FstDenominator << "\t" << thisSNPDxy << "\t" << scaffold << "\t" << loc << std::endl;
-            // physical windows, fst.cpp:589-629
-            // (the reference splits windowStartEnd at every site to compare its first field; the comparison alone is enough)
+                snpCategoryFstFile << annotation.category(scaffold, loc) << "\t" << num[s] / den[s] << "\t" << dxy[s] << "\t" << scaffold << "\t" << loc << std::endl;
+            // physical windows, fst.cpp:589-629: this site already belongs to the window it closes; a window is the included
+            // sites since the last one closed (or since the scaffold changed, which drops this site too)
             const size_t tab0 = windowStartEnd.find('\t');
             const size_t len0 = tab0 == string::npos ? windowStartEnd.size() : tab0;
             if (len0 == scaffold.size() && windowStartEnd.compare(0, len0, scaffold) == 0) {
-                if (atoi(loc.c_str()) > (fixedWindowStart + physicalWindowSize)) {
-                    int acc = physicalWindowSize;
-                    if (haveBed) acc = bed.basesIn(scaffold, fixedWindowStart, fixedWindowStart + physicalWindowSize);
-                    double fDxy = vector_tail_with_region(fwDxy, fwDxy.size(), acc);
-                    double fFst = calculateFst(vector_average(fwNum), vector_average(fwDen));
-                    double fPi1 = vector_tail_with_region(fwPi1, fwPi1.size(), acc);
-                    double fPi2 = vector_tail_with_region(fwPi2, fwPi2.size(), acc);
-                    int z1 = (int)std::count(fwPi1.begin(), fwPi1.end(), 0), z2 = (int)std::count(fwPi2.begin(), fwPi2.end(), 0);
-                    int nv1 = (int)fwPi1.size() - z1, nv2 = (int)fwPi2.size() - z2;
-                    fwFile << scaffold << "\t" << fixedWindowStart << "\t" << fixedWindowStart + physicalWindowSize << "\t" << fFst << "\t" << fDxy << "\t" << fPi1 << "\t" << fPi2 << "\t" << acc << "\t" << (double)nv1 / acc << "\t" << (double)nv2 / acc << std::endl;
-                    fwDxy.clear(); fwNum.clear(); fwDen.clear(); fwPi1.clear(); fwPi2.clear();
+                const int here = atoi(loc.c_str());
+                if (here > (fixedWindowStart + physicalWindowSize)) {
+                    Request r; r.kind = FIXED_WINDOW; r.lo = fwLo; r.hi = (int64_t)s + 1; r.carried = fwCarried; r.init = fwCarry;
+                    r.scaffold = scaffold; r.fwStart = fixedWindowStart;
+                    r.acc = haveBed ? bed.basesIn(scaffold, fixedWindowStart, fixedWindowStart + physicalWindowSize) : physicalWindowSize;
+                    std::ostringstream empty;                    // the windows without a site between this one and the next
                     int without = 0;
-                    while (atoi(loc.c_str()) > (fixedWindowStart + physicalWindowSize)) {
+                    while (here > (fixedWindowStart + physicalWindowSize)) {
                         if (without > 0) {
                             const int acc0 = haveBed ? bed.basesIn(scaffold, fixedWindowStart, fixedWindowStart + physicalWindowSize) : physicalWindowSize;
-                            fwFile << scaffold << "\t" << fixedWindowStart << "\t" << fixedWindowStart + physicalWindowSize << "\t" << "NA" << "\t" << 0 << "\t" << 0 << "\t" << 0 << "\t" << acc0 << "\t" << 0 << "\t" << 0 << std::endl;
+                            empty << scaffold << "\t" << fixedWindowStart << "\t" << fixedWindowStart + physicalWindowSize << "\t" << "NA" << "\t" << 0 << "\t" << 0 << "\t" << 0 << "\t" << acc0 << "\t" << 0 << "\t" << 0 << std::endl;
                         }
                         fixedWindowStart = fixedWindowStart + physicalWindowSize;
                         without++;
                     }
+                    r.after = empty.str();
+                    req.push_back(std::move(r));
+                    fwLo = (int64_t)s + 1; fwCarried = false;
                 }
             } else {
                 fixedWindowStart = 0;
-                fwDxy.clear(); fwNum.clear(); fwDen.clear(); fwPi1.clear(); fwPi2.clear();
+                fwLo = (int64_t)s + 1; fwCarried = false;
             }
             if (windowSize == 1) {                                   // fst.cpp:633-636
-                double Fst = FstNumerator / FstDenominator;
+                double Fst = num[s] / den[s];
                 if (Fst < 0) Fst = 0;
-                pFst << countedVariantNumber << "\t" << scaffold + "\t" + loc << "\t" << Fst << "\t" << thisSNPDxy << std::endl;
+                pFst << countedVariantNumber << "\t" << scaffold + "\t" + loc << "\t" << Fst << "\t" << dxy[s] << std::endl;
             } else if ((windowSize > 0) && (countedVariantNumber % windowStep == 0) && countedVariantNumber >= windowSize) {
-                const size_t W = (size_t)windowSize;
-                double windowFst = calculateFst(vector_average_tail(fstNumerators, W), vector_average_tail(fstDenominators, W));
-                double windowDxy = vector_average_tail(DxyVector, W);
-                if (windowSize == windowStep) {
-                    std::vector<string> s = split(windowStartEnd, '\t');
-                    if (s[0] == scaffold) {
+                Request r; r.kind = SNP_WINDOW; r.endCount = countedVariantNumber; r.hi = (int64_t)s + 1;
+                const int64_t first = firstSiteOf(r.endCount);
+                if (first >= 0) r.lo = first;
+                else { r.lo = 0; r.carried = true; r.init = openSnp.at(r.endCount); }
+                r.equalStep = windowSize == windowStep;
+                if (r.equalStep) {                                   // :640-650, 676-688: the window's coordinates
+                    const size_t t0 = windowStartEnd.find('\t');
+                    r.sameScaffold = windowStartEnd.compare(0, t0, scaffold) == 0 && t0 == scaffold.size();
+                    if (r.sameScaffold) {
+                        r.scaffold = scaffold; r.regionStart = split(windowStartEnd, '\t')[1];
                         windowStartEnd = windowStartEnd + "\t" + loc;
                         windowEnd = atoi(loc.c_str());
-                        double dxyInc = vector_tail_with_region(DxyVector, W, windowEnd - windowStart);
-                        pFst << countedVariantNumber - windowSize + 1 << "\t" << windowStartEnd << "\t" << windowFst << "\t" << windowDxy << "\t" << dxyInc << "\t" << W << std::endl;
-                        if (regAbove > 0) {
-                            if (windowFst >= regAbove && !inRegAbove) { inRegAbove = true; regionsAboveFstFile << s[0] << "\t" << s[1] << "\t"; }
-                            else if (windowFst < regAbove && inRegAbove) { inRegAbove = false; regionsAboveFstFile << s[1] << std::endl; }
-                        }
-                    }
-                } else {
-                    pFst << countedVariantNumber - windowSize + 1 << "\t" << windowMiddleVariant << "\t" << windowFst << "\t" << windowDxy << "\t" << W << std::endl;
-                }
-                double wS1 = vector_average_tail(het1S, W), wS2 = vector_average_tail(het2S, W);
-                double wN1 = vector_average_tail(het1N, W), wN2 = vector_average_tail(het2N, W);
-                double wPi1 = vector_tail_with_region(pi1V, W, windowEnd - windowStart);
-                double wPi2 = vector_tail_with_region(pi2V, W, windowEnd - windowStart);
-                if (windowSize == windowStep) {
-                    std::vector<string> s = split(windowStartEnd, '\t');
-                    if (s[0] == scaffold) {
-                        pHet << windowStartEnd << "\t" << wS1 << "\t" << wS2 << "\t" << wN1 << "\t" << wN2 << "\t" << wPi1 << "\t" << wPi2 << std::endl;
+                        r.where = windowStartEnd; r.region = windowEnd - windowStart;
                         windowStartEnd = scaffold + "\t" + loc;
                         windowStart = atoi(loc.c_str());
                     } else {
                         windowStartEnd = scaffold + "\t0";
                         windowStart = 0;
                     }
-                } else {
-                    pHet << windowMiddleVariant << "\t" << wS1 << "\t" << wS2 << "\t" << wN1 << "\t" << wN2 << std::endl;
+                } else {                                             // :662, 690-691
+                    r.where = windowMiddleVariant;
                     windowMiddleVariant = scaffold + "\t" + loc;
                 }
+                req.push_back(std::move(r));
             }
         }
+        // the windows that go on in the next batch, the physical window that is open, and the genome-wide sums
+        if (windowSize > 1) {
+            for (long long e = (countedVariantNumber / windowStep + 1) * (long long)windowStep; e - (long long)W + 1 <= countedVariantNumber; e += windowStep) {
+                if (e < (long long)W) continue;
+                Request r; r.kind = OPEN_SNP_WINDOW; r.endCount = e; r.hi = (int64_t)n;
+                const int64_t first = firstSiteOf(e);
+                if (first >= 0) r.lo = first;
+                else { r.lo = 0; r.carried = true; r.init = openSnp.at(e); }
+                req.push_back(std::move(r));
+            }
+        }
+        { Request r; r.kind = OPEN_FIXED_WINDOW; r.lo = fwLo; r.hi = (int64_t)n; r.carried = fwCarried; r.init = fwCarry; req.push_back(std::move(r)); }
+        { Request r; r.kind = WHOLE_BATCH; r.lo = 0; r.hi = (int64_t)n; r.carried = true; r.init = total; req.push_back(std::move(r)); }
+        const size_t nr = req.size();
+        rlo.resize(nr); rhi.resize(nr); rinit.assign(nr * 12, 0.0); rout.resize(nr * 12);
+        for (size_t i = 0; i < nr; ++i) {
+            rlo[i] = req[i].lo; rhi[i] = req[i].hi;
+            if (req[i].carried) std::copy(req[i].init.begin(), req[i].init.end(), rinit.begin() + (std::ptrdiff_t)(i * 12));
+        }
+        check(dev.ctx, evofst_get_pair_range_sums(dev.ctx, 0, (int64_t)nr, rlo.data(), rhi.data(), rinit.data(), rout.data()), "pair_range_sums");
+        std::map<long long, Sums> stillOpen;
+        for (size_t i = 0; i < nr; ++i) {
+            const Request &r = req[i];
+            Sums a;
+            std::copy(rout.begin() + (std::ptrdiff_t)(i * 12), rout.begin() + (std::ptrdiff_t)(i * 12 + 12), a.begin());
+            if (r.kind == OPEN_SNP_WINDOW) { stillOpen[r.endCount] = a; continue; }
+            if (r.kind == OPEN_FIXED_WINDOW) { fwCarry = a; fwCarried = true; continue; }
+            if (r.kind == WHOLE_BATCH) { total = a; continue; }
+            negNaN(a);
+            if (r.kind == FIXED_WINDOW) {                            // fst.cpp:598-612
+                const double fDxy = a[2] / (double)r.acc;
+                const double fFst = calculateFst(a[0] / a[9], a[1] / a[9]);
+                const double fPi1 = a[7] / (double)r.acc, fPi2 = a[8] / (double)r.acc;
+                const int nv1 = (int)a[10], nv2 = (int)a[11];
+                fwFile << r.scaffold << "\t" << r.fwStart << "\t" << r.fwStart + physicalWindowSize << "\t" << fFst << "\t" << fDxy << "\t" << fPi1 << "\t" << fPi2 << "\t" << r.acc << "\t" << (double)nv1 / r.acc << "\t" << (double)nv2 / r.acc << std::endl;
+                fwFile << r.after;
+                continue;
+            }
+            // SNP window, fst.cpp:638-692
+            const double windowFst = calculateFst(a[0] / (double)W, a[1] / (double)W);
+            const double windowDxy = a[2] / (double)W;
+            const double wS1 = a[3] / (double)W, wS2 = a[4] / (double)W, wN1 = a[5] / (double)W, wN2 = a[6] / (double)W;
+            if (r.equalStep) {
+                if (!r.sameScaffold) continue;
+                const double dxyInc = a[2] / (double)r.region;
+                pFst << r.endCount - windowSize + 1 << "\t" << r.where << "\t" << windowFst << "\t" << windowDxy << "\t" << dxyInc << "\t" << W << std::endl;
+                if (regAbove > 0) {
+                    if (windowFst >= regAbove && !inRegAbove) { inRegAbove = true; regionsAboveFstFile << r.scaffold << "\t" << r.regionStart << "\t"; }
+                    else if (windowFst < regAbove && inRegAbove) { inRegAbove = false; regionsAboveFstFile << r.regionStart << std::endl; }
+                }
+                const double wPi1 = a[7] / (double)r.region, wPi2 = a[8] / (double)r.region;
+                pHet << r.where << "\t" << wS1 << "\t" << wS2 << "\t" << wN1 << "\t" << wN2 << "\t" << wPi1 << "\t" << wPi2 << std::endl;
+            } else {
+                pFst << r.endCount - windowSize + 1 << "\t" << r.where << "\t" << windowFst << "\t" << windowDxy << "\t" << W << std::endl;
+                pHet << r.where << "\t" << wS1 << "\t" << wS2 << "\t" << wN1 << "\t" << wN2 << std::endl;
+            }
+        }
+        openSnp.swap(stillOpen);
         batch.clear();
     };
 
@@ -893,8 +952,10 @@ int fstMain(int argc, char **argv) {
         if (totalVariantNumber % 100000 == 0) std::cerr << totalVariantNumber << " variants processed..." << std::endl;
     }
     flush();
-    double Fst = calculateFst(vector_average(fstNumerators), vector_average(fstDenominators));   // fst.cpp:701-709
-    double oS1 = vector_average(het1S), oS2 = vector_average(het2S), oN1 = vector_average(het1N), oN2 = vector_average(het2N);
+    negNaN(total);
+    const double nCounted = (double)countedVariantNumber;                                          // fst.cpp:701-709
+    double Fst = calculateFst(total[0] / nCounted, total[1] / nCounted);
+    double oS1 = total[3] / nCounted, oS2 = total[4] / nCounted, oN1 = total[5] / nCounted, oN2 = total[6] / nCounted;
     std::cerr << "Fst: " << Fst << std::endl;
     std::cerr << "Heterozygosities: " << "\tS1:" << oS1 << "\tS2:" << oS2 << "\tNei1:" << oN1 << "\tNei2" << oN2 << std::endl;
     pHet << "#Heterozygosities: " << "\tS1:" << oS1 << "\tS2:" << oS2 << "\tNei1:" << oN1 << "\tNei2" << oN2 << std::endl;
