@@ -78,6 +78,7 @@ SIGNATURES = {
     "evofst_sync": (C.c_int, [_vp]),
     "evofst_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "evofst_last_pairs_pass": (C.c_int, [_vp]),
+    "evofst_device_count": (C.c_int, []),
     "evofst_get_pair_range_sums": (C.c_int, [_vp, C.c_int, C.c_int64, _i64p, _i64p, _dp, _dp]),
     "evofst_set_profiling": (C.c_int, [_vp, C.c_int]),
     "evofst_get_kernel_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <array>
+#include <functional>
 #include <numeric>
 #include <chrono>
 #include <cmath>
@@ -178,6 +179,8 @@ void x86_nan_sign(std::vector<double> &v) {
 struct Timing {
     bool on = getenv("EVO_TIMING") != nullptr;
     double pack = 0, device = 0, batches = 0;
+    std::mutex mu;                      // (several device threads report: evo fst --devices)
+    void add(double &field, double dt) { std::lock_guard<std::mutex> lock(mu); field += dt; }
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     static double since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
     ~Timing() {
@@ -214,8 +217,8 @@ struct Device {
     uint8_t *pinned[2] = {nullptr, nullptr};
     size_t pinnedBytes[2] = {0, 0};
     int turn = 0;
-    void open() {
-        ctx = evofst_create(0);
+    void open(int device = 0) {
+        ctx = evofst_create(device);
         if (!ctx) die(string("no usable GPU: ") + evofst_last_error(nullptr));
     }
     void close() {
@@ -248,12 +251,12 @@ struct Device {
                                   threads, tiles, b.flags.data()) != EVOFST_OK)
             die("malformed VCF line among lines " + numToString(firstLineNo) + ".." + numToString(firstLineNo + (long long)b.n - 1) +
                 " (diploid GT fields with single-digit alleles are required)");
-        g_timing.pack += Timing::since(t);
+        g_timing.add(g_timing.pack, Timing::since(t));
         t = std::chrono::steady_clock::now();
         check(ctx, evofst_upload(ctx, (int64_t)b.n, tiles, b.flags.data(), nullptr), "upload");
         check(ctx, evofst_run_counts(ctx), "run_counts");
         check(ctx, evofst_sync(ctx), "sync");
-        g_timing.device += Timing::since(t);
+        g_timing.add(g_timing.device, Timing::since(t));
     }
 };
 
@@ -392,7 +395,7 @@ struct GeneAnnotation {
 
 namespace fstopt {
 string vcfFile, sampleSets, sampleNameFile, runName = "", popsFile, pairsArg, accessibleBed, annotFile, ancSets;
-int windowSize = 0, windowStep = 0, physicalWindowSize = 10000;
+int windowSize = 0, windowStep = 0, physicalWindowSize = 10000, devices = 1;
 double regAbove = 0;
 }
 
@@ -410,6 +413,10 @@ const char *FST_USAGE =
     "                                               populations in one pass over the VCF, one RUN_<POP1>_<POP2>_w_<SIZE>_fst.txt per\n"
     "                                               pair = the _fst.txt file of `evo fst --sets` on those two populations (-w SIZE,STEP\n"
     "                                               with SIZE > 1 required; no heterozygosity / fixed-window files in this mode)\n"
+    "       --devices=N                             (GPU build, all-pairs mode) N device batches in flight, one per GPU: consecutive\n"
+    "                                               batches of the VCF are contiguous site shards, counted and walked at the same\n"
+    "                                               time; the files are the same bytes as with one device (N > GPUs: the shards\n"
+    "                                               share the GPUs in turn)\n"
     "       --physicalWindowSize=SIZE               (optional; default 10000bp)\n"
     "       --accessibleGenomeBED=BEDfile.bed       (optional) regions of the genome where SNPs could be called: the fixed-window\n"
     "                                               file reports and divides by the accessible bases of each window\n"
@@ -418,7 +425,7 @@ const char *FST_USAGE =
     "       --annot=ANNOTATION.gffExtract           (optional) gene annotation (scaffold, start, end, strand, transcript per line):\n"
     "                                               writes RUN_NAMESNPcategory_fst.txt with the category, Fst and dxy of every SNP\n\n";
 
-enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS, OPT_ACC_BED, OPT_ANNOT, OPT_ANC_SETS, OPT_AF };
+enum { OPT_VCF = 2, OPT_SETS, OPT_REG_ABOVE, OPT_PHYS, OPT_UNSUPPORTED, OPT_POPS, OPT_PAIRS, OPT_ACC_BED, OPT_ANNOT, OPT_ANC_SETS, OPT_AF, OPT_DEVICES };
 
 void parseFstOptions(int argc, char **argv) {
     static const struct option longopts[] = {
@@ -427,6 +434,7 @@ void parseFstOptions(int argc, char **argv) {
         {"physicalWindowSize", required_argument, NULL, OPT_PHYS}, {"samples", required_argument, NULL, 's'},
         {"run-name", required_argument, NULL, 'n'}, {"help", no_argument, NULL, 'h'},
         {"pops", required_argument, NULL, OPT_POPS}, {"pairs", required_argument, NULL, OPT_PAIRS},
+        {"devices", required_argument, NULL, OPT_DEVICES},
         {"ancSets", required_argument, NULL, OPT_ANC_SETS}, {"annot", required_argument, NULL, OPT_ANNOT},
         {"ms", required_argument, NULL, OPT_UNSUPPORTED}, {"eigen", required_argument, NULL, OPT_UNSUPPORTED},
         {"accessibleGenomeBED", required_argument, NULL, OPT_ACC_BED}, {NULL, 0, NULL, 0}};
@@ -439,6 +447,7 @@ void parseFstOptions(int argc, char **argv) {
             case OPT_SETS: arg >> fstopt::sampleSets; break;
             case OPT_POPS: arg >> fstopt::popsFile; break;
             case OPT_PAIRS: arg >> fstopt::pairsArg; break;
+            case OPT_DEVICES: arg >> fstopt::devices; break;
             case 'w':
                 ws = split(arg.str(), ',');
                 if (ws.size() < 2) die("-w needs SIZE,STEP");
@@ -465,6 +474,10 @@ void parseFstOptions(int argc, char **argv) {
             std::cerr << "The all-pairs mode needs -w SIZE,STEP with SIZE > 1\n";
             dieFlag = true;
         }
+        if (fstopt::devices < 1 || fstopt::devices > 64) { std::cerr << "--devices takes 1 .. 64\n"; dieFlag = true; }
+    } else if (fstopt::devices != 1) {
+        std::cerr << "--devices belongs to the all-pairs mode (--pops, --pairs=all)\n";
+        dieFlag = true;
     } else if (fstopt::vcfFile.empty() || fstopt::sampleSets.empty()) {
         std::cerr << "To calculate Fst statistics from a vcf, you need to use both the --vcf and the --sets options\n";
         dieFlag = true;
@@ -519,35 +532,40 @@ int fstAllPairsMain() {
     };
     std::vector<PairState> st(Q);
     LineReader vcf(vcfFile);
-    Device dev;
-    Batch batch;
-    int nSamples = 0;
+    // --devices N: N consecutive batches of the VCF are N contiguous site shards, one per context (one per GPU while there
+    // are GPUs; more shards than GPUs share them in turn).  What the shards exchange is what evo_amd/shard.py exchanges
+    // between ranks, here between host threads of one process (the messages are a few KB: no RCCL):
+    //   1. every shard counts (K1) and reports its included sites per pair  -> base offset of shard i = sites of all
+    //      shards before it;
+    //   2. every shard walks its windows from that offset and reports the sums behind its last complete segment, which the
+    //      next shard's first segment continues.
+    // The rows are written shard by shard in file order, so the files are the same bytes whatever N is.
+    const int nDev = devices;
+    struct Shard {
+        Device dev;
+        Batch batch;
+        long long firstLine = 0;
+        std::vector<int64_t> tot, firstSeg, nSeg, base;
+        std::vector<double> sNum, sDen, sK, carry;
+        std::vector<int32_t> sEnd;
+    };
+    std::vector<Shard> shard((size_t)nDev);
+    for (Shard &sh : shard) { sh.tot.resize(Q); sh.firstSeg.resize(Q); sh.nSeg.resize(Q); sh.base.resize(Q); sh.carry.resize(Q * 4); }
+    int nSamples = 0, cur = 0;
     long long totalVariantNumber = 0;
     bool haveHeader = false;
-    std::vector<int64_t> tot(Q), firstSeg(Q), nSeg(Q), base(Q);
-    std::vector<double> sNum, sDen, sK, carry(Q * 4);
-    std::vector<int32_t> sEnd;
     std::ostringstream row;
 
-    auto flush = [&]() {
-        if (batch.n == 0) return;
-        const size_t n = batch.n;
-        dev.load(batch, EVOFST_MODE_FST, nSamples, std::vector<int32_t>(), totalVariantNumber - (long long)n + 1);
-        for (size_t q = 0; q < Q; ++q) base[q] = st[q].base;
-        check(dev.ctx, evofst_set_base_offsets(dev.ctx, base.data()), "set_base_offsets");
-        check(dev.ctx, evofst_run_stats(dev.ctx), "run_stats");
-        check(dev.ctx, evofst_get_included_totals(dev.ctx, tot.data()), "included_totals");
-        const size_t cap = (size_t)evofst_max_segments(dev.ctx);
-        sNum.resize(cap * Q); sDen.resize(cap * Q); sK.resize(cap * Q); sEnd.resize(cap * Q);
-        check(dev.ctx, evofst_get_segments(dev.ctx, firstSeg.data(), nSeg.data(), sNum.data(), sDen.data(), sK.data(), sEnd.data()), "segments");
-        check(dev.ctx, evofst_get_boundary(dev.ctx, carry.data()), "boundary");
+    // the rows of one shard (all pairs), continuing the pairs' window state
+    auto emit = [&](Shard &sh) {
+        const Batch &batch = sh.batch;
         for (size_t q = 0; q < Q; ++q) {
             PairState &ps = st[q];
             row.str(""); row.clear();
-            for (int64_t r = 0; r < nSeg[q]; ++r) {
-                std::array<double, 3> seg = {sNum[(size_t)r * Q + q], sDen[(size_t)r * Q + q], sK[(size_t)r * Q + q]};
+            for (int64_t r = 0; r < sh.nSeg[q]; ++r) {
+                std::array<double, 3> seg = {sh.sNum[(size_t)r * Q + q], sh.sDen[(size_t)r * Q + q], sh.sK[(size_t)r * Q + q]};
                 if (r == 0) { seg[0] = ps.carry[0] + seg[0]; seg[1] = ps.carry[1] + seg[1]; seg[2] = ps.carry[2] + seg[2]; }
-                const int64_t counted = (firstSeg[q] + r + 1) * g;          // countedVariantNumber at the segment's last site
+                const int64_t counted = (sh.firstSeg[q] + r + 1) * g;       // countedVariantNumber at the segment's last site
                 ps.recent.push_back(seg);
                 if ((int)ps.recent.size() > per) ps.recent.pop_front();
                 if (counted % windowStep != 0 || counted < W) continue;      // fst.cpp:638
@@ -557,7 +575,7 @@ int fstAllPairsMain() {
                 if (wd != wd) wd = -__builtin_fabs(wd);
                 const double windowFst = calculateFst(wn / (double)W, wd / (double)W);
                 const double sumDxy = wk / ps.nn, windowDxy = sumDxy / (double)W;
-                const int32_t e = sEnd[(size_t)r * Q + q];
+                const int32_t e = sh.sEnd[(size_t)r * Q + q];
                 const string &scaffold = batch.chrom[e], &loc = batch.pos[e];
                 if (windowSize == windowStep) {                              // :640-650, 682-688
                     const size_t tab0 = ps.windowStartEnd.find('\t');
@@ -578,13 +596,42 @@ int fstAllPairsMain() {
                     ps.windowMiddleVariant = scaffold + "\t" + loc;
                 }
             }
-            if (nSeg[q] > 0) { ps.carry[0] = carry[q * 4]; ps.carry[1] = carry[q * 4 + 1]; ps.carry[2] = carry[q * 4 + 2]; }
-            else { ps.carry[0] += carry[q * 4]; ps.carry[1] += carry[q * 4 + 1]; ps.carry[2] += carry[q * 4 + 2]; }
-            ps.base += tot[q];
+            if (sh.nSeg[q] > 0) { ps.carry[0] = sh.carry[q * 4]; ps.carry[1] = sh.carry[q * 4 + 1]; ps.carry[2] = sh.carry[q * 4 + 2]; }
+            else { ps.carry[0] += sh.carry[q * 4]; ps.carry[1] += sh.carry[q * 4 + 1]; ps.carry[2] += sh.carry[q * 4 + 2]; }
+            ps.base += sh.tot[q];
             const string text = row.str();
             if (!text.empty()) { std::ofstream f(ps.path.c_str(), std::ios::app); f << text; }
         }
-        batch.clear();
+    };
+    // every shard that holds sites does `work` at the same time (one host thread per shard; a single shard runs inline)
+    auto onShards = [&](int nUsed, const std::function<void(Shard &)> &work) {
+        if (nUsed == 1) { work(shard[0]); return; }
+        std::vector<std::thread> th;
+        for (int i = 0; i < nUsed; ++i) th.emplace_back([&, i]() { work(shard[(size_t)i]); });
+        for (std::thread &t : th) t.join();
+    };
+    auto flush = [&]() {
+        int nUsed = 0;
+        while (nUsed < nDev && shard[(size_t)nUsed].batch.n > 0) ++nUsed;
+        if (nUsed == 0) return;
+        onShards(nUsed, [&](Shard &sh) {                                     // exchange 1: included sites per pair
+            sh.dev.load(sh.batch, EVOFST_MODE_FST, nSamples, std::vector<int32_t>(), sh.firstLine);
+            check(sh.dev.ctx, evofst_get_included_totals(sh.dev.ctx, sh.tot.data()), "included_totals");
+        });
+        for (size_t q = 0; q < Q; ++q) {
+            int64_t before = st[q].base;
+            for (int i = 0; i < nUsed; ++i) { shard[(size_t)i].base[q] = before; before += shard[(size_t)i].tot[q]; }
+        }
+        onShards(nUsed, [&](Shard &sh) {                                     // exchange 2: the walk from the shard's offset
+            check(sh.dev.ctx, evofst_set_base_offsets(sh.dev.ctx, sh.base.data()), "set_base_offsets");
+            check(sh.dev.ctx, evofst_run_stats(sh.dev.ctx), "run_stats");
+            const size_t cap = (size_t)evofst_max_segments(sh.dev.ctx);
+            sh.sNum.resize(cap * Q); sh.sDen.resize(cap * Q); sh.sK.resize(cap * Q); sh.sEnd.resize(cap * Q);
+            check(sh.dev.ctx, evofst_get_segments(sh.dev.ctx, sh.firstSeg.data(), sh.nSeg.data(), sh.sNum.data(), sh.sDen.data(), sh.sK.data(), sh.sEnd.data()), "segments");
+            check(sh.dev.ctx, evofst_get_boundary(sh.dev.ctx, sh.carry.data()), "boundary");
+        });
+        for (int i = 0; i < nUsed; ++i) { emit(shard[(size_t)i]); shard[(size_t)i].batch.clear(); }
+        cur = 0;
     };
 
     while (vcf.getline(line)) {
@@ -604,11 +651,15 @@ int fstAllPairsMain() {
                 if (it != idToPop.end()) { sp[i] = popIndex[it->second]; size[sp[i]]++; }
             }
             for (int k = 0; k < P; ++k) if (size[k] == 0) die("population \"" + pops[k] + "\" has no sample in the VCF");
-            dev.open();
-            check(dev.ctx, evofst_set_layout(dev.ctx, nSamples, P, sp.data()), "set_layout");
-            check(dev.ctx, evofst_set_pairs(dev.ctx, nullptr, nullptr, 0), "set_pairs");
-            check(dev.ctx, evofst_set_windows(dev.ctx, windowSize, windowStep), "set_windows");
-            check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
+            const int nGpu = std::max(1, evofst_device_count());
+            for (int i = 0; i < nDev; ++i) {
+                Device &dev = shard[(size_t)i].dev;
+                dev.open(i % nGpu);
+                check(dev.ctx, evofst_set_layout(dev.ctx, nSamples, P, sp.data()), "set_layout");
+                check(dev.ctx, evofst_set_pairs(dev.ctx, nullptr, nullptr, 0), "set_pairs");
+                check(dev.ctx, evofst_set_windows(dev.ctx, windowSize, windowStep), "set_windows");
+                check(dev.ctx, evofst_reserve(dev.ctx, kChunkSites), "reserve");
+            }
             for (size_t q = 0; q < Q; ++q) {
                 PairState &ps = st[q];
                 ps.nn = (double)(2 * size[pairs[q].first]) * (double)(2 * size[pairs[q].second]);
@@ -621,12 +672,14 @@ int fstAllPairsMain() {
         }
         if (!haveHeader) die("variant line before the #CHROM header");
         totalVariantNumber++;
-        batch.add(line, totalVariantNumber);
-        if (batch.n == (size_t)kChunkSites) flush();
+        Shard &sh = shard[(size_t)cur];
+        if (sh.batch.n == 0) sh.firstLine = totalVariantNumber;
+        sh.batch.add(line, totalVariantNumber);
+        if (sh.batch.n == (size_t)kChunkSites && ++cur == nDev) flush();
         if (totalVariantNumber % 100000 == 0) std::cerr << totalVariantNumber << " variants processed..." << std::endl;
     }
     flush();
-    dev.close();
+    for (Shard &sh : shard) sh.dev.close();
     return 0;
 }
 

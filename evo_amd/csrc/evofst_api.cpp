@@ -675,6 +675,11 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
 
 // ================================================================== lifecycle
 
+extern "C" int evofst_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 extern "C" evofst_ctx *evofst_create(int device_id) {
     if (device_id == -1) {
         evofst_ctx *h = new (std::nothrow) evofst_ctx();

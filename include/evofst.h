@@ -78,6 +78,8 @@ typedef struct {
  * packer functions (set_layout / pack / unpack / geometry); every device call on it fails with
  * EVOFST_ERR_STATE -- there is no CPU compute path. */
 evofst_ctx *evofst_create(int device_id);
+/* GPUs this process sees (0: none, or the runtime failed).  (No counterpart in the reference.) */
+int evofst_device_count(void);
 void evofst_destroy(evofst_ctx *ctx);
 const char *evofst_last_error(const evofst_ctx *ctx);
 const char *evofst_version(void);

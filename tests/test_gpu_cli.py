@@ -298,6 +298,33 @@ def test_cli_fst_all_pairs_several_device_batches(tmp_path):
     _all_pairs_case(tmp_path, np.random.default_rng(34), 60, 20, 70000, 10, ["a", "b", "c"], ("scaffold_0", "chrB"))
 
 
+def test_cli_fst_all_pairs_devices(tmp_path):
+    """evo fst --pairs=all --devices N: N consecutive device batches are N site shards on contexts of their own (host
+    threads; on a one-GPU box they share the GPU), the included-site totals and the carries go from shard to shard as in
+    evo_amd/shard.py.  The files are the same bytes as with one device, whatever N: 3 shards in one round (the last one
+    short), 2 shards in two rounds (the second round with one shard), 5 shards of which two stay empty."""
+    rng = np.random.default_rng(36)
+    vcf = str(tmp_path / "in.vcf")
+    names = write_vcf(vcf, rng, 70000, 12, scaffolds=("scaffold_0", "chrB"), miss=0.05)
+    pf = str(tmp_path / "pops.txt")
+    with open(pf, "w") as f:
+        for i, n in enumerate(names):
+            f.write("%s\t%s\n" % (n, ["a", "b", "c"][i % 3]))
+    outs = {}
+    for nd in (1, 2, 3, 5):
+        d = tmp_path / ("dev%d" % nd)
+        d.mkdir()
+        r = subprocess.run([EVO, "fst", "--vcf=" + vcf, "--pops=" + pf, "--pairs=all", "-n", "run", "-w", "60,20", "--devices=%d" % nd],
+                           cwd=str(d), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[nd] = {n: open(str(d / n), "rb").read() for n in sorted(os.listdir(str(d)))}
+    assert len(outs[1]) == 3 and all(len(v.splitlines()) > 100 for v in outs[1].values())
+    for nd in (2, 3, 5):
+        assert outs[nd] == outs[1], "files differ with --devices=%d" % nd
+    r = subprocess.run([EVO, "fst", "--vcf=" + vcf, "--sets=" + pf, "--devices=2"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode != 0                                   # the option belongs to the all-pairs mode
+
+
 def test_cli_fst_all_pairs_clean_chunks_across_batches(tmp_path):
     """No missing calls: most chunks are clean, K1 leaves them one byte per count and clean_walk_kernel takes them, with
     windows that run across the device batches (the ALT = "*" / indel lines of the file still mark their own chunks)."""
