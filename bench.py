@@ -559,7 +559,8 @@ def main():
     else:
         k2_bytes = S * P * cb + S * 8.0 + (S / cfg["step"]) * P * 16.0
     names = ["k1_count_kernel", "scan_kernel",
-             {"pairs": "walk(clean_walk_kernel + fused_pairs_kernel on K1 counts)", "gram": "gram_kernel"}.get(cfg["mode"], "global_window_kernel"), "stitch_kernel",
+             {"pairs": "walk(clean_walk_kernel + fused_pairs_kernel on K1 counts)", "gram": "gram_kernel"}.get(
+                 cfg["mode"], "global_tile_kernel" if e.last_global_walk() == 2 else "global_window_kernel"), "stitch_kernel",
              "fused_pairs_kernel"]
     if cfg["mode"] == "gram":
         kavg[2] = float(np.sum(gram_ms))          # popsums + gram launches of every batch of one step

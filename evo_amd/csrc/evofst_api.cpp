@@ -116,7 +116,9 @@ struct evofst_ctx {
     int opt_stream_blocks = 0;        // workgroups of the stream pass (0: as many as the device holds)
     bool check_dirty = false;                       // the check word is the stream pass's: its count of marked chunks lies behind it
     uint32_t stream_dirty_cum = 0, stream_dirty_last = 0; bool stream_dirty_known = false;   // (what the last synchronised passes marked)
+    int last_global_walk = 0;                       // evofst_last_global_walk
     int last_pairs_pass = 0;                        // evofst_last_pairs_pass
+    int opt_global_walk = 0;                        // against-all rows: 0 auto, 1 lane = population kernel, 2 two-phase kernel where it fits
     int opt_stream_sets = 0;                        // its sets of consumer waves (0: the library chooses)
     int opt_stream_bufs = 0;                        // its LDS buffers per workgroup (0: the library chooses)
     int opt_stream_prod = 0, opt_stream_cons = 0;   // its producer / consumer waves per workgroup (0: the library chooses)
@@ -315,6 +317,7 @@ GlobalParams make_global(evofst_ctx *c) {
     { int lo, hi; global_rcp_split(p.tn_max, max_n_use, &lo, &hi); p.rcp_lo = lo; p.rcp_hi = hi; }
     p.base = (const int64_t *)c->d_base.p;
     p.halo_n = c->halo_n;
+    p.n_full = (const int32_t *)c->d_nfull.p;
     p.halo_num = (const double *)c->d_halo_num.p; p.halo_den = (const double *)c->d_halo_den.p;
     p.halo_tag = (const int32_t *)c->d_halo_tag.p;
     p.row_cap = c->row_cap;
@@ -1555,7 +1558,12 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
 #ifdef EVOFST_EXPERIMENTS
         if (const char *e = getenv("EVOFST_DEBUG_GLOBAL_LDS")) lds += (size_t)atoi(e);   // occupancy experiments
 #endif
-        if (lds > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: SIZE * populations too large for the LDS deque");
+        // the two-phase kernel (lane = site for the evaluation, thread = window x population for the rows) where its
+        // ring of SIZE + 64 kept sites per population fits in LDS; the lane = population kernel otherwise
+        int kw = 0;
+        const size_t tile_lds = global_tile_lds_bytes(tn_max, max_n_use, nu, c->snp_size, &kw);
+        const bool tile_walk = c->opt_global_walk != 1 && tile_lds <= 150 * 1024 && nu <= 160 && c->halo_n <= c->snp_size;
+        if (!tile_walk && lds > 160 * 1024) return fail(c, EVOFST_ERR_UNSUPPORTED, "run_stats: SIZE * populations too large for the LDS deque");
         if ((rc = ensure(c, c->d_chunk_rows, (size_t)c->n_chunks * 4))) return rc;
         if ((rc = ensure(c, c->d_row_off, (size_t)c->n_chunks * 8))) return rc;
         if ((rc = ensure(c, c->d_row_tot, 8))) return rc;
@@ -1577,7 +1585,9 @@ extern "C" int evofst_run_stats(evofst_ctx *c) try {
         if (const char *e = getenv("EVOFST_GLOBAL_GROUP_TILES")) p.group = std::max(1, atoi(e) / std::max(1, c->chunk_tiles));
 #endif
         record(c, 2, 0);
-        HIPCHK(c, launch_global(p, c->count_bytes, lds, c->stream));
+        c->last_global_walk = tile_walk ? 2 : 1;
+        if (tile_walk) { p.kw = kw; HIPCHK(c, launch_global_tile(p, c->count_bytes, tile_lds, c->stream)); }
+        else HIPCHK(c, launch_global(p, c->count_bytes, lds, c->stream));
         record(c, 2, 1);
     }
     c->stats_done = true;
@@ -1773,6 +1783,9 @@ extern "C" int evofst_set_option(evofst_ctx *c, const char *name, int64_t value)
     } else if (n == "stream_blocks") {
         if (value < 0 || value > (1 << 20)) return fail(c, EVOFST_ERR_ARG, "set_option: stream_blocks is 0 (auto) or a number of workgroups");
         c->opt_stream_blocks = (int)value;
+    } else if (n == "global_walk") {
+        if (value < 0 || value > 2) return fail(c, EVOFST_ERR_ARG, "set_option: global_walk is 0 (auto), 1 (lane = population kernel) or 2 (two-phase kernel where it fits)");
+        c->opt_global_walk = (int)value;
     } else if (n == "stream_sets") {
         if (value < 0 || value > 2) return fail(c, EVOFST_ERR_ARG, "set_option: stream_sets is 0 (auto), 1 or 2");
         c->opt_stream_sets = (int)value;
@@ -1789,6 +1802,10 @@ extern "C" int evofst_set_option(evofst_ctx *c, const char *name, int64_t value)
     return EVOFST_OK;
 } catch (...) {
     return abi_exception(c);
+}
+
+extern "C" int evofst_last_global_walk(const evofst_ctx *c) {
+    return c ? c->last_global_walk : 0;
 }
 
 extern "C" int evofst_last_pairs_pass(const evofst_ctx *c) {

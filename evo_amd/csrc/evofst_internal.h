@@ -69,6 +69,13 @@ __device__ __forceinline__ int nth_set_bit(uint32_t m, int n) {
     }
     return pos;
 }
+// position of the n-th (1-based) set bit of the 64-bit mask {hi, lo}; needs 1 <= n <= popc
+__device__ __forceinline__ int nth_set_bit64(uint32_t lo, uint32_t hi, int n) {
+    const int cl = __popc(lo);
+    const bool up = n > cl;
+    return nth_set_bit(up ? hi : lo, up ? n - cl : n) + (up ? 32 : 0);
+}
+
 
 
 struct K1Params {
@@ -323,6 +330,8 @@ struct GlobalParams {
     double *row_num, *row_den;     // [row_cap][n_use]
     const int64_t *chunk_row_off;  // [n_chunks+1] first output row of the chunk
     int32_t group;                 // global_window_kernel: K1 chunks a workgroup walks in a row (0: launch_global chooses)
+    const int32_t *n_full;         // [P] chromosomes per population (global_tile_kernel)
+    int32_t kw;                    // global_tile_kernel: entries per population of its LDS ring (odd, >= size + 64)
     // per-site output (on demand)
     double *site_num, *site_den;   // [n_use][n_sites] or null
     uint8_t *site_kept;
@@ -407,6 +416,8 @@ size_t stream_lds_bytes(int P, int n_pairs, int chunk_tiles, int n_buf);
 hipError_t launch_stream(const StreamParams &p, int max_blocks, hipStream_t st);
 hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st);
 size_t global_lds_bytes(int tn_max, int max_n, int n_use, int size);
+size_t global_tile_lds_bytes(int tn_max, int max_n, int n_use, int size, int *kw_out);
+hipError_t launch_global_tile(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st);
 void global_rcp_split(int tn_max, int max_n, int *lo, int *hi);
 
 }  // namespace evofst

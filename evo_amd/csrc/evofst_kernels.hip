@@ -2337,6 +2337,243 @@ __global__ __launch_bounds__(1024) void global_window_kernel(GlobalParams p) {
     }
 }
 
+// ---- the same rows, tile by tile in two phases (what launch_global takes when the tables fit in LDS)
+// Sixteen waves per workgroup, one workgroup per group of K1 chunks.  Per tile of 64 sites:
+//   phase E   lane = site, the waves share the populations: every lane evaluates its site for one population after the
+//             other (64 of 64 lanes busy, the chains of different lanes independent) and writes {numerator,
+//             denominator} of the kept sites into the population's row of a ring in LDS, K[population][kept site];
+//   phase W   thread = (window that ends in the tile, population): the window's SIZE entries of its row, oldest to
+//             newest, added one after the other as vector_average does (evo_FstAgainstAll.cpp:265-280) -- the rows are
+//             bit for bit those of global_window_kernel.
+// The ring holds SIZE + 64 kept sites per population (odd row length: the lanes of phase W, one population each, hit
+// different LDS banks).  The deque before the first tile: zeros, then the halo of the shards before this one, then the
+// last kept sites before the group (replayed through phase E), as in the kernel above.
+constexpr int kGlobalTileThreads = 1024;
+constexpr int kGlobalTilePops = 10;          // populations per wave of global_tile_kernel at most (16 waves: 160 populations)
+size_t global_tile_lds_bytes(int tn_max, int max_n, int n_use, int size, int *kw_out) {
+    int lo, hi;
+    global_rcp_split(tn_max, max_n, &lo, &hi);
+    const int kw = (size + kTileSites) | 1;
+    if (kw_out) *kw_out = kw;
+    return (size_t)n_use * kw * 16 + (size_t)(lo + 1 + hi + 1) * 8 + (size_t)n_use * 64 + (size_t)kw * 4 + 64;
+}
+
+// global_eval for a population that has every allele called at all 64 sites of a tile whose sites have every allele of
+// every population called: n1, n2 and their reciprocals are the same for the whole wave (k = {n1, 1/n1, n2, 1/n2, n1 - 1,
+// 1/(n1 - 1), n2 - 1, 1/(n2 - 1)} as doubles, n1 >= 2, n2 >= 2, the 0.8 rule passed).  Same operations on the same values as
+// global_eval<true>, so the same bits.
+__device__ __forceinline__ void global_eval_full(uint32_t c, uint32_t Tc, const double *k, double &num, double &den) {
+    const double dc = (double)c, dc2 = (double)(int)(Tc - c);
+    const double p1 = rcp_div(dc, k[0], k[1]);
+    const double p2 = rcp_div(dc2, k[2], k[3]);
+    const double f1 = rcp_div(p1 * (1.0 - p1), k[4], k[5]);
+    const double f2 = rcp_div(p2 * (1.0 - p2), k[6], k[7]);
+    const double power = (p1 - p2) * (p1 - p2);
+    num = power - f1 - f2;
+    den = (p1 * (1.0 - p2)) + (p2 * (1.0 - p1));
+}
+
+template <typename CT, bool RCP>
+__global__ __launch_bounds__(kGlobalTileThreads) void global_tile_kernel(GlobalParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int nu = p.n_use, KW = p.kw, size = p.size;
+    double *K_n = reinterpret_cast<double *>(smem);                          // [n_use][KW]
+    double *K_d = K_n + (size_t)nu * KW;
+    double *rcp_tab = K_d + (size_t)nu * KW;                                 // [rcp_lo + 1] + [rcp_hi + 1]
+    double *full_k = rcp_tab + (p.rcp_lo + 1 + p.rcp_hi + 1);                // [n_use][8] global_eval_full's constants ([0] = 0: not for this population)
+    int32_t *K_s = reinterpret_cast<int32_t *>(full_k + (size_t)nu * 8);     // [KW] site of the entry (-1: the zero-initialised deque)
+    const GlobalRcp rcp{rcp_tab, p.rcp_lo, p.rcp_hi, p.tn_max};
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = kGlobalTileThreads / 64;
+    const int group = max(1, p.group);
+    const int c = blockIdx.x * group;
+    for (int i = tid; i < nu * KW; i += kGlobalTileThreads) { K_n[i] = 0.0; K_d[i] = 0.0; }
+    for (int i = tid; i < KW; i += kGlobalTileThreads) K_s[i] = -1;
+    for (int i = tid; i <= p.rcp_lo; i += kGlobalTileThreads) rcp_tab[i] = 1.0 / (double)i;
+    for (int i = tid; i <= p.rcp_hi; i += kGlobalTileThreads) rcp_tab[p.rcp_lo + 1 + i] = 1.0 / (double)(p.tn_max - i);
+    for (int u = tid; u < nu; u += kGlobalTileThreads) {
+        const int n1 = p.n_full[p.use_idx[u]], n2 = p.tn_max - n1;
+        const bool ok = n1 >= 2 && n2 >= 2 && (double)n1 >= p.thresholds[u];
+        const double v[8] = {(double)n1, 1.0 / (double)n1, (double)n2, 1.0 / (double)n2, (double)(n1 - 1), 1.0 / (double)(n1 - 1), (double)(n2 - 1), 1.0 / (double)(n2 - 1)};
+        for (int i = 0; i < 8; ++i) full_k[(size_t)u * 8 + i] = ok ? v[i] : 0.0;
+    }
+
+    const int t0 = c * p.chunk_tiles, t1 = min(t0 + group * p.chunk_tiles, p.n_tiles);
+    // where the replay starts: walk back until SIZE kept sites of this shard are found
+    int th = t0;
+    int need = size;
+    const int64_t kept_before = p.chunk_used_kept_off[(size_t)p.n_chunks + c] - p.base[1];
+    if (kept_before < need) need = (int)kept_before;   // the rest is the zero-initialised deque
+    int drop = 0;         // kept sites of tile th to ignore (older than the window)
+    while (need > 0 && th > 0) {
+        --th;
+        const int n = __popcll(p.kept_mask[th]);
+        if (n >= need) { drop = n - need; need = 0; }
+        else need -= n;
+    }
+    int64_t used = p.chunk_used_kept_off[c];
+    int64_t row = p.chunk_row_off[c];
+    int pos = 0;          // ring position of the next kept site
+    __syncthreads();
+    {   // multi-GPU: kept sites of the shards before this one stand where this shard has fewer than SIZE before the group
+        const int n_loc = (int)min((int64_t)size, kept_before);
+        const int n_h = min(size - n_loc, p.halo_n);
+        for (int e = p.halo_n - n_h; e < p.halo_n; ++e) {
+            for (int u = tid; u < nu; u += kGlobalTileThreads) {
+                K_n[(size_t)u * KW + pos] = p.halo_num[(size_t)e * nu + u];
+                K_d[(size_t)u * KW + pos] = p.halo_den[(size_t)e * nu + u];
+            }
+            if (tid == 0) K_s[pos] = p.halo_tag[e];
+            ++pos;                                       // (n_h <= SIZE < KW: no wrap yet)
+        }
+    }
+    const CT *cbase = reinterpret_cast<const CT *>(p.counts);
+    const uint64_t below = (1ull << lane) - 1ull;        // the sites before this lane's
+    const uint64_t upto = below | (1ull << lane);
+    const uint32_t ustep = (uint32_t)p.step;
+    // this wave's populations (wave, wave + 16, ...: at most kGlobalTilePops of them) and, one tile ahead of its use, the
+    // counts of this lane's site in each of them and the site's totals: the loads of tile t + 1 fly while tile t is evaluated
+    constexpr int MP = kGlobalTilePops;
+    int kk[MP];
+    double thr[MP];
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+        const int u = min(wave + i * NW, nu - 1);
+        kk[i] = p.use_idx[u]; thr[i] = p.thresholds[u];
+    }
+    const int npw = wave < nu ? (nu - wave + NW - 1) / NW : 0;     // populations of this wave
+    uint32_t cv[MP], nv[MP];
+    uint2 ctot, ntot;
+    auto request = [&](int t, uint32_t (&dst)[MP], uint2 &tot) {
+        const CT *crow = cbase + (size_t)t * p.P * kTileSites + lane;
+#pragma unroll
+        for (int i = 0; i < MP; ++i) dst[i] = i < npw ? (uint32_t)crow[(size_t)kk[i] * kTileSites] : 0u;
+        tot = p.totals[(size_t)t * kTileSites + lane];
+    };
+    if (th < t1) request(th, nv, ntot);
+    uint64_t nsm = th < t1 ? p.skip_mask[th] : 0ull, nkm = th < t1 ? p.kept_mask[th] : 0ull;   // the masks too come a tile ahead
+    for (int t = th; t < t1; ++t) {
+        const bool replay = t < t0;
+        const uint64_t sm = nsm;
+        uint64_t km = nkm;
+        { const int tn = min(t + 1, t1 - 1); nsm = p.skip_mask[tn]; nkm = p.kept_mask[tn]; }
+        if (replay && drop > 0) {                        // the oldest kept sites of the first replayed tile are older than the deque
+            for (; drop > 0 && km != 0ull; --drop) km &= km - 1ull;
+        }
+        const int nk = __popcll(km);
+#pragma unroll
+        for (int i = 0; i < MP; ++i) cv[i] = nv[i];
+        ctot = ntot;
+        request(min(t + 1, t1 - 1), nv, ntot);
+        // ---- phase E
+        const bool kept = (km >> lane) & 1ull;
+        int wpos = pos + __popcll(km & below);
+        if (wpos >= KW) wpos -= KW;
+        if (nk > 0) {
+            const bool tile_full = __builtin_amdgcn_ballot_w64(ctot.y != (uint32_t)p.tn_max) == 0ull;   // every allele of every population called
+#pragma unroll
+            for (int i = 0; i < MP; ++i) {
+                if (i < npw) {
+                    double num, den;
+                    const uint32_t cc_ = cv[i] & CountTraits<CT>::mask, nm_ = cv[i] >> CountTraits<CT>::shift;
+                    const double *fk = full_k + (size_t)(wave + i * NW) * 8;
+                    // (tile_full: the totals are the sum of the populations' own counts, so this one is complete too)
+                    if (tile_full && fk[0] != 0.0) global_eval_full(cc_, ctot.x, fk, num, den);
+                    else global_eval<RCP>(cc_, nm_, ctot.x, ctot.y, thr[i], rcp, num, den);
+                    if (kept) { const size_t o = (size_t)(wave + i * NW) * KW + wpos; K_n[o] = num; K_d[o] = den; }
+                }
+            }
+            if (wave == 0 && kept) K_s[wpos] = t * kTileSites + lane;
+        }
+        // the sites of this tile that complete a window (the same in every wave): kept, and the count of used sites up to
+        // and including it is a multiple of STEP beyond the first SIZE (evo_FstAgainstAll.cpp:263-264)
+        uint64_t emit = 0ull;
+        if (!replay && nk > 0) {
+            const int64_t used_here = used + (int64_t)__popcll(~sm & upto);
+            const bool e_ = kept && !((sm >> lane) & 1ull) && (used_here > size || size == (int)ustep) && (uint32_t)(used_here % ustep) == 0u;
+            emit = __builtin_amdgcn_ballot_w64(e_);
+        }
+        __syncthreads();
+        // ---- phase W
+        // a wave takes one window at a time (wave-uniform ring positions) and 64 populations of it
+        const int n_emit = __popcll(emit);
+        const int ublocks = (nu + 63) >> 6;                       // groups of 64 populations
+        for (int item = wave; item < n_emit * ublocks; item += NW) {
+            const int w = item / ublocks, u = (item - w * ublocks) * 64 + lane;
+            const int e = nth_set_bit64((uint32_t)emit, (uint32_t)(emit >> 32), w + 1);
+            int j = pos + __popcll(km & ((2ull << e) - 1ull)) - 1;        // ring position of site e's entry
+            if (j >= KW) j -= KW;
+            int i0 = j - size + 1;
+            if (i0 < 0) i0 += KW;
+            if (u < nu && row + w < p.row_cap) {                  // (row_cap: never reached, launch_global_rows counted the same rows)
+                const double *rn = K_n + (size_t)u * KW, *rd = K_d + (size_t)u * KW;
+                double an = 0.0, ad = 0.0;
+                // oldest to newest: ring positions i0 .. (two straight runs when the window wraps), four loads ahead of their adds
+                auto run = [&](int from, int to) {
+                    int i = from;
+                    for (; i + 4 <= to; i += 4) {
+                        const double n0 = rn[i], n1 = rn[i + 1], n2 = rn[i + 2], n3 = rn[i + 3];
+                        const double d0 = rd[i], d1 = rd[i + 1], d2 = rd[i + 2], d3 = rd[i + 3];
+                        an += n0; an += n1; an += n2; an += n3;
+                        ad += d0; ad += d1; ad += d2; ad += d3;
+                    }
+                    for (; i < to; ++i) { an += rn[i]; ad += rd[i]; }
+                };
+                if (i0 + size <= KW) run(i0, i0 + size);
+                else { run(i0, KW); run(0, i0 + size - KW); }
+                p.row_num[(size_t)(row + w) * nu + u] = an / (double)size;
+                p.row_den[(size_t)(row + w) * nu + u] = ad / (double)size;
+                if (u == 0) { p.row_start[row + w] = K_s[i0]; p.row_end[row + w] = t * kTileSites + e; }
+            }
+        }
+        row += n_emit;
+        pos += nk; if (pos >= KW) pos -= KW;
+        if (!replay) used += kTileSites - __popcll(sm);
+        __syncthreads();                                 // the next tile's entries may take the place of the oldest ones
+    }
+}
+
+template <typename CT, bool RCP>
+static hipError_t launch_global_tile_t(const GlobalParams &p_, size_t lds_bytes, hipStream_t st) {
+    const void *fn = reinterpret_cast<const void *>(&global_tile_kernel<CT, RCP>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    GlobalParams p = p_;
+    if (p.group <= 0) {
+        // one workgroup per CU at a time: the groups are cut so that the workgroups fill whole rounds of the device
+        static thread_local struct { int dev; int cus; } memo = {-1, 0};
+        int dev = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if (memo.dev != dev) {
+            int cus = 0;
+            if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+            memo = {dev, std::max(1, cus)};
+        }
+        const int64_t cap = memo.cus;
+        double best = -1.0;
+        p.group = 1;
+        for (int r = 1; r <= 8; ++r) {
+            const int g = (int)std::max<int64_t>(1, (p.n_chunks + cap * r - 1) / (cap * r));
+            const int64_t blocks = (p.n_chunks + g - 1) / g, rounds = (blocks + cap - 1) / cap;
+            const double tiles = (double)g * p.chunk_tiles;
+            const double score = (double)blocks / (double)(rounds * cap) * tiles / (tiles + 1.0);
+            if (score > best + 1e-9) { best = score; p.group = g; }
+        }
+    }
+    dim3 grid((p.n_chunks + p.group - 1) / p.group);
+    hipLaunchKernelGGL((global_tile_kernel<CT, RCP>), grid, dim3(kGlobalTileThreads), lds_bytes, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_global_tile(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st) {
+    if (p.n_chunks <= 0 || p.n_use <= 0) return hipSuccess;
+    if (p.kw < p.size + kTileSites || (p.kw & 1) == 0 || p.halo_n > p.size || lds_bytes > 160 * 1024 ||
+        p.n_use > kGlobalTilePops * (kGlobalTileThreads / 64)) return hipErrorInvalidValue;
+    if (count_bytes == 2) return launch_global_tile_t<uint16_t, true>(p, lds_bytes, st);
+    return launch_global_tile_t<uint32_t, true>(p, lds_bytes, st);
+}
+
 template <typename CT, bool RCP>
 static hipError_t launch_global_t(const GlobalParams &p_, size_t lds_bytes, dim3 block, hipStream_t st) {
     const void *fn = reinterpret_cast<const void *>(&global_window_kernel<CT, RCP>);

@@ -291,13 +291,6 @@ __device__ __forceinline__ bool stream_sum_rows(const StreamParams &p, const Str
     return true;
 }
 
-// position of the n-th (1-based) set bit of the 64-bit mask {hi, lo}; needs 1 <= n <= popc
-__device__ __forceinline__ int nth_set_bit64(uint32_t lo, uint32_t hi, int n) {
-    const int cl = __popc(lo);
-    const bool up = n > cl;
-    return nth_set_bit(up ? hi : lo, up ? n - cl : n) + (up ? 32 : 0);
-}
-
 // Per (tile, population) of a counted chunk: the sums of c and of c^2 over the tile's first 16, 32, 48 and 64 sites
 // ([4] x {C, Q}).  Every consumer wave fills the whole table itself before it reads it (the waves write the same words).
 __device__ __forceinline__ void stream_quarter_table(int lane, int nt, int P, const unsigned char *cpl, uint32_t *qtab) {

@@ -270,6 +270,11 @@ int evofst_set_option(evofst_ctx *ctx, const char *name, int64_t value);
 /* Which form of the pairs pass the last evofst_run took: 1 = separate kernels, 2 = stream pass, 3 = lock-step
  * one-kernel pass; 0 = none yet, or not pairs mode.  (No counterpart in the reference.) */
 int evofst_last_pairs_pass(const evofst_ctx *ctx);
+/* Which kernel made the window rows of the last against-all evofst_run_stats: 1 = lane = population with a deque per lane
+ * (global_window_kernel), 2 = the two-phase kernel (global_tile_kernel: lane = site evaluation, thread = window x
+ * population rows; taken where its LDS ring of SIZE + 64 kept sites per population fits); 0 = none yet.  The option
+ * "global_walk" of evofst_set_option chooses: 0 = the library (default), 1, 2 (where it fits). */
+int evofst_last_global_walk(const evofst_ctx *ctx);
 
 /* When enabled, evofst_run_* bracket every kernel with HIP events on the context's stream. */
 int evofst_set_profiling(evofst_ctx *ctx, int enabled);

@@ -24,16 +24,33 @@ def _run(engine, rng, S, N, P, miss, size, step, use=None, set_sizes=None, flags
     engine.set_windows(size, step)
     fl = (rng.random(S) < 0.07).astype(np.uint8) if flags else None
     engine.upload(engine.pack_codes(codes), S, site_flags=fl)
-    engine.run()
     oalt, onm = O.counts_from_codes(codes, sp, P)
     okept, onum, oden = O.global_site_stats(oalt, onm, use, set_sizes, fl)
+    ow = O.global_windows(okept, onum, oden, size, step, fl)
+    # both window kernels: lane = population with a deque per lane (1), and the two-phase one -- lane = site for the
+    # evaluation, thread = window x population for the rows (2: where its LDS ring fits, else the first again)
+    for walk in (1, 2):
+        engine.set_option("global_walk", walk)
+        try:
+            engine.run()
+            gw = engine.global_windows()
+            assert engine.last_global_walk() in ((1,) if walk == 1 else (1, 2))
+        finally:
+            engine.set_option("global_walk", 0)
+        assert len(gw["end_site"]) == len(ow["end_site"]), walk
+        assert np.array_equal(gw["end_site"], ow["end_site"]), walk
+        assert np.array_equal(gw["start_site"], ow["start_site"]), walk
+        with np.errstate(all="ignore"):
+            gf = gw["mean_num"] / gw["mean_den"]
+            gf[(gf < 0) | (gw["mean_den"] == 0)] = 0
+        assert_same_bits(gf, ow["fst"], "window Fst (global_walk %d)" % walk)
+    engine.run()
     gnum, gden, gkept = engine.global_site_stats()
     assert np.array_equal(gkept, okept)
     k = okept == 1
     with np.errstate(all="ignore"):
         assert_same_bits(gnum.T[k], onum[k], "global num")
         assert_same_bits(gden.T[k], oden[k], "global den")
-    ow = O.global_windows(okept, onum, oden, size, step, fl)
     gw = engine.global_windows()
     assert len(gw["end_site"]) == len(ow["end_site"])
     assert np.array_equal(gw["end_site"], ow["end_site"])
@@ -54,7 +71,9 @@ def _run(engine, rng, S, N, P, miss, size, step, use=None, set_sizes=None, flags
                                                   # 800 chromosomes, half of them missing: complement counts far from the total take the
                                                   # real-division path of the kernel's reciprocal table
                                                   (1200, 400, 4, 0.5, 20, 10), (1200, 400, 8, 0.35, 10, 5),
-                                                  (600, 20, 2, 0.1, 1, 1), (1500, 40, 4, 0.1, 50, 7), (900, 40, 4, 0.1, 5, 20)])
+                                                  (600, 20, 2, 0.1, 1, 1), (1500, 40, 4, 0.1, 50, 7), (900, 40, 4, 0.1, 5, 20),
+                                                  # no missing allele / a few: whole tiles take the kernel's constant-divisor evaluation
+                                                  (3000, 60, 6, 0.0, 20, 10), (6000, 120, 12, 0.0005, 20, 10)])
 def test_global_windows(engine, S, N, P, miss, size, step):
     rows = _run(engine, np.random.default_rng(S + P), S, N, P, miss, size, step, flags=True)
     assert rows > 0
