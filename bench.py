@@ -36,9 +36,9 @@ CONFIGS = {
                   label="synthetic 6.25M-site shard (1/8 of 50M) x 2000 samples, 20 pops (190 pairs), windows 100,100"),
     "cfg4m": dict(sites=6_250_000, samples=2000, pops=20, mode="pairs", size=100, step=100, miss=0.02,
                   label="cfg4s with 2% missing calls (diagnostic: every chunk takes the general walk)"),
-    "cfg5s": dict(sites=2_500_000, samples=5000, pops=500, mode="gram", size=100, step=100, miss=0.15,
+    "cfg5s": dict(sites=2_500_000, samples=5000, pops=500, mode="gram", size=100, step=100, miss=0.15, bp=10_000,
                   label="synthetic 2.5M-site shard (1/8 of 20M) x 5000 samples, 500 pops (124,750 pairs), 15% missing, "
-                        "Gram path (FP64 MFMA) over fixed 100-site windows"),
+                        "Gram path (FP64 MFMA) over 10 kb physical windows cut from the shard's positions (one site per 100 bp)"),
     "cfg5s_w1000": dict(sites=2_500_000, samples=5000, pops=500, mode="gram", size=1000, step=1000, miss=0.15,
                         label="cfg5s with 1000-site windows (diagnostic: prologue / epilogue amortised over 10x the sites)"),
 }
@@ -382,7 +382,17 @@ def main():
         e.set_against_all(np.arange(P, dtype=np.int32), np.full(P, N // P, np.int64))
         units_per_site = P
     if cfg["mode"] == "gram":
-        ws = np.arange(0, S + cfg["size"], cfg["size"], dtype=np.int64).clip(max=S)
+        if cfg.get("bp"):
+            # physical windows for configs[4].  The windows are cut from the positions that travel with the shard
+            # (synthetic: one site per 100 bp, evofst_synth), a window = the sites of one block of cfg["bp"] bases
+            # (fixedWindowStart .. fixedWindowStart + physicalWindowSize, process_vcf_fst.cpp:589-629)
+            e.reserve(S)
+            e.synth(S, seed=20261110, missing_rate=cfg["miss"], first_site_global=rank * S)
+            pos = e.positions().astype(np.int64)
+            blk = (pos - 1) // cfg["bp"]
+            ws = np.concatenate(([0], np.flatnonzero(np.diff(blk)) + 1, [S])).astype(np.int64)
+        else:
+            ws = np.arange(0, S + cfg["size"], cfg["size"], dtype=np.int64).clip(max=S)
         e.set_site_windows(ws)
         n_win = len(ws) - 1
         gram_batch = max(1, min(n_win, int(2e9 // (e.n_pairs * 32))))   # <= 2 GB of results resident
@@ -610,7 +620,6 @@ def main():
         t_s = kavg[2] * 1e-3
         useful = 2.0 * S * e.n_pairs * n_f64
         issued = 2.0 * S * (64 * 64) * (nblk * (nblk + 1) / 2) * n_f64
-        n_win = (S + cfg["size"] - 1) // cfg["size"]
         written = float(n_win) * (nblk * (nblk + 1) / 2) * 4096 * 32.0
         ach_u = useful / t_s / 1e12
         roofline.update({"bound": "mfma", "kernel": "gram_kernel", "achieved": ach_u, "peak": F64_MFMA_PEAK_TFLOPS,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "evofst_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "evofst_last_pairs_pass": (C.c_int, [_vp]),
     "evofst_device_count": (C.c_int, []),
+    "evofst_get_positions": (C.c_int, [_vp, C.c_int64, C.c_int64, _i32p]),
     "evofst_last_global_walk": (C.c_int, [_vp]),
     "evofst_get_pair_range_sums": (C.c_int, [_vp, C.c_int, C.c_int64, _i64p, _i64p, _dp, _dp]),
     "evofst_set_profiling": (C.c_int, [_vp, C.c_int]),
@@ -361,6 +362,13 @@ class EvoFst:
     def set_option(self, name, value):
         """Tuning / test switches of this context (include/evofst.h: evofst_set_option)."""
         self._chk(self.L.evofst_set_option(self.h, name.encode(), int(value)))
+
+    def positions(self, first=0, n=None):
+        """Positions of the shard's sites (evofst_get_positions)."""
+        n = self.n_sites - first if n is None else n
+        pos = np.empty(n, np.int32)
+        self._chk(self.L.evofst_get_positions(self.h, first, n, _ptr(pos, _i32p)))
+        return pos
 
     def last_global_walk(self):
         """1 = global_window_kernel, 2 = global_tile_kernel (the last against-all run's; 0: none)."""

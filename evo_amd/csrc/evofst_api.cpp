@@ -2244,6 +2244,20 @@ extern "C" int evofst_get_pop_site_div(evofst_ctx *c, int64_t first_site, int64_
     return abi_exception(c);
 }
 
+extern "C" int evofst_get_positions(evofst_ctx *c, int64_t first_site, int64_t n_sites, int32_t *pos) try {
+    if (!c || !pos) return EVOFST_ERR_ARG;
+    NEED_GPU(c);
+    int rc = check_range(c, first_site, n_sites);
+    if (rc) return rc;
+    if (!c->have_pos || !c->pos) return fail(c, EVOFST_ERR_STATE, "get_positions: the shard was loaded without positions");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(pos, c->pos + first_site, (size_t)n_sites * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EVOFST_OK;
+} catch (...) {
+    return abi_exception(c);
+}
+
 extern "C" int evofst_get_pair_range_sums(evofst_ctx *c, int pair, int64_t n_ranges, const int64_t *lo, const int64_t *hi,
                                           const double *init, double *out) try {
     if (!c || !lo || !hi || !out || n_ranges < 0) return EVOFST_ERR_ARG;

@@ -358,6 +358,11 @@ int evofst_get_indiv_hets(evofst_ctx *ctx, int32_t *het, int32_t *shared);
  * process_vcf_fst.cpp:325-371): arrays [n_pops][n_sites]; any pointer may be NULL. */
 int evofst_get_pop_site_div(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, double *het,
                             double *het_nei, double *pi);
+/* The positions that travelled with the shard (evofst_upload's pos, evofst_attach_device's d_pos, or the synthetic ones of
+ * evofst_synth: one site per 100 bp): pos[n_sites] for sites first_site ...  EVOFST_ERR_STATE when the shard has none.
+ * For callers that cut physical windows (process_vcf_fst.cpp:589-629) over data that only the device holds. */
+int evofst_get_positions(evofst_ctx *ctx, int64_t first_site, int64_t n_sites, int32_t *pos);
+
 /* Sums of ONE pair's per-site values over ranges of sites of the uploaded shard: the window sums of the two-set `evo fst`
  * (SNP windows process_vcf_fst.cpp:638-692, physical windows :589-629, the genome-wide averages :701-709), which the
  * reference forms by adding per-site values in site order (vector_average / vector_average_withRegion,

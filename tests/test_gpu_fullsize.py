@@ -226,3 +226,26 @@ def test_cfg5_shard_properties(engine):
             err = np.abs(a[fin] - b[fin])
             parity_log.record("cfg5_shard/first_windows/" + name, err, 1e-12 * scale[fin] + 1e-300)
             assert np.all(err <= 1e-12 * scale[fin] + 1e-300)
+
+    # Physical windows (10 kb for configs[4]; process_vcf_fst.cpp:589-629): cut from the positions that travel
+    # with the shard.  The synthetic positions hold one site per 100 bp, so 10 kb blocks are runs of 100 sites; blocks of
+    # 12 345 bases are ragged (123 or 124 sites) and their first two are checked against the oracle's per-site values.
+    pos = engine.positions().astype(np.int64)
+    assert np.all(np.diff(pos) > 0)
+    cut = lambda phys: np.concatenate(([0], np.flatnonzero(np.diff((pos - 1) // phys)) + 1, [S5])).astype(np.int64)
+    assert np.array_equal(cut(10_000), np.arange(0, S5 + 1, 100))
+    ws = cut(12_345)
+    assert set(np.diff(ws[:-1]).tolist()) <= {122, 123, 124, 125} and len(set(np.diff(ws[:-1]).tolist())) > 1 and ws[2] <= n
+    engine.set_site_windows(ws)
+    engine.run_gram(0, 2)
+    bp = engine.gram()
+    for w in range(2):
+        a_, b_ = int(ws[w]), int(ws[w + 1])
+        m = oinc[a_:b_] == 1
+        assert np.array_equal(bp["n_included"][w], m.sum(axis=0))
+        assert np.array_equal(bp["sum_dxy_k"][w], np.where(m, odxy_k[a_:b_], 0.0).sum(axis=0))
+        with np.errstate(all="ignore"):
+            rd = np.where(m, oden[a_:b_], 0.0).sum(axis=0)
+        fin = ~np.isnan(rd)
+        assert (np.isnan(bp["sum_den"][w]) == np.isnan(rd)).all()
+        assert np.all(np.abs(bp["sum_den"][w][fin] - rd[fin]) <= 1e-12 * rd[fin] + 1e-300)
