@@ -115,7 +115,7 @@ struct evofst_ctx {
     int opt_walk = 0;                 // K1 + scan + walk: 0 auto, 1 general walk on every chunk, 2 k2_window_kernel
     int opt_stream_blocks = 0;        // workgroups of the stream pass (0: as many as the device holds)
     bool check_dirty = false;                       // the check word is the stream pass's: its count of marked chunks lies behind it
-    uint32_t stream_dirty_cum = 0, stream_dirty_last = 0; bool stream_dirty_known = false;   // (what the last synchronised passes marked)
+    uint32_t stream_dirty_cum = 0, stream_dirty_last = 0, stream_launches = 0; bool stream_dirty_known = false;   // (what the last synchronised passes marked)
     int last_global_walk = 0;                       // evofst_last_global_walk
     int last_pairs_pass = 0;                        // evofst_last_pairs_pass
     int opt_global_walk = 0;                        // against-all rows: 0 auto, 1 lane = population kernel, 2 two-phase kernel where it fits
@@ -441,10 +441,13 @@ int fused_verdict(evofst_ctx *c) {
     c->check_word = nullptr;
     const uint32_t err = w[0];
     if (c->check_dirty && !err) {
-        c->stream_dirty_last = w[8] - c->stream_dirty_cum; c->stream_dirty_cum = w[8]; c->stream_dirty_known = true;
+        // marked chunks per launch of the passes since the last look (rounded up)
+        const uint32_t n = std::max(1u, c->stream_launches);
+        c->stream_dirty_last = (w[8] - c->stream_dirty_cum + n - 1) / n; c->stream_dirty_cum = w[8]; c->stream_dirty_known = true;
+        c->stream_launches = 0;
     }
     if (err) {
-        c->stream_dirty_cum = 0; c->stream_dirty_known = false;
+        c->stream_dirty_cum = 0; c->stream_dirty_known = false; c->stream_launches = 0;
         for (int i = 0; i < 3; ++i)
             if (c->check_zero[i]) HIPCHK(c, hipMemsetAsync(c->check_zero[i], 0, c->check_zero_bytes[i], c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -658,7 +661,10 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
     record(c, 2, 0);
     // the chunks the stream pass marked, if any: a launch that finds none costs 40 us with a grid that fills the device and
     // a few with a small one, so the grid follows what the passes before this one marked (known at evofst_sync)
-    if ((rc = launch_walks(c, k2, false, false, true, c->stream_dirty_known && c->stream_dirty_last == 0 ? 8 : 0))) return rc;
+    // (a shard whose last tile is short always marks its last chunk: a workgroup or two per marked chunk, up to the device)
+    ++c->stream_launches;
+    const int walk_blocks = c->stream_dirty_known && c->stream_dirty_last < 128 ? 8 + 2 * (int)c->stream_dirty_last : 0;
+    if ((rc = launch_walks(c, k2, false, false, true, walk_blocks))) return rc;
     record(c, 2, 1);
     record(c, 3, 0);
     HIPCHK(c, launch_stitch(k2, c->stream));

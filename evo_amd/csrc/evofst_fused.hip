@@ -227,12 +227,28 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 template <typename CT, bool use_rcp, bool WP, int SUB, bool HBM>
 __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WPS) void fused_pairs_kernel(FusedParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    if (HBM && p.chunk_dirty != nullptr) {        // before anything is set up: does this workgroup's stride hold a marked chunk at all?
-        // (one thread per stride of the grid, all loads at once: a launch that finds nothing costs one memory round trip)
+    // HBM mode with K1's / the stream pass's marks: which turns of this workgroup (regions a grid's stride apart) hold a
+    // marked chunk, as a bit map in LDS -- one thread per turn, all loads at once, so a launch that finds nothing costs one
+    // memory round trip and a workgroup with many turns (a small grid over a long shard) walks straight to its marked ones
+    constexpr int kMarkWords = 512;
+    __shared__ uint32_t marked_turns[HBM ? kMarkWords : 1];
+    int n_turns = 0;
+    bool have_marks = false;
+    if (HBM && p.chunk_dirty != nullptr) {
         const int per = WP ? (int)(blockDim.x >> 6) : 1;
+        const int n_regions = (p.n_chunks + per - 1) / per;
+        n_turns = (int)blockIdx.x < n_regions ? (n_regions - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        have_marks = n_turns <= kMarkWords * 32;
+        for (int i = threadIdx.x; i < kMarkWords; i += blockDim.x) marked_turns[i] = 0u;
+        __syncthreads();
         int any = 0;
-        for (int64_t kc_ = ((int64_t)blockIdx.x + (int64_t)threadIdx.x * gridDim.x) * per; kc_ < p.n_chunks; kc_ += (int64_t)blockDim.x * gridDim.x * per)
-            for (int w = 0; w < per; ++w) any |= (kc_ + w < p.n_chunks && p.chunk_dirty[kc_ + w] != 0u) ? 1 : 0;
+        for (int it = threadIdx.x; it < n_turns; it += blockDim.x) {
+            const int64_t kc_ = ((int64_t)blockIdx.x + (int64_t)it * gridDim.x) * per;
+            int m = 0;
+            for (int w = 0; w < per; ++w) m |= (kc_ + w < p.n_chunks && p.chunk_dirty[kc_ + w] != 0u) ? 1 : 0;
+            if (m && have_marks) atomicOr(&marked_turns[it >> 5], 1u << (it & 31));
+            any |= m;
+        }
         if (!__syncthreads_or(any)) return;
     }
     constexpr int SUBP = SUB + 1;                 // row stride in entries: pop-indexed reads stay conflict-free
@@ -318,6 +334,14 @@ __global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WP
     };
 
     for (int iter = 0;; ++iter) {
+        if (HBM && have_marks) {                       // on to the next marked turn
+            while (iter < n_turns) {
+                const uint32_t w = marked_turns[iter >> 5] >> (iter & 31);
+                if (w & 1u) break;
+                iter = w == 0u ? (iter | 31) + 1 : iter + __ffs((int)w) - 1;
+            }
+            if (iter >= n_turns) break;
+        }
         if (HBM) {                                     // regions in turn, a grid's stride apart; no ticket, nothing to wait for
             const int region = (int)blockIdx.x + iter * (int)gridDim.x, per = WP ? NWV : 1;
             if (region >= (p.n_chunks + per - 1) / per) break;

@@ -121,7 +121,7 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
             zf[(size_t)slot * 2 * P + lane] = ((uint64_t)(uint32_t)zhi << 32) | (uint32_t)zlo;
             zf[(size_t)slot * 2 * P + P + lane] = ((uint64_t)(uint32_t)fhi << 32) | (uint32_t)flo;
         }
-        const uint64_t im = __ballot(irregular != 0 && !skip), mm = __ballot(anymiss != 0), nn = __ballot(nanany != 0 && !skip);
+        const uint64_t im = __ballot(irregular != 0 && !skip), mm = __ballot(anymiss != 0 && !skip), nn = __ballot(nanany != 0 && !skip);
         if (lane == 0) { flg[slot * 4 + 0] = im; flg[slot * 4 + 1] = skipmask; flg[slot * 4 + 2] = mm; flg[slot * 4 + 3] = nn; }
     };
     int sidx = 0;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
                     if (fl & kSegLast) {
                         const uint32_t nfull = fl >> kSegNFullShift;
                         const uint32_t nm = nfull - mc;
-                        cp[pop * kStreamRow] = (unsigned char)c;
+                        cp[pop * kStreamRow] = (unsigned char)(skip ? 0u : c);   // a skipped site: no count, both ballots set -- excluded, and 0 in every sum
                         mp[pop * kTileSites] = (unsigned char)nm;
                         const uint64_t z = __ballot(c == 0) | skipmask;
                         const uint64_t f = __ballot(c == nm) | skipmask;
@@ -315,7 +315,7 @@ __device__ __forceinline__ void stream_quarter_table(int lane, int nt, int P, co
 }
 
 // The statistics walk of one pair (this lane) over the nt tiles of a chunk whose alt counts and ballots lie in LDS:
-// clean_walk_kernel's arithmetic (evofst_fused.hip), a tile of 64 sites per step.  No site of the chunk is skipped and
+// clean_walk_kernel's arithmetic (evofst_fused.hip), a tile of 64 sites per step.  Skipped sites hold count 0 and
 // no allele is missing, so p = c / n with the population's full n, and the window sums of d^2, p(1-p) and sumKij follow
 // exactly from integer sums of c_i c_j, c and c^2 (a chunk has at most 2^12 sites and c <= 255: every sum stays below
 // 2^32 and every product below 2^53).  Per tile a lane forms the sum of c_i c_j (sixteen v_dot4_u32_u8, kept per
@@ -509,9 +509,11 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
     const int P = p.P;
     const int gtile0 = chunk * p.chunk_tiles;
     const int nt = min(p.chunk_tiles, p.n_tiles - gtile0);
-    // a site skipped, an allele missing, a population with fewer than two chromosomes: the general walk's chunk
+    // an allele missing, a population with fewer than two chromosomes: the general walk's chunk.  (Skipped sites -- the
+    // packer's filters, the sites behind the shard's end in its last tile -- stay here: their counts were left out of the
+    // count plane and both of their ballots are set, so they are excluded and add exactly 0 to every integer sum.)
     uint64_t fw = 0;
-    if (lane < nt) fw = flg[lane * 4 + 0] | flg[lane * 4 + 1] | flg[lane * 4 + 2];
+    if (lane < nt) fw = flg[lane * 4 + 0] | flg[lane * 4 + 2];
     const bool dirty = __any(fw != 0);
     if (my_groups == 0) return true;
     // ---- the rows before this chunk: wait until their flags say they are complete, read them once per group of 64 pairs;
