@@ -4,25 +4,27 @@
 // (process_vcf_fst.cpp:243-280), the site filter (:543-544), calculateFstNumerator / Denominator
 // (process_vcf_fst.h:19-30), calculateDxy (process_vcf_fst.cpp:297-323) and the SNP windows (:638-650).
 //
-// A workgroup is a few PRODUCER waves and one or more CONSUMER waves (one per 64 pairs at most) and works through
-// chunks of a few tiles in ticket order (one atomic per chunk, drawn two iterations ahead).  In iteration i
-//   the producers  count chunk c_i: lane = site, 16-byte coalesced loads of the tile rows (three batches of four
-//                  rows requested ahead of the one being counted), popcounts under the wave-uniform masks of the
-//                  layout's descriptor stream (scalar cache), packed {alt, non-missing} counts and the zero / fixed
-//                  ballots of every population INTO LDS buffer i & 1 -- nothing but the tiles is read from HBM and no
+// A workgroup is a few PRODUCER waves and one or more CONSUMER waves (one per 64 pairs at most; optionally two sets of
+// them that take the chunks in turn) and works through chunks of a few tiles in ticket order (one atomic per chunk,
+// drawn by the producer that finishes the chunk before it first).  For chunk k of a workgroup, in LDS buffer k mod NB:
+//   the producers  count it: lane = site, 16-byte coalesced loads of the tile rows (three batches of four rows requested
+//                  ahead of the one being counted), popcounts under the wave-uniform masks of the layout's descriptor
+//                  stream (scalar cache), one alt-count byte and one non-missing byte per site and population and the
+//                  zero / fixed ballots of every population INTO LDS -- nothing but the tiles is read from HBM and no
 //                  count is written to it; then the census of included sites per pair (filter :543-544, lane = pair),
 //                  which the producer that finishes last publishes as one row of 4-byte words;
-//   the consumers  take chunk c_(i-1) from LDS buffer (i-1) & 1: look-back over the rows of the chunks before it (three
-//                  levels of fan-out 32: chunks of its group, groups of its super-group, super-groups); then the
-//                  statistics walk over the chunk's counts in LDS (exact integer sums, four sites per
-//                  v_dot4_u32_u8, segment rows at the window boundaries) -- the arithmetic of clean_walk_kernel.
-// One workgroup barrier per iteration.  The producers never wait for another workgroup, and a consumer only for
-// chunks with smaller tickets, whose producers are already running: whatever the dispatch order or the number of
-// workgroups resident, the smallest unpublished chunk is always being counted by somebody who waits for nothing.
-// While a consumer waits for its predecessors' granules the producers beside it keep the tile loads going, which
-// is what the lock-step one-kernel pass of evofst_fused.hip could not do.
+//   the consumers  take it once it is published: look-back over the rows of the chunks before it (three levels of
+//                  fan-out 32: chunks of its group, groups of its super-group, super-groups); then the statistics
+//                  walk over the chunk's counts in LDS (exact integer sums, four sites per v_dot4_u32_u8, segment rows
+//                  at the window boundaries) -- the arithmetic of clean_walk_kernel.
+// No workgroup barrier after the set-up: the waves hand buffers over through counters in LDS (producers arrived, chunk
+// published, consumers done), so a wave only waits for a wave that is ahead of it.  The producers never wait for
+// another workgroup, and a consumer only for chunks with smaller tickets, whose producers are already running:
+// whatever the dispatch order or the number of workgroups resident, the smallest unpublished chunk is always being
+// counted by somebody who waits for nothing.  While a consumer waits for its predecessors the producers beside it keep
+// the tile loads going, which is what the lock-step one-kernel pass of evofst_fused.hip could not do.
 //
-// A chunk with a skipped site or a missing allele (the walk above cannot take it) leaves its packed counts, ballots
+// A chunk with a missing allele (the walk above cannot take it; skipped sites it can) leaves its packed counts, ballots
 // and its pairs' offsets in HBM, exactly as K1 + scan would have, and is walked by fused_pairs_kernel's HBM mode in a
 // second launch that finds nothing to do on clean data.  stitch_kernel completes the segments that straddle chunks.
 //
