@@ -116,6 +116,9 @@ struct evofst_ctx {
     int opt_stream_blocks = 0;        // workgroups of the stream pass (0: as many as the device holds)
     bool check_dirty = false;                       // the check word is the stream pass's: its count of marked chunks lies behind it
     uint32_t stream_dirty_cum = 0, stream_dirty_last = 0, stream_launches = 0; bool stream_dirty_known = false;   // (what the last synchronised passes marked)
+    // chunks K1 marked for the general walk on the data that is loaded: asked once per data set at evofst_sync, so that later
+    // passes over the same data skip (or size) the general walk's launch instead of letting it find out
+    bool k1_marks_valid = false, k1_marks_known = false; uint32_t k1_marks = 0;
     int last_global_walk = 0;                       // evofst_last_global_walk
     int last_pairs_pass = 0;                        // evofst_last_pairs_pass
     int opt_global_walk = 0;                        // against-all rows: 0 auto, 1 lane = population kernel, 2 two-phase kernel where it fits
@@ -515,6 +518,11 @@ int launch_walks(evofst_ctx *c, const K2Params &p, bool with_clean, bool compact
         if (with_clean) {
             f.compact = compact ? 1 : 0;
             HIPCHK(c, launch_clean_walk(f, c->stream));
+            // (only for data the library owns: memory attached with evofst_attach_device may change between two runs)
+            if (c->k1_marks_known && c->k1_marks_valid && c->tiles == c->d_tiles.p) {   // K1's marks of this very data are known
+                if (c->k1_marks == 0) return EVOFST_OK;             // nothing for the general walk: no launch at all
+                if (c->k1_marks < 128 && max_blocks == 0) max_blocks = 8 + 2 * (int)c->k1_marks;
+            }
         }
         HIPCHK(c, launch_fused(f, c->count_bytes, wsub, max_blocks, c->stream));
         return EVOFST_OK;
@@ -629,6 +637,7 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
     p.zf_masks = (uint64_t *)c->d_zf.p; p.irr_mask = (uint64_t *)c->d_irr.p; p.skip_mask = (uint64_t *)c->d_skip.p;
     p.miss_mask = (uint64_t *)c->d_miss.p; p.nan_mask = (uint64_t *)c->d_nan.p;
     p.chunk_offsets = (int64_t *)c->d_offsets.p; p.chunk_dirty = (uint32_t *)c->d_dirty.p;
+    c->k1_marks_valid = c->k1_marks_known = false;      // the marks are this pass's now (its own chunks)
 #ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_DEBUG_STREAM")) p.debug = atoi(e);
     // in-kernel time stamps of one launch (the EVOFST_STREAM_STAMPS_AT-th of this context), written to the file named
@@ -1167,6 +1176,7 @@ static int begin_data(evofst_ctx *c, int64_t n_sites) {
     c->offsets_dirty = true;
     c->n_multi = 0;
     c->stream_dirty_known = false;       // new data: what the passes before marked says nothing about it
+    c->k1_marks_valid = c->k1_marks_known = false;
     return EVOFST_OK;
 }
 
@@ -1483,6 +1493,7 @@ int launch_k1_counts(evofst_ctx *c, int mode) {
         p.miss_mask = (uint64_t *)c->d_miss.p;
         if ((rc = ensure(c, c->d_dirty, (size_t)c->n_chunks * 4))) return rc;
         p.chunk_dirty = (uint32_t *)c->d_dirty.p;
+        if (!c->k1_marks_valid) { c->k1_marks_valid = true; c->k1_marks_known = false; }
         if ((rc = ensure(c, c->d_nan, (size_t)c->n_tiles * 8))) return rc;
         p.nan_mask = (uint64_t *)c->d_nan.p;
         p.compact = !c->prefer_plain && (size_t)c->n_pops * c->count_bytes <= 64 && clean_walk_applies(c) ? 1 : 0;
@@ -1769,6 +1780,15 @@ extern "C" int evofst_sync(evofst_ctx *c) try {
     NEED_GPU(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->mode == MODE_PAIRS && c->counts_done && c->k1_marks_valid && !c->k1_marks_known && c->d_dirty.p && c->n_chunks > 0) {
+        int rc = ensure(c, c->d_row_tot, 8);
+        if (rc) return rc;
+        uint32_t n = 0;
+        HIPCHK(c, launch_count_marks((const uint32_t *)c->d_dirty.p, c->n_chunks, (uint32_t *)c->d_row_tot.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&n, c->d_row_tot.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->k1_marks = n; c->k1_marks_known = true;
+    }
     return fused_verdict(c);
 } catch (...) {
     return abi_exception(c);

@@ -397,6 +397,7 @@ hipError_t launch_global_rows(const uint64_t *kept_mask, const uint64_t *skip_ma
                               int n_chunks, int chunk_tiles, int n_tiles, int size, int step,
                               uint32_t *chunk_rows, hipStream_t st);
 hipError_t launch_global(const GlobalParams &p, int count_bytes, size_t lds_bytes, hipStream_t st);
+hipError_t launch_count_marks(const uint32_t *marks, int n, uint32_t *out, hipStream_t st);
 hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 size_t gram_raw_bytes(int P, int64_t n_windows);

@@ -978,6 +978,24 @@ hipError_t launch_unpack_segments(const SegRow *rows, size_t n, double *num, dou
     return hipGetLastError();
 }
 
+// how many chunks K1 marked for the general walk (one block; asked once per data set, at evofst_sync)
+__global__ __launch_bounds__(256) void count_marks_kernel(const uint32_t *__restrict__ marks, int n, uint32_t *__restrict__ out) {
+    __shared__ uint32_t part[256];
+    uint32_t v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += marks[i] != 0u ? 1u : 0u;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = part[0];
+}
+hipError_t launch_count_marks(const uint32_t *marks, int n, uint32_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(count_marks_kernel, dim3(1), dim3(256), 0, st, marks, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_stitch(const K2Params &p, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
     const size_t n = (size_t)p.n_pairs * p.n_chunks;
