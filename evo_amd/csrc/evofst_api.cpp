@@ -538,7 +538,7 @@ int launch_walks(evofst_ctx *c, const K2Params &p, bool with_clean, bool compact
 constexpr int kStreamMaxChunks = 1 << 17;
 
 // Shape of the stream pass's workgroups: producer waves, consumer waves, tiles a producer counts per chunk.
-struct StreamPlan { int n_prod = 0, n_cons = 0, tr = 0, n_buf = 2, n_sets = 1; };
+struct StreamPlan { int n_prod = 0, n_cons = 0, tr = 0, tr2 = 0, n_buf = 2, n_sets = 1; };
 // tr == 0 when this shape goes through K1 + scan + walk.
 StreamPlan stream_plan(const evofst_ctx *c, int64_t n_sites) {
     StreamPlan pl;
@@ -559,18 +559,33 @@ StreamPlan stream_plan(const evofst_ctx *c, int64_t n_sites) {
     pl.n_cons *= pl.n_sets;
     if (pl.n_prod + pl.n_cons > kStreamMaxWaves) return StreamPlan();
     pl.n_buf = c->opt_stream_bufs > 0 ? c->opt_stream_bufs : 2;
-    int tr = c->opt_chunk_tiles > 0 ? std::max(1, c->opt_chunk_tiles / pl.n_prod) : 2;
-    while ((n_tiles + tr * pl.n_prod - 1) / (tr * pl.n_prod) > kStreamMaxChunks && tr < 16) ++tr;
     // as many workgroups per CU as 16 waves allow (two at the very least); LDS must not be what cuts that number
     // (a chunk size the options ask for may take the whole CU's LDS for one workgroup)
     const int wgs = c->opt_chunk_tiles > 0 ? 1 : std::max(pl.n_prod + pl.n_cons > 8 ? 1 : 2, 16 / (pl.n_prod + pl.n_cons));
     const size_t lds_cap = (size_t)(156 * 1024) / wgs;
-    while (tr > 1 && stream_lds_bytes(c->n_pops, np, tr * pl.n_prod, pl.n_buf) > lds_cap) --tr;
-    if (tr * pl.n_prod > 64 || stream_lds_bytes(c->n_pops, np, tr * pl.n_prod, pl.n_buf) > lds_cap) return StreamPlan();
-    if ((n_tiles + tr * pl.n_prod - 1) / (tr * pl.n_prod) > kStreamMaxChunks) return StreamPlan();
+    const int nf = std::min(pl.n_prod, 4), ns = pl.n_prod - nf;        // producers that are their SIMD's oldest wave, and the others
+    auto chunk_of = [&](int a, int b) { return nf * a + ns * b; };
+    auto fits = [&](int a, int b) {
+        const int ct = chunk_of(a, b);
+        return ct <= 64 && stream_lds_bytes(c->n_pops, np, ct, pl.n_buf) <= lds_cap && (n_tiles + ct - 1) / ct <= kStreamMaxChunks;
+    };
+    int tr = 0, tr2 = 0;
+    if (c->opt_chunk_tiles > 0) {
+        tr = tr2 = std::max(1, c->opt_chunk_tiles / pl.n_prod);
+        if (!fits(tr, tr2)) return StreamPlan();
+    } else {
+        // Chunks as long as the LDS holds two of: every chunk costs a look-back and a tail, and a chunk is in flight from its
+        // ticket to its last producer's arrival, which every later chunk's consumer waits for.  The second wave of a SIMD
+        // counts about a fifth slower than the first (the hardware serves the oldest wave first), so it takes 3 tiles to
+        // the other's 4 where 28-tile chunks fit: both kinds arrive together.
+        static const int shapes[][2] = {{4, 3}, {3, 3}, {3, 2}, {2, 2}, {2, 1}, {1, 1}};
+        for (const auto &sh : shapes)
+            if ((ns > 0 || sh[0] == sh[1]) && fits(sh[0], sh[1])) { tr = sh[0]; tr2 = sh[1]; break; }
+        if (tr == 0) return StreamPlan();
+    }
     // the chunks the integer walk cannot take go to the walk of evofst_fused.hip over counts in HBM
-    if (c->opt_walk == 2 || !lds_walk_fits(c, tr * pl.n_prod)) return StreamPlan();
-    pl.tr = tr;
+    if (c->opt_walk == 2 || !lds_walk_fits(c, chunk_of(tr, tr2))) return StreamPlan();
+    pl.tr = tr; pl.tr2 = tr2;
     return pl;
 }
 
@@ -578,7 +593,7 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
     const int tr = pl.tr;
     const size_t np = c->pairs.size();
     c->n_tiles = n_tiles_of(c->n_sites);
-    c->chunk_tiles = tr * pl.n_prod;
+    c->chunk_tiles = tr * std::min(pl.n_prod, 4) + pl.tr2 * std::max(pl.n_prod - 4, 0);
     c->n_chunks = (c->n_tiles + c->chunk_tiles - 1) / c->chunk_tiles;
     c->seg_cap = c->n_sites / c->g + 2;
     int rc;
@@ -596,7 +611,7 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
     const int64_t n1 = (c->n_chunks + kStreamFan - 1) / kStreamFan, n2 = (n1 + kStreamFan - 1) / kStreamFan;
     const int64_t rows = (int64_t)c->n_chunks + n1 + n2;
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b0 = a256((size_t)c->n_chunks * np * 4), b1 = a256((size_t)n1 * np * 8), b2 = a256((size_t)n2 * np * 8);
+    const size_t b0 = a256((size_t)((c->n_chunks + 1) / 2) * np * 4), b1 = a256((size_t)n1 * np * 4), b2 = a256((size_t)n2 * np * 4);
     const size_t copy_bytes = b0 + b1 + b2, flag_bytes = a256((size_t)rows * 4);
     if ((rc = ensure_zeroed(c, c->d_ssync, 256))) return rc;
     const bool fresh = c->d_sflag.bytes < 2 * flag_bytes || c->d_sagg.bytes < 2 * copy_bytes;
@@ -619,7 +634,7 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
 #ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_STREAM_POLL")) p.poll = std::max(0, atoi(e));
 #endif
-    p.tr = tr; p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
+    p.tr = tr; p.tr2 = pl.tr2; p.chunk_tiles = c->chunk_tiles; p.n_chunks = c->n_chunks;
     p.g = c->g;
     p.base = (const int64_t *)c->d_base.p;
     p.first_segment = (int64_t *)c->d_first_seg.p; p.incl_totals = (int64_t *)c->d_incl_totals.p;
@@ -628,7 +643,7 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
     p.tail = (double *)c->d_tail.p; p.tail_n = (int4 *)c->d_tail_n.p;
     for (int k = 0; k < 2; ++k) {
         unsigned char *base = (unsigned char *)c->d_sagg.p + (size_t)k * copy_bytes;
-        p.agg0[k] = (uint32_t *)base; p.agg1[k] = (uint64_t *)(base + b0); p.agg2[k] = (uint64_t *)(base + b0 + b1);
+        p.agg0[k] = (uint32_t *)base; p.agg1[k] = (uint32_t *)(base + b0); p.agg2[k] = (uint32_t *)(base + b0 + b1);
     }
     p.flags[0] = (uint32_t *)c->d_sflag.p; p.flags[1] = (uint32_t *)((unsigned char *)c->d_sflag.p + flag_bytes);
     p.l1_row = c->n_chunks; p.l2_row = c->n_chunks + (int)n1;

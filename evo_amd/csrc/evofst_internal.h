@@ -184,6 +184,8 @@ struct FusedParams {
 constexpr int kStreamMaxWaves = 12;                    // producer + consumer waves of a workgroup
 constexpr int kStreamMaxThreads = 64 * kStreamMaxWaves;
 constexpr int kStreamFan = 32;                         // look-back fan-out per level
+constexpr int kStreamAggShift = 26;                    // levels 1, 2: {contributions << 26 | included sites}
+constexpr uint32_t kStreamAggMask = (1u << kStreamAggShift) - 1u;
 constexpr int kStreamRow = 80;                         // bytes per (tile, population) row of alt counts in LDS: 64 sites + 16 of padding
 constexpr int kStreamMaxPairs = 256;
 #ifndef EVOFST_STREAM_WPS
@@ -202,7 +204,8 @@ struct StreamParams {
     int32_t poll;                   // s_sleep(16)s between two polls of the look-back flags
     int32_t n_sets;                 // sets of consumer waves (1 or 2) that take the workgroup's chunks in turn; n_cons = all of them
     int32_t n_buf;                  // LDS buffers (chunks of a workgroup in flight): 2 .. kStreamMaxBufs
-    int32_t tr;                     // tiles a producer wave counts per chunk
+    int32_t tr;                     // tiles a producer wave counts per chunk: waves 0 .. 3 (the oldest wave of their SIMD, which
+    int32_t tr2;                    // the hardware serves first), and the waves behind them (tr2 <= tr: both kinds then finish together)
     int32_t chunk_tiles, n_chunks;  // chunk_tiles = n_prod * tr
     int32_t g;
     const int64_t *base;            // [n_pairs] included sites of the pair before this shard
@@ -215,9 +218,9 @@ struct StreamParams {
     // look-back (evofst_stream.hip, "Look-back"): included sites per pair of a chunk (+ 1), of a group of 32 chunks and of a
     // group of 32 groups ({contributions, sum} in 64 bits), and one flag word per row (rows 0.., l1_row.., l2_row..) that
     // counts the row's contributions.  Two copies: a launch uses copy (launch counter & 1) and zeroes the other one
-    uint32_t *agg0[2];              // [n_chunks][n_pairs]
-    uint64_t *agg1[2];              // [ceil(n_chunks / 32)][n_pairs]
-    uint64_t *agg2[2];              // [ceil(n_chunks / 1024)][n_pairs]
+    uint32_t *agg0[2];              // [ceil(n_chunks / 2)][n_pairs] two chunks' 16-bit words each
+    uint32_t *agg1[2];              // [ceil(n_chunks / 32)][n_pairs] {contributions << 26 | sites}
+    uint32_t *agg2[2];              // [ceil(n_chunks / 1024)][n_pairs]
     uint32_t *flags[2];             // [n_chunks + ceil(n_chunks / 32) + ceil(n_chunks / 1024)]
     int32_t l1_row, l2_row;
     uint32_t *ticket;               // chunk tickets; back to 0 when the launch ends

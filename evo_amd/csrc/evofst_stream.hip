@@ -44,6 +44,7 @@ extern "C" __device__ int evofst_write_lane(int val, int lane, int old) __asm("l
 
 typedef __attribute__((address_space(1))) uint32_t gu32;
 typedef __attribute__((address_space(1))) uint64_t gu64;
+typedef __attribute__((address_space(1))) uint16_t gu16;
 
 #ifdef EVOFST_EXPERIMENTS
 // slot k of (workgroup, iteration): the 100 MHz real-time counter, written by one lane
@@ -57,23 +58,25 @@ constexpr uint32_t kStreamSpinLimit = 1u << 20;   // polls (with a sleep each) b
 static __host__ __device__ constexpr size_t s16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // One LDS buffer = one counted chunk: alt counts, one byte each, rows of kStreamRow bytes per (tile, population) (64 sites
-// + padding: rows of different populations start in different banks); non-missing counts, one byte each (only a chunk
-// the integer walk cannot take needs them); zero / fixed ballots [tile][z|f][P]; the four site masks of every tile; the quarter
-// table of the integer walk (stream_quarter_table), which the consumers fill in.
-struct StreamBuf { unsigned char *c, *m; uint64_t *zf, *flg; uint32_t *qt; };
+// + padding: rows of different populations start in different banks); zero / fixed ballots [tile][z|f][P]; five words per
+// tile (the four site masks and the populations whose row has a missing allele); the quarter table of the integer walk
+// (stream_quarter_table), which the consumers fill in.  The non-missing counts are not kept: a row without a missing
+// allele has n_full of them at every site, and a row with one -- its chunk goes to the general walk -- leaves the
+// producer as packed counts straight for HBM (stream_count_piece); the consumer writes the chunk's other rows.
+struct StreamBuf { unsigned char *c; uint64_t *zf, *flg; uint32_t *qt; };
+constexpr int kStreamFlg = 5;
 static __host__ __device__ size_t stream_c_bytes(int P, int chunk_tiles) { return s16((size_t)chunk_tiles * P * kStreamRow); }
-static __host__ __device__ size_t stream_m_bytes(int P, int chunk_tiles) { return s16((size_t)chunk_tiles * P * kTileSites); }
 static __host__ __device__ size_t stream_buf_bytes(int P, int chunk_tiles) {
-    return stream_c_bytes(P, chunk_tiles) + stream_m_bytes(P, chunk_tiles) + s16((size_t)chunk_tiles * 2 * P * 8) + s16((size_t)chunk_tiles * 4 * 8) +
+    return stream_c_bytes(P, chunk_tiles) + s16((size_t)chunk_tiles * 2 * P * 8) + s16((size_t)chunk_tiles * kStreamFlg * 8) +
            s16((size_t)chunk_tiles * P * 32);
 }
 size_t stream_buffer_bytes(int P, int chunk_tiles) { return stream_buf_bytes(P, chunk_tiles); }
 static __device__ __forceinline__ StreamBuf stream_buf(unsigned char *base, int P, int chunk_tiles) {
     StreamBuf b;
-    b.c = base; b.m = base + stream_c_bytes(P, chunk_tiles);
-    b.zf = reinterpret_cast<uint64_t *>(b.m + stream_m_bytes(P, chunk_tiles));
+    b.c = base;
+    b.zf = reinterpret_cast<uint64_t *>(b.c + stream_c_bytes(P, chunk_tiles));
     b.flg = b.zf + (size_t)chunk_tiles * 2 * P;
-    b.qt = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(b.flg) + s16((size_t)chunk_tiles * 4 * 8));
+    b.qt = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(b.flg) + s16((size_t)chunk_tiles * kStreamFlg * 8));
     return b;
 }
 // + the table of byte masks, the workgroup's words, three per-pair arrays
@@ -117,6 +120,7 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
     uint32_t irregular = 0, anymiss = 0, nanany = 0;     // per-lane 0 / 1 words (see K1)
     bool skip = false;
     uint64_t skipmask = 0;
+    int rowmiss = 0;                                     // lane = population: its row of this tile has a missing allele (set on the rare path only)
     int zlo = 0, zhi = 0, flo = 0, fhi = 0;              // ballots by population, lane = population
     auto tile_done = [&](int slot) {                     // the tile's ballots -> LDS
         if (lane < P) {
@@ -124,7 +128,11 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
             zf[(size_t)slot * 2 * P + P + lane] = ((uint64_t)(uint32_t)fhi << 32) | (uint32_t)flo;
         }
         const uint64_t im = __ballot(irregular != 0 && !skip), mm = __ballot(anymiss != 0 && !skip), nn = __ballot(nanany != 0 && !skip);
-        if (lane == 0) { flg[slot * 4 + 0] = im; flg[slot * 4 + 1] = skipmask; flg[slot * 4 + 2] = mm; flg[slot * 4 + 3] = nn; }
+        if (lane == 0) {
+            flg[slot * kStreamFlg + 0] = im; flg[slot * kStreamFlg + 1] = skipmask; flg[slot * kStreamFlg + 2] = mm; flg[slot * kStreamFlg + 3] = nn;
+        }
+        const uint64_t rm = __ballot(rowmiss != 0);
+        if (lane == 0) flg[slot * kStreamFlg + 4] = rm;
     };
     int sidx = 0;
     SegWords d = segs[0], dn = segs[1];
@@ -137,16 +145,15 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
             if (ti > 0) tile_done(slot0 + ti - 1);
             skip = (int64_t)t * kTileSites + lane >= p.n_sites || (have_flags && (cur.flag & 1u) != 0);
             skipmask = __ballot(skip);
-            c = 0; mc = 0; irregular = 0; anymiss = 0; nanany = 0;
+            c = 0; mc = 0; irregular = 0; anymiss = 0; nanany = 0; rowmiss = 0;
             sidx = 0; d = segs[0]; dn = segs[1];
         }
         load_item(spare);
         asm volatile("" :: "v"(cur.flag));               // the flag byte is the last load of its batch: the batch has arrived
         if (!live) return;
         unsigned char *cp = buf.c + (size_t)(slot0 + ti) * P * kStreamRow + lane;
-        unsigned char *mp = buf.m + (size_t)(slot0 + ti) * P * kTileSites + lane;
 #ifdef EVOFST_EXPERIMENTS
-        if (p.debug & 4) { c += (uint32_t)cur.r[0].x ^ (uint32_t)cur.r[1].y ^ (uint32_t)cur.r[2].x ^ (uint32_t)cur.r[3].y; if (c == 0x12345u) { cp[0] = 1; mp[0] = 1; } return; }
+        if (p.debug & 4) { c += (uint32_t)cur.r[0].x ^ (uint32_t)cur.r[1].y ^ (uint32_t)cur.r[2].x ^ (uint32_t)cur.r[3].y; if (c == 0x12345u) { cp[0] = 1; } return; }
 #endif
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -162,8 +169,8 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
                     if (fl & kSegLast) {
                         const uint32_t nfull = fl >> kSegNFullShift;
                         const uint32_t nm = nfull - mc;
-                        cp[pop * kStreamRow] = (unsigned char)(skip ? 0u : c);   // a skipped site: no count, both ballots set -- excluded, and 0 in every sum
-                        mp[pop * kTileSites] = (unsigned char)nm;
+                        const uint32_t cs = skip ? 0u : c;               // a skipped site: no count, both ballots set -- excluded, and 0 in every sum
+                        cp[pop * kStreamRow] = (unsigned char)cs;
                         const uint64_t z = __ballot(c == 0) | skipmask;
                         const uint64_t f = __ballot(c == nm) | skipmask;
                         const int pl = (int)pop;
@@ -172,7 +179,16 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
                         // sites the integer walk cannot take: a NaN in the reference (nm < 2) or an excluded site with a
                         // dxy term (fixed with missing alleles).  Both need a missing allele unless n_full < 2.
                         const bool anym = mc != 0;
-                        if (__any(anym) || nfull < 2u) {
+                        const bool rowm = __any(anym);
+                        if (rowm) {                                      // rare: the chunk goes to the general walk, which reads HBM
+                            // (as an instruction of its own: a store the compiler sees inside this loop turns every wait
+                            // for a prefetched batch into "everything outstanding"; unseen, it can only make one such
+                            // wait longer, and nothing in this kernel reads what it writes)
+                            const uint16_t *dst16 = reinterpret_cast<const uint16_t *>(p.counts) + (((size_t)t * P + pop) * kTileSites + lane);
+                            asm volatile("global_store_short %0, %1, off" :: "v"(dst16), "v"(cs | (nm << 8)) : "memory");
+                            rowmiss = evofst_write_lane(1, (int)pop, rowmiss);
+                        }
+                        if (rowm || nfull < 2u) {
                             const uint32_t few = nm < 2u ? 1u : 0u;
                             irregular |= few | ((c == nm && nm < nfull) ? 1u : 0u);
                             nanany |= few;
@@ -198,9 +214,11 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
 // ------------------------------------------------------------------------------------------------ consumer
 // Look-back.  Three tables, all written by the producer that publishes a chunk (stream_publish) and read by the
 // consumers of later chunks:
-//   level 0  agg0[chunk][pair]  32-bit words, included sites of the chunk + 1 (0: not there yet);
-//   level 1  agg1[group of 32 chunks][pair]: 64-bit words that every chunk of the group adds {1, its included sites} to
-//            (one atomic add): the sum is complete when the high half says 32 -- no chunk waits for another to form the
+//   level 0  agg0[chunk / 2][pair][chunk & 1]  16-bit halves of a word, included sites of the chunk + 1 (0: not there
+//            yet): a reader's 4-byte load brings two chunks;
+//   level 1  agg1[group of 32 chunks][pair]: 32-bit words that every chunk of the group adds {1 << 26 | its included
+//            sites} to (one atomic add): the sum is complete when the top six bits say 32 (a group holds at most
+//            32 * 32 * 4096 < 2^26 sites) -- no chunk waits for another to form the
 //            aggregate, and it is there as soon as the group's last chunk has been counted;
 //   level 2  agg2[group of 32 groups][pair]: the same with a group's total as the contribution, added by a consumer of
 //            the first chunk of the next group (stream_consume) -- 32 adds per word over a long time, where 1024 chunks
@@ -244,16 +262,17 @@ __device__ __forceinline__ bool stream_sum_rows(const StreamParams &p, const Str
     const uint32_t np = (uint32_t)p.n_pairs;
     uint32_t spins = 0;
     uint64_t sum = 0;
-    {   // level 0: at most 31 rows
+    {   // level 0: at most 31 rows, two to a word (the group starts at an even chunk)
         const uint32_t *a0 = p.agg0[par];                 // uniform base + 32-bit offsets: one address register per load
-        const uint32_t o0 = (uint32_t)(r.grp0 * F) * np + (uint32_t)q;
-        uint32_t x[B - 1];
+        const uint32_t o0 = (uint32_t)(r.grp0 * (F / 2)) * np + (uint32_t)q;
+        const int nw = (r.n0 + 1) >> 1;
+        uint32_t x[B / 2];
         while (r.n0 > 0) {
 #pragma unroll
-            for (int u = 0; u < B - 1; ++u) x[u] = __hip_atomic_load((gu32 *)(a0 + (o0 + (uint32_t)min(u, r.n0 - 1) * np)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < B / 2; ++u) x[u] = __hip_atomic_load((gu32 *)(a0 + (o0 + (uint32_t)min(u, nw - 1) * np)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < B - 1; ++u) ok = ok && x[u] != 0u;
+            for (int u = 0; u < B / 2; ++u) ok = ok && (x[u] & 0xffffu) != 0u && (2 * min(u, nw - 1) + 1 >= r.n0 || (x[u] >> 16) != 0u);
             if (__all(ok)) break;
             if (++spins > kStreamSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
             if ((spins & 63u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
@@ -261,24 +280,25 @@ __device__ __forceinline__ bool stream_sum_rows(const StreamParams &p, const Str
         }
         if (r.n0 > 0) {
 #pragma unroll
-            for (int u = 0; u < B - 1; ++u) sum += u < r.n0 ? x[u] - 1u : 0u;
+            for (int u = 0; u < B / 2; ++u) sum += (2 * u < r.n0 ? (x[u] & 0xffffu) - 1u : 0u) + (2 * u + 1 < r.n0 ? (x[u] >> 16) - 1u : 0u);
         }
     }
-    // levels 1 and 2 as one list of 64-bit words, 16 in flight (the two tables lie one behind the other: one base)
+    // levels 1 and 2 as one list of 32-bit words {contributions << 26 | sites}, 16 in flight (the two tables lie one
+    // behind the other: one base)
     constexpr int B2 = 16;
     const int total = r.n1 + r.n2;
-    const uint64_t *a1 = p.agg1[par];
+    const uint32_t *a1 = p.agg1[par];
     const uint32_t o1 = (uint32_t)(r.grp1 * F) * np + (uint32_t)q, o2 = (uint32_t)(p.agg2[par] - p.agg1[par]) + (uint32_t)q;
     for (int r0 = 0; r0 < total; r0 += B2) {
-        uint64_t x[B2];
+        uint32_t x[B2];
         for (;;) {
             bool ok = true;
 #pragma unroll
             for (int u = 0; u < B2; ++u) {
                 const int i = min(r0 + u, total - 1);
                 const uint32_t off = i < r.n1 ? o1 + (uint32_t)i * np : o2 + (uint32_t)(i - r.n1) * np;
-                x[u] = __hip_atomic_load((gu64 *)(a1 + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = ok && (uint32_t)(x[u] >> 32) == (uint32_t)F;
+                x[u] = __hip_atomic_load((gu32 *)(a1 + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (x[u] >> kStreamAggShift) == (uint32_t)F;
             }
             if (__all(ok)) break;
             if (++spins > kStreamSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
@@ -286,7 +306,7 @@ __device__ __forceinline__ bool stream_sum_rows(const StreamParams &p, const Str
             if (p.debug & 512) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(96);
         }
 #pragma unroll
-        for (int u = 0; u < B2; ++u) sum += r0 + u < total ? (x[u] & 0xffffffffull) : 0ull;
+        for (int u = 0; u < B2; ++u) sum += r0 + u < total ? (uint64_t)(x[u] & kStreamAggMask) : 0ull;
     }
     before = sum;
     retries = spins;
@@ -341,7 +361,6 @@ __device__ __forceinline__ void stream_walk_pair(const StreamParams &p, const un
     const int32_t left0 = left;
     const int32_t row0 = (int32_t)(m - first_seg);
     size_t orow = (size_t)row0 * p.n_pairs + q;
-    const size_t orow_end = (size_t)p.seg_cap * p.n_pairs;
     int32_t nflush = 0;
     uint32_t aCC = 0, aCi = 0, aCj = 0, aQi = 0, aQj = 0;                 // integer sums since the last boundary
     auto parts = [&](uint32_t iCC, uint32_t iCi, uint32_t iCj, uint32_t iQi, uint32_t iQj, double &num, double &den, double &k) {
@@ -399,12 +418,16 @@ __device__ __forceinline__ void stream_walk_pair(const StreamParams &p, const un
             pQj = __builtin_amdgcn_udot4(y.x, y.x, pQj, false); pQj = __builtin_amdgcn_udot4(y.y, y.y, pQj, false);
             pQj = __builtin_amdgcn_udot4(y.z, y.z, pQj, false); pQj = __builtin_amdgcn_udot4(y.w, y.w, pQj, false);
             SegRow row;
+#ifdef EVOFST_EXPERIMENTS
+            if (p.debug & 8192) { row.num = 1.0; row.den = 2.0; row.k = 3.0; } else   // (timing: rows stored, not computed)
+#endif
             parts(aCC + (pCC - dCC), aCi + (pCi - dCi), aCj + (pCj - dCj), aQi + (pQi - dQi), aQj + (pQj - dQj), row.num, row.den, row.k);
             row.end = (gtile0 + ti) * kTileSites + b; row.pad = 0;
 #ifdef EVOFST_EXPERIMENTS
+            if (p.debug & 4096) { asm volatile("" :: "v"(row.num), "v"(row.den), "v"(row.k)); } else   // (timing: rows computed, not stored)
             if ((p.debug & 16) && row.end != -12345) {} else
 #endif
-            if (orow >= orow_end) {   // never with a sound prefix; no store outside the table whatever the look-back handed over
+            if ((uint64_t)((int64_t)row0 + nflush) >= (uint64_t)p.seg_cap) {   // never with a sound prefix; no store outside the table whatever the look-back handed over
                 __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {   // two 16-byte stores into one 32-byte sector
                 uint4 *dst = reinterpret_cast<uint4 *>(p.seg_rows + orow);
@@ -468,22 +491,23 @@ __device__ __forceinline__ void stream_publish(const StreamParams &p, int lane, 
 #endif
     const size_t np = (size_t)p.n_pairs;
     const int grp0 = chunk / F, grp1 = grp0 / F;
-    uint32_t *row0 = p.agg0[par] + (size_t)chunk * np;
-    uint64_t *row1 = p.agg1[par] + (size_t)grp0 * np;
+    uint16_t *row0 = reinterpret_cast<uint16_t *>(p.agg0[par] + (size_t)(chunk >> 1) * np) + (chunk & 1);   // column q: [2 * q]
+    uint16_t *orow0 = reinterpret_cast<uint16_t *>(p.agg0[par ^ 1] + (size_t)(chunk >> 1) * np) + (chunk & 1);
+    uint32_t *row1 = p.agg1[par] + (size_t)grp0 * np;
     for (int g = 0; g < NG; ++g) {
         const int q = g * 64 + lane;
         if (q < p.n_pairs) {
             const uint32_t n = cen[q];
-            __hip_atomic_store((gu32 *)(row0 + q), n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t one = (1ull << 32) | n;             // {one more chunk, its included sites}
+            __hip_atomic_store((gu16 *)(row0 + 2 * q), (uint16_t)(n + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t one = (1u << kStreamAggShift) | n;   // {one more chunk, its included sites}
 #ifdef EVOFST_EXPERIMENTS
             if (!(p.debug & 128))
 #endif
-            __hip_atomic_fetch_add((gu64 *)(row1 + q), one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add((gu32 *)(row1 + q), one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // the other copy's rows, for the next launch
-            p.agg0[par ^ 1][(size_t)chunk * np + q] = 0u;
-            if (chunk % F == 0) p.agg1[par ^ 1][(size_t)grp0 * np + q] = 0ull;
-            if (chunk % (F * F) == 0) p.agg2[par ^ 1][(size_t)grp1 * np + q] = 0ull;
+            orow0[2 * q] = 0;
+            if (chunk % F == 0) p.agg1[par ^ 1][(size_t)grp0 * np + q] = 0u;
+            if (chunk % (F * F) == 0) p.agg2[par ^ 1][(size_t)grp1 * np + q] = 0u;
         }
     }
     // (the release makes this wave's reads of the census complete before the consumers may clear it)
@@ -515,7 +539,7 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
     // packer's filters, the sites behind the shard's end in its last tile -- stay here: their counts were left out of the
     // count plane and both of their ballots are set, so they are excluded and add exactly 0 to every integer sum.)
     uint64_t fw = 0;
-    if (lane < nt) fw = flg[lane * 4 + 0] | flg[lane * 4 + 2];
+    if (lane < nt) fw = flg[lane * kStreamFlg + 0] | flg[lane * kStreamFlg + 2];
     const bool dirty = __any(fw != 0);
     if (my_groups == 0) return true;
     // ---- the rows before this chunk: wait until their flags say they are complete, read them once per group of 64 pairs;
@@ -538,17 +562,17 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
 #pragma unroll 1
         for (int g = cw; g < NG; g += ncw) {
             const int q = g * 64 + lane;
-            const uint64_t *src = p.agg1[par] + ((uint32_t)gprev * np + (uint32_t)(q < p.n_pairs ? q : 0));
-            uint64_t v;
+            const uint32_t *src = p.agg1[par] + ((uint32_t)gprev * np + (uint32_t)(q < p.n_pairs ? q : 0));
+            uint32_t v;
             for (;;) {
-                v = __hip_atomic_load((gu64 *)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all((uint32_t)(v >> 32) == (uint32_t)kStreamFan)) break;
+                v = __hip_atomic_load((gu32 *)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((v >> kStreamAggShift) == (uint32_t)kStreamFan)) break;
                 if (++spins > kStreamSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
                 if ((spins & 63u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
                 __builtin_amdgcn_s_sleep(8);
             }
             if (q < p.n_pairs)
-                __hip_atomic_fetch_add((gu64 *)(p.agg2[par] + ((uint32_t)(gprev / kStreamFan) * np + (uint32_t)q)), (1ull << 32) | (v & 0xffffffffull),
+                __hip_atomic_fetch_add((gu32 *)(p.agg2[par] + ((uint32_t)(gprev / kStreamFan) * np + (uint32_t)q)), (1u << kStreamAggShift) | (v & kStreamAggMask),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (cw == 0 && lane == 0) __hip_atomic_fetch_add((gu32 *)(p.flags[par] + p.l2_row + gprev / kStreamFan), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -605,13 +629,17 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
     if (cw == 0) STREAM_STAMP(p, it, 8);                  // walked
     if (cw != 0) return true;
     if (dirty) {
-        // K1's outputs for this chunk: packed counts [tile][P][64], ballots [tile][z|f][P], the four site masks
-        const int nv = nt * P * 4;                         // groups of 16 sites: 16 alt bytes + 16 non-missing bytes -> 16 packed counts
+        // K1's outputs for this chunk: packed counts [tile][P][64] (the rows without a missing allele: the producers
+        // wrote the others), ballots [tile][z|f][P], the four site masks
+        const int nv = nt * P * 4;                         // groups of 16 sites: 16 alt bytes + n_full -> 16 packed counts
         uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.counts) + (size_t)gtile0 * P * kTileSites);
         for (int v = lane; v < nv; v += 64) {
             const int row = v >> 2, part = v & 3;          // row = slot * P + population
+            const int slot = row / P, pop = row - slot * P;
+            if ((flg[slot * kStreamFlg + 4] >> pop) & 1ull) continue;
             const uint4 c16 = *reinterpret_cast<const uint4 *>(buf.c + (size_t)row * kStreamRow + part * 16);
-            const uint4 n16 = *reinterpret_cast<const uint4 *>(buf.m + (size_t)row * kTileSites + part * 16);
+            const uint32_t nn = (uint32_t)p.n_full[pop] * 0x01010101u;
+            const uint4 n16 = make_uint4(nn, nn, nn, nn);
             dst[2 * v] = make_uint4(__builtin_amdgcn_perm(n16.x, c16.x, 0x05010400u), __builtin_amdgcn_perm(n16.x, c16.x, 0x07030602u),
                                     __builtin_amdgcn_perm(n16.y, c16.y, 0x05010400u), __builtin_amdgcn_perm(n16.y, c16.y, 0x07030602u));
             dst[2 * v + 1] = make_uint4(__builtin_amdgcn_perm(n16.z, c16.z, 0x05010400u), __builtin_amdgcn_perm(n16.z, c16.z, 0x07030602u),
@@ -619,8 +647,8 @@ __device__ __forceinline__ bool stream_consume(const StreamParams &p, int it, in
         }
         for (int i = lane; i < nt * 2 * P; i += 64) p.zf_masks[(size_t)gtile0 * 2 * P + i] = zf[i];
         if (lane < nt) {
-            p.irr_mask[gtile0 + lane] = flg[lane * 4 + 0]; p.skip_mask[gtile0 + lane] = flg[lane * 4 + 1];
-            p.miss_mask[gtile0 + lane] = flg[lane * 4 + 2]; p.nan_mask[gtile0 + lane] = flg[lane * 4 + 3];
+            p.irr_mask[gtile0 + lane] = flg[lane * kStreamFlg + 0]; p.skip_mask[gtile0 + lane] = flg[lane * kStreamFlg + 1];
+            p.miss_mask[gtile0 + lane] = flg[lane * kStreamFlg + 2]; p.nan_mask[gtile0 + lane] = flg[lane * kStreamFlg + 3];
         }
     }
     if (lane == 0) p.chunk_dirty[chunk] = dirty ? 1u : 0u;
@@ -711,19 +739,20 @@ __global__ __launch_bounds__(kStreamMaxThreads, EVOFST_STREAM_WPS) void stream_p
             const StreamBuf bk = stream_buf(bufs + (size_t)kb * buf_bytes, p.P, p.chunk_tiles);
             if (use > 0 && !wait_word(lfree + kb, (uint32_t)(NC / p.n_sets * use))) break;
             if (wave == 0) STREAM_STAMP(p, k, 1);             // buffer free
-            const int t0 = __builtin_amdgcn_readfirstlane(ci * p.chunk_tiles + wave * p.tr);
-            const int n_own = __builtin_amdgcn_readfirstlane(min(p.tr, p.n_tiles - t0));
+            const int slot0 = wave < 4 ? wave * p.tr : min(NP, 4) * p.tr + (wave - 4) * p.tr2;
+            const int t0 = __builtin_amdgcn_readfirstlane(ci * p.chunk_tiles + slot0);
+            const int n_own = __builtin_amdgcn_readfirstlane(min(wave < 4 ? p.tr : p.tr2, p.n_tiles - t0));
 #ifdef EVOFST_EXPERIMENTS
             const unsigned long long tc0 = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (n_own > 0) stream_count_piece(p, lane, t0, n_own, wave * p.tr, bk, segs);
+            if (n_own > 0) stream_count_piece(p, lane, t0, n_own, slot0, bk, segs);
             if (wave == 0) STREAM_STAMP(p, k, 2);             // counted
 #ifdef EVOFST_EXPERIMENTS
             if (p.stamps && k < kStreamStampIters && lane == 0 && wave < 8)   // every producer's counting time, 10 ns units, 16 bits each
                 reinterpret_cast<unsigned short *>(p.stamps + ((size_t)blockIdx.x * kStreamStampIters + k) * 16 + 14)[wave] =
                     (unsigned short)min(__builtin_amdgcn_s_memrealtime() - tc0, 65535ull);
 #endif
-            stream_census(p, lane, wave * p.tr, n_own, bk.zf, lpairs, lcen + (size_t)kb * pw);
+            stream_census(p, lane, slot0, n_own, bk.zf, lpairs, lcen + (size_t)kb * pw);
             // arrival: the first producer there draws the next ticket (the others are still counting, nobody waits for
             // the round trip, and a chunk is counted straight after its ticket is drawn: chunks with smaller tickets
             // are never far behind); the last one publishes -- unless it is also the first, then it publishes first
@@ -792,8 +821,8 @@ __global__ __launch_bounds__(kStreamMaxThreads, EVOFST_STREAM_WPS) void stream_p
 
 hipError_t launch_stream(const StreamParams &p, int max_blocks, hipStream_t st) {
     if (p.n_chunks <= 0 || p.n_pairs <= 0) return hipSuccess;
-    if (p.n_pairs > kStreamMaxPairs || p.P > 64 || p.tr <= 0 || p.n_prod < 1 || p.n_cons < 1 || p.n_prod + p.n_cons > kStreamMaxWaves ||
-        p.chunk_tiles != p.tr * p.n_prod || p.chunk_tiles > 64 || p.n_buf < 2 || p.n_buf > kStreamMaxBufs ||
+    if (p.n_pairs > kStreamMaxPairs || p.P > 64 || p.tr <= 0 || p.tr2 <= 0 || p.tr2 > p.tr || p.n_prod < 1 || p.n_cons < 1 || p.n_prod + p.n_cons > kStreamMaxWaves ||
+        p.chunk_tiles != p.tr * std::min(p.n_prod, 4) + p.tr2 * std::max(p.n_prod - 4, 0) || p.chunk_tiles > 64 || p.n_buf < 2 || p.n_buf > kStreamMaxBufs ||
         p.n_sets < 1 || p.n_sets > 2 || p.n_cons % p.n_sets != 0) return hipErrorInvalidValue;
     const int threads = 64 * (p.n_prod + p.n_cons);
     const void *fn = reinterpret_cast<const void *>(&stream_pairs_kernel);
