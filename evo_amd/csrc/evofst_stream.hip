@@ -9,10 +9,13 @@
 // drawn by the producer that finishes the chunk before it first).  For chunk k of a workgroup, in LDS buffer k mod NB:
 //   the producers  count it: lane = site, 16-byte coalesced loads of the tile rows (three batches of four rows requested
 //                  ahead of the one being counted), popcounts under the wave-uniform masks of the layout's descriptor
-//                  stream (scalar cache), one alt-count byte and one non-missing byte per site and population and the
-//                  zero / fixed ballots of every population INTO LDS -- nothing but the tiles is read from HBM and no
-//                  count is written to it; then the census of included sites per pair (filter :543-544, lane = pair),
-//                  which the producer that finishes last publishes as one row of 4-byte words;
+//                  stream (scalar cache), one alt-count byte per site and population and the zero / fixed ballots of
+//                  every population INTO LDS -- nothing but the tiles is read from HBM and, on data without missing
+//                  alleles, no count is written to it (a (tile, population) row with a missing allele leaves as packed
+//                  counts right away: its chunk goes to the general walk); then the census of included sites per pair
+//                  (filter :543-544, lane = pair), which the producer that finishes last publishes as one row of
+//                  2-byte words.  A SIMD's first producer wave takes tr tiles of the chunk, its second tr2 <= tr: the
+//                  hardware serves the older wave first, and with 4 : 3 both arrive together;
 //   the consumers  take it once it is published: look-back over the rows of the chunks before it (three levels of
 //                  fan-out 32: chunks of its group, groups of its super-group, super-groups); then the statistics
 //                  walk over the chunk's counts in LDS (exact integer sums, four sites per v_dot4_u32_u8, segment rows
