@@ -688,7 +688,10 @@ int run_stream(evofst_ctx *c, const StreamPlan &pl) {
     // (a shard whose last tile is short always marks its last chunk: a workgroup or two per marked chunk, up to the device)
     ++c->stream_launches;
     const int walk_blocks = c->stream_dirty_known && c->stream_dirty_last < 128 ? 8 + 2 * (int)c->stream_dirty_last : 0;
-    if ((rc = launch_walks(c, k2, false, false, true, walk_blocks))) return rc;
+    // (nothing marked by the passes before this one over the same data in the library's own memory -- which only
+    // evofst_upload / evofst_synth change, and they reset what is known: nothing to launch; attached memory may have changed)
+    const bool none_marked = c->stream_dirty_known && c->stream_dirty_last == 0 && c->tiles == c->d_tiles.p;
+    if (!none_marked && (rc = launch_walks(c, k2, false, false, true, walk_blocks))) return rc;
     record(c, 2, 1);
     record(c, 3, 0);
     HIPCHK(c, launch_stitch(k2, c->stream));
