@@ -544,6 +544,34 @@ def main():
             except Exception:
                 kms[i, k] = 0.0
     kavg = kms[:reps].mean(axis=0)
+    # A short dominant kernel (cfg2's K1: 37 us) is measured a second way: an event pair around ONE launch adds about 3 us
+    # of its own (the events above say 40 us where rocprofv3's timestamps say 36.6), so K1 is also launched back to
+    # back, four rounds over the resident batches on one stream, between one pair of events -- the gaps between the
+    # launches count, the events' own time does not.  The batches then run a whole pass again (their results are read below).
+    k1_b2b_ms = 0.0
+    if (not multi and cfg["mode"] == "pairs" and n_batches > 1 and e.last_pairs_pass() == 1 and kavg[0] > 0
+            and kavg[0] < 0.5 and kavg[0] >= kavg[2]):
+        s0 = streams[0]
+        torch.cuda.synchronize()
+        for x in es:
+            x.set_profiling(False); x.set_stream(s0.cuda_stream)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rounds = 4
+        with torch.cuda.stream(s0):
+            for x in es:
+                x.run_counts()                      # (warm: the first launch after a change of stream)
+            ev0.record(s0)
+            for i in range(rounds * n_batches):
+                es[i % n_batches].run_counts()
+            ev1.record(s0)
+        ev1.synchronize()
+        k1_b2b_ms = ev0.elapsed_time(ev1) / (rounds * n_batches)
+        for b_, x in enumerate(es):
+            x.set_stream(streams[b_ % len(streams)].cuda_stream)
+            x.set_profiling(True)
+            x.run()
+        for x in es:
+            x.sync()
     flush()          # every rank: the carries of the last profiled pass, for the exchange check below
     fence()
     if multi:
@@ -587,7 +615,8 @@ def main():
     else:
         dom = 0 if kavg[0] >= kavg[2] else 2
         dom_bytes = k1_bytes if dom == 0 else k2_bytes
-    achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9 if kavg[dom] > 0 else 0.0
+    dom_ms = k1_b2b_ms if dom == 0 and k1_b2b_ms > 0 else kavg[dom]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 +
     # WRITE_SIZE; profiles/README.md says how they were collected) -- null for a configuration not profiled
     traffic = None
@@ -604,7 +633,9 @@ def main():
                 "pipeline_GBps": pipeline_bytes * world / (dt / args.steps) / 1e9,
                 "kernels_ms": {names[k]: float(kavg[k]) for k in range(5) if kavg[k] > 0},
                 "k1_GBps": k1_bytes / (kavg[0] * 1e-3) / 1e9 if kavg[0] > 0 else 0.0,
-                "algorithmic_bytes": dom_bytes}
+                "algorithmic_bytes": dom_bytes, "kernel_ms": float(dom_ms),
+                "kernel_ms_how": ("%d launches back to back on one stream between one pair of HIP events" % (4 * n_batches)) if dom == 0 and k1_b2b_ms > 0
+                                 else "a pair of HIP events around every launch"}
 
     if cfg["mode"] == "gram" and kavg[2] > 0:
         # SURVEY 8d counts 2 S flops per pair and contraction.  Of the contractions behind a window's sums only the two of
