@@ -221,11 +221,15 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
 // HBM: the statistics half on its own (evofst_run_stats after evofst_run_counts, the multi-GPU pass): a region is one of
 // K1's chunks, its counts and ballots come from HBM in pieces of a few tiles (the next piece is requested before the
 // current one is walked) and its offsets from the scan kernel; no phase A, no look-back, no tickets.
+// W3 (HBM mode, shared tables): registers for three waves per SIMD instead of two.  The walk is bound by the latency of
+// its LDS round trips, not by issue slots: where the LDS holds three workgroups per CU the third wave per SIMD is worth
+// more than the two dozen registers it spills (cfg4 shard with missing calls: 1.81 -> 1.40 ms); where the LDS holds two
+// anyway (wave-private tables, many populations) it would only add the spills (cfg2 with missing calls: 93 -> 106 us).
 #ifndef EVOFST_WALK_WPS
 #define EVOFST_WALK_WPS 2
 #endif
-template <typename CT, bool use_rcp, bool WP, int SUB, bool HBM>
-__global__ __launch_bounds__(kK2Threads, HBM ? EVOFST_WALK_WPS : EVOFST_FUSED_WPS) void fused_pairs_kernel(FusedParams p) {
+template <typename CT, bool use_rcp, bool WP, int SUB, bool HBM, bool W3 = false>
+__global__ __launch_bounds__(kK2Threads, HBM ? (W3 ? 3 : EVOFST_WALK_WPS) : EVOFST_FUSED_WPS) void fused_pairs_kernel(FusedParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     // HBM mode with K1's / the stream pass's marks: which turns of this workgroup (regions a grid's stride apart) hold a
     // marked chunk, as a bit map in LDS -- one thread per turn, all loads at once, so a launch that finds nothing costs one
@@ -1063,9 +1067,9 @@ hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st) {
     return wp ? launch_clean_walk_t<true, 2>(p, lds, threads, st) : launch_clean_walk_t<false, 2>(p, lds, threads, st);
 }
 
-template <typename CT, bool RCP, bool WP, int SUB, bool HBM>
+template <typename CT, bool RCP, bool WP, int SUB, bool HBM, bool W3>
 static hipError_t launch_fused_t(const FusedParams &p, size_t lds, int threads, int max_blocks, hipStream_t st) {
-    const void *fn = reinterpret_cast<const void *>(&fused_pairs_kernel<CT, RCP, WP, SUB, HBM>);
+    const void *fn = reinterpret_cast<const void *>(&fused_pairs_kernel<CT, RCP, WP, SUB, HBM, W3>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1086,7 +1090,7 @@ static hipError_t launch_fused_t(const FusedParams &p, size_t lds, int threads, 
         grid = memo.grid;
     }
     grid = std::max(1, std::min(grid, HBM && WP ? (p.n_chunks + kFuseWaves - 1) / kFuseWaves : p.n_chunks));
-    hipLaunchKernelGGL((fused_pairs_kernel<CT, RCP, WP, SUB, HBM>), dim3(grid), dim3(threads), lds, st, p);
+    hipLaunchKernelGGL((fused_pairs_kernel<CT, RCP, WP, SUB, HBM, W3>), dim3(grid), dim3(threads), lds, st, p);
     return hipGetLastError();
 }
 
@@ -1103,8 +1107,11 @@ hipError_t launch_fused(const FusedParams &p, int count_bytes, int sub, int max_
     const size_t lds = fused_lds_bytes(p.P, p.n_segs, p.max_n, p.n_pairs, hbm ? 2 * p.piece_tiles * (wp ? kFuseWaves : 1) : p.chunk_tiles, count_bytes, sub);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool rcp = p.max_n <= kRcpMax;
-#define EVOFST_FUSED_GO(CT, R, W_, S_) do { if (hbm) return launch_fused_t<CT, R, W_, S_, true>(p, lds, threads, max_blocks, st); \
-                                            return launch_fused_t<CT, R, W_, S_, false>(p, lds, threads, max_blocks, st); } while (0)
+    // three waves per SIMD where three workgroups of four waves fit a CU's LDS (see W3 above)
+    const bool w3 = hbm && !wp && threads <= 256 && 3 * (lds + 1024) <= 160 * 1024;
+#define EVOFST_FUSED_GO(CT, R, W_, S_) do { if (hbm && !W_ && w3) return launch_fused_t<CT, R, W_, S_, true, !W_>(p, lds, threads, max_blocks, st); \
+                                            if (hbm) return launch_fused_t<CT, R, W_, S_, true, false>(p, lds, threads, max_blocks, st); \
+                                            return launch_fused_t<CT, R, W_, S_, false, false>(p, lds, threads, max_blocks, st); } while (0)
 #define EVOFST_FUSED_SUB(CT, R, W_) do { if (sub == 16) EVOFST_FUSED_GO(CT, R, W_, 16); else EVOFST_FUSED_GO(CT, R, W_, 32); } while (0)
 #define EVOFST_FUSED_WP(CT, R) do { if (wp) EVOFST_FUSED_SUB(CT, R, true); else EVOFST_FUSED_SUB(CT, R, false); } while (0)
     if (count_bytes == 2) { if (rcp) EVOFST_FUSED_WP(uint16_t, true); else EVOFST_FUSED_WP(uint16_t, false); }
