@@ -244,7 +244,10 @@ def test_pair_range_sums_in_site_order(engine):
 
 
 @pytest.mark.parametrize("prod,cons,chunk_tiles,bufs,sets", [(8, 0, 16, 2, 1), (6, 0, 12, 3, 1), (6, 0, 12, 3, 2), (3, 1, 3, 4, 2),
-                                                             (1, 0, 2, 2, 1), (8, 0, 8, 4, 1)])
+                                                             (1, 0, 2, 2, 1), (8, 0, 8, 4, 1),
+                                                             # chunk_tiles 0: the library's own shape -- 4 tiles for a SIMD's first
+                                                             # producer wave, 3 for the waves behind it (28- and 19-tile chunks)
+                                                             (8, 0, 0, 2, 1), (5, 0, 0, 2, 1)])
 def test_stream_pass_shapes(engine, prod, cons, chunk_tiles, bufs, sets):
     """The stream pass (evofst_stream.hip) with every knob of evofst_set_option turned: producer and consumer waves per
     workgroup, tiles per chunk, LDS buffers (chunks of a workgroup in flight) and consumer sets; 78 pairs (two groups of
