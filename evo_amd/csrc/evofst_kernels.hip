@@ -58,11 +58,13 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
     constexpr int NB = 4;   // rows per batch
     constexpr bool kBallots = MODE == MODE_PAIRS || MODE == MODE_GRAM;
     const int P = p.P;
-    // LDS: per wave [P] zero-masks, [P] fixed-masks (+ [P] nm < 2, [P] nm == 0 in Gram mode), then per wave
-    // [n_pairs] census counters, the pair list, and (ST) per wave the [P][64] packed counts of the current tile
+    // LDS: (pairs and Gram mode) per wave [P] zero-masks, [P] fixed-masks (+ [P] nm < 2, [P] nm == 0 in Gram mode), then per
+    // wave [n_pairs] census counters, the pair list, and (ST) per wave the [P][64] packed counts of the current tile.
+    // The other modes keep no ballots: their workgroups take next to no LDS and fit beside a kernel that fills a CU's
+    // (the against-all tile kernel of another batch on another stream).
     uint64_t *zm = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 4 * P;
     uint64_t *fm = zm + P;
-    uint32_t *cen_all = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem) + (size_t)NW * 4 * P);
+    uint32_t *cen_all = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem) + (kBallots ? (size_t)NW * 4 * P : 0));
     const int npq = MODE == MODE_PAIRS ? p.n_pairs : 0;
     uint32_t *cen = cen_all + (size_t)wave * npq;
     uint32_t *lpairs = cen_all + (size_t)NW * npq;                                   // [n_pairs]
@@ -352,7 +354,8 @@ hipError_t launch_k1(const K1Params &p_, int count_bytes, int mode, hipStream_t 
 #endif
     constexpr int NW = kK1Threads / 64;
     const size_t npq = mode == MODE_PAIRS ? p.n_pairs : 0;
-    const size_t base = (size_t)NW * 4 * p.P * 8 + (NW + 1) * npq * 4 + 16;
+    const bool ballots = mode == MODE_PAIRS || mode == MODE_GRAM;
+    const size_t base = (ballots ? (size_t)NW * 4 * p.P * 8 : 0) + (NW + 1) * npq * 4 + 16;
     const size_t stage = (size_t)NW * p.P * kTileSites * count_bytes;
     // staged: a tile's counts leave as at most four 16-byte stores per lane (more populations: they go out as they complete)
     const bool staged = (size_t)p.P * count_bytes <= 64;
