@@ -9,6 +9,7 @@
 //   4  as 2, but only every 8th lane writes (8 x as often): few active lanes per store instruction
 //   5  as 1, into 4 KiB per wave over and over (the writes stay in the L2: what of the cost is the memory side?)
 //   6  as 1, but only one workgroup in eight writes, eight times as often (the writes come from few CUs)
+//   9  as 1 with 4 bytes per lane (256 bytes per instruction): the same number of store instructions, a quarter of the bytes
 //   8  as 1 in bursts: eight stores of 1 KiB back to back, an eighth as often (16: sixteen)
 //   7  the fourth wave of every workgroup writes and reads nothing (1 KiB, then a sleep, as often as makes the same volume);
 //      the other three waves read everything: no wave ever waits for a store of its own
@@ -64,6 +65,9 @@ __global__ __launch_bounds__(256) void mix_kernel(const uint4 *src, size_t n_row
             if (pattern == 1) {                              // 1 KiB contiguous
                 if ((wpos + 1) * 64 <= slice) my[wpos * 64 + lane] = v;
                 ++wpos;
+            } else if (pattern == 9) {
+                if ((wpos + 1) * 64 <= slice) reinterpret_cast<uint32_t *>(my + wpos * 64)[lane] = acc;
+                ++wpos;
             } else if (pattern == 8 || pattern == 16) {
                 if (++turn == pattern) {
                     turn = 0;
@@ -111,7 +115,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     for (int wgs_per_cu : {2}) {
         const int grid = prop.multiProcessorCount * wgs_per_cu;
-        for (int pattern : {0, 1, 8, 16}) {
+        for (int pattern : {0, 1, 9}) {
             // every: rows read per write event; bytes written per event: pattern 1: 1 KiB, 2/3: 2 KiB, 4: 256 B
             for (int every : {16, 32, 64}) {
                 if (pattern == 0 && every != 16) continue;
@@ -126,7 +130,7 @@ int main(int argc, char **argv) {
                 CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
                 float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
                 const double us = ms * 1e3 / iters;
-                const double wper = pattern == 0 ? 0.0 : (pattern == 1 || pattern >= 5) ? 1024.0 : pattern == 4 ? 256.0 : 2048.0;
+                const double wper = pattern == 0 ? 0.0 : pattern == 9 ? 256.0 : (pattern == 1 || pattern >= 5) ? 1024.0 : pattern == 4 ? 256.0 : 2048.0;
                 const double wfrac = pattern ? wper / (ev * 1024.0) : 0.0;
                 printf("wgs/cu %d pattern %d every %3d rows (writes %.1f %% of the reads, %.0f MB): %.1f us  read rate %.2f TB/s\n", wgs_per_cu, pattern, ev,
                        100.0 * wfrac, wfrac * bytes / 1e6, us, bytes / us / 1e6);
