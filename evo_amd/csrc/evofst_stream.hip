@@ -279,7 +279,10 @@ __device__ __forceinline__ bool stream_sum_rows(const StreamParams &p, const Str
             if (__all(ok)) break;
             if (++spins > kStreamSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
             if ((spins & 63u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (p.debug & 512) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(96);
+#ifdef EVOFST_EXPERIMENTS
+            if (p.debug & 512) __builtin_amdgcn_s_sleep(4); else
+#endif
+            __builtin_amdgcn_s_sleep(96);
         }
         if (r.n0 > 0) {
 #pragma unroll
@@ -306,7 +309,10 @@ __device__ __forceinline__ bool stream_sum_rows(const StreamParams &p, const Str
             if (__all(ok)) break;
             if (++spins > kStreamSpinLimit) { __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
             if ((spins & 63u) == 0u && __hip_atomic_load((gu32 *)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (p.debug & 512) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(96);
+#ifdef EVOFST_EXPERIMENTS
+            if (p.debug & 512) __builtin_amdgcn_s_sleep(4); else
+#endif
+            __builtin_amdgcn_s_sleep(96);
         }
 #pragma unroll
         for (int u = 0; u < B2; ++u) sum += r0 + u < total ? (uint64_t)(x[u] & kStreamAggMask) : 0ull;
