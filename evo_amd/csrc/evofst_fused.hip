@@ -183,8 +183,8 @@ __device__ __forceinline__ void count_wave_tiles(const FusedParams &p, int lane,
                 bool more = true;
                 while (more) {
                     const uint4 dn = lsegs[sidx + 1];      // the table ends with one spare entry
-                    c = __popc(xlo & d.x) + c; c = __popc(xhi & d.y) + c;
-                    mc = __popc(ylo & d.x) + mc; mc = __popc(yhi & d.y) + mc;
+                    c = popc_acc(xlo & d.x, c); c = popc_acc(xhi & d.y, c);
+                    mc = popc_acc(ylo & d.x, mc); mc = popc_acc(yhi & d.y, mc);
                     const uint32_t fl = d.w;
                     if (fl & kSegLast) {                   // population d.z is complete
                         const uint32_t nfull = fl >> kSegNFullShift;

@@ -36,6 +36,14 @@ template <> struct CountTraits<uint16_t> { static constexpr int shift = 8; stati
 template <> struct CountTraits<uint32_t> { static constexpr int shift = 16; static constexpr uint32_t mask = 0xffffu; };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// acc + popcount(x) as the one instruction the hardware has for it (v_bcnt_u32_b32 adds its second operand).  Left to
+// itself the compiler counts into fresh registers and adds three ways (v_bcnt, v_bcnt, v_add3): a fifth more vector
+// instructions in the counting loops, which a single K1 launch on short rows is bound by.
+__device__ __forceinline__ uint32_t popc_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 
 constexpr int kRcpMax = 1023;
 constexpr int kSub = 32;            // sites per LDS table fill (half a tile)

@@ -285,8 +285,8 @@ __global__ __launch_bounds__(kK1Threads) void k1_count_kernel(K1Params p) {
                 bool more = true;
                 while (more) {
                     const SegWords dnn = segs[sidx + 2];
-                    c = __popc(xlo & d.x) + c; c = __popc(xhi & d.y) + c;
-                    mc = __popc(ylo & d.x) + mc; mc = __popc(yhi & d.y) + mc;
+                    c = popc_acc(xlo & d.x, c); c = popc_acc(xhi & d.y, c);
+                    mc = popc_acc(ylo & d.x, mc); mc = popc_acc(yhi & d.y, mc);
                     const uint32_t fl = d.w, pop = d.z;
                     if (fl & kSegLast) {
                         const uint32_t nfull = fl >> kSegNFullShift;

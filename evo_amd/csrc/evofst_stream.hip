@@ -166,8 +166,8 @@ __device__ __forceinline__ void stream_count_piece(const StreamParams &p, int la
                 bool more = true;
                 while (more) {
                     const SegWords dnn = segs[sidx + 2];
-                    c = __popc(xlo & d.x) + c; c = __popc(xhi & d.y) + c;
-                    mc = __popc(ylo & d.x) + mc; mc = __popc(yhi & d.y) + mc;
+                    c = popc_acc(xlo & d.x, c); c = popc_acc(xhi & d.y, c);
+                    mc = popc_acc(ylo & d.x, mc); mc = popc_acc(yhi & d.y, mc);
                     const uint32_t fl = d.w, pop = d.z;
                     if (fl & kSegLast) {
                         const uint32_t nfull = fl >> kSegNFullShift;
