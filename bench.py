@@ -667,8 +667,10 @@ def main():
         # is the table of results it writes (hbm_write_GBps), not the matrix cores.
         Pp = 64 * ((P + 63) // 64)
         nblk = Pp // 64
-        n_f64 = 2
-        n_i8 = 6 if cfg["miss"] > 0 else 4
+        n_f64 = 2                                # SURVEY 8d's algorithm: the two contractions of the denominator
+        # what ran: one FP64 contraction (centred frequencies, u u^T) + one more int8 one where the library takes that form
+        ran_f64 = e.last_gram_streams() or 2
+        n_i8 = (6 if cfg["miss"] > 0 else 4) + (1 if ran_f64 == 1 and cfg["miss"] > 0 else 0)
         t_s = kavg[2] * 1e-3
         useful = 2.0 * S * e.n_pairs * n_f64
         issued = 2.0 * S * (64 * 64) * (nblk * (nblk + 1) / 2) * n_f64
@@ -678,7 +680,10 @@ def main():
                          "unit": "TFLOP/s", "frac": ach_u / F64_MFMA_PEAK_TFLOPS, "algorithmic_flops": useful,
                          "issued_flops": issued, "issued_TFLOPs": issued / t_s / 1e12,
                          "issued_frac": issued / t_s / 1e12 / F64_MFMA_PEAK_TFLOPS,
-                         "streams": {"f64_mfma": n_f64, "int8_mfma": n_i8},
+                         "streams": {"f64_mfma": ran_f64, "int8_mfma": n_i8},
+                         "executed_f64_TFLOPs": useful / n_f64 * ran_f64 / t_s / 1e12,
+                         "executed_f64_frac": useful / n_f64 * ran_f64 / t_s / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                         "issued_f64_frac": issued / n_f64 * ran_f64 / t_s / 1e12 / F64_MFMA_PEAK_TFLOPS,
                          "all_contractions_as_f64_TFLOPs": 2.0 * S * e.n_pairs * (5 if cfg["miss"] > 0 else 3) / t_s / 1e12,
                          "hbm_write_bytes": written, "hbm_write_GBps": written / t_s / 1e9,
                          "hbm_write_frac": written / t_s / 1e9 / HBM_PEAK_GBS, "traffic": None})

@@ -81,6 +81,7 @@ SIGNATURES = {
     "evofst_device_count": (C.c_int, []),
     "evofst_get_positions": (C.c_int, [_vp, C.c_int64, C.c_int64, _i32p]),
     "evofst_last_global_walk": (C.c_int, [_vp]),
+    "evofst_last_gram_streams": (C.c_int, [_vp]),
     "evofst_get_pair_range_sums": (C.c_int, [_vp, C.c_int, C.c_int64, _i64p, _i64p, _dp, _dp]),
     "evofst_set_profiling": (C.c_int, [_vp, C.c_int]),
     "evofst_get_kernel_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
@@ -373,6 +374,10 @@ class EvoFst:
     def last_global_walk(self):
         """1 = global_window_kernel, 2 = global_tile_kernel (the last against-all run's; 0: none)."""
         return int(self.L.evofst_last_global_walk(self.h))
+
+    def last_gram_streams(self):
+        """FP64 contractions the last run_gram spent on the denominators: 1 (centred frequencies) or 2 (0: none yet)."""
+        return int(self.L.evofst_last_gram_streams(self.h))
 
     def last_pairs_pass(self):
         """1 = separate kernels, 2 = stream pass, 3 = lock-step one-kernel pass (the last run's; 0: none)."""

@@ -112,6 +112,7 @@ struct evofst_ctx {
     // options (evofst_set_option): read when a pass is planned, never from the process environment
     int opt_pairs_pass = 0;           // 0 auto, 1 K1 + scan + walk, 2 the producer / consumer stream pass, 3 the lock-step one-kernel pass
     int opt_chunk_tiles = 0;          // tiles per chunk (0: the library chooses)
+    int opt_gram_den = 0;             // Gram denominator: 0 the library chooses, 2 always both FP64 streams
     int opt_walk = 0;                 // K1 + scan + walk: 0 auto, 1 general walk on every chunk, 2 k2_window_kernel
     int opt_stream_blocks = 0;        // workgroups of the stream pass (0: as many as the device holds)
     bool check_dirty = false;                       // the check word is the stream pass's: its count of marked chunks lies behind it
@@ -120,6 +121,7 @@ struct evofst_ctx {
     // passes over the same data skip (or size) the general walk's launch instead of letting it find out
     bool k1_marks_valid = false, k1_marks_known = false; uint32_t k1_marks = 0;
     int last_global_walk = 0;                       // evofst_last_global_walk
+    int last_gram_streams = 0;                      // evofst_last_gram_streams
     int last_pairs_pass = 0;                        // evofst_last_pairs_pass
     int opt_global_walk = 0;                        // against-all rows: 0 auto, 1 lane = population kernel, 2 two-phase kernel where it fits
     int opt_stream_sets = 0;                        // its sets of consumer waves (0: the library chooses)
@@ -1662,6 +1664,9 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     p.tile_poison = (const uint32_t *)c->d_poison.p;
     p.win_start = (const int64_t *)c->d_win.p;
     p.first_window = first_window; p.n_windows = (int32_t)n_windows;
+    for (int64_t w = first_window; w < first_window + n_windows; ++w)
+        p.max_window_sites = std::max(p.max_window_sites, c->win_start[(size_t)w + 1] - c->win_start[(size_t)w]);
+    if (c->opt_gram_den == 2) p.max_window_sites = 0;         // evofst_set_option "gram_denominator" 2: the two-stream form
     p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p;
     p.n_pairs = np;
     p.out_raw = (double2 *)c->d_graw.p;
@@ -1670,6 +1675,7 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
 #endif
     record(c, 2, 0);
     HIPCHK(c, launch_gram(p, c->count_bytes, c->gram_missing != 0, c->stream));
+    c->last_gram_streams = gram_one_stream(p, c->count_bytes) ? 1 : 2;
     record(c, 2, 1);
     c->gram_windows = n_windows;
     return EVOFST_OK;
@@ -1818,6 +1824,9 @@ extern "C" int evofst_set_option(evofst_ctx *c, const char *name, int64_t value)
     if (n == "pairs_pass") {
         if (value < 0 || value > 3) return fail(c, EVOFST_ERR_ARG, "set_option: pairs_pass is 0 (auto), 1 (counts + scan + walk), 2 (stream pass) or 3 (lock-step one-kernel pass)");
         c->opt_pairs_pass = (int)value;
+    } else if (n == "gram_denominator") {
+        if (value != 0 && value != 2) return fail(c, EVOFST_ERR_ARG, "set_option: gram_denominator is 0 (auto) or 2 (always two FP64 streams)");
+        c->opt_gram_den = (int)value;
     } else if (n == "chunk_tiles") {
         if (value < 0 || value > 256) return fail(c, EVOFST_ERR_ARG, "set_option: chunk_tiles is 0 (auto) .. 256");
         c->opt_chunk_tiles = (int)value;
@@ -1850,6 +1859,10 @@ extern "C" int evofst_set_option(evofst_ctx *c, const char *name, int64_t value)
 
 extern "C" int evofst_last_global_walk(const evofst_ctx *c) {
     return c ? c->last_global_walk : 0;
+}
+
+extern "C" int evofst_last_gram_streams(const evofst_ctx *c) {
+    return c ? c->last_gram_streams : 0;
 }
 
 extern "C" int evofst_last_pairs_pass(const evofst_ctx *c) {

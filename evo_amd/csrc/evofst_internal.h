@@ -361,6 +361,7 @@ struct GramParams {
     const uint32_t *tile_poison; // [n_tiles] from K1 (Gram mode): != 0 when one of the nm < 2 / nm == 0 masks of the tile has a bit set
     const int64_t *win_start;    // [n_windows_total + 1] first site of every window (device)
     int64_t first_window;        // this launch covers windows [first_window, first_window + n_windows)
+    int64_t max_window_sites;    // the longest window of the set (0: not known): picks the one-stream denominator
     int32_t n_windows;
     double *U, *C;               // [n_windows][P] per-population sums of t + h and of c over the window
     int64_t n_pairs;             // P (P - 1) / 2, pair (i < j) at i (2P - i - 1) / 2 + j - i - 1
@@ -414,6 +415,7 @@ hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 size_t gram_raw_bytes(int P, int64_t n_windows);
 hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, double *num, double *den, double *k, double *cnt, hipStream_t st);
 bool gram_uses_i8(int count_bytes, int max_n);
+bool gram_one_stream(const GramParams &p, int count_bytes);     // the denominator as one FP64 contraction (gram_kernel<..., ONE>)
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st);
 size_t k2_lds_bytes(int P, int max_n);
 size_t fused_lds_bytes(int P, int n_segs, int max_n, int n_pairs, int chunk_tiles, int count_bytes, int sub);

@@ -1160,13 +1160,22 @@ constexpr int kGramMaskTiles = 4;    // tiles of a window whose masks are staged
 // I8 (8-bit counts, every population has <= 127 chromosomes): the integer contractions -- sum c_i c_j and the
 // fixed-with-missing term of sumKij -- run on the int8 matrix cores (v_mfma_i32_16x16x32_i8, one instruction per 32
 // sites and tile pair, exact in 32 bits), which leaves the FP64 cores the two streams of the denominator.
+// ONE (with TAB and I8, short windows of few chromosomes -- launch_gram): the denominator on ONE FP64 stream.  With
+// u = p - 1/2, p_i (1 - p_j) + p_j (1 - p_i) = 1/2 - 2 u_i u_j, so sum den = n_both / 2 - 2 sum u_i u_j, n_both = the
+// window's sites where both populations have a called allele (an int8 contraction of 0 / 1 bytes, exact; u = 0 where a
+// population has none, as P = Q = 0 there).  Sites both populations are fixed at the same allele give u_i u_j = 1/4 exactly
+// and sums of quarters are exact, so the rounding errors are those of the polymorphic sites: one ulp(sites / 4) / 2 each,
+// against a bar of 1e-12 of a denominator that is at least 1 / max_n per such site -- inside the bar for every window
+// as long as sites x max_n <= 2^14, which is what launch_gram asks before it takes this form.
 typedef int int4_t __attribute__((ext_vector_type(4)));
-template <typename CT, bool MISS, bool TAB, bool I8>
+template <typename CT, bool MISS, bool TAB, bool I8, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
+    static_assert(!ONE || (TAB && I8), "the one-stream denominator reads the table and the int8 contractions");
     __shared__ uint64_t spread[I8 ? 256 : 1];            // bit e of the index -> byte e 0xff
     __shared__ double rcp[TAB ? 2 : 2048];
-    __shared__ double2 tab_pq[TAB ? 1024 : 1], tab_cf[TAB ? 1024 : 1];
-    __shared__ double tab_fi[TAB ? 1024 : 1];
+    __shared__ double2 tab_pq[TAB && !ONE ? 1024 : 1], tab_cf[TAB && !ONE ? 1024 : 1];
+    __shared__ double tab_fi[TAB && !ONE ? 1024 : 1];
+    __shared__ double tab_u[ONE ? 1024 : 1];             // (2 c - nm) / (2 nm): p - 1/2 rounded once; 0 without a called allele
     __shared__ uint64_t lmask[kGramMaskTiles][4][128];   // [tile][z|f|nm<2|nm==0][64 row pops, 64 column pops]
     __shared__ double lU[128], lC[128], lN[128];         // U, C of the window and n_full, same 128 populations
     constexpr int EV = 8;                               // sites per lane and step
@@ -1190,6 +1199,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         for (int i = threadIdx.x; i < 1024; i += blockDim.x) {      // entry (nm << 5) | c; impossible ones (c > nm) are 0: entry 1 serves sites outside the window
             const int c = i & 31, nm = i >> 5;
             const bool okc = c <= nm && nm <= p.max_n;
+            if (ONE) { tab_u[i] = okc && nm ? (double)(2 * c - nm) / (double)(2 * nm) : 0.0; continue; }
             const double pp = okc && nm ? (double)c / (double)nm : 0.0;
             tab_pq[i] = make_double2(pp, okc && nm ? 1.0 - pp : 0.0);
             tab_cf[i] = make_double2(okc ? (double)c : 0.0, okc && c == nm ? (double)nm : 0.0);
@@ -1291,11 +1301,12 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     double4_t acc_den[2][2], acc_cc[2][2], acc_m[2][2];
     int4_t icc[2][2], im[2][2], iex[2][2];               // I8: the integer sums (C/D layout: col = lane & 15, row = 4 (lane >> 4) + v);
                                                          // iex: sites of the window the filter excludes for the pair
+    int4_t inb[2][2];                                    // ONE, MISS: sites of the window where both populations have a called allele
     uint32_t vcount = 0;                                 // this lane's valid (in the window, not skipped) sites
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { icc[i][j] = int4_t{0, 0, 0, 0}; im[i][j] = int4_t{0, 0, 0, 0}; iex[i][j] = int4_t{0, 0, 0, 0}; }
+        for (int j = 0; j < 2; ++j) { icc[i][j] = int4_t{0, 0, 0, 0}; im[i][j] = int4_t{0, 0, 0, 0}; iex[i][j] = int4_t{0, 0, 0, 0}; inb[i][j] = int4_t{0, 0, 0, 0}; }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1342,7 +1353,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         }
         if (I8 && __builtin_amdgcn_ballot_w64(valid != 0u) != 0) {
             // the step's 32 sites at once: lane = population (lane & 15), bytes = its 8 sites
-            long C8[4], FN8[4], FM8[4], Z8[4], F8[4], B8[4], BN8[4];
+            long C8[4], FN8[4], FM8[4], Z8[4], F8[4], B8[4], BN8[4], D8[4];
             vcount += (uint32_t)__popc(valid);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
@@ -1364,6 +1375,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                     B8[x] = Z8[x] & F8[x];
                     BN8[x] = (long)(((uint64_t)(zhi & fhi) << 32) | (zlo & flo));                          // -1 where both
                 }
+                if (ONE && MISS)                                 // D = [nm > 0], sites of the window only (nlo, nhi are masked)
+                    D8[x] = (long)(((uint64_t)(~fixed_bytes(nhi) & 0x01010101u) << 32) | (~fixed_bytes(nlo) & 0x01010101u));
                 if (MISS) {
                     const uint32_t n4 = nfull[x] * 0x01010101u;
                     FN8[x] = (long)(((uint64_t)(nhi & fhi) << 32) | (nlo & flo));                        // F nm
@@ -1382,6 +1395,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                         im[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(FN8[i], FM8[2 + j], im[i][j], 0, 0, 0);
                         im[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(FM8[i], FN8[2 + j], im[i][j], 0, 0, 0);
                     }
+                    if (ONE && MISS) inb[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(D8[i], D8[2 + j], inb[i][j], 0, 0, 0);
                 }
         }
         if (base + 4 * EV < b) fetch(base + 4 * EV);     // the next step's vectors travel while this one is contracted
@@ -1397,6 +1411,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 uint32_t c = cnt[x][e] & CountTraits<CT>::mask, nm = cnt[x][e] >> CountTraits<CT>::shift;
                 if (TAB) {
                     const uint32_t idx = ok && pop[x] < p.P ? (nm << 5) | c : 1u;
+                    if (ONE) { P_[x] = tab_u[idx]; continue; }
                     const double2 pq = tab_pq[idx], cf = tab_cf[idx];
                     P_[x] = pq.x; Q_[x] = pq.y; C_[x] = cf.x;
                     if (MISS) { FN[x] = cf.y; FM[x] = fma((double)nfull[x], tab_fi[idx], -cf.y); }   // F (n - nm)
@@ -1423,6 +1438,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if (ONE) { acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(P_[i], P_[2 + j], acc_den[i][j], 0, 0, 0); continue; }   // sum u_i u_j
                     acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(P_[i], Q_[2 + j], acc_den[i][j], 0, 0, 0);
                     acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(Q_[i], P_[2 + j], acc_den[i][j], 0, 0, 0);
                     if (I8) continue;
@@ -1467,7 +1483,18 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 const int slot = (j * 2 + i) * 4 + v;
                 const int li = lrow + i * 16 + kq + 4 * v;          // FP64 accumulators: row kq + 4 v
                 const uint32_t bit = 1u << slot;
-                const double den = acc_den[i][j][v];
+                double den = acc_den[i][j][v];
+                if (ONE) {
+                    // n_both of this element: the 32-bit accumulators hold row 4 kq + v, so the element (row kq + 4 v) of
+                    // this lane is register kq of the lane with the same column in lane group v
+                    double nb = (double)nvalid;
+                    if (MISS) {
+                        const int src = r + 16 * v;
+                        const int n0 = __shfl(inb[i][j][0], src), n1 = __shfl(inb[i][j][1], src), n2 = __shfl(inb[i][j][2], src), n3 = __shfl(inb[i][j][3], src);
+                        nb = (double)(kq == 0 ? n0 : kq == 1 ? n1 : kq == 2 ? n2 : n3);
+                    }
+                    den = 0.5 * nb - 2.0 * den;
+                }
                 const double num = den - lU[li] - Uj;
                 rawA[slot * 64] = make_double2((poison_n & bit) ? kNaN : num, (poison_d & bit) ? kNaN : den);
                 if (!I8) {
@@ -1531,6 +1558,11 @@ hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool
     return hipGetLastError();
 }
 
+// the denominator on one FP64 stream where every window stays inside the 1e-12 bar by construction (see gram_kernel)
+bool gram_one_stream(const GramParams &p, int count_bytes) {
+    return gram_uses_i8(count_bytes, p.max_n) && count_bytes == 2 && p.max_n <= 31 && p.max_window_sites > 0 &&
+           p.max_window_sites * (int64_t)p.max_n <= (1 << 14);
+}
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st) {
     if (p.n_windows <= 0 || p.P < 2) return hipSuccess;
     if (!(p.debug & 4)) {
@@ -1546,8 +1578,12 @@ hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, h
     const bool i8 = gram_uses_i8(count_bytes, p.max_n);
 #define EVOFST_GRAM_GO(CT, M, T) do { if (i8) hipLaunchKernelGGL((gram_kernel<CT, M, T, sizeof(CT) == 2>), grid, block, 0, st, p); \
                                       else hipLaunchKernelGGL((gram_kernel<CT, M, T, false>), grid, block, 0, st, p); } while (0)
+    const bool one = gram_one_stream(p, count_bytes);
     if (count_bytes == 2) {
-        if (p.max_n <= 31) {
+        if (p.max_n <= 31 && one) {
+            if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true, true, true, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((gram_kernel<uint16_t, false, true, true, true>), grid, block, 0, st, p);
+        } else if (p.max_n <= 31) {
             if (has_missing) EVOFST_GRAM_GO(uint16_t, true, true);
             else EVOFST_GRAM_GO(uint16_t, false, true);
         } else {

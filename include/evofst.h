@@ -264,6 +264,9 @@ int64_t evofst_noalloc_scratch_bytes(void);
  *                   0 = chosen by the library
  *   "stream_buffers" chunks of a workgroup in flight (LDS buffers), 2 .. 4, 0 = chosen by the library
  *   "stream_sets"   sets of consumer waves that take a workgroup's chunks in turn, 1 or 2, 0 = chosen by the library
+ *   "gram_denominator"  evofst_run_gram's window denominators: 0 = the library chooses (one FP64 contraction of the
+ *                   centred frequencies where longest window x most chromosomes of a population <= 2^14, which keeps
+ *                   every window inside 1e-12 of its own terms; else the two of p q^T + q p^T), 2 = always the two
  * Unknown names and values out of range return EVOFST_ERR_ARG.  A shape an option does not fit (LDS, waves) takes
  * the next pass in the order stream, lock-step, separate kernels. */
 int evofst_set_option(evofst_ctx *ctx, const char *name, int64_t value);
@@ -275,6 +278,9 @@ int evofst_last_pairs_pass(const evofst_ctx *ctx);
  * population rows; taken where its LDS ring of SIZE + 64 kept sites per population fits); 0 = none yet.  The option
  * "global_walk" of evofst_set_option chooses: 0 = the library (default), 1, 2 (where it fits). */
 int evofst_last_global_walk(const evofst_ctx *ctx);
+/* How many FP64 contractions the last evofst_run_gram spent on the window denominators: 1 or 2 (see "gram_denominator");
+ * 0 = none yet.  (No counterpart in the reference.) */
+int evofst_last_gram_streams(const evofst_ctx *ctx);
 
 /* When enabled, evofst_run_* bracket every kernel with HIP events on the context's stream. */
 int evofst_set_profiling(evofst_ctx *ctx, int enabled);

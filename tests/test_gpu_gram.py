@@ -9,7 +9,7 @@ exactly where the reference's sum is NaN.
 import numpy as np
 import pytest
 
-from tests.helpers import random_codes, round_robin_pops, n_full_of
+from tests.helpers import options, random_codes, round_robin_pops, n_full_of
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -31,6 +31,33 @@ def _oracle_windows(onum, oden, odxy_k, oinc, ws):
     return out
 
 
+def _check_gram(engine, codes, sp, P, fl, ws, tag):
+    """run_gram over the windows ws of the loaded data against the oracle; returns the worst error as a fraction of the bar."""
+    from tests import parity_log
+    g = engine.gram()
+    nf = n_full_of(sp, P)
+    pi, pj = np.triu_indices(P, 1)
+    pi = pi.astype(np.int32); pj = pj.astype(np.int32)
+    oalt, onm = O.counts_from_codes(codes, sp, P)
+    onum, oden, odxy, oinc = O.pair_site_stats(oalt, onm, nf, pi, pj, fl)
+    # the oracle returns dxy = k / (n_i n_j); k itself is an integer
+    odxy_k = np.rint(odxy * (nf[pi] * nf[pj])[None, :].astype(np.float64))
+    ow = _oracle_windows(onum, oden, odxy_k, oinc, ws)
+
+    assert np.array_equal(g["n_included"], ow["cnt"])
+    assert np.array_equal(g["sum_dxy_k"], ow["k"])
+    worst = 0.0
+    for name, ref, scale in (("sum_den", ow["den"], ow["absden"]), ("sum_num", ow["num"], ow["absnum"] + ow["absden"])):
+        a = g[name]
+        assert (np.isnan(a) == np.isnan(ref)).all(), name
+        fin = ~np.isnan(ref)
+        err, bar = np.abs(a[fin] - ref[fin]), 1e-12 * np.maximum(scale[fin], 1e-300) + 1e-300
+        parity_log.record("%s/%s" % (tag, name), err, bar)
+        assert np.all(err <= bar), (name, float(np.max(err / bar)))
+        worst = max(worst, float(np.max(err / bar))) if err.size else worst
+    return worst
+
+
 @pytest.mark.parametrize("S,N,P,miss,flags,edge,seed", [(1500, 48, 12, 0.0, False, False, 1), (2000, 100, 20, 0.15, True, True, 2),
                                                         (900, 150, 75, 0.1, False, True, 3), (700, 66, 33, 0.3, True, True, 4),
                                                         (1300, 520, 130, 0.0, False, False, 5), (640, 40, 2, 0.2, False, True, 6),
@@ -49,24 +76,50 @@ def test_gram_windows(engine, S, N, P, miss, flags, edge, seed):
     engine.set_site_windows(ws)
     engine.run_counts()
     engine.run_gram()
-    g = engine.gram()
+    # the denominator on one FP64 contraction (centred frequencies) where 8-bit counts, <= 31 chromosomes a population and
+    # longest window x chromosomes <= 2^14 allow it -- five of these shapes -- else, and when asked, on the two of p q^T + q p^T
+    max_n = int(n_full_of(sp, P).max())
+    one = max_n <= 31 and int(np.diff(ws).max()) * max_n <= (1 << 14)
+    assert engine.last_gram_streams() == (1 if one else 2)
+    _check_gram(engine, codes, sp, P, fl, ws, "gram_windows_one_stream" if one else "gram_windows")
+    if one:
+        with options(engine, gram_denominator=2):
+            engine.run_gram()
+            assert engine.last_gram_streams() == 2
+            _check_gram(engine, codes, sp, P, fl, ws, "gram_windows")
 
-    nf = n_full_of(sp, P)
-    pi, pj = np.triu_indices(P, 1)
-    pi = pi.astype(np.int32); pj = pj.astype(np.int32)
-    oalt, onm = O.counts_from_codes(codes, sp, P)
-    onum, oden, odxy, oinc = O.pair_site_stats(oalt, onm, nf, pi, pj, fl)
-    # the oracle returns dxy = k / (n_i n_j); k itself is an integer
-    odxy_k = np.rint(odxy * (nf[pi] * nf[pj])[None, :].astype(np.float64))
-    ow = _oracle_windows(onum, oden, odxy_k, oinc, ws)
 
-    assert np.array_equal(g["n_included"], ow["cnt"])
-    assert np.array_equal(g["sum_dxy_k"], ow["k"])
-    for name, ref, scale in (("sum_den", ow["den"], ow["absden"]), ("sum_num", ow["num"], ow["absnum"] + ow["absden"])):
-        a = g[name]
-        assert (np.isnan(a) == np.isnan(ref)).all(), name
-        fin = ~np.isnan(ref)
-        assert np.all(np.abs(a[fin] - ref[fin]) <= 1e-12 * np.maximum(scale[fin], 1e-300) + 1e-300), name
+def test_gram_one_stream_hard_windows(engine):
+    """The one-contraction denominator where it has least room: windows as long as its rule allows (1600 sites at 10
+    chromosomes a population), nearly every site fixed for the same allele in all populations (their terms cancel exactly:
+    u_i u_j = 1/4), and a single site or two per window where one population carries one other allele -- a denominator of
+    0.1 or 0.18 formed as 800 - 2 x 399.95.  Populations without a called allele at a site (n_both) and fixed sites with
+    missing alleles are in there too.  Every window inside 1e-12 of its own terms."""
+    rng = np.random.default_rng(2026)
+    S, P, per = 9600, 6, 5
+    N = P * per
+    sp = round_robin_pops(N, P)
+    codes = np.ones((S, 2 * N), np.uint8)                      # fixed for ALT everywhere ...
+    codes[rng.random(S) < 0.3] = 0                             # ... or for REF
+    ws = np.arange(0, S + 1, 1600, dtype=np.int64)
+    chrom_of_pop = [np.where(np.repeat(sp, 2) == k)[0] for k in range(P)]
+    for w in range(len(ws) - 1):
+        for s_ in rng.choice(np.arange(ws[w], ws[w + 1]), 2, replace=False):
+            k = int(rng.integers(P))
+            codes[s_, chrom_of_pop[k][0]] ^= 1                 # one allele of one population differs
+        for s_ in rng.choice(np.arange(ws[w], ws[w + 1]), 40, replace=False):
+            k = int(rng.integers(P))
+            n_miss = int(rng.choice([1, 3, 2 * per]))          # some alleles, or all, of a population missing at a fixed site
+            codes[s_, chrom_of_pop[k][:n_miss]] = 2
+    engine.set_layout(sp, P)
+    engine.upload(engine.pack_codes(codes), S)
+    engine.set_gram()
+    engine.set_site_windows(ws)
+    engine.run_counts()
+    engine.run_gram()
+    assert engine.last_gram_streams() == 1
+    worst = _check_gram(engine, codes, sp, P, None, ws, "gram_one_stream_hard_windows")
+    assert worst <= 0.25, worst
 
 
 def test_gram_window_batches(engine):
