@@ -674,7 +674,7 @@ def main():
         t_s = kavg[2] * 1e-3
         useful = 2.0 * S * e.n_pairs * n_f64
         issued = 2.0 * S * (64 * 64) * (nblk * (nblk + 1) / 2) * n_f64
-        written = float(n_win) * (nblk * (nblk + 1) / 2) * 4096 * 32.0
+        written = float(n_win) * (nblk * (nblk + 1) / 2) * 4096 * (16.0 if ran_f64 == 1 else 32.0)   # (upper bound: waves below the diagonal write nothing)
         ach_u = useful / t_s / 1e12
         roofline.update({"bound": "mfma", "kernel": "gram_kernel", "achieved": ach_u, "peak": F64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach_u / F64_MFMA_PEAK_TFLOPS, "algorithmic_flops": useful,

@@ -1695,7 +1695,7 @@ extern "C" int evofst_get_gram(evofst_ctx *c, double *sum_num, double *sum_den, 
         (rc = ensure(c, c->d_gcnt, n * 8))) return rc;
     HIPCHK(c, launch_gram_unpack((const double2 *)c->d_graw.p, c->n_pops, c->gram_windows,
                                  gram_uses_i8(c->count_bytes, *std::max_element(c->n_full.begin(), c->n_full.end())),
-                                 (double *)c->d_gnum.p, (double *)c->d_gden.p, (double *)c->d_gk.p, (double *)c->d_gcnt.p, c->stream));
+                                 c->last_gram_streams == 1, (const double *)c->d_gU.p, (double *)c->d_gnum.p, (double *)c->d_gden.p, (double *)c->d_gk.p, (double *)c->d_gcnt.p, c->stream));
     if ((rc = d2h(c, sum_num, c->d_gnum.p, n)) || (rc = d2h(c, sum_den, c->d_gden.p, n)) ||
         (rc = d2h(c, sum_dxy_k, c->d_gk.p, n)) || (rc = d2h(c, n_included, c->d_gcnt.p, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));

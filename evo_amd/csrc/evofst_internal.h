@@ -413,7 +413,8 @@ hipError_t launch_count_marks(const uint32_t *marks, int n, uint32_t *out, hipSt
 hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 size_t gram_raw_bytes(int P, int64_t n_windows);
-hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, double *num, double *den, double *k, double *cnt, hipStream_t st);
+hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, bool one, const double *U, double *num, double *den, double *k,
+                              double *cnt, hipStream_t st);
 bool gram_uses_i8(int count_bytes, int max_n);
 bool gram_one_stream(const GramParams &p, int count_bytes);     // the denominator as one FP64 contraction (gram_kernel<..., ONE>)
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st);

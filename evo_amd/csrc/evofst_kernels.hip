@@ -1473,6 +1473,16 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     const int nbp = nblk * (nblk + 1) / 2;
     double2 *rawA = p.out_raw + (((size_t)w * nbp + blockIdx.y) * 2 * 4 + wave) * 1024 + lane;
     double2 *rawB = rawA + 4 * 1024;
+    // ONE: the same table with 8-byte entries -- A = the denominator (the getter forms num = den - U_i - U_j from it and the
+    // per-population sums, the very subtraction done here otherwise), B = {k, n_included | num is NaN << 31} as 32-bit
+    // integers (k <= sites x n_i n_j < 2^24 under the rule that admits this form): half the bytes of the result stream
+    double *rawA1 = reinterpret_cast<double *>(p.out_raw) + (((size_t)w * nbp + blockIdx.y) * 2 * 4 + wave) * 1024 + lane;
+    uint2 *rawB1 = reinterpret_cast<uint2 *>(rawA1 + 4 * 1024);
+    uint32_t pn8[4] = {0u, 0u, 0u, 0u};                      // poison_n of the lanes whose FP64 element is this lane's 32-bit one
+    if (ONE && MISS) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) pn8[v] = (uint32_t)__shfl((int)poison_n, r + 16 * v);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const double Uj = lU[lcol + j * 16 + r], Cj = lC[lcol + j * 16 + r], nj = lN[lcol + j * 16 + r];
@@ -1495,6 +1505,15 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                     }
                     den = 0.5 * nb - 2.0 * den;
                 }
+                if (ONE) {
+                    rawA1[slot * 64] = (poison_d & bit) ? kNaN : den;
+                    const int l8 = lrow + i * 16 + 4 * kq + v;      // 32-bit accumulators: row 4 kq + v = FP64 slot kq of lane group v
+                    double kk = nj * lC[l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
+                    if (MISS) kk -= (double)im[i][j][v];
+                    const uint32_t nan_num = (pn8[v] >> ((j * 2 + i) * 4 + kq)) & 1u;
+                    rawB1[slot * 64] = make_uint2((uint32_t)(long long)kk, (uint32_t)((int)nvalid - iex[i][j][v]) | (nan_num << 31));
+                    continue;
+                }
                 const double num = den - lU[li] - Uj;
                 rawA[slot * 64] = make_double2((poison_n & bit) ? kNaN : num, (poison_d & bit) ? kNaN : den);
                 if (!I8) {
@@ -1514,7 +1533,10 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
 
 // [n_windows][block pairs][A|B][wave][slot][lane] -> the four [n_windows][n_pairs] arrays (pair (i < j) at
 // i (2P - i - 1) / 2 + j - i - 1).  i8: B's rows follow the 32-bit accumulator layout (row 4 kq + v), else the FP64 one.
-__global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restrict__ raw, int P, int64_t n_windows, bool i8,
+// one (the one-contraction denominator): 8-byte entries, A = den, B = {k, n_included | num is NaN << 31}; num = den - U_i - U_j
+// as gram_kernel forms it in the other case (U: the launch's [window][P] per-population sums).
+__global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restrict__ raw, int P, int64_t n_windows, bool i8, bool one,
+                                                           const double *__restrict__ U,
                                                            double *__restrict__ num, double *__restrict__ den,
                                                            double *__restrict__ k, double *__restrict__ cnt) {
     const int pj = blockIdx.x * blockDim.x + threadIdx.x, pi = blockIdx.y;
@@ -1529,9 +1551,16 @@ __global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restr
     const size_t base = (((size_t)w * nbp + bp) * 2 * 4 + wave) * 1024;
     const int slotA = (j * 2 + i) * 4 + (r16 >> 2), laneA = (r16 & 3) * 16 + r;             // row kq + 4 v
     const int slotB = i8 ? (j * 2 + i) * 4 + (r16 & 3) : slotA, laneB = i8 ? (r16 >> 2) * 16 + r : laneA;   // row 4 kq + v
-    const double2 a = raw[base + slotA * 64 + laneA], b = raw[base + 4 * 1024 + slotB * 64 + laneB];
     const size_t np = (size_t)P * (P - 1) / 2;
     const size_t o = (size_t)w * np + (size_t)pi * (2 * (size_t)P - pi - 1) / 2 + (size_t)(pj - pi - 1);
+    if (one) {
+        const double d = reinterpret_cast<const double *>(raw)[base + slotA * 64 + laneA];
+        const uint2 b = reinterpret_cast<const uint2 *>(raw)[base + 4 * 1024 + slotB * 64 + laneB];
+        num[o] = (b.y >> 31) ? __longlong_as_double(0x7ff8000000000000ll) : d - U[(size_t)w * P + pi] - U[(size_t)w * P + pj];
+        den[o] = d; k[o] = (double)b.x; cnt[o] = (double)(b.y & 0x7fffffffu);
+        return;
+    }
+    const double2 a = raw[base + slotA * 64 + laneA], b = raw[base + 4 * 1024 + slotB * 64 + laneB];
     num[o] = a.x; den[o] = a.y; k[o] = b.x; cnt[o] = b.y;
 }
 
@@ -1546,14 +1575,17 @@ bool gram_uses_i8(int count_bytes, int max_n) {
 #endif
     return i8;
 }
-hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, double *num, double *den, double *k, double *cnt, hipStream_t st) {
+hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, bool one, const double *U, double *num, double *den, double *k,
+                              double *cnt, hipStream_t st) {
     if (n_windows <= 0 || P < 2) return hipSuccess;
     for (int64_t w0 = 0; w0 < n_windows; w0 += 65535) {          // gridDim.z
         const int64_t nw = std::min<int64_t>(65535, n_windows - w0);
         const size_t nblk = (P + 63) / 64, per_w = (nblk * (nblk + 1) / 2) * 2 * 4 * 1024, np = (size_t)P * (P - 1) / 2;
         dim3 grid((P + 255) / 256, P, (unsigned)nw), block(256);
-        hipLaunchKernelGGL(gram_unpack_kernel, grid, block, 0, st, raw + (size_t)w0 * per_w, P, nw, i8, num + (size_t)w0 * np, den + (size_t)w0 * np,
-                           k + (size_t)w0 * np, cnt + (size_t)w0 * np);
+        // (with 8-byte entries a window's part of the table is half as long)
+        const double2 *rw = one ? reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(raw) + (size_t)w0 * per_w) : raw + (size_t)w0 * per_w;
+        hipLaunchKernelGGL(gram_unpack_kernel, grid, block, 0, st, rw, P, nw, i8, one, U + (size_t)w0 * P, num + (size_t)w0 * np,
+                           den + (size_t)w0 * np, k + (size_t)w0 * np, cnt + (size_t)w0 * np);
     }
     return hipGetLastError();
 }
