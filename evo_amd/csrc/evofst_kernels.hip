@@ -1177,7 +1177,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     __shared__ double tab_fi[TAB && !ONE ? 1024 : 1];
     __shared__ double tab_u[ONE ? 1024 : 1];             // (2 c - nm) / (2 nm): p - 1/2 rounded once; 0 without a called allele
     __shared__ uint64_t lmask[kGramMaskTiles][4][128];   // [tile][z|f|nm<2|nm==0][64 row pops, 64 column pops]
-    __shared__ double lU[128], lC[128], lN[128];         // U, C of the window and n_full, same 128 populations
+    __shared__ double lU[ONE ? 1 : kGramWPB][128], lC[kGramWPB][128], lN[128];   // U, C of the block's windows and n_full, same 128 populations
+                                                         // (ONE: the getter subtracts U)
     constexpr int EV = 8;                               // sites per lane and step
     constexpr int NVEC = sizeof(CT) == 2 ? 1 : 2;       // 16-byte vectors per 8 packed counts
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -1221,11 +1222,55 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     const CT *cb = reinterpret_cast<const CT *>(p.counts);
     const double kNaN = __longlong_as_double(0x7ff8000000000000ll);
 
-    // a block works through kGramWPB consecutive windows: the tables above are built once for all of them
-    for (int wi = 0; wi < kGramWPB; ++wi) {
-    const int w = blockIdx.x * kGramWPB + wi;
-    if (w >= p.n_windows) break;
-    const int64_t a = p.win_start[p.first_window + w], b = min(p.win_start[p.first_window + w + 1], p.n_sites);
+    // a block works through kGramWPB consecutive windows: the tables above are built once for all of them, and what a
+    // window needs before its first site -- its bounds, whether K1 announced a NaN poison in it, the per-population sums
+    // for its epilogue -- is fetched here for all of them at once (one memory latency per block instead of three per
+    // window, and no barrier between windows that stage no masks)
+    const int w_first = blockIdx.x * kGramWPB;
+    const int nw_blk = (int)min((int64_t)kGramWPB, p.n_windows - w_first);
+    if (nw_blk <= 0) return;                             // (uniform; before the first barrier)
+    const int64_t ws_l = p.win_start[p.first_window + w_first + min(lane, nw_blk)];   // lane l: start of the block's window l (l >= nw_blk: the end of its last)
+    uint32_t need_bits = 0;                              // bit l: window l stages K1's masks
+    if (I8 && MISS) {
+        // the included sites of every pair come out of the int8 contraction below; K1's masks are only needed where the
+        // reference would poison a window with NaN (a population with fewer than two called alleles at an included site),
+        // which the two masks behind it announce -- all zero in all but pathological windows
+        const int64_t al = ws_l, bl = min((int64_t)__shfl_down((long long)ws_l, 1), p.n_sites);
+        bool need = false;
+        if (lane < nw_blk && bl > al)
+            for (int t = (int)(al >> 6); t <= (int)((bl - 1) >> 6); ++t) need = need || p.tile_poison[t] != 0u;
+        need_bits = (uint32_t)__builtin_amdgcn_ballot_w64(need);
+    } else if (!I8) {
+        need_bits = ~0u;
+    }
+    for (int i = threadIdx.x; i < nw_blk * 128; i += blockDim.x) {
+        const int x = i & 127, ww = i >> 7, pop_ = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
+        lC[ww][x] = pop_ < p.P ? p.C[(size_t)(w_first + ww) * p.P + pop_] : 0.0;
+        if (!ONE) lU[ww][x] = pop_ < p.P ? p.U[(size_t)(w_first + ww) * p.P + pop_] : 0.0;
+    }
+    __syncthreads();
+    auto window_start = [&](int l) {                     // l uniform, <= nw_blk
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ws_l, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)ws_l >> 32), l);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    uint4 nxt[4][NVEC] = {};                             // (live across windows: see prefetched)
+    uint64_t nxt_skip = 0;                               // skip mask of the tile of those sites, requested with them
+    auto fetch = [&](int64_t base) {                     // the 4 populations' count vectors of this lane's 8 sites
+        const int64_t sv = base + (int64_t)kq * EV;
+        const int t = (int)min(sv >> 6, (int64_t)p.n_tiles - 1), o = (int)(sv & 63);
+        nxt_skip = p.skip_mask[t];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const CT *src = cb + ((size_t)t * p.P + min(pop[x], p.P - 1)) * kTileSites + o;
+#pragma unroll
+            for (int v = 0; v < NVEC; ++v) nxt[x][v] = reinterpret_cast<const uint4 *>(src)[v];
+        }
+    };
+    bool prefetched = false;                             // nxt holds the first step of the window (requested before the last one's epilogue)
+
+    for (int wi = 0; wi < nw_blk; ++wi) {
+    const int w = w_first + wi;
+    const int64_t a = window_start(wi), b = min(window_start(wi + 1), p.n_sites);
     const int tw0 = (int)(a >> 6), tw1 = b > a ? (int)((b - 1) >> 6) : tw0 - 1;
     // K1's masks of the block's 128 populations for ng tiles from tile tg on
     // (m_first = 2: only the two masks behind the NaN poison; returns whether one of them has a bit set)
@@ -1241,21 +1286,12 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         }
         return any;
     };
-    // I8: the included sites of every pair come out of the int8 contraction below; K1's masks are only needed where the
-    // reference would poison a window with NaN (a population with fewer than two called alleles at an included site),
-    // which the two masks behind it announce -- all zero in all but pathological windows
-    bool masks_needed = !I8;
-    if (I8 && MISS)
-        for (int t = tw0; t <= tw1; ++t) masks_needed = masks_needed || p.tile_poison[t] != 0u;   // uniform over the block
-    if (wi) __syncthreads();                             // the previous window's epilogue is done with lmask, lU, lC
-    // the window's per-population sums of the block's 128 populations, for the epilogue (requested here, read there)
-    if (threadIdx.x < 128) {
-        const int x = threadIdx.x, pop_ = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
-        lU[x] = pop_ < p.P ? p.U[(size_t)w * p.P + pop_] : 0.0;
-        lC[x] = pop_ < p.P ? p.C[(size_t)w * p.P + pop_] : 0.0;
+    const bool masks_needed = (need_bits >> wi) & 1u;    // uniform over the block
+    if (masks_needed) {
+        __syncthreads();                                 // the windows before are done with lmask
+        stage_masks(tw0, min(kGramMaskTiles, tw1 - tw0 + 1), 0, 4);
+        __syncthreads();
     }
-    if (masks_needed) stage_masks(tw0, min(kGramMaskTiles, tw1 - tw0 + 1), 0, 4);
-    __syncthreads();
 
     // included sites and NaN poison of every pair from K1's masks, kGramMaskTiles tiles at a time through LDS.  The
     // first group is counted here, before the contraction (18 registers carried through it are cheaper than counting
@@ -1313,21 +1349,9 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         for (int j = 0; j < 2; ++j) { acc_den[i][j] = double4_t{0, 0, 0, 0}; acc_cc[i][j] = double4_t{0, 0, 0, 0}; acc_m[i][j] = double4_t{0, 0, 0, 0}; }
 
     const int64_t base0 = a & ~(int64_t)7;
-    uint4 nxt[4][NVEC];
-    uint64_t nxt_skip = 0;                               // skip mask of the tile of those sites, requested with them
-    auto fetch = [&](int64_t base) {                     // the 4 populations' count vectors of this lane's 8 sites
-        const int64_t sv = base + (int64_t)kq * EV;
-        const int t = (int)min(sv >> 6, (int64_t)p.n_tiles - 1), o = (int)(sv & 63);
-        nxt_skip = p.skip_mask[t];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const CT *src = cb + ((size_t)t * p.P + min(pop[x], p.P - 1)) * kTileSites + o;
-#pragma unroll
-            for (int v = 0; v < NVEC; ++v) nxt[x][v] = reinterpret_cast<const uint4 *>(src)[v];
-        }
-    };
     const int64_t bend = (idle || (p.debug & 1)) ? base0 : b;        // an idle wave contracts nothing and writes nothing
-    if (base0 < bend) fetch(base0);
+    if (base0 < bend && !prefetched) fetch(base0);
+    prefetched = false;
     for (int64_t base = base0; base < bend; base += 4 * EV) {
         const int64_t sv = base + (int64_t)kq * EV;      // this lane's 8 sites (inside one tile)
         const int o = (int)(sv & 63);
@@ -1351,7 +1375,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 cnt[x][4] = v1.x; cnt[x][5] = v1.y; cnt[x][6] = v1.z; cnt[x][7] = v1.w;
             }
         }
-        if (I8 && __builtin_amdgcn_ballot_w64(valid != 0u) != 0) {
+        const bool any_valid = __builtin_amdgcn_ballot_w64(valid != 0u) != 0;   // (uniform)
+        if (I8 && any_valid) {
             // the step's 32 sites at once: lane = population (lane & 15), bytes = its 8 sites
             long C8[4], FN8[4], FM8[4], Z8[4], F8[4], B8[4], BN8[4], D8[4];
             vcount += (uint32_t)__popc(valid);
@@ -1398,7 +1423,44 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                     if (ONE && MISS) inb[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(D8[i], D8[2 + j], inb[i][j], 0, 0, 0);
                 }
         }
+        // ONE: the table offsets of the step's packed counts, two sites per word and no branch: entry (nm << 5) | c of tab_u
+        // is at byte nm * 256 + c * 8, both in place in a 16-bit packed count but for c's shift, and the sites outside the
+        // window (or skipped) go to entry 0 (= 0.0) through the masks.  (Rows of populations >= P contract a copy of
+        // population P - 1: their elements of the result are never read.)
+        uint32_t T[4][4];
+        if (ONE && any_valid) {
+            const uint64_t vm = spread[valid];
+            const uint32_t vlo = (uint32_t)vm, vhi = (uint32_t)(vm >> 32);
+            const uint32_t mk[4] = {__builtin_amdgcn_perm(vlo, vlo, 0x01010000u), __builtin_amdgcn_perm(vlo, vlo, 0x03030202u),
+                                    __builtin_amdgcn_perm(vhi, vhi, 0x01010000u), __builtin_amdgcn_perm(vhi, vhi, 0x03030202u)};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const uint32_t wv[4] = {nxt[x][0].x, nxt[x][0].y, nxt[x][0].z, nxt[x][0].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) T[x][k] = (wv[k] & (mk[k] & 0x1f001f00u)) | ((wv[k] << 3) & (mk[k] & 0x00f800f8u));
+            }
+        }
         if (base + 4 * EV < b) fetch(base + 4 * EV);     // the next step's vectors travel while this one is contracted
+        if (ONE) {
+            if (!any_valid) continue;
+#pragma unroll
+            for (int e = 0; e < EV; ++e) {
+                // a site index no lane of the wave has inside the window (the ragged ends of a window): see below
+                if (__builtin_amdgcn_ballot_w64((valid >> e) & 1u) == 0) continue;
+                double U_[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const uint32_t off = (e & 1) ? T[x][e >> 1] >> 16 : T[x][e >> 1] & 0xffffu;
+                    U_[x] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_u) + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(U_[i], U_[2 + j], acc_den[i][j], 0, 0, 0);   // sum u_i u_j
+            }
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < EV; ++e) {
             double P_[4], Q_[4], C_[4], FN[4], FM[4];
@@ -1411,7 +1473,6 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 uint32_t c = cnt[x][e] & CountTraits<CT>::mask, nm = cnt[x][e] >> CountTraits<CT>::shift;
                 if (TAB) {
                     const uint32_t idx = ok && pop[x] < p.P ? (nm << 5) | c : 1u;
-                    if (ONE) { P_[x] = tab_u[idx]; continue; }
                     const double2 pq = tab_pq[idx], cf = tab_cf[idx];
                     P_[x] = pq.x; Q_[x] = pq.y; C_[x] = cf.x;
                     if (MISS) { FN[x] = cf.y; FM[x] = fma((double)nfull[x], tab_fi[idx], -cf.y); }   // F (n - nm)
@@ -1438,7 +1499,6 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (ONE) { acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(P_[i], P_[2 + j], acc_den[i][j], 0, 0, 0); continue; }   // sum u_i u_j
                     acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(P_[i], Q_[2 + j], acc_den[i][j], 0, 0, 0);
                     acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(Q_[i], P_[2 + j], acc_den[i][j], 0, 0, 0);
                     if (I8) continue;
@@ -1449,6 +1509,11 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                     }
                 }
         }
+    }
+
+    if (!idle && wi + 1 < nw_blk && !(p.debug & 1)) {    // the next window's first vectors travel during this one's epilogue
+        const int64_t a2 = window_start(wi + 1), b2 = min(window_start(wi + 2), p.n_sites);
+        if ((a2 & ~(int64_t)7) < b2) { fetch(a2 & ~(int64_t)7); prefetched = true; }
     }
 
     // ---- epilogue: C/D layout col = lane & 15, row = (lane >> 4) + 4 v
@@ -1485,7 +1550,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const double Uj = lU[lcol + j * 16 + r], Cj = lC[lcol + j * 16 + r], nj = lN[lcol + j * 16 + r];
+        const double Uj = ONE ? 0.0 : lU[ONE ? 0 : wi][lcol + j * 16 + r], Cj = lC[wi][lcol + j * 16 + r], nj = lN[lcol + j * 16 + r];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1508,21 +1573,21 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 if (ONE) {
                     rawA1[slot * 64] = (poison_d & bit) ? kNaN : den;
                     const int l8 = lrow + i * 16 + 4 * kq + v;      // 32-bit accumulators: row 4 kq + v = FP64 slot kq of lane group v
-                    double kk = nj * lC[l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
+                    double kk = nj * lC[wi][l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
                     if (MISS) kk -= (double)im[i][j][v];
                     const uint32_t nan_num = (pn8[v] >> ((j * 2 + i) * 4 + kq)) & 1u;
                     rawB1[slot * 64] = make_uint2((uint32_t)(long long)kk, (uint32_t)((int)nvalid - iex[i][j][v]) | (nan_num << 31));
                     continue;
                 }
-                const double num = den - lU[li] - Uj;
+                const double num = den - lU[ONE ? 0 : wi][li] - Uj;
                 rawA[slot * 64] = make_double2((poison_n & bit) ? kNaN : num, (poison_d & bit) ? kNaN : den);
                 if (!I8) {
-                    double kk = nj * lC[li] + lN[li] * Cj - 2.0 * acc_cc[i][j][v];
+                    double kk = nj * lC[wi][li] + lN[li] * Cj - 2.0 * acc_cc[i][j][v];
                     if (MISS) kk -= acc_m[i][j][v];
                     rawB[slot * 64] = make_double2(kk, (double)cnt_in[j][i][v]);
                 } else {
                     const int l8 = lrow + i * 16 + 4 * kq + v;      // 32-bit accumulators: row 4 kq + v
-                    double kk = nj * lC[l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
+                    double kk = nj * lC[wi][l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
                     if (MISS) kk -= (double)im[i][j][v];
                     rawB[slot * 64] = make_double2(kk, (double)((int)nvalid - iex[i][j][v]));
                 }
