@@ -1384,29 +1384,31 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
             for (int x = 0; x < 4; ++x) {
                 const uint4 v = nxt[x][0];
                 const uint64_t vm = pop[x] < p.P ? spread[valid] : 0ull;
-                const uint32_t vlo = (uint32_t)vm, vhi = (uint32_t)(vm >> 32);
-                const uint32_t clo = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u) & vlo, chi = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u) & vhi;
-                C8[x] = (long)(((uint64_t)chi << 32) | clo);
-                auto fixed_bytes = [](uint32_t t) {               // 0xff in the bytes of t that are zero
-                    const uint32_t nz = (((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
-                    return ((nz ^ 0x80808080u) >> 7) * 0xffu;
-                };
-                const uint32_t nlo = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u) & vlo, nhi = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u) & vhi;
-                const uint32_t flo = fixed_bytes(clo ^ nlo) & vlo, fhi = fixed_bytes(chi ^ nhi) & vhi;   // F = [c == nm], sites of the window only
-                {   // the site filter (process_vcf_fst.cpp:543-544) as 0/1 bytes: excluded = z_i z_j + f_i f_j - (z f)_i (z f)_j
-                    const uint32_t zlo = fixed_bytes(clo) & vlo, zhi = fixed_bytes(chi) & vhi;            // Z = [c == 0]
-                    Z8[x] = (long)(((uint64_t)(zhi & 0x01010101u) << 32) | (zlo & 0x01010101u));
-                    F8[x] = (long)(((uint64_t)(fhi & 0x01010101u) << 32) | (flo & 0x01010101u));
-                    B8[x] = Z8[x] & F8[x];
-                    BN8[x] = (long)(((uint64_t)(zhi & fhi) << 32) | (zlo & flo));                          // -1 where both
+                const uint32_t n4 = nfull[x] * 0x01010101u;
+                // the operand bytes of four sites.  Counts are below 128 here, so bit 7 of 0x80 - t says "byte t is zero"
+                // without a borrow between bytes, and a 0x7f mask keeps every value a fixed site contributes.
+                uint32_t c_[2], z_[2], f_[2], b_[2], bn_[2], d_[2], fn_[2], fm_[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t m = h ? (uint32_t)(vm >> 32) : (uint32_t)vm, m80 = m & 0x80808080u;
+                    const uint32_t wa = h ? v.z : v.x, wb = h ? v.w : v.y;
+                    const uint32_t c = __builtin_amdgcn_perm(wb, wa, 0x06040200u) & m, n = __builtin_amdgcn_perm(wb, wa, 0x07050301u) & m;
+                    const uint32_t z7 = (0x80808080u - c) & m80;          // Z = [c == 0], sites of the window only
+                    const uint32_t f7 = (0x80808080u - (c ^ n)) & m80;    // F = [c == nm]
+                    const uint32_t b7 = z7 & f7;
+                    const uint32_t f1 = f7 >> 7, b1 = b7 >> 7, f7f = f7 - f1;
+                    c_[h] = c; z_[h] = z7 >> 7; f_[h] = f1; b_[h] = b1;
+                    bn_[h] = b7 | (b7 - b1);                              // -1 where both
+                    d_[h] = ((n + 0x7f7f7f7fu) & 0x80808080u) >> 7;       // D = [nm > 0] (n is masked already)
+                    fn_[h] = n & f7f;                                     // F nm
+                    fm_[h] = (n4 - n) & f7f;                              // F (n - nm); bytewise, no borrows
                 }
-                if (ONE && MISS)                                 // D = [nm > 0], sites of the window only (nlo, nhi are masked)
-                    D8[x] = (long)(((uint64_t)(~fixed_bytes(nhi) & 0x01010101u) << 32) | (~fixed_bytes(nlo) & 0x01010101u));
-                if (MISS) {
-                    const uint32_t n4 = nfull[x] * 0x01010101u;
-                    FN8[x] = (long)(((uint64_t)(nhi & fhi) << 32) | (nlo & flo));                        // F nm
-                    FM8[x] = (long)(((uint64_t)((n4 - nhi) & fhi) << 32) | ((n4 - nlo) & flo));          // F (n - nm); bytewise, no borrows
-                }
+                auto pack = [](const uint32_t (&t)[2]) { return (long)(((uint64_t)t[1] << 32) | t[0]); };
+                C8[x] = pack(c_);
+                // the site filter (process_vcf_fst.cpp:543-544) as 0/1 bytes: excluded = z_i z_j + f_i f_j - (z f)_i (z f)_j
+                Z8[x] = pack(z_); F8[x] = pack(f_); B8[x] = pack(b_); BN8[x] = pack(bn_);
+                if (ONE && MISS) D8[x] = pack(d_);
+                if (MISS) { FN8[x] = pack(fn_); FM8[x] = pack(fm_); }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)

@@ -61,7 +61,8 @@ def _check_gram(engine, codes, sp, P, fl, ws, tag):
 @pytest.mark.parametrize("S,N,P,miss,flags,edge,seed", [(1500, 48, 12, 0.0, False, False, 1), (2000, 100, 20, 0.15, True, True, 2),
                                                         (900, 150, 75, 0.1, False, True, 3), (700, 66, 33, 0.3, True, True, 4),
                                                         (1300, 520, 130, 0.0, False, False, 5), (640, 40, 2, 0.2, False, True, 6),
-                                                        (800, 1200, 3, 0.1, True, True, 7), (500, 2200, 2, 0.05, False, True, 8)])
+                                                        (800, 1200, 3, 0.1, True, True, 7), (500, 2200, 2, 0.05, False, True, 8),
+                                                        (600, 126, 2, 0.2, True, True, 9)])   # 126 chromosomes: the top of the int8 range
 def test_gram_windows(engine, S, N, P, miss, flags, edge, seed):
     rng = np.random.default_rng(seed)
     sp = round_robin_pops(N, P)
