@@ -1654,7 +1654,7 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     }
     const int64_t P = c->n_pops, np = P * (P - 1) / 2;
     if ((rc = ensure(c, c->d_gU, (size_t)n_windows * P * 8))) return rc;
-    if ((rc = ensure(c, c->d_gC, (size_t)n_windows * P * 8))) return rc;
+    if ((rc = ensure(c, c->d_gC, (size_t)n_windows * P * 8 * 2))) return rc;   // C, then D (sites with a called allele)
     if ((rc = ensure(c, c->d_graw, gram_raw_bytes(c->n_pops, n_windows)))) return rc;
     GramParams p{};
     p.counts = c->d_counts.p; p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.P = c->n_pops;
@@ -1667,7 +1667,7 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     for (int64_t w = first_window; w < first_window + n_windows; ++w)
         p.max_window_sites = std::max(p.max_window_sites, c->win_start[(size_t)w + 1] - c->win_start[(size_t)w]);
     if (c->opt_gram_den == 2) p.max_window_sites = 0;         // evofst_set_option "gram_denominator" 2: the two-stream form
-    p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p;
+    p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p; p.D = p.C + (size_t)n_windows * P;
     p.n_pairs = np;
     p.out_raw = (double2 *)c->d_graw.p;
 #ifdef EVOFST_EXPERIMENTS

@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void gram_popsums_tab_kernel(GramParams p) {
     const uint16_t *cb = reinterpret_cast<const uint16_t *>(p.counts);
     for (int k = group; k < p.P; k += 32) {
         double U = 0.0;
-        uint32_t C = 0;
+        uint32_t C = 0, D = 0;                                            // D: sites where the population has a called allele
         for (int t = tw0; t <= tw1; ++t) {
             uint64_t vm = ~p.skip_mask[t];                                // sites of the tile inside the window and not skipped
             if (t == tw0) vm &= ~0ull << (a & 63);
@@ -1140,12 +1140,13 @@ __global__ __launch_bounds__(256) void gram_popsums_tab_kernel(GramParams p) {
                 const uint32_t c = x & 0xffu, nm = x >> 8;
                 U += th[(nm << 5) | c];
                 C += c;
+                D += nm ? 1u : 0u;
             }
         }
         double Cd = (double)C;
 #pragma unroll
-        for (int d = 4; d >= 1; d >>= 1) { U += __shfl_xor(U, d); Cd += __shfl_xor(Cd, d); }
-        if (j == 0) { p.U[(size_t)w * p.P + k] = U; p.C[(size_t)w * p.P + k] = Cd; }
+        for (int d = 4; d >= 1; d >>= 1) { U += __shfl_xor(U, d); Cd += __shfl_xor(Cd, d); D += (uint32_t)__shfl_xor((int)D, d); }
+        if (j == 0) { p.U[(size_t)w * p.P + k] = U; p.C[(size_t)w * p.P + k] = Cd; p.D[(size_t)w * p.P + k] = (double)D; }
     }
 }
 
@@ -1177,8 +1178,9 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     __shared__ double tab_fi[TAB && !ONE ? 1024 : 1];
     __shared__ double tab_u[ONE ? 1024 : 1];             // (2 c - nm) / (2 nm): p - 1/2 rounded once; 0 without a called allele
     __shared__ uint64_t lmask[kGramMaskTiles][4][128];   // [tile][z|f|nm<2|nm==0][64 row pops, 64 column pops]
-    __shared__ double lU[ONE ? 1 : kGramWPB][128], lC[kGramWPB][128], lN[128];   // U, C of the block's windows and n_full, same 128 populations
-                                                         // (ONE: the getter subtracts U)
+    __shared__ double lU[ONE ? 1 : kGramWPB][128], lC[ONE ? 1 : kGramWPB][128], lN[128];   // U, C of the block's windows and n_full, same 128 populations
+    __shared__ int lCi[ONE ? kGramWPB : 1][128], lDi[ONE ? kGramWPB : 1][128], lNi[ONE ? 128 : 1];   // ONE: C, n_full and the sites with a called allele
+                                                         // as integers (the getter subtracts U)
     constexpr int EV = 8;                               // sites per lane and step
     constexpr int NVEC = sizeof(CT) == 2 ? 1 : 2;       // 16-byte vectors per 8 packed counts
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -1212,6 +1214,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     if (threadIdx.x < 128) {
         const int x = threadIdx.x, pop_ = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
         lN[x] = pop_ < p.P ? (double)p.n_full[pop_] : 0.0;
+        if (ONE) lNi[x] = pop_ < p.P ? p.n_full[pop_] : 0;
     }
     const bool idle = r0 > c0 + 31 || r0 >= p.P || c0 >= p.P;   // a wave below the diagonal or outside: only joins the barriers
     int pop[4];                                          // row tile 0, 1, column tile 0, 1
@@ -1245,8 +1248,13 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     }
     for (int i = threadIdx.x; i < nw_blk * 128; i += blockDim.x) {
         const int x = i & 127, ww = i >> 7, pop_ = x < 64 ? bi * 64 + x : bj * 64 + x - 64;
+        if (ONE) {
+            lCi[ww][x] = pop_ < p.P ? (int)p.C[(size_t)(w_first + ww) * p.P + pop_] : 0;
+            if (MISS) lDi[ww][x] = pop_ < p.P ? (int)p.D[(size_t)(w_first + ww) * p.P + pop_] : 0;
+            continue;
+        }
         lC[ww][x] = pop_ < p.P ? p.C[(size_t)(w_first + ww) * p.P + pop_] : 0.0;
-        if (!ONE) lU[ww][x] = pop_ < p.P ? p.U[(size_t)(w_first + ww) * p.P + pop_] : 0.0;
+        lU[ww][x] = pop_ < p.P ? p.U[(size_t)(w_first + ww) * p.P + pop_] : 0.0;
     }
     __syncthreads();
     auto window_start = [&](int l) {                     // l uniform, <= nw_blk
@@ -1387,6 +1395,9 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 const uint32_t n4 = nfull[x] * 0x01010101u;
                 // the operand bytes of four sites.  Counts are below 128 here, so bit 7 of 0x80 - t says "byte t is zero"
                 // without a borrow between bytes, and a 0x7f mask keeps every value a fixed site contributes.
+                // ONE: a site where both of a pair have no called allele (Z and F both set, B below) is counted through D
+                // instead -- B = valid - D, so sum B_i B_j = n_valid - nD_i - nD_j + sum D_i D_j (the epilogue) -- and
+                // without missing data there is no such site.
                 uint32_t c_[2], z_[2], f_[2], b_[2], bn_[2], d_[2], fn_[2], fm_[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -1395,10 +1406,12 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                     const uint32_t c = __builtin_amdgcn_perm(wb, wa, 0x06040200u) & m, n = __builtin_amdgcn_perm(wb, wa, 0x07050301u) & m;
                     const uint32_t z7 = (0x80808080u - c) & m80;          // Z = [c == 0], sites of the window only
                     const uint32_t f7 = (0x80808080u - (c ^ n)) & m80;    // F = [c == nm]
-                    const uint32_t b7 = z7 & f7;
-                    const uint32_t f1 = f7 >> 7, b1 = b7 >> 7, f7f = f7 - f1;
-                    c_[h] = c; z_[h] = z7 >> 7; f_[h] = f1; b_[h] = b1;
-                    bn_[h] = b7 | (b7 - b1);                              // -1 where both
+                    const uint32_t f1 = f7 >> 7, f7f = f7 - f1;
+                    c_[h] = c; z_[h] = z7 >> 7; f_[h] = f1;
+                    if (!ONE) {
+                        const uint32_t b7 = z7 & f7, b1 = b7 >> 7;
+                        b_[h] = b1; bn_[h] = b7 | (b7 - b1);              // -1 where both
+                    }
                     d_[h] = ((n + 0x7f7f7f7fu) & 0x80808080u) >> 7;       // D = [nm > 0] (n is masked already)
                     fn_[h] = n & f7f;                                     // F nm
                     fm_[h] = (n4 - n) & f7f;                              // F (n - nm); bytewise, no borrows
@@ -1406,7 +1419,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 auto pack = [](const uint32_t (&t)[2]) { return (long)(((uint64_t)t[1] << 32) | t[0]); };
                 C8[x] = pack(c_);
                 // the site filter (process_vcf_fst.cpp:543-544) as 0/1 bytes: excluded = z_i z_j + f_i f_j - (z f)_i (z f)_j
-                Z8[x] = pack(z_); F8[x] = pack(f_); B8[x] = pack(b_); BN8[x] = pack(bn_);
+                Z8[x] = pack(z_); F8[x] = pack(f_);
+                if (!ONE) { B8[x] = pack(b_); BN8[x] = pack(bn_); }
                 if (ONE && MISS) D8[x] = pack(d_);
                 if (MISS) { FN8[x] = pack(fn_); FM8[x] = pack(fm_); }
             }
@@ -1417,7 +1431,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                     icc[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(C8[i], C8[2 + j], icc[i][j], 0, 0, 0);
                     iex[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(Z8[i], Z8[2 + j], iex[i][j], 0, 0, 0);
                     iex[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(F8[i], F8[2 + j], iex[i][j], 0, 0, 0);
-                    iex[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(BN8[i], B8[2 + j], iex[i][j], 0, 0, 0);
+                    if (!ONE) iex[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(BN8[i], B8[2 + j], iex[i][j], 0, 0, 0);
                     if (MISS) {
                         im[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(FN8[i], FM8[2 + j], im[i][j], 0, 0, 0);
                         im[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(FM8[i], FN8[2 + j], im[i][j], 0, 0, 0);
@@ -1540,19 +1554,46 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     const int nbp = nblk * (nblk + 1) / 2;
     double2 *rawA = p.out_raw + (((size_t)w * nbp + blockIdx.y) * 2 * 4 + wave) * 1024 + lane;
     double2 *rawB = rawA + 4 * 1024;
-    // ONE: the same table with 8-byte entries -- A = the denominator (the getter forms num = den - U_i - U_j from it and the
-    // per-population sums, the very subtraction done here otherwise), B = {k, n_included | num is NaN << 31} as 32-bit
-    // integers (k <= sites x n_i n_j < 2^24 under the rule that admits this form): half the bytes of the result stream
+    // ONE: the same table with 8-byte entries and what is left of the arithmetic to the getter -- A = sum u_i u_j (NaN where
+    // the denominator is poisoned), B = {k, n_included | n_both << 15 | num is NaN << 31} as 32-bit integers in the layout
+    // their accumulators have (windows of this form have <= 2^14 sites, k <= sites x n_i n_j < 2^24); the getter forms
+    // den = n_both / 2 - 2 A and num = den - U_i - U_j, the very operations done here otherwise.  Half the bytes of the
+    // result stream, no exchange between the two accumulator layouts, integer arithmetic for k.
     double *rawA1 = reinterpret_cast<double *>(p.out_raw) + (((size_t)w * nbp + blockIdx.y) * 2 * 4 + wave) * 1024 + lane;
     uint2 *rawB1 = reinterpret_cast<uint2 *>(rawA1 + 4 * 1024);
-    uint32_t pn8[4] = {0u, 0u, 0u, 0u};                      // poison_n of the lanes whose FP64 element is this lane's 32-bit one
-    if (ONE && MISS) {
+    if (ONE) {
+        uint32_t pn8[4] = {0u, 0u, 0u, 0u};                  // poison_n of the lanes whose FP64 element is this lane's 32-bit one
+        if (MISS) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) pn8[v] = (uint32_t)__shfl((int)poison_n, r + 16 * v);
+            for (int v = 0; v < 4; ++v) pn8[v] = (uint32_t)__shfl((int)poison_n, r + 16 * v);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int xj = lcol + j * 16 + r;
+            const int Cj = lCi[wi][xj], nj = lNi[xj], Dj = MISS ? lDi[wi][xj] : 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int slot = (j * 2 + i) * 4 + v;
+                    rawA1[slot * 64] = (poison_d & (1u << slot)) ? kNaN : acc_den[i][j][v];       // FP64 accumulators: row kq + 4 v
+                    const int l8 = lrow + i * 16 + 4 * kq + v;                                     // 32-bit accumulators: row 4 kq + v
+                    int kk = (int)__umul24((uint32_t)nj, (uint32_t)lCi[wi][l8]) + (int)__umul24((uint32_t)lNi[l8], (uint32_t)Cj) - 2 * icc[i][j][v];
+                    int nb = (int)nvalid, nin = (int)nvalid - iex[i][j][v];
+                    if (MISS) {
+                        kk -= im[i][j][v];
+                        nb = inb[i][j][v];
+                        nin += (int)nvalid - lDi[wi][l8] - Dj + nb;                                // sites neither has a called allele at: in both Z and F
+                    }
+                    const uint32_t nan_num = (pn8[v] >> ((j * 2 + i) * 4 + kq)) & 1u;
+                    rawB1[slot * 64] = make_uint2((uint32_t)kk, (uint32_t)nin | ((uint32_t)nb << 15) | (nan_num << 31));
+                }
+        }
+        continue;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const double Uj = ONE ? 0.0 : lU[ONE ? 0 : wi][lcol + j * 16 + r], Cj = lC[wi][lcol + j * 16 + r], nj = lN[lcol + j * 16 + r];
+        const double Uj = lU[ONE ? 0 : wi][lcol + j * 16 + r], Cj = lC[ONE ? 0 : wi][lcol + j * 16 + r], nj = lN[lcol + j * 16 + r];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1560,36 +1601,16 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 const int slot = (j * 2 + i) * 4 + v;
                 const int li = lrow + i * 16 + kq + 4 * v;          // FP64 accumulators: row kq + 4 v
                 const uint32_t bit = 1u << slot;
-                double den = acc_den[i][j][v];
-                if (ONE) {
-                    // n_both of this element: the 32-bit accumulators hold row 4 kq + v, so the element (row kq + 4 v) of
-                    // this lane is register kq of the lane with the same column in lane group v
-                    double nb = (double)nvalid;
-                    if (MISS) {
-                        const int src = r + 16 * v;
-                        const int n0 = __shfl(inb[i][j][0], src), n1 = __shfl(inb[i][j][1], src), n2 = __shfl(inb[i][j][2], src), n3 = __shfl(inb[i][j][3], src);
-                        nb = (double)(kq == 0 ? n0 : kq == 1 ? n1 : kq == 2 ? n2 : n3);
-                    }
-                    den = 0.5 * nb - 2.0 * den;
-                }
-                if (ONE) {
-                    rawA1[slot * 64] = (poison_d & bit) ? kNaN : den;
-                    const int l8 = lrow + i * 16 + 4 * kq + v;      // 32-bit accumulators: row 4 kq + v = FP64 slot kq of lane group v
-                    double kk = nj * lC[wi][l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
-                    if (MISS) kk -= (double)im[i][j][v];
-                    const uint32_t nan_num = (pn8[v] >> ((j * 2 + i) * 4 + kq)) & 1u;
-                    rawB1[slot * 64] = make_uint2((uint32_t)(long long)kk, (uint32_t)((int)nvalid - iex[i][j][v]) | (nan_num << 31));
-                    continue;
-                }
+                const double den = acc_den[i][j][v];
                 const double num = den - lU[ONE ? 0 : wi][li] - Uj;
                 rawA[slot * 64] = make_double2((poison_n & bit) ? kNaN : num, (poison_d & bit) ? kNaN : den);
                 if (!I8) {
-                    double kk = nj * lC[wi][li] + lN[li] * Cj - 2.0 * acc_cc[i][j][v];
+                    double kk = nj * lC[ONE ? 0 : wi][li] + lN[li] * Cj - 2.0 * acc_cc[i][j][v];
                     if (MISS) kk -= acc_m[i][j][v];
                     rawB[slot * 64] = make_double2(kk, (double)cnt_in[j][i][v]);
                 } else {
                     const int l8 = lrow + i * 16 + 4 * kq + v;      // 32-bit accumulators: row 4 kq + v
-                    double kk = nj * lC[wi][l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
+                    double kk = nj * lC[ONE ? 0 : wi][l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
                     if (MISS) kk -= (double)im[i][j][v];
                     rawB[slot * 64] = make_double2(kk, (double)((int)nvalid - iex[i][j][v]));
                 }
@@ -1623,8 +1644,9 @@ __global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restr
     if (one) {
         const double d = reinterpret_cast<const double *>(raw)[base + slotA * 64 + laneA];
         const uint2 b = reinterpret_cast<const uint2 *>(raw)[base + 4 * 1024 + slotB * 64 + laneB];
-        num[o] = (b.y >> 31) ? __longlong_as_double(0x7ff8000000000000ll) : d - U[(size_t)w * P + pi] - U[(size_t)w * P + pj];
-        den[o] = d; k[o] = (double)b.x; cnt[o] = (double)(b.y & 0x7fffffffu);
+        const double dn = 0.5 * (double)((b.y >> 15) & 0x7fffu) - 2.0 * d;      // n_both / 2 - 2 sum u_i u_j
+        num[o] = (b.y >> 31) ? __longlong_as_double(0x7ff8000000000000ll) : dn - U[(size_t)w * P + pi] - U[(size_t)w * P + pj];
+        den[o] = dn; k[o] = (double)b.x; cnt[o] = (double)(b.y & 0x7fffu);
         return;
     }
     const double2 a = raw[base + slotA * 64 + laneA], b = raw[base + 4 * 1024 + slotB * 64 + laneB];
