@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                                                          // as integers (the getter subtracts U)
     constexpr int EV = 8;                               // sites per lane and step
     constexpr int NVEC = sizeof(CT) == 2 ? 1 : 2;       // 16-byte vectors per 8 packed counts
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform, and known to be: scalar branches below)
     const int r = lane & 15, kq = lane >> 4;
     // block pair (bi <= bj) from the linear index
     const int nblk = (p.P + 63) / 64;
@@ -1261,15 +1261,19 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ws_l, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)ws_l >> 32), l);
         return (int64_t)(((uint64_t)hi << 32) | lo);
     };
+    uint32_t popc[4];                                    // (rows of populations >= P read population P - 1)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) popc[x] = (uint32_t)min(pop[x], p.P - 1);
     uint4 nxt[4][NVEC] = {};                             // (live across windows: see prefetched)
     uint64_t nxt_skip = 0;                               // skip mask of the tile of those sites, requested with them
     auto fetch = [&](int64_t base) {                     // the 4 populations' count vectors of this lane's 8 sites
         const int64_t sv = base + (int64_t)kq * EV;
         const int t = (int)min(sv >> 6, (int64_t)p.n_tiles - 1), o = (int)(sv & 63);
         nxt_skip = p.skip_mask[t];
+        const uint32_t tp = (uint32_t)t * (uint32_t)p.P;  // (tiles x populations x 128 B is the table in HBM: far below 2^32 rows)
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const CT *src = cb + ((size_t)t * p.P + min(pop[x], p.P - 1)) * kTileSites + o;
+            const CT *src = cb + (size_t)(tp + popc[x]) * kTileSites + o;
 #pragma unroll
             for (int v = 0; v < NVEC; ++v) nxt[x][v] = reinterpret_cast<const uint4 *>(src)[v];
         }
@@ -1383,7 +1387,10 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 cnt[x][4] = v1.x; cnt[x][5] = v1.y; cnt[x][6] = v1.z; cnt[x][7] = v1.w;
             }
         }
-        const bool any_valid = __builtin_amdgcn_ballot_w64(valid != 0u) != 0;   // (uniform)
+        // the site indices some lane of the wave has inside the window, as a scalar (the 16 lanes of a group share their sites)
+        const uint32_t emask = (uint32_t)(__builtin_amdgcn_readlane((int)valid, 0) | __builtin_amdgcn_readlane((int)valid, 16) |
+                                          __builtin_amdgcn_readlane((int)valid, 32) | __builtin_amdgcn_readlane((int)valid, 48));
+        const bool any_valid = emask != 0u;
         if (I8 && any_valid) {
             // the step's 32 sites at once: lane = population (lane & 15), bytes = its 8 sites
             long C8[4], FN8[4], FM8[4], Z8[4], F8[4], B8[4], BN8[4], D8[4];
@@ -1462,7 +1469,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
 #pragma unroll
             for (int e = 0; e < EV; ++e) {
                 // a site index no lane of the wave has inside the window (the ragged ends of a window): see below
-                if (__builtin_amdgcn_ballot_w64((valid >> e) & 1u) == 0) continue;
+                if (!((emask >> e) & 1u)) continue;
                 double U_[4];
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
@@ -1483,7 +1490,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
             const bool ok = (valid >> e) & 1u;
             // a site index no lane of the wave has inside the window (the ragged ends of a window): all operands would be
             // zero, so the 12 or 20 MFMAs of this index are skipped -- exact, and ~6 % of the work with 100-site windows
-            if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
+            if (!((emask >> e) & 1u)) continue;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 uint32_t c = cnt[x][e] & CountTraits<CT>::mask, nm = cnt[x][e] >> CountTraits<CT>::shift;
