@@ -13,6 +13,7 @@
 //   stitch_kernel           completes the segment that straddles a chunk boundary.
 //   site_stats / pop_div    per-site outputs on demand (parity hooks and the CLI front-end).
 //   global_*                Fst-against-all evaluation and deque windows.
+#include <type_traits>
 #include "evofst_internal.h"
 
 #include <algorithm>
@@ -1569,33 +1570,38 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     double *rawA1 = reinterpret_cast<double *>(p.out_raw) + (((size_t)w * nbp + blockIdx.y) * 2 * 4 + wave) * 1024 + lane;
     uint2 *rawB1 = reinterpret_cast<uint2 *>(rawA1 + 4 * 1024);
     if (ONE) {
-        uint32_t pn8[4] = {0u, 0u, 0u, 0u};                  // poison_n of the lanes whose FP64 element is this lane's 32-bit one
-        if (MISS) {
+        // (a window without a poison announcement -- nearly all -- takes the copy without the NaN selects)
+        auto emit = [&](auto with_poison) {
+            constexpr bool PZ = decltype(with_poison)::value;
+            uint32_t pn8[4] = {0u, 0u, 0u, 0u};              // poison_n of the lanes whose FP64 element is this lane's 32-bit one
+            if (PZ) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) pn8[v] = (uint32_t)__shfl((int)poison_n, r + 16 * v);
-        }
+                for (int v = 0; v < 4; ++v) pn8[v] = (uint32_t)__shfl((int)poison_n, r + 16 * v);
+            }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int xj = lcol + j * 16 + r;
-            const int Cj = lCi[wi][xj], nj = lNi[xj], Dj = MISS ? lDi[wi][xj] : 0;
+            for (int j = 0; j < 2; ++j) {
+                const int xj = lcol + j * 16 + r;
+                const int Cj = lCi[wi][xj], nj = lNi[xj], Dj = MISS ? lDi[wi][xj] : 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int slot = (j * 2 + i) * 4 + v;
-                    rawA1[slot * 64] = (poison_d & (1u << slot)) ? kNaN : acc_den[i][j][v];       // FP64 accumulators: row kq + 4 v
-                    const int l8 = lrow + i * 16 + 4 * kq + v;                                     // 32-bit accumulators: row 4 kq + v
-                    int kk = (int)__umul24((uint32_t)nj, (uint32_t)lCi[wi][l8]) + (int)__umul24((uint32_t)lNi[l8], (uint32_t)Cj) - 2 * icc[i][j][v];
-                    int nb = (int)nvalid, nin = (int)nvalid - iex[i][j][v];
-                    if (MISS) {
-                        kk -= im[i][j][v];
-                        nb = inb[i][j][v];
-                        nin += (int)nvalid - lDi[wi][l8] - Dj + nb;                                // sites neither has a called allele at: in both Z and F
+                    for (int v = 0; v < 4; ++v) {
+                        const int slot = (j * 2 + i) * 4 + v;
+                        rawA1[slot * 64] = PZ && (poison_d & (1u << slot)) ? kNaN : acc_den[i][j][v];   // FP64 accumulators: row kq + 4 v
+                        const int l8 = lrow + i * 16 + 4 * kq + v;                                 // 32-bit accumulators: row 4 kq + v
+                        int kk = (int)__umul24((uint32_t)nj, (uint32_t)lCi[wi][l8]) + (int)__umul24((uint32_t)lNi[l8], (uint32_t)Cj) - 2 * icc[i][j][v];
+                        int nb = (int)nvalid, nin = (int)nvalid - iex[i][j][v];
+                        if (MISS) {
+                            kk -= im[i][j][v];
+                            nb = inb[i][j][v];
+                            nin += (int)nvalid - lDi[wi][l8] - Dj + nb;                            // sites neither has a called allele at: in both Z and F
+                        }
+                        const uint32_t nan_num = PZ ? (pn8[v] >> ((j * 2 + i) * 4 + kq)) & 1u : 0u;
+                        rawB1[slot * 64] = make_uint2((uint32_t)kk, (uint32_t)nin | ((uint32_t)nb << 15) | (nan_num << 31));
                     }
-                    const uint32_t nan_num = (pn8[v] >> ((j * 2 + i) * 4 + kq)) & 1u;
-                    rawB1[slot * 64] = make_uint2((uint32_t)kk, (uint32_t)nin | ((uint32_t)nb << 15) | (nan_num << 31));
-                }
-        }
+            }
+        };
+        if (MISS && masks_needed) emit(std::true_type{}); else emit(std::false_type{});
         continue;
     }
 #pragma unroll
