@@ -1369,12 +1369,11 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         const int64_t sv = base + (int64_t)kq * EV;      // this lane's 8 sites (inside one tile)
         const int o = (int)(sv & 63);
         // sites of the vector that belong to the window and are not skipped
-        uint32_t valid = 0;
-        if (sv < b && sv + EV > a) {
-            const uint32_t lo = sv < a ? (uint32_t)(a - sv) : 0u, hi = sv + EV > b ? (uint32_t)(b - sv) : (uint32_t)EV;
-            valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            valid &= ~(uint32_t)(nxt_skip >> o);
-        }
+        // (branch-free: the window's bounds relative to this lane's first site, clamped to its 8)
+        const int da = (int)(a - base) - kq * EV, db = (int)(b - base) - kq * EV;
+        const int lo = min(max(da, 0), EV), hi = min(max(db, 0), EV);
+        uint32_t valid = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+        valid &= ~(uint32_t)(nxt_skip >> o);
         uint32_t cnt[4][EV];                             // packed counts of the 4 populations
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
@@ -1399,7 +1398,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const uint4 v = nxt[x][0];
-                const uint64_t vm = pop[x] < p.P ? spread[valid] : 0ull;
+                const uint64_t vm = spread[valid];                // (rows of populations >= P contract a copy of population P - 1:
+                                                                  //  their elements of the result are never read)
                 const uint32_t n4 = nfull[x] * 0x01010101u;
                 // the operand bytes of four sites.  Counts are below 128 here, so bit 7 of 0x80 - t says "byte t is zero"
                 // without a borrow between bytes, and a 0x7f mask keeps every value a fixed site contributes.
