@@ -313,6 +313,8 @@ def main():
                     help="no GPU work: the ranks only meet (gloo, CPU) and rank 0 prints how many there are -- tests the launch path")
     ap.add_argument("--batches", type=int, default=0,
                     help="resident synthetic batches the timed loop rotates over (0 = enough to exceed the 256 MiB Infinity Cache)")
+    ap.add_argument("--gram-gb", type=float, default=8.0,
+                    help="Gram path: windows per evofst_run_gram call, as GB of its four result arrays held at a time")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the resident batches are spread over (1: the steps run one after the other; more: "
                          "independent batches overlap, as a run that keeps several batches in flight would)")
@@ -416,7 +418,7 @@ def main():
             ws = np.arange(0, S + cfg["size"], cfg["size"], dtype=np.int64).clip(max=S)
         e.set_site_windows(ws)
         n_win = len(ws) - 1
-        gram_batch = max(1, min(n_win, int(2e9 // (e.n_pairs * 32))))   # <= 2 GB of results resident
+        gram_batch = max(1, min(n_win, int(args.gram_gb * 1e9 // (e.n_pairs * 32))))   # <= that many GB of results resident
     else:
         e.set_windows(cfg["size"], cfg["step"])
     e.reserve(S)
@@ -476,7 +478,7 @@ def main():
 
     e_prof = [False]
 
-    gram_ms = []
+    gram_ms, popsums_ms = [], []
 
     def step():
         if cfg["mode"] == "gram":
@@ -485,7 +487,7 @@ def main():
             for w0 in range(0, n_win, gram_batch):
                 e.run_gram(w0, min(gram_batch, n_win - w0))
                 if e_prof[0]:
-                    e.sync(); gram_ms.append(e.kernel_ms(2))
+                    e.sync(); gram_ms.append(e.kernel_ms(2)); popsums_ms.append(e.kernel_ms(3))
         elif not multi:
             es[turn[0] % n_batches].run()
             turn[0] += 1
@@ -622,7 +624,9 @@ def main():
                  cfg["mode"], "global_tile_kernel" if e.last_global_walk() == 2 else "global_window_kernel"), "stitch_kernel",
              "fused_pairs_kernel"]
     if cfg["mode"] == "gram":
-        kavg[2] = float(np.sum(gram_ms))          # popsums + gram launches of every batch of one step
+        kavg[2] = float(np.sum(gram_ms))          # the gram_kernel launches of every batch of one step
+        kavg[3] = float(np.sum(popsums_ms))       # and the launches of the per-population window sums before them
+        names[3] = "gram_popsums_kernel"
     fused = cfg["mode"] == "pairs" and not multi and kavg[4] > 0
     if fused:
         names[4] = "stream_pairs_kernel" if e.last_pairs_pass() == 2 else "fused_pairs_kernel"
@@ -685,6 +689,7 @@ def main():
                          "executed_f64_frac": useful / n_f64 * ran_f64 / t_s / 1e12 / F64_MFMA_PEAK_TFLOPS,
                          "issued_f64_frac": issued / n_f64 * ran_f64 / t_s / 1e12 / F64_MFMA_PEAK_TFLOPS,
                          "all_contractions_as_f64_TFLOPs": 2.0 * S * e.n_pairs * (5 if cfg["miss"] > 0 else 3) / t_s / 1e12,
+                         "launches": len(gram_ms), "launch_ms": float(np.mean(gram_ms)), "windows_per_launch": gram_batch,
                          "hbm_write_bytes": written, "hbm_write_GBps": written / t_s / 1e9,
                          "hbm_write_frac": written / t_s / 1e9 / HBM_PEAK_GBS, "traffic": None})
     out = {

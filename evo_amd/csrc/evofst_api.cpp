@@ -1673,6 +1673,9 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
 #ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_DEBUG_GRAM")) p.debug = atoi(e);
 #endif
+    record(c, 3, 0);
+    HIPCHK(c, launch_gram_popsums(p, c->count_bytes, c->stream));
+    record(c, 3, 1);
     record(c, 2, 0);
     HIPCHK(c, launch_gram(p, c->count_bytes, c->gram_missing != 0, c->stream));
     c->last_gram_streams = gram_one_stream(p, c->count_bytes) ? 1 : 2;

@@ -418,6 +418,7 @@ hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool
                               double *cnt, hipStream_t st);
 bool gram_uses_i8(int count_bytes, int max_n);
 bool gram_one_stream(const GramParams &p, int count_bytes);     // the denominator as one FP64 contraction (gram_kernel<..., ONE>)
+hipError_t launch_gram_popsums(const GramParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st);
 size_t k2_lds_bytes(int P, int max_n);
 size_t fused_lds_bytes(int P, int n_segs, int max_n, int n_pairs, int chunk_tiles, int count_bytes, int sub);

@@ -1697,16 +1697,17 @@ bool gram_one_stream(const GramParams &p, int count_bytes) {
     return gram_uses_i8(count_bytes, p.max_n) && count_bytes == 2 && p.max_n <= 31 && p.max_window_sites > 0 &&
            p.max_window_sites * (int64_t)p.max_n <= (1 << 14);
 }
+// the windows' per-population sums (U, C, D of GramParams), which the contraction's epilogue and the getter read
+hipError_t launch_gram_popsums(const GramParams &p, int count_bytes, hipStream_t st) {
+    if (p.n_windows <= 0 || p.P < 2 || (p.debug & 4)) return hipSuccess;
+    dim3 grid(p.n_windows, (p.P + 3) / 4), block(256);
+    if (count_bytes == 2 && p.max_n <= 31) hipLaunchKernelGGL(gram_popsums_tab_kernel, dim3(p.n_windows), block, 0, st, p);
+    else if (count_bytes == 2) hipLaunchKernelGGL((gram_popsums_kernel<uint16_t>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gram_popsums_kernel<uint32_t>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
 hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, hipStream_t st) {
     if (p.n_windows <= 0 || p.P < 2) return hipSuccess;
-    if (!(p.debug & 4)) {
-        dim3 grid(p.n_windows, (p.P + 3) / 4), block(256);
-        if (count_bytes == 2 && p.max_n <= 31) hipLaunchKernelGGL(gram_popsums_tab_kernel, dim3(p.n_windows), block, 0, st, p);
-        else if (count_bytes == 2) hipLaunchKernelGGL((gram_popsums_kernel<uint16_t>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gram_popsums_kernel<uint32_t>), grid, block, 0, st, p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
     const int nblk = (p.P + 63) / 64;
     dim3 grid((p.n_windows + kGramWPB - 1) / kGramWPB, nblk * (nblk + 1) / 2), block(256);
     const bool i8 = gram_uses_i8(count_bytes, p.max_n);

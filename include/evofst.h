@@ -285,7 +285,7 @@ int evofst_last_gram_streams(const evofst_ctx *ctx);
 /* When enabled, evofst_run_* bracket every kernel with HIP events on the context's stream. */
 int evofst_set_profiling(evofst_ctx *ctx, int enabled);
 /* Milliseconds of the last run of kernel `which` (0 = counts, 1 = offsets scan, 2 = pair/global
- * stats, 3 = stitch).  Waits for the stream. */
+ * stats or the Gram contraction, 3 = stitch, or the per-population window sums of the Gram path).  Waits for the stream. */
 int evofst_get_kernel_ms(evofst_ctx *ctx, int which, float *ms);
 
 /* ------------------------------------------------------------------ results */
