@@ -364,7 +364,7 @@ struct GramParams {
     int64_t max_window_sites;    // the longest window of the set (0: not known): picks the one-stream denominator
     int32_t n_windows;
     double *U, *C;               // [n_windows][P] per-population sums of t + h and of c over the window
-    double *D;                   // [n_windows][P] the window's included-by-flags sites where the population has a called allele (16-bit counts, <= 31 chromosomes)
+    double *D;                   // [n_windows][P] the window's included-by-flags sites where the population has a called allele (16-bit counts, <= 63 chromosomes)
     int64_t n_pairs;             // P (P - 1) / 2, pair (i < j) at i (2P - i - 1) / 2 + j - i - 1
     // results as the workgroups hold them: [n_windows][block pairs][A|B][wave 4][slot 16][lane 64] x 16 bytes, A = {num, den},
     // B = {k, n_included}; every store instruction of the epilogue writes 1 KiB of consecutive, aligned bytes

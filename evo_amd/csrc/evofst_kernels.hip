@@ -1105,10 +1105,12 @@ __global__ __launch_bounds__(256) void gram_popsums_kernel(GramParams p) {
 // workgroup: the two divisions per entry that the kernel above makes per site and population), and a group walks
 // populations g, g + 32, ... with the window's two or three tiles each.  12.5 M one-wave work items of a few
 // instructions each become 25 k workgroups of streaming loads.
+// TB: bits of a count in the table's index (5: up to 31 chromosomes a population, 6: up to 63).
+template <int TB>
 __global__ __launch_bounds__(256) void gram_popsums_tab_kernel(GramParams p) {
-    __shared__ double th[1024];
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
-        const int c = i & 31, nm = i >> 5;
+    __shared__ double th[1 << (2 * TB)];
+    for (int i = threadIdx.x; i < (1 << (2 * TB)); i += blockDim.x) {
+        const int c = i & ((1 << TB) - 1), nm = i >> TB;
         double v = 0.0;
         if (nm > 0 && c <= nm) {
             const double pp = (double)c / (double)nm;
@@ -1139,7 +1141,7 @@ __global__ __launch_bounds__(256) void gram_popsums_tab_kernel(GramParams p) {
             for (int e = 0; e < 8; ++e) {
                 const uint32_t x = ((bits >> e) & 1u) ? (wv[e >> 1] >> (16 * (e & 1))) & 0xffffu : 0u;   // packed count, 0 outside
                 const uint32_t c = x & 0xffu, nm = x >> 8;
-                U += th[(nm << 5) | c];
+                U += th[(nm << TB) | c];
                 C += c;
                 D += nm ? 1u : 0u;
             }
@@ -1162,22 +1164,27 @@ constexpr int kGramMaskTiles = 4;    // tiles of a window whose masks are staged
 // I8 (8-bit counts, every population has <= 127 chromosomes): the integer contractions -- sum c_i c_j and the
 // fixed-with-missing term of sumKij -- run on the int8 matrix cores (v_mfma_i32_16x16x32_i8, one instruction per 32
 // sites and tile pair, exact in 32 bits), which leaves the FP64 cores the two streams of the denominator.
-// ONE (with TAB and I8, short windows of few chromosomes -- launch_gram): the denominator on ONE FP64 stream.  With
+// ONE (with I8 and a table of its own, up to 63 chromosomes a population, short windows -- launch_gram): the denominator on ONE FP64 stream.  With
 // u = p - 1/2, p_i (1 - p_j) + p_j (1 - p_i) = 1/2 - 2 u_i u_j, so sum den = n_both / 2 - 2 sum u_i u_j, n_both = the
 // window's sites where both populations have a called allele (an int8 contraction of 0 / 1 bytes, exact; u = 0 where a
 // population has none, as P = Q = 0 there).  Sites both populations are fixed at the same allele give u_i u_j = 1/4 exactly
-// and sums of quarters are exact, so the rounding errors are those of the polymorphic sites: one ulp(sites / 4) / 2 each,
-// against a bar of 1e-12 of a denominator that is at least 1 / max_n per such site -- inside the bar for every window
-// as long as sites x max_n <= 2^14, which is what launch_gram asks before it takes this form.
+// and sums of quarters are exact, so the rounding errors are those of the polymorphic sites: half an ulp of the running sum
+// when the site's term is added and half an ulp of every binade the sum enters afterwards, in all at most one ulp(sites / 4)
+// per such site, twice that in the denominator = sites x 2^-53, against a bar of 1e-12 of a denominator that is at least
+// 1 / max_n per such site -- inside the bar for every window (<= 0.91 of it) as long as sites x max_n <= 2^13, which is
+// what launch_gram asks before it takes this form (kGramOneRule).
+constexpr int64_t kGramOneRule = 1 << 13;
 typedef int int4_t __attribute__((ext_vector_type(4)));
-template <typename CT, bool MISS, bool TAB, bool I8, bool ONE = false>
+template <typename CT, bool MISS, bool TAB, bool I8, bool ONE = false, int TB = 5>
 __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
+    static_assert(TB == 5 || (ONE && TB == 6), "the 64 x 64 table exists for the one-stream form only");
     static_assert(!ONE || (TAB && I8), "the one-stream denominator reads the table and the int8 contractions");
     __shared__ uint64_t spread[I8 ? 256 : 1];            // bit e of the index -> byte e 0xff
     __shared__ double rcp[TAB ? 2 : 2048];
     __shared__ double2 tab_pq[TAB && !ONE ? 1024 : 1], tab_cf[TAB && !ONE ? 1024 : 1];
     __shared__ double tab_fi[TAB && !ONE ? 1024 : 1];
-    __shared__ double tab_u[ONE ? 1024 : 1];             // (2 c - nm) / (2 nm): p - 1/2 rounded once; 0 without a called allele
+    __shared__ double tab_u[ONE ? (1 << (2 * TB)) : 1];  // entry (nm << TB) | c: (2 c - nm) / (2 nm), p - 1/2 rounded once; 0 without a called allele
+                                                         // (TB = 6: populations of up to 63 chromosomes, 32 KB)
     __shared__ uint64_t lmask[kGramMaskTiles][4][128];   // [tile][z|f|nm<2|nm==0][64 row pops, 64 column pops]
     __shared__ double lU[ONE ? 1 : kGramWPB][128], lC[ONE ? 1 : kGramWPB][128], lN[128];   // U, C of the block's windows and n_full, same 128 populations
     __shared__ int lCi[ONE ? kGramWPB : 1][128], lDi[ONE ? kGramWPB : 1][128], lNi[ONE ? 128 : 1];   // ONE: C, n_full and the sites with a called allele
@@ -1200,8 +1207,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
             spread[i] = m;
         }
     if (TAB) {
-        for (int i = threadIdx.x; i < 1024; i += blockDim.x) {      // entry (nm << 5) | c; impossible ones (c > nm) are 0: entry 1 serves sites outside the window
-            const int c = i & 31, nm = i >> 5;
+        for (int i = threadIdx.x; i < (1 << (2 * TB)); i += blockDim.x) {      // entry (nm << TB) | c; impossible ones (c > nm) are 0: entry 1 serves sites outside the window
+            const int c = i & ((1 << TB) - 1), nm = i >> TB;
             const bool okc = c <= nm && nm <= p.max_n;
             if (ONE) { tab_u[i] = okc && nm ? (double)(2 * c - nm) / (double)(2 * nm) : 0.0; continue; }
             const double pp = okc && nm ? (double)c / (double)nm : 0.0;
@@ -1448,7 +1455,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 }
         }
         // ONE: the table offsets of the step's packed counts, two sites per word and no branch: entry (nm << 5) | c of tab_u
-        // is at byte nm * 256 + c * 8, both in place in a 16-bit packed count but for c's shift, and the sites outside the
+        // is at byte nm * 256 + c * 8, both in place in a 16-bit packed count but for c's shift (TB = 6: nm * 512 + c * 8,
+        // at most 32 760: still 16 bits), and the sites outside the
         // window (or skipped) go to entry 0 (= 0.0) through the masks.  (Rows of populations >= P contract a copy of
         // population P - 1: their elements of the result are never read.)
         uint32_t T[4][4];
@@ -1461,7 +1469,9 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
             for (int x = 0; x < 4; ++x) {
                 const uint32_t wv[4] = {nxt[x][0].x, nxt[x][0].y, nxt[x][0].z, nxt[x][0].w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) T[x][k] = (wv[k] & (mk[k] & 0x1f001f00u)) | ((wv[k] << 3) & (mk[k] & 0x00f800f8u));
+                for (int k = 0; k < 4; ++k)
+                    T[x][k] = TB == 5 ? (wv[k] & (mk[k] & 0x1f001f00u)) | ((wv[k] << 3) & (mk[k] & 0x00f800f8u))
+                                      : ((wv[k] << 1) & (mk[k] & 0x7e007e00u)) | ((wv[k] << 3) & (mk[k] & 0x01f801f8u));   // nm * 512 + c * 8
             }
         }
         if (base + 4 * EV < b) fetch(base + 4 * EV);     // the next step's vectors travel while this one is contracted
@@ -1496,7 +1506,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
             for (int x = 0; x < 4; ++x) {
                 uint32_t c = cnt[x][e] & CountTraits<CT>::mask, nm = cnt[x][e] >> CountTraits<CT>::shift;
                 if (TAB) {
-                    const uint32_t idx = ok && pop[x] < p.P ? (nm << 5) | c : 1u;
+                    const uint32_t idx = ok && pop[x] < p.P ? (nm << TB) | c : 1u;
                     const double2 pq = tab_pq[idx], cf = tab_cf[idx];
                     P_[x] = pq.x; Q_[x] = pq.y; C_[x] = cf.x;
                     if (MISS) { FN[x] = cf.y; FM[x] = fma((double)nfull[x], tab_fi[idx], -cf.y); }   // F (n - nm)
@@ -1564,7 +1574,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
     double2 *rawB = rawA + 4 * 1024;
     // ONE: the same table with 8-byte entries and what is left of the arithmetic to the getter -- A = sum u_i u_j (NaN where
     // the denominator is poisoned), B = {k, n_included | n_both << 15 | num is NaN << 31} as 32-bit integers in the layout
-    // their accumulators have (windows of this form have <= 2^14 sites, k <= sites x n_i n_j < 2^24); the getter forms
+    // their accumulators have (windows of this form have <= 2^13 sites, k <= sites x n_i n_j < 2^24); the getter forms
     // den = n_both / 2 - 2 A and num = den - U_i - U_j, the very operations done here otherwise.  Half the bytes of the
     // result stream, no exchange between the two accumulator layouts, integer arithmetic for k.
     double *rawA1 = reinterpret_cast<double *>(p.out_raw) + (((size_t)w * nbp + blockIdx.y) * 2 * 4 + wave) * 1024 + lane;
@@ -1694,14 +1704,15 @@ hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool
 
 // the denominator on one FP64 stream where every window stays inside the 1e-12 bar by construction (see gram_kernel)
 bool gram_one_stream(const GramParams &p, int count_bytes) {
-    return gram_uses_i8(count_bytes, p.max_n) && count_bytes == 2 && p.max_n <= 31 && p.max_window_sites > 0 &&
-           p.max_window_sites * (int64_t)p.max_n <= (1 << 14);
+    return gram_uses_i8(count_bytes, p.max_n) && count_bytes == 2 && p.max_n <= 63 && p.max_window_sites > 0 &&
+           p.max_window_sites * (int64_t)p.max_n <= kGramOneRule;
 }
 // the windows' per-population sums (U, C, D of GramParams), which the contraction's epilogue and the getter read
 hipError_t launch_gram_popsums(const GramParams &p, int count_bytes, hipStream_t st) {
     if (p.n_windows <= 0 || p.P < 2 || (p.debug & 4)) return hipSuccess;
     dim3 grid(p.n_windows, (p.P + 3) / 4), block(256);
-    if (count_bytes == 2 && p.max_n <= 31) hipLaunchKernelGGL(gram_popsums_tab_kernel, dim3(p.n_windows), block, 0, st, p);
+    if (count_bytes == 2 && p.max_n <= 31) hipLaunchKernelGGL(gram_popsums_tab_kernel<5>, dim3(p.n_windows), block, 0, st, p);
+    else if (count_bytes == 2 && p.max_n <= 63) hipLaunchKernelGGL(gram_popsums_tab_kernel<6>, dim3(p.n_windows), block, 0, st, p);
     else if (count_bytes == 2) hipLaunchKernelGGL((gram_popsums_kernel<uint16_t>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((gram_popsums_kernel<uint32_t>), grid, block, 0, st, p);
     return hipGetLastError();
@@ -1715,9 +1726,12 @@ hipError_t launch_gram(const GramParams &p, int count_bytes, bool has_missing, h
                                       else hipLaunchKernelGGL((gram_kernel<CT, M, T, false>), grid, block, 0, st, p); } while (0)
     const bool one = gram_one_stream(p, count_bytes);
     if (count_bytes == 2) {
-        if (p.max_n <= 31 && one) {
+        if (one && p.max_n <= 31) {
             if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true, true, true, true>), grid, block, 0, st, p);
             else hipLaunchKernelGGL((gram_kernel<uint16_t, false, true, true, true>), grid, block, 0, st, p);
+        } else if (one) {                            // 32 .. 63 chromosomes: the 64 x 64 table
+            if (has_missing) hipLaunchKernelGGL((gram_kernel<uint16_t, true, true, true, true, 6>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((gram_kernel<uint16_t, false, true, true, true, 6>), grid, block, 0, st, p);
         } else if (p.max_n <= 31) {
             if (has_missing) EVOFST_GRAM_GO(uint16_t, true, true);
             else EVOFST_GRAM_GO(uint16_t, false, true);
