@@ -636,7 +636,9 @@ __global__ __launch_bounds__(kK2Threads, HBM ? (W3 ? 3 : EVOFST_WALK_WPS) : EVOF
                     // sumKij (fst.cpp:299-321) of the segment, exact: differences are taken modulo 2^32 / 2^64
                     uint64_t kk = (uint64_t)nj * (uint64_t)(Ci - prevCi) + (uint64_t)ni * (uint64_t)(Cj - prevCj) - 2ull * (ccc - prevCC) - (ckx - prevKx);
                     double numI = 0.0, denI = 0.0;
-                    if (kInt) int_parts(iCC, iCi, iCj, iQi, iQj, numI, denI, kk);
+                    // (nothing to add where the segment has no clean fill -- data with missing alleles in every fill -- and the
+                    //  64-bit products and conversions are most of this function's instructions)
+                    if (kInt && (iCC | iCi | iCj | iQi | iQj) != 0ull) int_parts(iCC, iCi, iCj, iQi, iQj, numI, denI, kk);
                     SegRow row;
                     row.num = cbn != prevBn ? kNaN : (segN + cumN) + numI;      // cumN, cumD: this fill's sums up to b
                     row.den = cbd != prevBd ? kNaN : (segD + cumD) + denI;
