@@ -313,6 +313,8 @@ def main():
                     help="no GPU work: the ranks only meet (gloo, CPU) and rank 0 prints how many there are -- tests the launch path")
     ap.add_argument("--batches", type=int, default=0,
                     help="resident synthetic batches the timed loop rotates over (0 = enough to exceed the 256 MiB Infinity Cache)")
+    ap.add_argument("--gram-denominator", type=int, default=0, choices=(0, 2),
+                    help="evofst_set_option gram_denominator: 0 the library's choice, 2 always the two FP64 streams")
     ap.add_argument("--gram-gb", type=float, default=8.0,
                     help="Gram path: windows per evofst_run_gram call, as GB of its four result arrays held at a time")
     ap.add_argument("--streams", type=int, default=3,
@@ -383,6 +385,8 @@ def main():
     from evo_amd import EvoFst
     def tune(x):
         x.set_option("pairs_pass", args.pairs_pass)
+        if args.gram_denominator:
+            x.set_option("gram_denominator", args.gram_denominator)
         x.set_option("chunk_tiles", args.chunk_tiles)
         x.set_option("stream_blocks", args.stream_blocks)
         x.set_option("stream_buffers", args.stream_buffers)
@@ -678,7 +682,10 @@ def main():
         t_s = kavg[2] * 1e-3
         useful = 2.0 * S * e.n_pairs * n_f64
         issued = 2.0 * S * (64 * 64) * (nblk * (nblk + 1) / 2) * n_f64
-        written = float(n_win) * (nblk * (nblk + 1) / 2) * 4096 * (16.0 if ran_f64 == 1 else 32.0)   # (upper bound: waves below the diagonal write nothing)
+        # 8-byte entries wherever the integer contractions run on the int8 cores (16-bit packed counts, <= 127 chromosomes a
+        # population; GramParams::fmt), 16-byte ones otherwise.  (Upper bound: waves below the diagonal write nothing.)
+        compact = ran_f64 == 1 or (cb == 2 and 2 * (N // P + 1) <= 127)
+        written = float(n_win) * (nblk * (nblk + 1) / 2) * 4096 * (16.0 if compact else 32.0)
         ach_u = useful / t_s / 1e12
         roofline.update({"bound": "mfma", "kernel": "gram_kernel", "achieved": ach_u, "peak": F64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach_u / F64_MFMA_PEAK_TFLOPS, "algorithmic_flops": useful,

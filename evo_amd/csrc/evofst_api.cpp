@@ -122,6 +122,7 @@ struct evofst_ctx {
     bool k1_marks_valid = false, k1_marks_known = false; uint32_t k1_marks = 0;
     int last_global_walk = 0;                       // evofst_last_global_walk
     int last_gram_streams = 0;                      // evofst_last_gram_streams
+    int last_gram_fmt = 0;                          // GramParams::fmt of the last launch (what evofst_get_gram unpacks)
     int last_pairs_pass = 0;                        // evofst_last_pairs_pass
     int opt_global_walk = 0;                        // against-all rows: 0 auto, 1 lane = population kernel, 2 two-phase kernel where it fits
     int opt_stream_sets = 0;                        // its sets of consumer waves (0: the library chooses)
@@ -1666,10 +1667,11 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     p.first_window = first_window; p.n_windows = (int32_t)n_windows;
     for (int64_t w = first_window; w < first_window + n_windows; ++w)
         p.max_window_sites = std::max(p.max_window_sites, c->win_start[(size_t)w + 1] - c->win_start[(size_t)w]);
-    if (c->opt_gram_den == 2) p.max_window_sites = 0;         // evofst_set_option "gram_denominator" 2: the two-stream form
+    p.two_streams = c->opt_gram_den == 2;                     // evofst_set_option "gram_denominator" 2
     p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p; p.D = p.C + (size_t)n_windows * P;
     p.n_pairs = np;
     p.out_raw = (double2 *)c->d_graw.p;
+    p.fmt = gram_result_format(p, c->count_bytes);
 #ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_DEBUG_GRAM")) p.debug = atoi(e);
 #endif
@@ -1679,6 +1681,7 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     record(c, 2, 0);
     HIPCHK(c, launch_gram(p, c->count_bytes, c->gram_missing != 0, c->stream));
     c->last_gram_streams = gram_one_stream(p, c->count_bytes) ? 1 : 2;
+    c->last_gram_fmt = p.fmt;
     record(c, 2, 1);
     c->gram_windows = n_windows;
     return EVOFST_OK;
@@ -1698,7 +1701,7 @@ extern "C" int evofst_get_gram(evofst_ctx *c, double *sum_num, double *sum_den, 
         (rc = ensure(c, c->d_gcnt, n * 8))) return rc;
     HIPCHK(c, launch_gram_unpack((const double2 *)c->d_graw.p, c->n_pops, c->gram_windows,
                                  gram_uses_i8(c->count_bytes, *std::max_element(c->n_full.begin(), c->n_full.end())),
-                                 c->last_gram_streams == 1, (const double *)c->d_gU.p, (double *)c->d_gnum.p, (double *)c->d_gden.p, (double *)c->d_gk.p, (double *)c->d_gcnt.p, c->stream));
+                                 c->last_gram_fmt, (const double *)c->d_gU.p, (double *)c->d_gnum.p, (double *)c->d_gden.p, (double *)c->d_gk.p, (double *)c->d_gcnt.p, c->stream));
     if ((rc = d2h(c, sum_num, c->d_gnum.p, n)) || (rc = d2h(c, sum_den, c->d_gden.p, n)) ||
         (rc = d2h(c, sum_dxy_k, c->d_gk.p, n)) || (rc = d2h(c, n_included, c->d_gcnt.p, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -370,6 +370,9 @@ struct GramParams {
     // B = {k, n_included}; every store instruction of the epilogue writes 1 KiB of consecutive, aligned bytes
     // (gram_unpack_kernel turns the table into the four [n_windows][n_pairs] arrays the getter hands out)
     double2 *out_raw;
+    int32_t two_streams;         // never the one-contraction form (evofst_set_option "gram_denominator" 2)
+    int32_t fmt;                 // entries of out_raw (gram_result_format): 0 = 16 B {num, den} / {k, n_included}, 1 = 8 B, the one-contraction
+                                 // form's, 2 = 8 B {den} / {k, n_included | num is NaN << 31} as 32-bit integers, num left to the getter
     int32_t debug;               // EVOFST_DEBUG_GRAM (timing experiments): 1 no contraction loop, 2 no epilogue, 4 no popsums
 };
 
@@ -414,7 +417,8 @@ hipError_t launch_count_marks(const uint32_t *marks, int n, uint32_t *out, hipSt
 hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream_t st);
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 size_t gram_raw_bytes(int P, int64_t n_windows);
-hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, bool one, const double *U, double *num, double *den, double *k,
+int gram_result_format(const GramParams &p, int count_bytes);
+hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, int fmt, const double *U, double *num, double *den, double *k,
                               double *cnt, hipStream_t st);
 bool gram_uses_i8(int count_bytes, int max_n);
 bool gram_one_stream(const GramParams &p, int count_bytes);     // the denominator as one FP64 contraction (gram_kernel<..., ONE>)

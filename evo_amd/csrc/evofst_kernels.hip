@@ -1459,8 +1459,11 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         // at most 32 760: still 16 bits), and the sites outside the
         // window (or skipped) go to entry 0 (= 0.0) through the masks.  (Rows of populations >= P contract a copy of
         // population P - 1: their elements of the result are never read.)
+        // (the two-stream form with the {p, q} table and the int8 contractions takes its operands the same way: 16-byte
+        //  entries at nm * 512 + c * 16)
+        constexpr bool TPQ = TAB && I8 && !ONE && sizeof(CT) == 2;
         uint32_t T[4][4];
-        if (ONE && any_valid) {
+        if ((ONE || TPQ) && any_valid) {
             const uint64_t vm = spread[valid];
             const uint32_t vlo = (uint32_t)vm, vhi = (uint32_t)(vm >> 32);
             const uint32_t mk[4] = {__builtin_amdgcn_perm(vlo, vlo, 0x01010000u), __builtin_amdgcn_perm(vlo, vlo, 0x03030202u),
@@ -1470,7 +1473,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 const uint32_t wv[4] = {nxt[x][0].x, nxt[x][0].y, nxt[x][0].z, nxt[x][0].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    T[x][k] = TB == 5 ? (wv[k] & (mk[k] & 0x1f001f00u)) | ((wv[k] << 3) & (mk[k] & 0x00f800f8u))
+                    T[x][k] = TPQ ? ((wv[k] << 1) & (mk[k] & 0x3e003e00u)) | ((wv[k] << 4) & (mk[k] & 0x01f001f0u))       // nm * 512 + c * 16
+                            : TB == 5 ? (wv[k] & (mk[k] & 0x1f001f00u)) | ((wv[k] << 3) & (mk[k] & 0x00f800f8u))
                                       : ((wv[k] << 1) & (mk[k] & 0x7e007e00u)) | ((wv[k] << 3) & (mk[k] & 0x01f801f8u));   // nm * 512 + c * 8
             }
         }
@@ -1492,6 +1496,27 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(U_[i], U_[2 + j], acc_den[i][j], 0, 0, 0);   // sum u_i u_j
+            }
+            continue;
+        }
+        if (TPQ) {
+            if (!any_valid) continue;
+#pragma unroll
+            for (int e = 0; e < EV; ++e) {
+                if (!((emask >> e) & 1u)) continue;
+                double2 PQ[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const uint32_t off = (e & 1) ? T[x][e >> 1] >> 16 : T[x][e >> 1] & 0xffffu;
+                    PQ[x] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab_pq) + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(PQ[i].x, PQ[2 + j].y, acc_den[i][j], 0, 0, 0);
+                        acc_den[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(PQ[i].y, PQ[2 + j].x, acc_den[i][j], 0, 0, 0);
+                    }
             }
             continue;
         }
@@ -1614,6 +1639,32 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         if (MISS && masks_needed) emit(std::true_type{}); else emit(std::false_type{});
         continue;
     }
+    if (!ONE && I8 && p.fmt == 2) {
+        // 8-byte entries as in the one-contraction form: A = den (NaN where it is poisoned), B = {k, n_included | num is NaN << 31}
+        // in the layout of the int8 accumulators; num = den - U_i - U_j is the getter's (the same subtractions in the same order)
+        uint32_t pn8[4] = {0u, 0u, 0u, 0u};
+        if (MISS && masks_needed) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pn8[v] = (uint32_t)__shfl((int)poison_n, r + 16 * v);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double Cj = lC[ONE ? 0 : wi][lcol + j * 16 + r], nj = lN[lcol + j * 16 + r];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int slot = (j * 2 + i) * 4 + v;
+                    rawA1[slot * 64] = (poison_d & (1u << slot)) ? kNaN : acc_den[i][j][v];
+                    const int l8 = lrow + i * 16 + 4 * kq + v;
+                    double kk = nj * lC[ONE ? 0 : wi][l8] + lN[l8] * Cj - 2.0 * (double)icc[i][j][v];
+                    if (MISS) kk -= (double)im[i][j][v];
+                    const uint32_t nan_num = (pn8[v] >> ((j * 2 + i) * 4 + kq)) & 1u;
+                    rawB1[slot * 64] = make_uint2((uint32_t)(long long)kk, (uint32_t)((int)nvalid - iex[i][j][v]) | (nan_num << 31));
+                }
+        }
+        continue;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const double Uj = lU[ONE ? 0 : wi][lcol + j * 16 + r], Cj = lC[ONE ? 0 : wi][lcol + j * 16 + r], nj = lN[lcol + j * 16 + r];
@@ -1646,7 +1697,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
 // i (2P - i - 1) / 2 + j - i - 1).  i8: B's rows follow the 32-bit accumulator layout (row 4 kq + v), else the FP64 one.
 // one (the one-contraction denominator): 8-byte entries, A = den, B = {k, n_included | num is NaN << 31}; num = den - U_i - U_j
 // as gram_kernel forms it in the other case (U: the launch's [window][P] per-population sums).
-__global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restrict__ raw, int P, int64_t n_windows, bool i8, bool one,
+__global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restrict__ raw, int P, int64_t n_windows, bool i8, int fmt,
                                                            const double *__restrict__ U,
                                                            double *__restrict__ num, double *__restrict__ den,
                                                            double *__restrict__ k, double *__restrict__ cnt) {
@@ -1664,7 +1715,14 @@ __global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restr
     const int slotB = i8 ? (j * 2 + i) * 4 + (r16 & 3) : slotA, laneB = i8 ? (r16 >> 2) * 16 + r : laneA;   // row 4 kq + v
     const size_t np = (size_t)P * (P - 1) / 2;
     const size_t o = (size_t)w * np + (size_t)pi * (2 * (size_t)P - pi - 1) / 2 + (size_t)(pj - pi - 1);
-    if (one) {
+    if (fmt == 2) {                                    // A = den, B = {k, n_included | num is NaN << 31}
+        const double d = reinterpret_cast<const double *>(raw)[base + slotA * 64 + laneA];
+        const uint2 b = reinterpret_cast<const uint2 *>(raw)[base + 4 * 1024 + slotB * 64 + laneB];
+        num[o] = (b.y >> 31) ? __longlong_as_double(0x7ff8000000000000ll) : d - U[(size_t)w * P + pi] - U[(size_t)w * P + pj];
+        den[o] = d; k[o] = (double)b.x; cnt[o] = (double)(b.y & 0x7fffffffu);
+        return;
+    }
+    if (fmt == 1) {
         const double d = reinterpret_cast<const double *>(raw)[base + slotA * 64 + laneA];
         const uint2 b = reinterpret_cast<const uint2 *>(raw)[base + 4 * 1024 + slotB * 64 + laneB];
         const double dn = 0.5 * (double)((b.y >> 15) & 0x7fffu) - 2.0 * d;      // n_both / 2 - 2 sum u_i u_j
@@ -1687,7 +1745,7 @@ bool gram_uses_i8(int count_bytes, int max_n) {
 #endif
     return i8;
 }
-hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, bool one, const double *U, double *num, double *den, double *k,
+hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, int fmt, const double *U, double *num, double *den, double *k,
                               double *cnt, hipStream_t st) {
     if (n_windows <= 0 || P < 2) return hipSuccess;
     for (int64_t w0 = 0; w0 < n_windows; w0 += 65535) {          // gridDim.z
@@ -1695,8 +1753,8 @@ hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool
         const size_t nblk = (P + 63) / 64, per_w = (nblk * (nblk + 1) / 2) * 2 * 4 * 1024, np = (size_t)P * (P - 1) / 2;
         dim3 grid((P + 255) / 256, P, (unsigned)nw), block(256);
         // (with 8-byte entries a window's part of the table is half as long)
-        const double2 *rw = one ? reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(raw) + (size_t)w0 * per_w) : raw + (size_t)w0 * per_w;
-        hipLaunchKernelGGL(gram_unpack_kernel, grid, block, 0, st, rw, P, nw, i8, one, U + (size_t)w0 * P, num + (size_t)w0 * np,
+        const double2 *rw = fmt ? reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(raw) + (size_t)w0 * per_w) : raw + (size_t)w0 * per_w;
+        hipLaunchKernelGGL(gram_unpack_kernel, grid, block, 0, st, rw, P, nw, i8, fmt, U + (size_t)w0 * P, num + (size_t)w0 * np,
                            den + (size_t)w0 * np, k + (size_t)w0 * np, cnt + (size_t)w0 * np);
     }
     return hipGetLastError();
@@ -1704,10 +1762,19 @@ hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool
 
 // the denominator on one FP64 stream where every window stays inside the 1e-12 bar by construction (see gram_kernel)
 bool gram_one_stream(const GramParams &p, int count_bytes) {
-    return gram_uses_i8(count_bytes, p.max_n) && count_bytes == 2 && p.max_n <= 63 && p.max_window_sites > 0 &&
+    return !p.two_streams && gram_uses_i8(count_bytes, p.max_n) && count_bytes == 2 && p.max_n <= 63 && p.max_window_sites > 0 &&
            p.max_window_sites * (int64_t)p.max_n <= kGramOneRule;
 }
 // the windows' per-population sums (U, C, D of GramParams), which the contraction's epilogue and the getter read
+// The entries of the result table a launch writes (GramParams::fmt): the one-contraction form has its own 8-byte entries;
+// the other forms with int8 contractions write 8-byte entries too where k = sumKij <= sites x n_i n_j and the site count
+// fit 32 and 31 bits, and leave num = den - U_i - U_j to the getter; 16-byte {num, den} / {k, n_included} otherwise.
+int gram_result_format(const GramParams &p, int count_bytes) {
+    if (gram_one_stream(p, count_bytes)) return 1;
+    if (gram_uses_i8(count_bytes, p.max_n) && p.max_window_sites > 0 &&
+        (double)p.max_window_sites * (double)p.max_n * (double)p.max_n < 4.0e9 && p.max_window_sites < (1ll << 30)) return 2;
+    return 0;
+}
 hipError_t launch_gram_popsums(const GramParams &p, int count_bytes, hipStream_t st) {
     if (p.n_windows <= 0 || p.P < 2 || (p.debug & 4)) return hipSuccess;
     dim3 grid(p.n_windows, (p.P + 3) / 4), block(256);
