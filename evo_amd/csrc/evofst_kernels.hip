@@ -1126,30 +1126,48 @@ __global__ __launch_bounds__(256) void gram_popsums_tab_kernel(GramParams p) {
     const int group = threadIdx.x >> 3, j = threadIdx.x & 7;            // 32 groups of 8 lanes; lane j: sites 8 j .. 8 j + 7 of a tile
     const int tw0 = (int)(a >> 6), tw1 = b > a ? (int)((b - 1) >> 6) : tw0 - 1;
     const uint16_t *cb = reinterpret_cast<const uint16_t *>(p.counts);
-    for (int k = group; k < p.P; k += 32) {
-        double U = 0.0;
-        uint32_t C = 0, D = 0;                                            // D: sites where the population has a called allele
+    // KU populations of a group at a time: their count vectors of a tile are requested together (the loop waits on the
+    // loads' latency: one in flight per group took 100 us per launch of 1 820 windows where four take ~40)
+    constexpr int KU = 4;
+    for (int kb = group; kb < p.P; kb += 32 * KU) {
+        double U[KU];
+        uint32_t C[KU], D[KU];                                            // D: sites where the population has a called allele
+#pragma unroll
+        for (int u = 0; u < KU; ++u) { U[u] = 0.0; C[u] = 0; D[u] = 0; }
         for (int t = tw0; t <= tw1; ++t) {
             uint64_t vm = ~p.skip_mask[t];                                // sites of the tile inside the window and not skipped
             if (t == tw0) vm &= ~0ull << (a & 63);
             if (t == tw1 && (b & 63)) vm &= ~0ull >> (64 - (b & 63));
             const uint32_t bits = (uint32_t)(vm >> (8 * j)) & 0xffu;
             if (__builtin_amdgcn_ballot_w64(bits != 0u) == 0) continue;
-            const uint4 v = *reinterpret_cast<const uint4 *>(cb + ((size_t)t * p.P + k) * kTileSites + 8 * j);
-            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+            uint4 v[KU];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t x = ((bits >> e) & 1u) ? (wv[e >> 1] >> (16 * (e & 1))) & 0xffffu : 0u;   // packed count, 0 outside
-                const uint32_t c = x & 0xffu, nm = x >> 8;
-                U += th[(nm << TB) | c];
-                C += c;
-                D += nm ? 1u : 0u;
+            for (int u = 0; u < KU; ++u) {
+                const int k = min(kb + 32 * u, p.P - 1);
+                v[u] = *reinterpret_cast<const uint4 *>(cb + ((size_t)t * p.P + k) * kTileSites + 8 * j);
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const uint32_t wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t x = ((bits >> e) & 1u) ? (wv[e >> 1] >> (16 * (e & 1))) & 0xffffu : 0u;   // packed count, 0 outside
+                    const uint32_t c = x & 0xffu, nm = x >> 8;
+                    U[u] += th[(nm << TB) | c];
+                    C[u] += c;
+                    D[u] += nm ? 1u : 0u;
+                }
             }
         }
-        double Cd = (double)C;
 #pragma unroll
-        for (int d = 4; d >= 1; d >>= 1) { U += __shfl_xor(U, d); Cd += __shfl_xor(Cd, d); D += (uint32_t)__shfl_xor((int)D, d); }
-        if (j == 0) { p.U[(size_t)w * p.P + k] = U; p.C[(size_t)w * p.P + k] = Cd; p.D[(size_t)w * p.P + k] = (double)D; }
+        for (int u = 0; u < KU; ++u) {
+            const int k = kb + 32 * u;
+            double Us = U[u], Cd = (double)C[u];
+            uint32_t Ds = D[u];
+#pragma unroll
+            for (int d = 4; d >= 1; d >>= 1) { Us += __shfl_xor(Us, d); Cd += __shfl_xor(Cd, d); Ds += (uint32_t)__shfl_xor((int)Ds, d); }
+            if (j == 0 && k < p.P) { p.U[(size_t)w * p.P + k] = Us; p.C[(size_t)w * p.P + k] = Cd; p.D[(size_t)w * p.P + k] = (double)Ds; }
+        }
     }
 }
 
