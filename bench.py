@@ -315,6 +315,8 @@ def main():
                     help="resident synthetic batches the timed loop rotates over (0 = enough to exceed the 256 MiB Infinity Cache)")
     ap.add_argument("--gram-denominator", type=int, default=0, choices=(0, 2),
                     help="evofst_set_option gram_denominator: 0 the library's choice, 2 always the two FP64 streams")
+    ap.add_argument("--gram-bp", type=int, default=0,
+                    help="experiments only: another physical window length for the Gram configuration (the label says so)")
     ap.add_argument("--gram-gb", type=float, default=8.0,
                     help="Gram path: windows per evofst_run_gram call, as GB of its four result arrays held at a time")
     ap.add_argument("--streams", type=int, default=3,
@@ -409,6 +411,8 @@ def main():
         e.set_against_all(np.arange(P, dtype=np.int32), np.full(P, N // P, np.int64))
         units_per_site = P
     if cfg["mode"] == "gram":
+        if args.gram_bp > 0 and cfg.get("bp"):
+            cfg = dict(cfg, bp=args.gram_bp, label=cfg["label"] + " [EXPERIMENT: %d bp windows]" % args.gram_bp)
         if cfg.get("bp"):
             # physical windows for configs[4].  The windows are cut from the positions that travel with the shard
             # (synthetic: one site per 100 bp, evofst_synth), a window = the sites of one block of cfg["bp"] bases

@@ -88,6 +88,13 @@ struct evofst_ctx {
         d_nrows, d_totals;
     int64_t seg_cap = 0;
     std::vector<int64_t> win_start;   // Gram mode: site windows
+    // ... and their pieces, where windows are longer than the one-contraction form of the Gram path takes (evofst_run_gram):
+    // piece starts (+ the end of the last), and the first piece of every window (+ the number of pieces)
+    std::vector<int64_t> gram_sub, gram_suboff;
+    int64_t gram_sub_rule = -1;       // the piece length they were cut for (-1: not cut yet)
+    DevBuf d_gsub, d_gsuboff;
+    bool gram_split = false;          // the last evofst_run_gram ran pieces
+    int64_t gram_sub_base = 0, gram_first_window = 0;   // its first piece and first window
     bool base_host_valid = true;      // c->base mirrors d_base (false after a device-to-device set_base_offsets)
     const int64_t *gathered = nullptr; // pending evofst_set_base_offsets_gathered: the next scan sums these rows into d_base
     int64_t gathered_stride = 0;
@@ -768,7 +775,7 @@ extern "C" void evofst_destroy(evofst_ctx *c) {
     DevBuf *bufs[] = {&c->d_segs, &c->d_wss, &c->d_nfull, &c->d_pairs, &c->d_use, &c->d_thr, &c->d_base, &c->d_first_seg,
                       &c->d_tiles, &c->d_flags, &c->d_pos, &c->d_counts, &c->d_census, &c->d_offsets, &c->d_incl_totals,
                       &c->d_seg_rows, &c->d_seg_num, &c->d_seg_den, &c->d_seg_k, &c->d_seg_end, &c->d_zf, &c->d_irr,
-                      &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_halo_num, &c->d_halo_den, &c->d_halo_tag, &c->d_gU, &c->d_gC, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_graw, &c->d_carry,
+                      &c->d_tail, &c->d_tail_n, &c->d_win, &c->d_halo_num, &c->d_halo_den, &c->d_halo_tag, &c->d_gU, &c->d_gC, &c->d_gsub, &c->d_gsuboff, &c->d_gnum, &c->d_gden, &c->d_gk, &c->d_gcnt, &c->d_graw, &c->d_carry,
                       &c->d_nrows, &c->d_totals, &c->d_gtotals, &c->d_kept, &c->d_skip, &c->d_used_kept, &c->d_uk_off,
                       &c->d_uk_tot, &c->d_chunk_rows, &c->d_row_off, &c->d_row_tot, &c->d_row_start, &c->d_row_end,
                       &c->d_row_num, &c->d_row_den, &c->d_planes, &c->d_multi_site, &c->d_multi_alleles, &c->d_agg0, &c->d_agg1,
@@ -1386,6 +1393,7 @@ extern "C" int evofst_set_site_windows(evofst_ctx *c, const int64_t *win_start, 
         if (win_start[w] < 0 || win_start[w + 1] < win_start[w]) return fail(c, EVOFST_ERR_ARG, "set_site_windows: starts must be non-negative and non-decreasing");
     HIPCHK(c, hipSetDevice(c->device));
     c->win_start.assign(win_start, win_start + n_windows + 1);
+    c->gram_sub_rule = -1;
     return upload_vec(c, c->d_win, c->win_start);
 } catch (...) {
     return abi_exception(c);
@@ -1654,19 +1662,46 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
         for (uint64_t m : irr) if (m) { c->gram_missing = 1; break; }
     }
     const int64_t P = c->n_pops, np = P * (P - 1) / 2;
+    GramParams p{};
+    p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
+    for (int64_t w = first_window; w < first_window + n_windows; ++w)
+        p.max_window_sites = std::max(p.max_window_sites, c->win_start[(size_t)w + 1] - c->win_start[(size_t)w]);
+    // Windows longer than the one-contraction form takes (gram_kernel: longest window x chromosomes <= 2^13) run as pieces
+    // that are short enough, and evofst_get_gram adds the pieces' sums: every piece is inside the bar of its own terms and so
+    // is their sum.  The pieces of all windows are cut once per set of windows.
+    const int64_t rule = c->opt_gram_den == 2 ? 0 : gram_one_rule_sites(c->count_bytes, p.max_n);
+    const bool split = rule > 0 && p.max_window_sites > rule;
+    const int64_t n_run = n_windows;          // windows of the call
+    if (split) {
+        if (c->gram_sub_rule != rule) {
+            c->gram_sub.clear(); c->gram_suboff.clear();
+            for (size_t w = 0; w + 1 < c->win_start.size(); ++w) {
+                c->gram_suboff.push_back((int64_t)c->gram_sub.size());
+                const int64_t a = c->win_start[w], b = c->win_start[w + 1];
+                c->gram_sub.push_back(a);                                  // (an empty window is one empty piece)
+                for (int64_t x = a + rule; x < b; x += rule) c->gram_sub.push_back(x);
+            }
+            c->gram_suboff.push_back((int64_t)c->gram_sub.size());
+            c->gram_sub.push_back(c->win_start.back());
+            if ((rc = upload_vec(c, c->d_gsub, c->gram_sub)) || (rc = upload_vec(c, c->d_gsuboff, c->gram_suboff))) return rc;
+            c->gram_sub_rule = rule;
+        }
+        const int64_t s0 = c->gram_suboff[(size_t)first_window], s1 = c->gram_suboff[(size_t)(first_window + n_windows)];
+        if (s1 - s0 > 0x7fffffff) return fail(c, EVOFST_ERR_ARG, "run_gram: too many window pieces in one call");
+        c->gram_sub_base = s0; c->gram_first_window = first_window;
+        first_window = s0; n_windows = s1 - s0;           // the kernels run pieces
+        p.max_window_sites = std::min(p.max_window_sites, rule);
+    }
+    c->gram_split = split;
     if ((rc = ensure(c, c->d_gU, (size_t)n_windows * P * 8))) return rc;
     if ((rc = ensure(c, c->d_gC, (size_t)n_windows * P * 8 * 2))) return rc;   // C, then D (sites with a called allele)
     if ((rc = ensure(c, c->d_graw, gram_raw_bytes(c->n_pops, n_windows)))) return rc;
-    GramParams p{};
     p.counts = c->d_counts.p; p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.P = c->n_pops;
-    p.max_n = *std::max_element(c->n_full.begin(), c->n_full.end());
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.masks = (const uint64_t *)c->d_zf.p; p.skip_mask = (const uint64_t *)c->d_skip.p;
     p.tile_poison = (const uint32_t *)c->d_poison.p;
-    p.win_start = (const int64_t *)c->d_win.p;
+    p.win_start = (const int64_t *)(split ? c->d_gsub.p : c->d_win.p);
     p.first_window = first_window; p.n_windows = (int32_t)n_windows;
-    for (int64_t w = first_window; w < first_window + n_windows; ++w)
-        p.max_window_sites = std::max(p.max_window_sites, c->win_start[(size_t)w + 1] - c->win_start[(size_t)w]);
     p.two_streams = c->opt_gram_den == 2;                     // evofst_set_option "gram_denominator" 2
     p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p; p.D = p.C + (size_t)n_windows * P;
     p.n_pairs = np;
@@ -1683,7 +1718,7 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
     c->last_gram_streams = gram_one_stream(p, c->count_bytes) ? 1 : 2;
     c->last_gram_fmt = p.fmt;
     record(c, 2, 1);
-    c->gram_windows = n_windows;
+    c->gram_windows = n_run;
     return EVOFST_OK;
 } catch (...) {
     return abi_exception(c);
@@ -1701,7 +1736,8 @@ extern "C" int evofst_get_gram(evofst_ctx *c, double *sum_num, double *sum_den, 
         (rc = ensure(c, c->d_gcnt, n * 8))) return rc;
     HIPCHK(c, launch_gram_unpack((const double2 *)c->d_graw.p, c->n_pops, c->gram_windows,
                                  gram_uses_i8(c->count_bytes, *std::max_element(c->n_full.begin(), c->n_full.end())),
-                                 c->last_gram_fmt, (const double *)c->d_gU.p, (double *)c->d_gnum.p, (double *)c->d_gden.p, (double *)c->d_gk.p, (double *)c->d_gcnt.p, c->stream));
+                                 c->last_gram_fmt, c->gram_split ? (const int64_t *)c->d_gsuboff.p + c->gram_first_window : nullptr, c->gram_sub_base,
+                                 (const double *)c->d_gU.p, (double *)c->d_gnum.p, (double *)c->d_gden.p, (double *)c->d_gk.p, (double *)c->d_gcnt.p, c->stream));
     if ((rc = d2h(c, sum_num, c->d_gnum.p, n)) || (rc = d2h(c, sum_den, c->d_gden.p, n)) ||
         (rc = d2h(c, sum_dxy_k, c->d_gk.p, n)) || (rc = d2h(c, n_included, c->d_gcnt.p, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));

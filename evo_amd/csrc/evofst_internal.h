@@ -418,7 +418,8 @@ hipError_t launch_global_sites(const GlobalParams &p, int count_bytes, hipStream
 hipError_t launch_synth(const SynthParams &p, hipStream_t st);
 size_t gram_raw_bytes(int P, int64_t n_windows);
 int gram_result_format(const GramParams &p, int count_bytes);
-hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, int fmt, const double *U, double *num, double *den, double *k,
+int64_t gram_one_rule_sites(int count_bytes, int max_n);   // longest window of the one-contraction form (0: not for these populations)
+hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, int fmt, const int64_t *sub_off, int64_t sub_base, const double *U, double *num, double *den, double *k,
                               double *cnt, hipStream_t st);
 bool gram_uses_i8(int count_bytes, int max_n);
 bool gram_one_stream(const GramParams &p, int count_bytes);     // the denominator as one FP64 contraction (gram_kernel<..., ONE>)

@@ -1190,7 +1190,8 @@ constexpr int kGramMaskTiles = 4;    // tiles of a window whose masks are staged
 // when the site's term is added and half an ulp of every binade the sum enters afterwards, in all at most one ulp(sites / 4)
 // per such site, twice that in the denominator = sites x 2^-53, against a bar of 1e-12 of a denominator that is at least
 // 1 / max_n per such site -- inside the bar for every window (<= 0.91 of it) as long as sites x max_n <= 2^13, which is
-// what launch_gram asks before it takes this form (kGramOneRule).
+// what launch_gram asks before it takes this form (kGramOneRule).  evofst_run_gram cuts longer windows into pieces of that
+// length (the kernel sees the pieces as windows) and the getter adds the pieces' sums.
 constexpr int64_t kGramOneRule = 1 << 13;
 typedef int int4_t __attribute__((ext_vector_type(4)));
 template <typename CT, bool MISS, bool TAB, bool I8, bool ONE = false, int TB = 5>
@@ -1715,8 +1716,10 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
 // i (2P - i - 1) / 2 + j - i - 1).  i8: B's rows follow the 32-bit accumulator layout (row 4 kq + v), else the FP64 one.
 // one (the one-contraction denominator): 8-byte entries, A = den, B = {k, n_included | num is NaN << 31}; num = den - U_i - U_j
 // as gram_kernel forms it in the other case (U: the launch's [window][P] per-population sums).
+// sub_off (fmt 1 only): the table holds pieces of the windows -- window w is pieces sub_off[w] .. sub_off[w + 1] - 1, the
+// table's first being piece sub_base -- each short enough for the one-contraction form; their sums are added here (evofst_run_gram).
 __global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restrict__ raw, int P, int64_t n_windows, bool i8, int fmt,
-                                                           const double *__restrict__ U,
+                                                           const int64_t *__restrict__ sub_off, int64_t sub_base, const double *__restrict__ U,
                                                            double *__restrict__ num, double *__restrict__ den,
                                                            double *__restrict__ k, double *__restrict__ cnt) {
     const int pj = blockIdx.x * blockDim.x + threadIdx.x, pi = blockIdx.y;
@@ -1728,7 +1731,7 @@ __global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restr
     const int rho = pi & 63, chi = pj & 63;
     const int wave = (rho >> 5) * 2 + (chi >> 5);
     const int i = (rho >> 4) & 1, j = (chi >> 4) & 1, r16 = rho & 15, r = chi & 15;
-    const size_t base = (((size_t)w * nbp + bp) * 2 * 4 + wave) * 1024;
+    size_t base = (((size_t)w * nbp + bp) * 2 * 4 + wave) * 1024;
     const int slotA = (j * 2 + i) * 4 + (r16 >> 2), laneA = (r16 & 3) * 16 + r;             // row kq + 4 v
     const int slotB = i8 ? (j * 2 + i) * 4 + (r16 & 3) : slotA, laneB = i8 ? (r16 >> 2) * 16 + r : laneA;   // row 4 kq + v
     const size_t np = (size_t)P * (P - 1) / 2;
@@ -1738,6 +1741,21 @@ __global__ __launch_bounds__(256) void gram_unpack_kernel(const double2 *__restr
         const uint2 b = reinterpret_cast<const uint2 *>(raw)[base + 4 * 1024 + slotB * 64 + laneB];
         num[o] = (b.y >> 31) ? __longlong_as_double(0x7ff8000000000000ll) : d - U[(size_t)w * P + pi] - U[(size_t)w * P + pj];
         den[o] = d; k[o] = (double)b.x; cnt[o] = (double)(b.y & 0x7fffffffu);
+        return;
+    }
+    if (fmt == 1 && sub_off) {
+        double dn = 0.0, Ui = 0.0, Uj = 0.0, kk = 0.0;
+        uint32_t cn = 0, nan = 0;
+        for (int64_t s_ = sub_off[w] - sub_base; s_ < sub_off[w + 1] - sub_base; ++s_) {
+            base = (((size_t)s_ * nbp + bp) * 2 * 4 + wave) * 1024;
+            const double d = reinterpret_cast<const double *>(raw)[base + slotA * 64 + laneA];
+            const uint2 b = reinterpret_cast<const uint2 *>(raw)[base + 4 * 1024 + slotB * 64 + laneB];
+            dn += 0.5 * (double)((b.y >> 15) & 0x7fffu) - 2.0 * d;
+            kk += (double)b.x; cn += b.y & 0x7fffu; nan |= b.y >> 31;
+            Ui += U[(size_t)s_ * P + pi]; Uj += U[(size_t)s_ * P + pj];
+        }
+        num[o] = nan ? __longlong_as_double(0x7ff8000000000000ll) : dn - Ui - Uj;
+        den[o] = dn; k[o] = kk; cnt[o] = (double)cn;
         return;
     }
     if (fmt == 1) {
@@ -1763,7 +1781,7 @@ bool gram_uses_i8(int count_bytes, int max_n) {
 #endif
     return i8;
 }
-hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, int fmt, const double *U, double *num, double *den, double *k,
+hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool i8, int fmt, const int64_t *sub_off, int64_t sub_base, const double *U, double *num, double *den, double *k,
                               double *cnt, hipStream_t st) {
     if (n_windows <= 0 || P < 2) return hipSuccess;
     for (int64_t w0 = 0; w0 < n_windows; w0 += 65535) {          // gridDim.z
@@ -1772,12 +1790,19 @@ hipError_t launch_gram_unpack(const double2 *raw, int P, int64_t n_windows, bool
         dim3 grid((P + 255) / 256, P, (unsigned)nw), block(256);
         // (with 8-byte entries a window's part of the table is half as long)
         const double2 *rw = fmt ? reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(raw) + (size_t)w0 * per_w) : raw + (size_t)w0 * per_w;
-        hipLaunchKernelGGL(gram_unpack_kernel, grid, block, 0, st, rw, P, nw, i8, fmt, U + (size_t)w0 * P, num + (size_t)w0 * np,
+        if (sub_off)      // (pieces are counted from the table's first: neither the table nor U moves with w0)
+            hipLaunchKernelGGL(gram_unpack_kernel, grid, block, 0, st, raw, P, nw, i8, fmt, sub_off + w0, sub_base, U, num + (size_t)w0 * np,
+                               den + (size_t)w0 * np, k + (size_t)w0 * np, cnt + (size_t)w0 * np);
+        else
+        hipLaunchKernelGGL(gram_unpack_kernel, grid, block, 0, st, rw, P, nw, i8, fmt, (const int64_t *)nullptr, (int64_t)0, U + (size_t)w0 * P, num + (size_t)w0 * np,
                            den + (size_t)w0 * np, k + (size_t)w0 * np, cnt + (size_t)w0 * np);
     }
     return hipGetLastError();
 }
 
+int64_t gram_one_rule_sites(int count_bytes, int max_n) {
+    return gram_uses_i8(count_bytes, max_n) && count_bytes == 2 && max_n >= 1 && max_n <= 63 ? kGramOneRule / max_n : 0;
+}
 // the denominator on one FP64 stream where every window stays inside the 1e-12 bar by construction (see gram_kernel)
 bool gram_one_stream(const GramParams &p, int count_bytes) {
     return !p.two_streams && gram_uses_i8(count_bytes, p.max_n) && count_bytes == 2 && p.max_n <= 63 && p.max_window_sites > 0 &&

@@ -265,9 +265,10 @@ int64_t evofst_noalloc_scratch_bytes(void);
  *   "stream_buffers" chunks of a workgroup in flight (LDS buffers), 2 .. 4, 0 = chosen by the library
  *   "stream_sets"   sets of consumer waves that take a workgroup's chunks in turn, 1 or 2, 0 = chosen by the library
  *   "gram_denominator"  evofst_run_gram's window denominators: 0 = the library chooses (one FP64 contraction of the
- *                   centred frequencies where no population has more than 63 chromosomes and longest window x most
- *                   chromosomes of a population <= 2^13, which keeps every window inside 1e-12 of its own terms;
- *                   else the two of p q^T + q p^T), 2 = always the two
+ *                   centred frequencies where no population has more than 63 chromosomes, in pieces of at most
+ *                   2^13 / most chromosomes of a population sites -- longer windows run as several pieces whose sums
+ *                   evofst_get_gram adds -- which keeps every window inside 1e-12 of its own terms; else the two of
+ *                   p q^T + q p^T), 2 = always the two
  * Unknown names and values out of range return EVOFST_ERR_ARG.  A shape an option does not fit (LDS, waves) takes
  * the next pass in the order stream, lock-step, separate kernels. */
 int evofst_set_option(evofst_ctx *ctx, const char *name, int64_t value);

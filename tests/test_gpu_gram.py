@@ -79,10 +79,11 @@ def test_gram_windows(engine, S, N, P, miss, flags, edge, seed):
     engine.set_site_windows(ws)
     engine.run_counts()
     engine.run_gram()
-    # the denominator on one FP64 contraction (centred frequencies) where 8-bit counts, <= 63 chromosomes a population and
-    # longest window x chromosomes <= 2^13 allow it -- most of these shapes -- else, and when asked, on the two of p q^T + q p^T
+    # the denominator on one FP64 contraction (centred frequencies) where populations have <= 63 chromosomes -- most of these
+    # shapes; windows longer than 2^13 / chromosomes run as pieces, (640, 40, 2) has such -- else, and when asked, on the two
+    # of p q^T + q p^T
     max_n = int(n_full_of(sp, P).max())
-    one = max_n <= 63 and int(np.diff(ws).max()) * max_n <= (1 << 13)
+    one = max_n <= 63
     assert engine.last_gram_streams() == (1 if one else 2)
     _check_gram(engine, codes, sp, P, fl, ws, "gram_windows_one_stream" if one else "gram_windows")
     if one:
@@ -92,10 +93,11 @@ def test_gram_windows(engine, S, N, P, miss, flags, edge, seed):
             _check_gram(engine, codes, sp, P, fl, ws, "gram_windows")
 
 
-@pytest.mark.parametrize("per,win", [(5, 800), (25, 160)])
+@pytest.mark.parametrize("per,win", [(5, 800), (25, 160), (5, 3200), (25, 1200)])
 def test_gram_one_stream_hard_windows(engine, per, win):
     """The one-contraction denominator where it has least room: windows as long as its rule allows (800 sites at 10
-    chromosomes a population, 160 at 50 -- the 64 x 64 table), nearly every site fixed for the same allele in all populations (their terms cancel exactly:
+    chromosomes a population, 160 at 50 -- the 64 x 64 table) and longer ones, which run as pieces of that length (3200 =
+    four pieces, 1200 = eight), nearly every site fixed for the same allele in all populations (their terms cancel exactly:
     u_i u_j = 1/4), and a single site or two per window where one population carries one other allele -- a denominator of
     0.1 or 0.18 formed as 400 - 2 x 199.95 (in every other window near its start, where the term lives through the most
     binades of the running sum).  Populations without a called allele at a site (n_both) and fixed sites with
@@ -127,21 +129,22 @@ def test_gram_one_stream_hard_windows(engine, per, win):
     assert worst <= 0.6, worst
 
 
-def test_gram_window_batches(engine):
+@pytest.mark.parametrize("S,win,first,n", [(3000, 100, 7, 11), (9000, 1500, 2, 3)])   # (1500-site windows run as two pieces each)
+def test_gram_window_batches(engine, S, win, first, n):
     """run_gram over sub-ranges of the windows gives the same rows as one call."""
     rng = np.random.default_rng(11)
-    S, N, P = 3000, 80, 16
+    N, P = 80, 16
     sp = round_robin_pops(N, P)
     codes = random_codes(rng, S, sp, P, miss=0.05)
     engine.set_layout(sp, P)
     engine.upload(engine.pack_codes(codes), S)
     engine.set_gram()
-    ws = np.arange(0, S + 1, 100, dtype=np.int64)
+    ws = np.arange(0, S + 1, win, dtype=np.int64)
     engine.set_site_windows(ws)
     engine.run_counts()
     engine.run_gram()
     full = engine.gram()
-    engine.run_gram(7, 11)
+    engine.run_gram(first, n)
     part = engine.gram()
     for k in full:
-        assert np.array_equal(full[k][7:18], part[k], equal_nan=True)
+        assert np.array_equal(full[k][first:first + n], part[k], equal_nan=True)
