@@ -1,6 +1,7 @@
-"""Randomised parity soak of the Gram path against the CPU oracle (a checker like the tests: it imports oracle/).
+"""Randomised parity soak of the Gram path against the CPU oracle (a checker like the tests, which is why it lives here:
+it imports oracle/; pytest does not collect it).
 
-    python3 tools/gpu_gram_soak.py [cases] [seed]
+    python3 tests/gram_soak.py [cases] [seed]
 
 Shapes the fixed tests do not enumerate: population counts around the 64-wide blocks, 1 .. 70 chromosomes a
 population (the 32 x 32 and 64 x 64 operand tables, the two-stream forms beyond them), missing rates up to 40 %,
