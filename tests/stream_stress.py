@@ -1,7 +1,7 @@
 """Random shapes through the stream pass against the oracle (the checks of tests/test_gpu_pairs.py::_check_windows_once):
 layouts, shard lengths (down to less than a chunk), missing-call rates, skipped sites, windows, producer counts and the
 library's own or a given chunk size.  Not a test of the suite -- a soak run for a change of evofst_stream.hip.
-Run through gpurun:  python3 tools/gpu_stream_stress.py [cases] [seed]"""
+Run through gpurun:  python3 tests/stream_stress.py [cases] [seed]   (a checker that calls the oracle: it lives under tests/; pytest does not collect it)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
