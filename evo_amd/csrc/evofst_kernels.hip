@@ -2689,7 +2689,9 @@ __device__ __forceinline__ void global_eval_full(uint32_t c, uint32_t Tc, const 
     den = (p1 * (1.0 - p2)) + (p2 * (1.0 - p1));
 }
 
-template <typename CT, bool RCP>
+// MP: populations per wave at most (the loops over them are unrolled and their counts live in registers one tile ahead: a
+// kernel cut for 7 -- 112 populations -- carries less than one cut for kGlobalTilePops)
+template <typename CT, bool RCP, int MP>
 __global__ __launch_bounds__(kGlobalTileThreads) void global_tile_kernel(GlobalParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int nu = p.n_use, KW = p.kw, size = p.size;
@@ -2750,7 +2752,6 @@ __global__ __launch_bounds__(kGlobalTileThreads) void global_tile_kernel(GlobalP
     const uint32_t ustep = (uint32_t)p.step;
     // this wave's populations (wave, wave + 16, ...: at most kGlobalTilePops of them) and, one tile ahead of its use, the
     // counts of this lane's site in each of them and the site's totals: the loads of tile t + 1 fly while tile t is evaluated
-    constexpr int MP = kGlobalTilePops;
     int kk[MP];
     double thr[MP];
 #pragma unroll
@@ -2850,9 +2851,9 @@ __global__ __launch_bounds__(kGlobalTileThreads) void global_tile_kernel(GlobalP
     }
 }
 
-template <typename CT, bool RCP>
+template <typename CT, bool RCP, int MP>
 static hipError_t launch_global_tile_t(const GlobalParams &p_, size_t lds_bytes, hipStream_t st) {
-    const void *fn = reinterpret_cast<const void *>(&global_tile_kernel<CT, RCP>);
+    const void *fn = reinterpret_cast<const void *>(&global_tile_kernel<CT, RCP, MP>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     GlobalParams p = p_;
@@ -2878,7 +2879,7 @@ static hipError_t launch_global_tile_t(const GlobalParams &p_, size_t lds_bytes,
         }
     }
     dim3 grid((p.n_chunks + p.group - 1) / p.group);
-    hipLaunchKernelGGL((global_tile_kernel<CT, RCP>), grid, dim3(kGlobalTileThreads), lds_bytes, st, p);
+    hipLaunchKernelGGL((global_tile_kernel<CT, RCP, MP>), grid, dim3(kGlobalTileThreads), lds_bytes, st, p);
     return hipGetLastError();
 }
 
@@ -2886,8 +2887,15 @@ hipError_t launch_global_tile(const GlobalParams &p, int count_bytes, size_t lds
     if (p.n_chunks <= 0 || p.n_use <= 0) return hipSuccess;
     if (p.kw < p.size + kTileSites || (p.kw & 1) == 0 || p.halo_n > p.size || lds_bytes > 160 * 1024 ||
         p.n_use > kGlobalTilePops * (kGlobalTileThreads / 64)) return hipErrorInvalidValue;
-    if (count_bytes == 2) return launch_global_tile_t<uint16_t, true>(p, lds_bytes, st);
-    return launch_global_tile_t<uint32_t, true>(p, lds_bytes, st);
+    const int per_wave = (p.n_use + kGlobalTileThreads / 64 - 1) / (kGlobalTileThreads / 64);
+    if (count_bytes == 2) {
+        if (per_wave <= 4) return launch_global_tile_t<uint16_t, true, 4>(p, lds_bytes, st);
+        if (per_wave <= 7) return launch_global_tile_t<uint16_t, true, 7>(p, lds_bytes, st);
+        return launch_global_tile_t<uint16_t, true, kGlobalTilePops>(p, lds_bytes, st);
+    }
+    if (per_wave <= 4) return launch_global_tile_t<uint32_t, true, 4>(p, lds_bytes, st);
+    if (per_wave <= 7) return launch_global_tile_t<uint32_t, true, 7>(p, lds_bytes, st);
+    return launch_global_tile_t<uint32_t, true, kGlobalTilePops>(p, lds_bytes, st);
 }
 
 template <typename CT, bool RCP>
