@@ -1693,20 +1693,20 @@ extern "C" int evofst_run_gram(evofst_ctx *c, int64_t first_window, int64_t n_wi
         p.max_window_sites = std::min(p.max_window_sites, rule);
     }
     c->gram_split = split;
+    p.two_streams = c->opt_gram_den == 2;                     // evofst_set_option "gram_denominator" 2
+    p.fmt = gram_result_format(p, c->count_bytes);
     if ((rc = ensure(c, c->d_gU, (size_t)n_windows * P * 8))) return rc;
     if ((rc = ensure(c, c->d_gC, (size_t)n_windows * P * 8 * 2))) return rc;   // C, then D (sites with a called allele)
-    if ((rc = ensure(c, c->d_graw, gram_raw_bytes(c->n_pops, n_windows)))) return rc;
+    if ((rc = ensure(c, c->d_graw, gram_raw_bytes(c->n_pops, n_windows) >> (p.fmt ? 1 : 0)))) return rc;   // (8-byte entries: half the table)
     p.counts = c->d_counts.p; p.n_sites = c->n_sites; p.n_tiles = c->n_tiles; p.P = c->n_pops;
     p.n_full = (const int32_t *)c->d_nfull.p;
     p.masks = (const uint64_t *)c->d_zf.p; p.skip_mask = (const uint64_t *)c->d_skip.p;
     p.tile_poison = (const uint32_t *)c->d_poison.p;
     p.win_start = (const int64_t *)(split ? c->d_gsub.p : c->d_win.p);
     p.first_window = first_window; p.n_windows = (int32_t)n_windows;
-    p.two_streams = c->opt_gram_den == 2;                     // evofst_set_option "gram_denominator" 2
     p.U = (double *)c->d_gU.p; p.C = (double *)c->d_gC.p; p.D = p.C + (size_t)n_windows * P;
     p.n_pairs = np;
     p.out_raw = (double2 *)c->d_graw.p;
-    p.fmt = gram_result_format(p, c->count_bytes);
 #ifdef EVOFST_EXPERIMENTS
     if (const char *e = getenv("EVOFST_DEBUG_GRAM")) p.debug = atoi(e);
 #endif
