@@ -49,6 +49,7 @@ static size_t fused_region_bytes(int P, int tiles, int count_bytes, int sub) {
     b += 2 * a16((size_t)P * 8);                // carH, carT
     b += 2 * a16((size_t)P * subp * 4);         // xt, PC
     b += a16((size_t)P * 4);                    // carC
+    b += a16((size_t)P * ((size_t)sub + 8));    // c of the fill as bytes
     b += a16((size_t)tiles * P * kTileSites * count_bytes);
     b += a16((size_t)tiles * 2 * P * 8);        // zero / fixed ballots
     b += 4 * a16((size_t)tiles * 8);            // irregular, skip, any-missing, NaN sites
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(kK2Threads, HBM ? (W3 ? 3 : EVOFST_WALK_WPS) : EVOF
         lb = reinterpret_cast<uint32_t *>(carve((size_t)kFuseWaves * 3 * 64 * 4));      // [wave][level][pair] look-back partial sums
         const size_t rb = ((size_t)3 * (((size_t)P * SUBP * 8 + 15) & ~(size_t)15)) + 2 * (((size_t)P * 8 + 15) & ~(size_t)15) +
                           2 * (((size_t)P * SUBP * 4 + 15) & ~(size_t)15) + (((size_t)P * 4 + 15) & ~(size_t)15) +
+                          (((size_t)P * (SUB + 8) + 15) & ~(size_t)15) +
                           (((size_t)TRL * P * kTileSites * sizeof(CT) + 15) & ~(size_t)15) + (((size_t)TRL * 2 * P * 8 + 15) & ~(size_t)15) +
                           4 * (((size_t)TRL * 8 + 15) & ~(size_t)15);
         off += (size_t)wave * rb;
@@ -290,6 +292,10 @@ __global__ __launch_bounds__(kK2Threads, HBM ? (W3 ? 3 : EVOFST_WALK_WPS) : EVOF
     uint32_t *xt = reinterpret_cast<uint32_t *>(carve((size_t)P * SUBP * 4));   // c | flags
     uint32_t *PC = reinterpret_cast<uint32_t *>(carve((size_t)P * SUBP * 4));   // sum of c
     uint32_t *carC = reinterpret_cast<uint32_t *>(carve((size_t)P * 4));
+    // the fill's c as bytes, [P][SUB + 8] (rows 8-byte aligned): the regular sums loop takes c_i c_j of four sites with one
+    // v_dot4_u32_u8 on two 4-byte reads instead of four 24-bit multiplies on eight (the loop is bound by the LDS bytes it reads)
+    constexpr int SUBB = SUB + 8;
+    unsigned char *cbt = carve((size_t)P * SUBB);
     CT *lcnt = reinterpret_cast<CT *>(carve((size_t)TRL * P * kTileSites * sizeof(CT)));  // [tile][P][64]
     uint64_t *lzf = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 2 * P * 8));         // [tile][z|f][P]
     uint64_t *lirr = reinterpret_cast<uint64_t *>(carve((size_t)TRL * 8));
@@ -547,6 +553,10 @@ __global__ __launch_bounds__(kK2Threads, HBM ? (W3 ? 3 : EVOFST_WALK_WPS) : EVOF
                 if (r >= d) { eh += yh; et += yt; ec += yc; }
             }
             const double ch = 0.0, ct = 0.0;                          // the h / t tables start at the fill (see segN below)
+            if (sizeof(CT) == 2) {                                   // (EPT = 8 counts of at most 255)
+                *reinterpret_cast<uint2 *>(cbt + k * SUBB + r * EPT) =
+                    make_uint2(cv[0] | (cv[1] << 8) | (cv[2] << 16) | (cv[3] << 24), cv[4 % EPT] | (cv[5 % EPT] << 8) | (cv[6 % EPT] << 16) | (cv[7 % EPT] << 24));
+            }
             const uint32_t ccar = carC[k];
             if (r == VPR - 1) carC[k] = ccar + ec;
             double ah = ch + (eh - rh), at = ct + (et - rt);       // sums before this vector
@@ -723,21 +733,27 @@ __global__ __launch_bounds__(kK2Threads, HBM ? (W3 ? 3 : EVOFST_WALK_WPS) : EVOF
                 uint64_t scc = cc;
                 uint32_t sexi = exi, sexj = exj, sbn = bn, sbd = bd;   // (the regular loop leaves these four alone)
                 if (!general) {
+                    constexpr bool kBytes = sizeof(CT) == 2 && kGrp == 4;
 #pragma unroll
                     for (int sb = 0; sb < SUB; sb += kGrp) {
                         double a[kGrp], bb[kGrp];
                         uint32_t xi[kGrp], xj[kGrp];
+                        uint32_t ci4 = 0, cj4 = 0;
+                        if (kBytes) {
+                            ci4 = *reinterpret_cast<const uint32_t *>(cbt + pi * SUBB + sb);
+                            cj4 = *reinterpret_cast<const uint32_t *>(cbt + pj * SUBB + sb);
+                        }
 #pragma unroll
                         for (int u = 0; u < kGrp; ++u) {
                             a[u] = pt[io + sb + u]; bb[u] = pt[jo + sb + u];
-                            xi[u] = xt[io + sb + u]; xj[u] = xt[jo + sb + u];
+                            if (!kBytes) { xi[u] = xt[io + sb + u]; xj[u] = xt[jo + sb + u]; }
                         }
-                        uint32_t cch = 0;                      // c_i c_j of kGrp sites (< 2^30)
+                        uint32_t cch = kBytes ? __builtin_amdgcn_udot4(ci4, cj4, 0u, false) : 0u;   // c_i c_j of kGrp sites (< 2^30)
 #pragma unroll
                         for (int u = 0; u < kGrp; ++u) {
                             const double d = a[u] - bb[u];
                             D = fma(d, d, D);
-                            cch += __umul24(xi[u], xj[u]);     // low 24 bits: c (the flags sit above)
+                            if (!kBytes) cch += __umul24(xi[u], xj[u]);     // low 24 bits: c (the flags sit above)
                         }
                         cc += cch;
                         if (sb == bgrp) { sD = D; scc = cc; }
