@@ -1082,8 +1082,9 @@ hipError_t launch_clean_walk(const FusedParams &p, hipStream_t st) {
     size_t lds = clean_walk_lds_bytes(p.P, p.n_pairs, p.piece_tiles, p.compact != 0);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     // At most three workgroups per CU, by the LDS asked for: the kernel is no slower for it (24.3 us on cfg2 at six, three or
-    // two), and the registers the others would hold are what the next batch's K1 runs in beside it (two K1 waves per SIMD
-    // instead of none once the walk has filled a CU): the overlapped cfg2 step 43.1 -> 41.4 us.
+    // two), and the registers the others would hold are what the next batch's K1 runs in beside it (at five workgroups of 88
+    // registers a SIMD has 72 left, at three 248: a K1 wave of 128 instead of none once the walk has filled a CU): the
+    // overlapped cfg2 step 43.1 -> 41.4 us.
     lds = std::max(lds, (size_t)41000);
     if (p.compact) return wp ? launch_clean_walk_t<true, 1>(p, lds, threads, st) : launch_clean_walk_t<false, 1>(p, lds, threads, st);
     return wp ? launch_clean_walk_t<true, 2>(p, lds, threads, st) : launch_clean_walk_t<false, 2>(p, lds, threads, st);
