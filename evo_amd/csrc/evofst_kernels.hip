@@ -1500,16 +1500,23 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         if (base + 4 * EV < b) fetch(base + 4 * EV);     // the next step's vectors travel while this one is contracted
         if (ONE) {
             if (!any_valid) continue;
-#pragma unroll
-            for (int e = 0; e < EV; ++e) {
-                // a site index no lane of the wave has inside the window (the ragged ends of a window): see below
-                if (!((emask >> e) & 1u)) continue;
-                double U_[4];
+            // the operands of site index e + 1 are read before the contractions of e are issued (the reads' round trip then
+            // passes behind the matrix instructions); an index no lane of the wave has inside the window (the ragged ends of a
+            // window) is read all the same and its four contractions skipped
+            double Un[4];
+            auto read_u = [&](int e, double (&u)[4]) {
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const uint32_t off = (e & 1) ? T[x][e >> 1] >> 16 : T[x][e >> 1] & 0xffffu;
-                    U_[x] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_u) + off);
+                    u[x] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_u) + off);
                 }
+            };
+            read_u(0, Un);
+#pragma unroll
+            for (int e = 0; e < EV; ++e) {
+                double U_[4] = {Un[0], Un[1], Un[2], Un[3]};
+                if (e + 1 < EV) read_u(e + 1, Un);
+                if (!((emask >> e) & 1u)) continue;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
