@@ -1417,6 +1417,15 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         const uint32_t emask = (uint32_t)(__builtin_amdgcn_readlane((int)valid, 0) | __builtin_amdgcn_readlane((int)valid, 16) |
                                           __builtin_amdgcn_readlane((int)valid, 32) | __builtin_amdgcn_readlane((int)valid, 48));
         const bool any_valid = emask != 0u;
+        // ONE: the table offsets of the step's packed counts, two sites per word and no branch: entry (nm << 5) | c of tab_u
+        // is at byte nm * 256 + c * 8, both in place in a 16-bit packed count but for c's shift (TB = 6: nm * 512 + c * 8,
+        // at most 32 760: still 16 bits), and the sites outside the window (or skipped) go to entry 0 (= 0.0) through the
+        // masks.  (Rows of populations >= P contract a copy of population P - 1: their elements of the result are never
+        // read.)  The two-stream form with the {p, q} table takes its operands the same way: 16-byte entries at
+        // nm * 512 + c * 16.  The offsets are formed between the int8 contractions below, one population per tile pair:
+        // vector work the matrix cores' int8 instructions run beside.
+        constexpr bool TPQ = TAB && I8 && !ONE && sizeof(CT) == 2;
+        uint32_t T[4][4];
         if (I8 && any_valid) {
             // the step's 32 sites at once: lane = population (lane & 15), bytes = its 8 sites
             long C8[4], FN8[4], FM8[4], Z8[4], F8[4], B8[4], BN8[4], D8[4];
@@ -1458,6 +1467,13 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                 if (ONE && MISS) D8[x] = pack(d_);
                 if (MISS) { FN8[x] = pack(fn_); FM8[x] = pack(fm_); }
             }
+            uint32_t mk[4] = {0u, 0u, 0u, 0u};
+            if (ONE || TPQ) {
+                const uint64_t vm = spread[valid];
+                const uint32_t vlo = (uint32_t)vm, vhi = (uint32_t)(vm >> 32);
+                mk[0] = __builtin_amdgcn_perm(vlo, vlo, 0x01010000u); mk[1] = __builtin_amdgcn_perm(vlo, vlo, 0x03030202u);
+                mk[2] = __builtin_amdgcn_perm(vhi, vhi, 0x01010000u); mk[3] = __builtin_amdgcn_perm(vhi, vhi, 0x03030202u);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1471,31 +1487,16 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
                         im[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(FM8[i], FN8[2 + j], im[i][j], 0, 0, 0);
                     }
                     if (ONE && MISS) inb[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(D8[i], D8[2 + j], inb[i][j], 0, 0, 0);
+                    if (ONE || TPQ) {
+                        const int x = i * 2 + j;
+                        const uint32_t wv[4] = {nxt[x][0].x, nxt[x][0].y, nxt[x][0].z, nxt[x][0].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            T[x][k] = TPQ ? ((wv[k] << 1) & (mk[k] & 0x3e003e00u)) | ((wv[k] << 4) & (mk[k] & 0x01f001f0u))       // nm * 512 + c * 16
+                                    : TB == 5 ? (wv[k] & (mk[k] & 0x1f001f00u)) | ((wv[k] << 3) & (mk[k] & 0x00f800f8u))
+                                              : ((wv[k] << 1) & (mk[k] & 0x7e007e00u)) | ((wv[k] << 3) & (mk[k] & 0x01f801f8u));   // nm * 512 + c * 8
+                    }
                 }
-        }
-        // ONE: the table offsets of the step's packed counts, two sites per word and no branch: entry (nm << 5) | c of tab_u
-        // is at byte nm * 256 + c * 8, both in place in a 16-bit packed count but for c's shift (TB = 6: nm * 512 + c * 8,
-        // at most 32 760: still 16 bits), and the sites outside the
-        // window (or skipped) go to entry 0 (= 0.0) through the masks.  (Rows of populations >= P contract a copy of
-        // population P - 1: their elements of the result are never read.)
-        // (the two-stream form with the {p, q} table and the int8 contractions takes its operands the same way: 16-byte
-        //  entries at nm * 512 + c * 16)
-        constexpr bool TPQ = TAB && I8 && !ONE && sizeof(CT) == 2;
-        uint32_t T[4][4];
-        if ((ONE || TPQ) && any_valid) {
-            const uint64_t vm = spread[valid];
-            const uint32_t vlo = (uint32_t)vm, vhi = (uint32_t)(vm >> 32);
-            const uint32_t mk[4] = {__builtin_amdgcn_perm(vlo, vlo, 0x01010000u), __builtin_amdgcn_perm(vlo, vlo, 0x03030202u),
-                                    __builtin_amdgcn_perm(vhi, vhi, 0x01010000u), __builtin_amdgcn_perm(vhi, vhi, 0x03030202u)};
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const uint32_t wv[4] = {nxt[x][0].x, nxt[x][0].y, nxt[x][0].z, nxt[x][0].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    T[x][k] = TPQ ? ((wv[k] << 1) & (mk[k] & 0x3e003e00u)) | ((wv[k] << 4) & (mk[k] & 0x01f001f0u))       // nm * 512 + c * 16
-                            : TB == 5 ? (wv[k] & (mk[k] & 0x1f001f00u)) | ((wv[k] << 3) & (mk[k] & 0x00f800f8u))
-                                      : ((wv[k] << 1) & (mk[k] & 0x7e007e00u)) | ((wv[k] << 3) & (mk[k] & 0x01f801f8u));   // nm * 512 + c * 8
-            }
         }
         if (base + 4 * EV < b) fetch(base + 4 * EV);     // the next step's vectors travel while this one is contracted
         if (ONE) {
