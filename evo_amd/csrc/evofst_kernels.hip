@@ -1528,15 +1528,20 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramParams p) {
         }
         if (TPQ) {
             if (!any_valid) continue;
-#pragma unroll
-            for (int e = 0; e < EV; ++e) {
-                if (!((emask >> e) & 1u)) continue;
-                double2 PQ[4];
+            double2 PQn[4];                               // (read one site index ahead, as in the one-contraction form)
+            auto read_pq = [&](int e, double2 (&u)[4]) {
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const uint32_t off = (e & 1) ? T[x][e >> 1] >> 16 : T[x][e >> 1] & 0xffffu;
-                    PQ[x] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab_pq) + off);
+                    u[x] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab_pq) + off);
                 }
+            };
+            read_pq(0, PQn);
+#pragma unroll
+            for (int e = 0; e < EV; ++e) {
+                double2 PQ[4] = {PQn[0], PQn[1], PQn[2], PQn[3]};
+                if (e + 1 < EV) read_pq(e + 1, PQn);
+                if (!((emask >> e) & 1u)) continue;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
